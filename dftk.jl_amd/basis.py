@@ -1,0 +1,208 @@
+"""``PlaneWaveBasis`` / ``Kpoint`` host mirror bound to the device library.
+
+Reference: src/PlaneWaveBasis.jl:25-97,129-261,323-369 (struct, constructor), src/Kpoint.jl:6-41,
+src/fft.jl:24-31,76-98,231-287 (G vectors, normalisations, FFT size rule), structure.jl:50-61.
+
+Array layout: cubes are torch tensors of shape (nz, ny, nx) -- x fastest, i.e.
+Julia's (nx, ny, nz) column-major array; orbital blocks are tensors of shape (n_bands, n_G)
+(= column-major n_G x n_bands, one column per band); everything fp64 / complex128 in HBM.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .comm import KptComm, distribute_kpoints
+from .model import ExplicitKpoints, Model, MonkhorstPack
+
+
+def estimate_integer_lattice_bounds(M, delta, shift=(0, 0, 0), tol=math.sqrt(np.finfo(float).eps)):
+    """structure.jl:50-61."""
+    inv_t = np.linalg.inv(np.asarray(M, dtype=float).T)
+    xlims = [np.linalg.norm(inv_t[:, i]) * delta + shift[i] for i in range(3)]
+    return [0 if x == 0 else int(math.ceil(x - tol)) for x in xlims]
+
+
+def next_compatible_fft_size(size, smallprimes=(2, 3, 5), factors=(1,)):
+    """fft.jl:277-287."""
+    def smooth(n):
+        for p in smallprimes:
+            while n % p == 0:
+                n //= p
+        return n == 1
+    f = int(np.prod(factors))
+    while not (size % f == 0 and (not smallprimes or smooth(size))):
+        size += 1
+    return size
+
+
+def compute_fft_size(model_or_lattice, Ecut, supersampling=2, factors=(1,)):
+    """``compute_fft_size(model, Ecut; algorithm=:fast)`` (fft.jl:231-267, 331-337)."""
+    lattice = getattr(model_or_lattice, "lattice", model_or_lattice)
+    recip = 2 * math.pi * np.linalg.inv(np.asarray(lattice, dtype=float).T)
+    Glims = estimate_integer_lattice_bounds(recip, supersampling * math.sqrt(2 * Ecut))
+    return tuple(next_compatible_fft_size(2 * g + 1, factors=factors) for g in Glims)
+
+
+def G_axis(n):
+    """[0..floor((n-1)/2), -ceil((n-1)/2)..-1] (fft.jl:24-31)."""
+    stop = (n - 1) // 2
+    return np.array(list(range(0, stop + 1)) + list(range(stop - (n - 1), 0)), dtype=np.int64)
+
+
+class Kpoint:
+    """Kpoint.jl:6-18 + the device-side k-block handle (sphere tables, kinetic vector)."""
+
+    def __init__(self, basis, coordinate, spin=1):
+        self.basis = basis
+        self.spin = spin
+        self.coordinate = np.asarray(coordinate, dtype=float)
+        dev = basis.device
+        # enumerate the cube in column-major order, keep |B (G + k)|^2 / 2 <= Ecut (Kpoint.jl:28-35)
+        gx, gy, gz = basis.G_vectors_cube()
+        B = torch.tensor(basis.model.recip_lattice, dtype=torch.float64, device=dev)
+        k = torch.tensor(self.coordinate, dtype=torch.float64, device=dev)
+        G = torch.stack([gx.reshape(-1), gy.reshape(-1), gz.reshape(-1)], dim=1).to(torch.float64)
+        Gk = (G + k[None, :]) @ B.T
+        kin_all = (Gk * Gk).sum(dim=1) / 2
+        mapping = torch.nonzero(kin_all <= basis.Ecut).reshape(-1)
+        self.mapping = mapping.cpu().numpy().astype(np.int64)            # 0-based, ascending
+        self.mapping_device = mapping
+        self.G_vectors = G[mapping].to(torch.int64)                     # (n_G, 3) on device
+        self.Gplusk_cart = Gk[mapping]                                  # (n_G, 3) cartesian, device
+        self.kinetic = kin_all[mapping].contiguous()                    # 1/2 |k+G|^2 (kinetic.jl:31-35)
+        self.n_G = int(mapping.numel())
+        self.handle = C.c_void_p()
+        self._keep = {}
+        if basis.handle is not None:
+            kin_h = np.ascontiguousarray(self.kinetic.cpu().numpy())
+            _lib.check(basis.lib.dftk_mi_kblock_create(basis.handle, self.n_G, self.mapping.ctypes.data,
+                                                       kin_h.ctypes.data, C.byref(self.handle)))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.basis.lib.dftk_mi_kblock_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class PlaneWaveBasis:
+    """``PlaneWaveBasis(model; Ecut, kgrid, fft_size, architecture=GPU, comm_kpts)``.
+
+    ``device="cuda"`` binds the basis to the MI355X library (required for the hot path);
+    ``device="cpu"`` builds the descriptors only (set-up / sharding tests): any hot-path call
+    then raises, there is no CPU fallback.
+    """
+
+    def __init__(self, model: Model, Ecut: float, kgrid=None, fft_size=None, device="cuda",
+                 comm_kpts: KptComm | None = None, build_terms=True):
+        self.model = model
+        self.Ecut = float(Ecut)
+        self.device = torch.device(device)
+        self.comm_kpts = comm_kpts if comm_kpts is not None else KptComm.single()
+        self.fft_size = tuple(int(n) for n in (fft_size or compute_fft_size(model, Ecut)))
+        nx, ny, nz = self.fft_size
+        self.N = nx * ny * nz
+        self.dvol = model.unit_cell_volume / self.N
+        self.ifft_normalization = 1 / math.sqrt(model.unit_cell_volume)      # fft.jl:87
+        self.fft_normalization = math.sqrt(model.unit_cell_volume) / self.N  # fft.jl:88
+        self.lib = None
+        self.handle = None
+        if self.device.type == "cuda":
+            self.lib = _lib.load()
+            self.handle = C.c_void_p()
+            idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            self.device = torch.device("cuda", idx)
+            _lib.check(self.lib.dftk_mi_basis_create(nx, ny, nz, model.unit_cell_volume, idx,
+                                                     C.byref(self.handle)))
+        # k-points: explicit list or unreduced Monkhorst-Pack mesh, split over comm_kpts
+        if kgrid is None:
+            kgrid = MonkhorstPack((1, 1, 1))
+        if isinstance(kgrid, MonkhorstPack):
+            kgrid = kgrid.reducible()
+        (kc, kw, self.kcoords_global, self.kweights_global,
+         self.krange_allprocs) = distribute_kpoints(kgrid.kcoords, kgrid.kweights, self.comm_kpts)
+        self.krange_thisproc = self.krange_allprocs[self.comm_kpts.rank]
+        self.kweights = kw
+        self.kpoints = [Kpoint(self, k) for k in kc]
+        # the full cube as a degenerate "sphere": gives hand-written cube FFTs for Hartree etc.
+        self._cube_handle = C.c_void_p()
+        if self.handle is not None:
+            full = np.arange(self.N, dtype=np.int64)
+            _lib.check(self.lib.dftk_mi_kblock_create(self.handle, self.N, full.ctypes.data, None,
+                                                      C.byref(self._cube_handle)))
+        self.terms = None
+        if build_terms:
+            from .terms import instantiate_terms
+            self.terms = instantiate_terms(self)
+
+    # ---- grids ---------------------------------------------------------------------------
+    def G_vectors_cube(self):
+        nx, ny, nz = self.fft_size
+        ax = [torch.tensor(G_axis(n), device=self.device) for n in (nx, ny, nz)]
+        gz, gy, gx = torch.meshgrid(ax[2], ax[1], ax[0], indexing="ij")
+        return gx, gy, gz
+
+    def G_vectors_cart_cube(self):
+        gx, gy, gz = self.G_vectors_cube()
+        B = torch.tensor(self.model.recip_lattice, dtype=torch.float64, device=self.device)
+        G = torch.stack([gx, gy, gz], dim=-1).to(torch.float64)
+        return G @ B.T
+
+    def enforce_real_mask(self):
+        """1 where the -G partner exists on the grid (symmetry.jl:318-337,550-552), else 0."""
+        nx, ny, nz = self.fft_size
+        mask = torch.ones((nz, ny, nx), dtype=torch.float64, device=self.device)
+        for axis, n in ((0, nz), (1, ny), (2, nx)):
+            if n % 2 == 0:
+                idx = [slice(None)] * 3
+                idx[axis] = n // 2          # G = -n/2 sits at FFT index n/2
+                mask[tuple(idx)] = 0
+        return mask
+
+    # ---- cube FFTs through the library (normalised as fft.jl:106-109,155-161) -----------------
+    def _require_gpu(self):
+        if self.handle is None:
+            raise RuntimeError("PlaneWaveBasis was built with device='cpu': the MI355X hot path is unavailable "
+                               "(no CPU fallback)")
+
+    def sync(self):
+        self._require_gpu()
+        _lib.check(self.lib.dftk_mi_basis_sync(self.handle))
+
+    def fft(self, f_real: torch.Tensor) -> torch.Tensor:
+        """cube -> Fourier coefficients (c_G = sqrt(Omega)/N sum_r f(r) e^{-iG.r})."""
+        self._require_gpu()
+        f = f_real.to(torch.complex128).contiguous()
+        out = torch.empty_like(f)
+        torch.cuda.current_stream(self.device).synchronize()
+        _lib.check(self.lib.dftk_mi_fft_sphere(self._cube_handle, f.data_ptr(), out.data_ptr()))
+        self.sync()
+        return out * self.fft_normalization
+
+    def ifft(self, f_fourier: torch.Tensor) -> torch.Tensor:
+        self._require_gpu()
+        f = f_fourier.to(torch.complex128).contiguous()
+        out = torch.empty_like(f)
+        torch.cuda.current_stream(self.device).synchronize()
+        _lib.check(self.lib.dftk_mi_ifft_sphere(self._cube_handle, f.data_ptr(), out.data_ptr()))
+        self.sync()
+        return out * self.ifft_normalization
+
+    def irfft(self, f_fourier: torch.Tensor) -> torch.Tensor:
+        return self.ifft(f_fourier).real.contiguous()
+
+    def __del__(self):
+        try:
+            if self.handle is not None:
+                self.kpoints = []
+                if self._cube_handle:
+                    self.lib.dftk_mi_kblock_destroy(self._cube_handle)
+                self.lib.dftk_mi_basis_destroy(self.handle)
+        except Exception:
+            pass

@@ -1,0 +1,518 @@
+// api.cpp -- the extern "C" boundary (include/dftk_mi355x.h), handles and host-side planning.
+#include "common.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+static thread_local char g_err[1024] = "";
+
+void dftk_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* dftk_mi_last_error(void) { return g_err; }
+extern "C" const char* dftk_mi_version(void) {
+    return "dftk_mi355x 0.1.0 (gfx950; fp64; pruned batched FFT pipeline, f64-MFMA zgemm, blocked-Jacobi heev)";
+}
+
+// ------------------------------------------------------------------------------------ profiling
+int prof_begin(dftk_mi_basis* b, int fam, double work) {
+    Prof* p = b->prof;
+    if (!p || !p->on) return -1;
+    if (p->pending.size() >= 60000) prof_resolve(b);
+    Prof::Pair pr;
+    if (!p->pool.empty()) {
+        pr = p->pool.back();
+        p->pool.pop_back();
+    } else {
+        if (hipEventCreate(&pr.a) != hipSuccess || hipEventCreate(&pr.b) != hipSuccess) return -1;
+    }
+    pr.fam = fam;
+    p->work[fam] += work;
+    p->launches[fam] += 1;
+    hipEventRecord(pr.a, b->stream);
+    p->pending.push_back(pr);
+    return (int)p->pending.size() - 1;
+}
+void prof_end(dftk_mi_basis* b, int slot) {
+    if (slot < 0) return;
+    hipEventRecord(b->prof->pending[slot].b, b->stream);
+}
+int prof_resolve(dftk_mi_basis* b) {
+    Prof* p = b->prof;
+    if (!p) return 0;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (auto& pr : p->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pr.a, pr.b) == hipSuccess) p->ms[pr.fam] += ms;
+        p->pool.push_back(pr);
+    }
+    p->pending.clear();
+    return 0;
+}
+extern "C" int dftk_mi_prof_enable(dftk_mi_basis* b, int on) {
+    if (!b) return DFTK_MI_EINVAL;
+    CHK(prof_resolve(b));
+    if (on) {
+        for (int i = 0; i < PROF_NFAM; ++i) {
+            b->prof->ms[i] = 0;
+            b->prof->work[i] = 0;
+            b->prof->launches[i] = 0;
+        }
+    }
+    b->prof->on = on != 0;
+    return 0;
+}
+extern "C" int dftk_mi_prof_get(dftk_mi_basis* b, int family, double* total_ms, double* work, int64_t* launches) {
+    if (!b || family < 0 || family >= PROF_NFAM) return DFTK_MI_EINVAL;
+    CHK(prof_resolve(b));
+    if (total_ms) *total_ms = b->prof->ms[family];
+    if (work) *work = b->prof->work[family];
+    if (launches) *launches = b->prof->launches[family];
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ 1-D plans
+int plan_radices(int n, int* nrad, int* rad) {
+    int k = 0, m = n;
+    const int pref[4] = {5, 4, 3, 2};
+    for (int r : pref)
+        while (m % r == 0 && m > 1) {
+            if (k >= DFTK_MAX_RADICES) return -1;
+            rad[k++] = r;
+            m /= r;
+        }
+    for (int p = 7; m > 1; p += 2)
+        while (m % p == 0) {
+            if (k >= DFTK_MAX_RADICES || p > 64) return -1;
+            rad[k++] = p;
+            m /= p;
+        }
+    if (n == 1) {
+        rad[0] = 1;
+        k = 0;
+    }
+    *nrad = k;
+    return 0;
+}
+
+// pos[e] = position at which a decimation-in-time pass expects input element e, equivalently the
+// position at which a decimation-in-frequency pass leaves output frequency e.
+// position p has digits q_s = (p / m_s) % r_s with m_s = r_0...r_{s-1}; it holds element
+// e = q_{k-1} + r_{k-1} (q_{k-2} + r_{k-2} ( ... q_0)).
+void plan_positions(int n, int nrad, const int* rad, int* pos) {
+    if (nrad == 0) {
+        for (int i = 0; i < n; ++i) pos[i] = i;
+        return;
+    }
+    std::vector<int> m(nrad + 1, 1);
+    for (int s = 0; s < nrad; ++s) m[s + 1] = m[s] * rad[s];
+    for (int p = 0; p < n; ++p) {
+        int e = (p / m[0]) % rad[0];
+        for (int s = 1; s < nrad; ++s) e = (p / m[s]) % rad[s] + rad[s] * e;
+        pos[e] = p;
+    }
+}
+
+extern "C" int dftk_mi_fft_plan_host(int n, int* n_radices, int* radices, int* pos) {
+    if (n < 1 || !n_radices || !radices || !pos) return DFTK_MI_EINVAL;
+    if (plan_radices(n, n_radices, radices) != 0) {
+        dftk_set_error("cannot plan FFT of length %d (prime factor > 64)", n);
+        return DFTK_MI_EINVAL;
+    }
+    plan_positions(n, *n_radices, radices, pos);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ sphere tables
+struct SphereTables {
+    std::vector<int64_t> line_id;      // iy + ny*iz
+    std::vector<int64_t> line_start;   // [n_lines+1]
+    std::vector<int> zval;             // distinct iz, ascending
+    std::vector<int> zls;              // [nzx+1] first line of each plane
+};
+
+static int build_sphere_tables(int nx, int ny, int nz, int64_t n_G, const int64_t* mapping, SphereTables& t) {
+    const int64_t N = (int64_t)nx * ny * nz;
+    int64_t prev = -1, prev_line = -1;
+    int prev_z = -1;
+    for (int64_t c = 0; c < n_G; ++c) {
+        const int64_t g = mapping[c];
+        if (g < 0 || g >= N || g <= prev) {
+            dftk_set_error("mapping must be strictly ascending and within the cube (entry %lld = %lld)", (long long)c,
+                           (long long)g);
+            return DFTK_MI_EINVAL;
+        }
+        prev = g;
+        const int64_t line = g / nx;
+        if (line != prev_line) {
+            t.line_id.push_back(line);
+            t.line_start.push_back(c);
+            prev_line = line;
+            const int iz = (int)(line / ny);
+            if (iz != prev_z) {
+                t.zval.push_back(iz);
+                t.zls.push_back((int)t.line_id.size() - 1);
+                prev_z = iz;
+            }
+        }
+    }
+    t.line_start.push_back(n_G);
+    t.zls.push_back((int)t.line_id.size());
+    return 0;
+}
+
+extern "C" int dftk_mi_sphere_tables_host(int nx, int ny, int nz, int64_t n_G, const int64_t* mapping0_h,
+                                          int64_t* n_lines, int* n_zplanes, int64_t* line_id, int64_t* line_start) {
+    if (nx < 1 || ny < 1 || nz < 1 || n_G < 0 || (n_G > 0 && !mapping0_h)) return DFTK_MI_EINVAL;
+    SphereTables t;
+    CHK(build_sphere_tables(nx, ny, nz, n_G, mapping0_h, t));
+    if (n_lines) *n_lines = (int64_t)t.line_id.size();
+    if (n_zplanes) *n_zplanes = (int)t.zval.size();
+    if (line_id) std::copy(t.line_id.begin(), t.line_id.end(), line_id);
+    if (line_start) std::copy(t.line_start.begin(), t.line_start.end(), line_start);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ basis
+template <typename T>
+static int upload(const std::vector<T>& v, T** d) {
+    *d = nullptr;
+    if (v.empty()) return 0;
+    HIPCHK(hipMalloc((void**)d, v.size() * sizeof(T)));
+    HIPCHK(hipMemcpy(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int check_device(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        dftk_set_error("no HIP device visible (%s): this library has no CPU fallback",
+                       e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        return DFTK_MI_ENOGPU;
+    }
+    if (device < 0 || device >= count) {
+        dftk_set_error("device %d out of range (%d visible)", device, count);
+        return DFTK_MI_EINVAL;
+    }
+    return 0;
+}
+
+extern "C" int dftk_mi_basis_create(int nx, int ny, int nz, double unit_cell_volume, int device,
+                                    dftk_mi_basis** out) {
+    if (!out || nx < 1 || ny < 1 || nz < 1 || !(unit_cell_volume > 0)) return DFTK_MI_EINVAL;
+    CHK(check_device(device));
+    HIPCHK(hipSetDevice(device));
+    dftk_mi_basis* b = new dftk_mi_basis();
+    memset(b, 0, sizeof(*b));
+    b->nx = nx;
+    b->ny = ny;
+    b->nz = nz;
+    b->nxp = ((nx + 7) / 8) * 8;
+    b->volume = unit_cell_volume;
+    b->device = device;
+    b->fft_batch = 8;
+    b->prof = new Prof();
+    const char* g = getenv("DFTK_MI_GEMM");
+    b->use_mfma = !(g && strcmp(g, "naive") == 0);
+    const char* fb = getenv("DFTK_MI_FFT_BATCH");
+    if (fb && atoi(fb) > 0) b->fft_batch = std::min(atoi(fb), 256);
+    HIPCHK(hipStreamCreate(&b->stream));
+    const int dims[3] = {nx, ny, nz};
+    for (int a = 0; a < 3; ++a) {
+        const int n = dims[a];
+        FftAxis& ax = b->ax[a];
+        ax.n = n;
+        if (plan_radices(n, &ax.nrad, ax.rad) != 0) {
+            dftk_set_error("cannot plan FFT axis of length %d", n);
+            return DFTK_MI_EINVAL;
+        }
+        std::vector<int> pos(n);
+        plan_positions(n, ax.nrad, ax.rad, pos.data());
+        std::vector<double> tw(2 * (size_t)n);
+        for (int t = 0; t < n; ++t) {
+            // exact octant reduction keeps the table accurate to ~1 ulp
+            const long double ang = 2.0L * 3.14159265358979323846264338327950288L * (long double)t / (long double)n;
+            tw[2 * t] = (double)cosl(ang);
+            tw[2 * t + 1] = (double)sinl(ang);
+        }
+        double* dtw;
+        int* dpos;
+        CHK(upload(tw, &dtw));
+        CHK(upload(pos, &dpos));
+        ax.tw = reinterpret_cast<const cd*>(dtw);
+        ax.pos = dpos;
+        b->d_tables[2 * a] = dtw;
+        b->d_tables[2 * a + 1] = dpos;
+    }
+    HIPCHK(hipMalloc((void**)&b->d_scalars, 256 * sizeof(double)));
+    HIPCHK(hipHostMalloc((void**)&b->h_scalars, 256 * sizeof(double)));
+    *out = b;
+    return 0;
+}
+
+extern "C" int dftk_mi_basis_destroy(dftk_mi_basis* b) {
+    if (!b) return 0;
+    hipSetDevice(b->device);
+    hipStreamSynchronize(b->stream);
+    for (void* p : b->d_tables)
+        if (p) hipFree(p);
+    if (b->T1) hipFree(b->T1);
+    if (b->T2) hipFree(b->T2);
+    if (b->ws) hipFree(b->ws);
+    if (b->d_scalars) hipFree(b->d_scalars);
+    if (b->h_scalars) hipHostFree(b->h_scalars);
+    if (b->prof) {
+        prof_resolve(b);
+        for (auto& pr : b->prof->pool) {
+            hipEventDestroy(pr.a);
+            hipEventDestroy(pr.b);
+        }
+        delete b->prof;
+    }
+    hipStreamDestroy(b->stream);
+    delete b;
+    return 0;
+}
+
+extern "C" int dftk_mi_basis_sync(dftk_mi_basis* b) {
+    if (!b) return DFTK_MI_EINVAL;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+extern "C" int dftk_mi_basis_set_fft_batch(dftk_mi_basis* b, int n) {
+    if (!b || n < 1 || n > 256) return DFTK_MI_EINVAL;
+    b->fft_batch = n;
+    return 0;
+}
+
+extern "C" void* dftk_mi_basis_stream(dftk_mi_basis* b) { return b ? (void*)b->stream : nullptr; }
+
+// ------------------------------------------------------------------------------------ k-block
+extern "C" int dftk_mi_kblock_create(dftk_mi_basis* b, int64_t n_G, const int64_t* mapping0_h, const double* kinetic_h,
+                                     dftk_mi_kblock** out) {
+    if (!b || !out || n_G < 1 || !mapping0_h) return DFTK_MI_EINVAL;
+    if (n_G > INT32_MAX) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(b->device));
+    SphereTables t;
+    CHK(build_sphere_tables(b->nx, b->ny, b->nz, n_G, mapping0_h, t));
+    // per-axis permutation tables (host copies)
+    std::vector<int> pos[3];
+    const int dims[3] = {b->nx, b->ny, b->nz};
+    for (int a = 0; a < 3; ++a) {
+        pos[a].resize(dims[a]);
+        plan_positions(dims[a], b->ax[a].nrad, b->ax[a].rad, pos[a].data());
+    }
+    const int64_t n_lines = (int64_t)t.line_id.size();
+    std::vector<int> cpos(n_G), cx(n_G), line_start(n_lines + 1), line_ypos(n_lines), line_yval(n_lines);
+    for (int64_t l = 0; l < n_lines; ++l) {
+        const int iy = (int)(t.line_id[l] % b->ny);
+        line_yval[l] = iy;
+        line_ypos[l] = pos[1][iy];
+        line_start[l] = (int)t.line_start[l];
+        for (int64_t c = t.line_start[l]; c < t.line_start[l + 1]; ++c) {
+            const int ix = (int)(mapping0_h[c] - t.line_id[l] * b->nx);
+            cx[c] = ix;
+            cpos[c] = pos[0][ix];
+        }
+    }
+    line_start[n_lines] = (int)n_G;
+    std::vector<int> zpos(t.zval.size());
+    for (size_t i = 0; i < t.zval.size(); ++i) zpos[i] = pos[2][t.zval[i]];
+
+    dftk_mi_kblock* kb = new dftk_mi_kblock();
+    memset(kb, 0, sizeof(*kb));
+    kb->basis = b;
+    kb->device = b->device;
+    kb->n_G = n_G;
+    kb->n_lines = n_lines;
+    kb->nzx = (int)t.zval.size();
+    CHK(upload(cpos, &kb->d_cpos));
+    CHK(upload(cx, &kb->d_cx));
+    CHK(upload(line_start, &kb->d_line_start));
+    CHK(upload(line_ypos, &kb->d_line_ypos));
+    CHK(upload(line_yval, &kb->d_line_yval));
+    CHK(upload(t.zls, &kb->d_zls));
+    CHK(upload(zpos, &kb->d_zpos));
+    CHK(upload(t.zval, &kb->d_zval));
+    std::vector<double> kin(n_G, 0.0);
+    if (kinetic_h) std::copy(kinetic_h, kinetic_h + n_G, kin.begin());
+    CHK(upload(kin, &kb->d_kin));
+    *out = kb;
+    return 0;
+}
+
+extern "C" int dftk_mi_kblock_destroy(dftk_mi_kblock* kb) {
+    if (!kb) return 0;
+    hipSetDevice(kb->device);
+    hipDeviceSynchronize();   // the basis may already be gone: never dereference it here
+    void* ptrs[] = {kb->d_cpos, kb->d_cx, kb->d_line_start, kb->d_line_ypos, kb->d_line_yval, kb->d_zls,
+                    kb->d_zpos, kb->d_zval, kb->d_kin, kb->d_Vs, kb->d_D, kb->lob_buf};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    delete kb;
+    return 0;
+}
+
+extern "C" int dftk_mi_kblock_set_projectors(dftk_mi_kblock* kb, int n_p, const dftk_mi_cplx* P_d, int64_t ldP,
+                                             const double* D_h) {
+    if (!kb || n_p < 0) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(kb->basis->device));
+    HIPCHK(hipStreamSynchronize(kb->basis->stream));
+    if (kb->d_D) {
+        HIPCHK(hipFree(kb->d_D));
+        kb->d_D = nullptr;
+    }
+    kb->n_p = 0;
+    kb->P = nullptr;
+    if (n_p == 0) return 0;
+    if (!P_d || !D_h || ldP < kb->n_G) return DFTK_MI_EINVAL;
+    int bw = 0;
+    for (int j = 0; j < n_p; ++j)
+        for (int i = 0; i < n_p; ++i)
+            if (D_h[i + (size_t)j * n_p] != 0.0) bw = std::max(bw, std::abs(i - j));
+    std::vector<double> D(D_h, D_h + (size_t)n_p * n_p);
+    CHK(upload(D, &kb->d_D));
+    kb->D_bw = bw;
+    kb->n_p = n_p;
+    kb->P = reinterpret_cast<const cd*>(P_d);
+    kb->ldP = ldP;
+    return 0;
+}
+
+extern "C" int dftk_mi_kblock_set_potential(dftk_mi_kblock* kb, const double* V_d) {
+    if (!kb) return DFTK_MI_EINVAL;
+    dftk_mi_basis* b = kb->basis;
+    HIPCHK(hipSetDevice(b->device));
+    if (!V_d) {
+        HIPCHK(hipStreamSynchronize(b->stream));
+        if (kb->d_Vs) HIPCHK(hipFree(kb->d_Vs));
+        kb->d_Vs = nullptr;
+        return 0;
+    }
+    if (!kb->d_Vs) HIPCHK(hipMalloc((void**)&kb->d_Vs, (size_t)b->nz * b->ny * b->nxp * sizeof(double)));
+    return launch_pad_potential(kb, V_d);
+}
+
+// ------------------------------------------------------------------------------------ H psi
+static int apply_nonlocal(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, cd* Hpsi, int64_t ldH,
+                          bool accumulate) {
+    // Hpsi (+)= P (D (P' psi))   (operators.jl:126-128)
+    dftk_mi_basis* b = kb->basis;
+    const cd one = {1.0, 0.0}, zero = {0.0, 0.0};
+    if (kb->n_p == 0) {
+        if (!accumulate)
+            for (int c = 0; c < nb; ++c) HIPCHK(hipMemsetAsync(Hpsi + (int64_t)c * ldH, 0, kb->n_G * sizeof(cd), b->stream));
+        return 0;
+    }
+    // scratch for the two n_p x nb panels lives in T1 (free outside the FFT pipeline)
+    const size_t need = 2 * (size_t)kb->n_p * nb * sizeof(cd);
+    if (need > b->T1_bytes) {
+        HIPCHK(hipStreamSynchronize(b->stream));
+        if (b->T1) HIPCHK(hipFree(b->T1));
+        b->T1 = nullptr;
+        b->T1_bytes = 0;
+        HIPCHK(hipMalloc((void**)&b->T1, need));
+        b->T1_bytes = need;
+    }
+    cd* Ppsi = b->T1;
+    cd* DPpsi = b->T1 + (size_t)kb->n_p * nb;
+    CHK(zgemm(b, 'C', kb->n_p, nb, kb->n_G, one, kb->P, kb->ldP, psi, ldpsi, zero, Ppsi, kb->n_p));
+    CHK(apply_D(kb, nb, Ppsi, DPpsi));
+    CHK(zgemm(b, 'N', kb->n_G, nb, kb->n_p, one, kb->P, kb->ldP, DPpsi, kb->n_p, accumulate ? one : zero, Hpsi, ldH));
+    return 0;
+}
+
+extern "C" int dftk_mi_apply_H_parts(dftk_mi_kblock* kb, int which, int n_bands, const dftk_mi_cplx* psi_d,
+                                     int64_t ld_psi, dftk_mi_cplx* Hpsi_d, int64_t ld_Hpsi) {
+    if (!kb || !psi_d || !Hpsi_d || n_bands < 0 || ld_psi < kb->n_G || ld_Hpsi < kb->n_G || (which & ~7))
+        return DFTK_MI_EINVAL;
+    if (n_bands == 0) return 0;   // "Nothing to do if psi empty" (Hamiltonian.jl:141)
+    HIPCHK(hipSetDevice(kb->basis->device));
+    const cd* psi = reinterpret_cast<const cd*>(psi_d);
+    cd* H = reinterpret_cast<cd*>(Hpsi_d);
+    const bool local = (which & 1) && kb->d_Vs != nullptr;
+    const bool kinetic = which & 2;
+    const bool nonlocal = which & 4;
+    const int slot = prof_begin(kb->basis, PROF_APPLY_H, (double)n_bands);
+    // local (+ kinetic fused into the gather epilogue), or kinetic only / zero
+    CHK(launch_local_apply(kb, n_bands, psi, ld_psi, H, ld_Hpsi, kinetic, local));
+    if (nonlocal) CHK(apply_nonlocal(kb, n_bands, psi, ld_psi, H, ld_Hpsi, true));
+    prof_end(kb->basis, slot);
+    return 0;
+}
+
+extern "C" int dftk_mi_apply_H(dftk_mi_kblock* kb, int n_bands, const dftk_mi_cplx* psi_d, int64_t ld_psi,
+                               dftk_mi_cplx* Hpsi_d, int64_t ld_Hpsi) {
+    return dftk_mi_apply_H_parts(kb, 7, n_bands, psi_d, ld_psi, Hpsi_d, ld_Hpsi);
+}
+
+extern "C" int dftk_mi_ifft_sphere(dftk_mi_kblock* kb, const dftk_mi_cplx* c_d, dftk_mi_cplx* cube_d) {
+    if (!kb || !c_d || !cube_d) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(kb->basis->device));
+    return launch_ifft_to_cube(kb, reinterpret_cast<const cd*>(c_d), reinterpret_cast<cd*>(cube_d));
+}
+
+extern "C" int dftk_mi_fft_sphere(dftk_mi_kblock* kb, const dftk_mi_cplx* cube_d, dftk_mi_cplx* c_d) {
+    if (!kb || !c_d || !cube_d) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(kb->basis->device));
+    return launch_fft_from_cube(kb, reinterpret_cast<const cd*>(cube_d), reinterpret_cast<cd*>(c_d));
+}
+
+extern "C" int dftk_mi_density_accumulate(dftk_mi_kblock* kb, int n_bands, const dftk_mi_cplx* psi_d, int64_t ld_psi,
+                                          const double* weight_h, double* rho_d) {
+    if (!kb || !psi_d || !weight_h || !rho_d || n_bands < 0 || ld_psi < kb->n_G) return DFTK_MI_EINVAL;
+    if (n_bands == 0) return 0;
+    HIPCHK(hipSetDevice(kb->basis->device));
+    return launch_density(kb, n_bands, reinterpret_cast<const cd*>(psi_d), ld_psi, weight_h, rho_d);
+}
+
+extern "C" int dftk_mi_lobpcg(dftk_mi_kblock* kb, int M, dftk_mi_cplx* X_d, int64_t ldX, double tol, int miniter,
+                              int maxiter, int n_conv_check, int use_tpa, uint64_t seed, double* lambda_h,
+                              double* resid_h, int* n_iter, int* converged, int64_t* n_matvec) {
+    if (!kb || !X_d || M < 1 || ldX < kb->n_G || !lambda_h || !resid_h || !n_iter || !converged || !n_matvec ||
+        maxiter < 0)
+        return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(kb->basis->device));
+    return lobpcg_run(kb, M, reinterpret_cast<cd*>(X_d), ldX, tol, miniter, maxiter, n_conv_check, use_tpa, seed,
+                      lambda_h, resid_h, n_iter, converged, n_matvec);
+}
+
+extern "C" const dftk_mi_cplx* dftk_mi_lobpcg_last_AX(dftk_mi_kblock* kb) {
+    return kb ? reinterpret_cast<const dftk_mi_cplx*>(kb->last_AX) : nullptr;
+}
+
+// ------------------------------------------------------------------------------------ dense helpers
+extern "C" int dftk_mi_zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, dftk_mi_cplx alpha,
+                             const dftk_mi_cplx* A_d, int64_t lda, const dftk_mi_cplx* B_d, int64_t ldb,
+                             dftk_mi_cplx beta, dftk_mi_cplx* C_d, int64_t ldc) {
+    if (!b || m < 0 || n < 0 || k < 0 || !C_d) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(b->device));
+    cd al = {alpha.re, alpha.im}, be = {beta.re, beta.im};
+    return zgemm(b, transA, m, n, k, al, reinterpret_cast<const cd*>(A_d), lda, reinterpret_cast<const cd*>(B_d), ldb,
+                 be, reinterpret_cast<cd*>(C_d), ldc);
+}
+
+extern "C" int dftk_mi_heev(dftk_mi_basis* b, int n, dftk_mi_cplx* A_d, int64_t lda, double* W_h, dftk_mi_cplx* V_d,
+                            int64_t ldv) {
+    if (!b || n < 1 || !A_d || !W_h || !V_d || lda < n || ldv < n) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(b->device));
+    return dense_heev(b, n, reinterpret_cast<cd*>(A_d), lda, W_h, reinterpret_cast<cd*>(V_d), ldv);
+}
+
+extern "C" int dftk_mi_potrf_trtri(dftk_mi_basis* b, int n, dftk_mi_cplx* A_d, int64_t lda, dftk_mi_cplx* invR_d,
+                                   int64_t ldi) {
+    if (!b || n < 1 || !A_d || !invR_d || lda < n || ldi < n) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(b->device));
+    double a, c;
+    return dense_potrf_trtri(b, n, reinterpret_cast<cd*>(A_d), lda, reinterpret_cast<cd*>(invR_d), ldi, &a, &c);
+}

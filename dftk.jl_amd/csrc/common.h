@@ -1,0 +1,165 @@
+// common.h -- shared declarations of the MI355X plane-wave SCF hot-path library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include "../../include/dftk_mi355x.h"
+
+typedef double2 cd;   // complex fp64, (x, y) = (re, im); layout-compatible with dftk_mi_cplx
+
+void dftk_set_error(const char* fmt, ...);
+
+#define HIPCHK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            dftk_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return DFTK_MI_EHIP;                                                          \
+        }                                                                                 \
+    } while (0)
+
+#define CHK(expr)                                 \
+    do {                                          \
+        int _s = (expr);                          \
+        if (_s != 0) return _s;                   \
+    } while (0)
+
+// ------------------------------------------------------------------------------------ 1-D plans
+#define DFTK_MAX_RADICES 32
+struct FftAxis {            // passed to kernels by value
+    int n;                  // transform length
+    int nrad;               // number of stages
+    int rad[DFTK_MAX_RADICES];
+    const cd* tw;           // device: tw[t] = exp(+2 pi i t / n), t in [0, n)
+    const int* pos;         // device: in-place permutation (see dftk_mi_fft_plan_host)
+};
+
+int  plan_radices(int n, int* nrad, int* rad);          // host: factorise into {5,4,3,2,primes}
+void plan_positions(int n, int nrad, const int* rad, int* pos);
+
+// ------------------------------------------------------------------------------------ handles
+struct dftk_mi_basis {
+    int nx, ny, nz, nxp;          // nxp = nx rounded up to a multiple of FFT_L (padded x pitch)
+    double volume;
+    int device;
+    hipStream_t stream;
+    FftAxis ax[3];                // x, y, z
+    void* d_tables[6];            // device tw/pos buffers (owned)
+    int fft_batch;                // bands per launch group
+    // scratch pool (grown on demand)
+    cd* T1; size_t T1_bytes;
+    cd* T2; size_t T2_bytes;
+    // general workspace for dense algebra (split-K slabs, small matrices)
+    void* ws; size_t ws_bytes;
+    double* d_scalars;            // small device buffer for reductions (256 doubles)
+    double* h_scalars;            // pinned host mirror
+    int use_mfma;                 // 0 => naive GEMM kernels (env DFTK_MI_GEMM=naive)
+    struct Prof* prof;            // per-family HIP-event timing (dftk_mi_prof_*)
+};
+
+// ------------------------------------------------------------------------------------ profiling
+// Kernel families timed with HIP events on the basis' stream (bench.py roofline numbers).
+enum ProfFamily {
+    PROF_ZGEMM = 0,      // work = 8 m n k flops
+    PROF_FFT_A = 1,      // x-lines backward + scatter      (work = algorithmic bytes, dense 3-pass convention)
+    PROF_FFT_B = 2,      // y backward
+    PROF_FFT_C = 3,      // fused z backward * V * z forward
+    PROF_FFT_D = 4,      // y forward
+    PROF_FFT_E = 5,      // x forward + gather + kinetic
+    PROF_DENS_Z = 6,     // z backward + |psi|^2 accumulate
+    PROF_HEEV = 7,       // dense Hermitian eigensolver (whole call)
+    PROF_CHOL = 8,       // potrf + trtri (whole call)
+    PROF_APPLY_H = 9,    // whole dftk_mi_apply_H call (work = bands)
+    PROF_NFAM = 16
+};
+struct Prof {
+    bool on = false;
+    struct Pair { hipEvent_t a, b; int fam; };
+    std::vector<Pair> pending;
+    std::vector<Pair> pool;
+    double ms[PROF_NFAM] = {0};
+    double work[PROF_NFAM] = {0};
+    int64_t launches[PROF_NFAM] = {0};
+};
+int prof_begin(dftk_mi_basis* b, int fam, double work);   // returns slot index or -1
+void prof_end(dftk_mi_basis* b, int slot);
+int prof_resolve(dftk_mi_basis* b);
+
+struct dftk_mi_kblock {
+    dftk_mi_basis* basis;
+    int device;                   // copy of basis->device (destroy must not touch the basis)
+    int64_t n_G;
+    int64_t n_lines;              // non-empty x-lines (iy, iz)
+    int nzx;                      // distinct z planes touched by the sphere
+    // device tables (owned)
+    int*   d_cpos;                // [n_G]   pos_x[ix] of each coefficient
+    int*   d_line_start;          // [n_lines+1] first coefficient of each line
+    int*   d_line_ypos;           // [n_lines] pos_y[iy] of each line
+    int*   d_zls;                 // [nzx+1] first line of each z plane
+    int*   d_zpos;                // [nzx]   pos_z[iz] of each plane
+    int*   d_zval;                // [nzx]   iz of each plane (natural index)
+    int*   d_line_yval;           // [n_lines] iy of each line (natural index)
+    int*   d_cx;                  // [n_G]   ix of each coefficient (natural index)
+    double* d_kin;                // [n_G]
+    double* d_Vs;                 // [nz*ny*nxp] potential / N, padded pitch (owned) or null
+    // nonlocal
+    int n_p;
+    const cd* P;                  // borrowed device pointer, n_G x n_p
+    int64_t ldP;
+    double* d_D;                  // [n_p*n_p] dense (owned)
+    int D_bw;                     // half bandwidth of D
+    // LOBPCG workspace (owned, grown on demand)
+    cd* lob_buf; size_t lob_bytes;
+    cd* last_AX;
+};
+
+// ------------------------------------------------------------------------------------ internal API
+// fft_kernels.hip
+int fft_ensure_scratch(dftk_mi_basis* b, dftk_mi_kblock* kb, int nb);
+int launch_local_apply(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, cd* out,
+                       int64_t ldout, bool add_kinetic, bool have_local);
+int launch_ifft_to_cube(dftk_mi_kblock* kb, const cd* c, cd* cube);
+int launch_fft_from_cube(dftk_mi_kblock* kb, const cd* cube, cd* c);
+int launch_density(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, const double* w_h,
+                   double* rho);
+int launch_pad_potential(dftk_mi_kblock* kb, const double* V);
+int launch_kinetic_only(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, cd* out,
+                        int64_t ldout, bool accumulate, bool use_kin);
+
+// gemm_kernels.hip
+int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alpha, const cd* A,
+          int64_t lda, const cd* B, int64_t ldb, cd beta, cd* C, int64_t ldc);
+int ensure_ws(dftk_mi_basis* b, size_t bytes);
+
+// dense_kernels.hip
+int dense_potrf_trtri(dftk_mi_basis* b, int n, cd* A, int64_t lda, cd* invR, int64_t ldi,
+                      double* normest_R, double* normest_invR);   // host outputs
+int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, int64_t ldv);
+int apply_D(dftk_mi_kblock* kb, int n_bands, const cd* X /*n_p x nb*/, cd* Y);
+// elementwise / reductions used by LOBPCG (all on b->stream)
+int ew_colnorms(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, double* out_d);
+int ew_coldots(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, const cd* Y, int64_t ldy,
+               double* out_re_d);
+int ew_weighted_colnorm2(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx,
+                         const double* w, double* out_d);
+int ew_residual(dftk_mi_basis* b, int64_t n, int m, const cd* AX, int64_t lda, const cd* X, int64_t ldx,
+                const double* lam_d, cd* R, int64_t ldr, double* norms_d);
+int ew_tpa(dftk_mi_basis* b, int64_t n, int m, cd* R, int64_t ldr, const double* kin,
+           const double* mean_kin_d);
+int ew_scale_cols(dftk_mi_basis* b, int64_t n, int m, cd* X, int64_t ldx, const double* s_d, bool invert);
+int ew_copy(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, cd* Y, int64_t ldy);
+int ew_fill_zero(dftk_mi_basis* b, cd* X, size_t count);
+int ew_sub_identity_shifted(dftk_mi_basis* b, int rows, int cols, cd* C, int64_t ldc, int row0);
+int ew_gather_cols(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, const int* perm_d,
+                   cd* Y, int64_t ldy);
+int ew_add_diag(dftk_mi_basis* b, int n, cd* A, int64_t lda, double shift);
+int ew_frob2(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, double* out_d);
+int ew_hermitize_upper(dftk_mi_basis* b, int n, cd* A, int64_t lda);
+int ew_has_nonfinite(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, double* out_d);
+
+// lobpcg.cpp
+int lobpcg_run(dftk_mi_kblock* kb, int M, cd* X, int64_t ldX, double tol, int miniter, int maxiter,
+               int n_conv_check, int use_tpa, uint64_t seed, double* lambda_h, double* resid_h,
+               int* n_iter, int* converged, int64_t* n_matvec);

@@ -1,0 +1,684 @@
+// fft_kernels.hip -- pruned, batched sphere<->cube 3-D FFT pipeline with the local-potential
+// multiply fused in (gfx950).  Replaces the per-band loop of DFTK's
+//   mul!(Hpsi, ::DftHamiltonianBlock, psi)   src/terms/Hamiltonian.jl:155-163
+//   ifft!/fft! on the sphere                 src/fft.jl:110-122, 162-172
+//   compute_density inner loop               src/densities.jl:35-43
+//
+// Pipeline per batch of bands ("FFT pipeline"):
+//   A  x-lines that intersect the sphere:  scatter coefficients -> LDS, backward FFT_x -> T1
+//   B  (x-tile, z-plane in sphere extent):  backward FFT_y of the non-empty lines       -> T2
+//   C  (x-tile, y): backward FFT_z, multiply by V/N, forward FFT_z, keep sphere planes  -> T2
+//   D  forward FFT_y, keep the sphere's lines                                            -> T1
+//   E  forward FFT_x, gather coefficients, add the kinetic diagonal                      -> Hpsi
+// Only the part of the zero-padded cube that can be non-zero is ever read or written.
+//
+// One workgroup = 256 threads = a tile of FFT_L = 8 lines held in LDS as buf[elem*FFT_LS + line];
+// each line is transformed in place by a mixed-radix Stockham-free scheme: decimation in time
+// (input placed at the permuted position `pos`, natural output) for backward transforms and
+// decimation in frequency (natural input, output read back through `pos`) for forward ones.
+#include "common.h"
+
+#define FFT_L 8
+#define FFT_LS 9
+#define FFT_THREADS 256
+#define FFT_TPL (FFT_THREADS / FFT_L)
+#define DENS_MAXACC 12   // supports nz <= 12*32 = 384
+
+__device__ __forceinline__ cd cmul(cd a, cd w) {
+    return make_double2(fma(a.x, w.x, -a.y * w.y), fma(a.x, w.y, a.y * w.x));
+}
+__device__ __forceinline__ cd cadd(cd a, cd b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cd csub(cd a, cd b) { return make_double2(a.x - b.x, a.y - b.y); }
+// multiply by (+i*s) : (x + i y) * i s = (-y s, x s)
+__device__ __forceinline__ cd cmuli(cd a, double s) { return make_double2(-a.y * s, a.x * s); }
+
+template <int R>
+__device__ __forceinline__ void dft_small(cd (&a)[R], double sgn, const cd* __restrict__ tw, int nOverR) {
+    if constexpr (R == 2) {
+        cd t = a[0];
+        a[0] = cadd(t, a[1]);
+        a[1] = csub(t, a[1]);
+    } else if constexpr (R == 3) {
+        const double s3 = 0.86602540378443864676;   // sin(2 pi / 3)
+        cd t1 = cadd(a[1], a[2]);
+        cd t2 = make_double2(a[0].x - 0.5 * t1.x, a[0].y - 0.5 * t1.y);
+        cd t3 = cmuli(csub(a[1], a[2]), sgn * s3);
+        a[0] = cadd(a[0], t1);
+        a[1] = cadd(t2, t3);
+        a[2] = csub(t2, t3);
+    } else if constexpr (R == 4) {
+        cd s02 = cadd(a[0], a[2]), d02 = csub(a[0], a[2]);
+        cd s13 = cadd(a[1], a[3]), d13 = cmuli(csub(a[1], a[3]), sgn);
+        a[0] = cadd(s02, s13);
+        a[2] = csub(s02, s13);
+        a[1] = cadd(d02, d13);
+        a[3] = csub(d02, d13);
+    } else if constexpr (R == 5) {
+        const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
+        const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
+        cd t1 = cadd(a[1], a[4]), t2 = cadd(a[2], a[3]);
+        cd t3 = csub(a[1], a[4]), t4 = csub(a[2], a[3]);
+        cd m1 = make_double2(a[0].x + c1 * t1.x + c2 * t2.x, a[0].y + c1 * t1.y + c2 * t2.y);
+        cd m2 = make_double2(a[0].x + c2 * t1.x + c1 * t2.x, a[0].y + c2 * t1.y + c1 * t2.y);
+        cd n1 = make_double2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+        cd n2 = make_double2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+        cd in1 = cmuli(n1, sgn), in2 = cmuli(n2, sgn);
+        a[0] = make_double2(a[0].x + t1.x + t2.x, a[0].y + t1.y + t2.y);
+        a[1] = cadd(m1, in1);
+        a[4] = csub(m1, in1);
+        a[2] = cadd(m2, in2);
+        a[3] = csub(m2, in2);
+    } else {
+        cd b[R];
+#pragma unroll
+        for (int p = 0; p < R; ++p) {
+            cd acc = a[0];
+#pragma unroll
+            for (int q = 1; q < R; ++q) {
+                cd w = tw[((p * q) % R) * nOverR];
+                w.y *= sgn;
+                cd t = cmul(a[q], w);
+                acc.x += t.x;
+                acc.y += t.y;
+            }
+            b[p] = acc;
+        }
+#pragma unroll
+        for (int p = 0; p < R; ++p) a[p] = b[p];
+    }
+}
+
+// One radix-R pass over the tile.  m = product of the radices already combined (DIT) or still
+// to be split (DIF).  Thread (l, j) owns line l and butterflies j, j+TPL, ...
+template <int R, bool DIF>
+__device__ __forceinline__ void fft_stage(cd* buf, const cd* __restrict__ tw, int n, int m, double sgn,
+                                          int l, int j) {
+    const int nb = n / R;
+    const int twstep = n / (R * m);
+    const int nOverR = n / R;
+    for (int b = j; b < nb; b += FFT_TPL) {
+        const int g = b / m;
+        const int jj = b - g * m;
+        const int base = g * R * m + jj;
+        cd a[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) a[q] = buf[(base + q * m) * FFT_LS + l];
+        if (!DIF && m > 1) {
+#pragma unroll
+            for (int q = 1; q < R; ++q) {
+                cd w = tw[q * jj * twstep];
+                w.y *= sgn;
+                a[q] = cmul(a[q], w);
+            }
+        }
+        dft_small<R>(a, sgn, tw, nOverR);
+        if (DIF && m > 1) {
+#pragma unroll
+            for (int p = 1; p < R; ++p) {
+                cd w = tw[p * jj * twstep];
+                w.y *= sgn;
+                a[p] = cmul(a[p], w);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < R; ++p) buf[(base + p * m) * FFT_LS + l] = a[p];
+    }
+}
+
+// Arbitrary (prime) radix up to 64: slow path used only for non 2-3-5-7-11-13 sizes.
+template <bool DIF>
+__device__ void fft_stage_generic(cd* buf, const cd* __restrict__ tw, int n, int m, int R, double sgn,
+                                  int l, int j) {
+    const int nb = n / R;
+    const int twstep = n / (R * m);
+    const int nOverR = n / R;
+    for (int b = j; b < nb; b += FFT_TPL) {
+        const int g = b / m;
+        const int jj = b - g * m;
+        const int base = g * R * m + jj;
+        cd a[64], o[64];
+        for (int q = 0; q < R; ++q) {
+            cd v = buf[(base + q * m) * FFT_LS + l];
+            if (!DIF && m > 1 && q > 0) {
+                cd w = tw[q * jj * twstep];
+                w.y *= sgn;
+                v = cmul(v, w);
+            }
+            a[q] = v;
+        }
+        for (int p = 0; p < R; ++p) {
+            cd acc = a[0];
+            for (int q = 1; q < R; ++q) {
+                cd w = tw[((p * q) % R) * nOverR];
+                w.y *= sgn;
+                cd t = cmul(a[q], w);
+                acc.x += t.x;
+                acc.y += t.y;
+            }
+            if (DIF && m > 1 && p > 0) {
+                cd w = tw[p * jj * twstep];
+                w.y *= sgn;
+                acc = cmul(acc, w);
+            }
+            o[p] = acc;
+        }
+        for (int p = 0; p < R; ++p) buf[(base + p * m) * FFT_LS + l] = o[p];
+    }
+}
+
+// GEN = false: 2-3-5-smooth lengths only (the hot path; keeps the register footprint small).
+// GEN = true : additionally radix 7 and the generic (scratch-backed) prime radix.
+template <bool DIF, bool GEN>
+__device__ __forceinline__ void fft_stage_dispatch(int R, cd* buf, const cd* tw, int n, int m, double sgn,
+                                                   int l, int j) {
+    switch (R) {
+        case 2: fft_stage<2, DIF>(buf, tw, n, m, sgn, l, j); break;
+        case 3: fft_stage<3, DIF>(buf, tw, n, m, sgn, l, j); break;
+        case 4: fft_stage<4, DIF>(buf, tw, n, m, sgn, l, j); break;
+        case 5: fft_stage<5, DIF>(buf, tw, n, m, sgn, l, j); break;
+        default:
+            if constexpr (GEN) {
+                if (R == 7)
+                    fft_stage<7, DIF>(buf, tw, n, m, sgn, l, j);
+                else
+                    fft_stage_generic<DIF>(buf, tw, n, m, R, sgn, l, j);
+            }
+            break;
+    }
+}
+
+// In-place transform of the whole tile; caller has synchronised after filling buf.
+// Ends with a __syncthreads().
+template <bool DIF, bool GEN>
+__device__ __forceinline__ void fft_tile(cd* buf, const cd* tw, const FftAxis& ax, double sgn, int l, int j) {
+    const int n = ax.n;
+    if (!DIF) {
+        int m = 1;
+        for (int s = 0; s < ax.nrad; ++s) {
+            const int R = ax.rad[s];
+            fft_stage_dispatch<false, GEN>(R, buf, tw, n, m, sgn, l, j);
+            __syncthreads();
+            m *= R;
+        }
+    } else {
+        int m = n;
+        for (int s = ax.nrad - 1; s >= 0; --s) {
+            const int R = ax.rad[s];
+            m /= R;
+            fft_stage_dispatch<true, GEN>(R, buf, tw, n, m, sgn, l, j);
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ void tile_prologue(cd* buf, cd* tw, const FftAxis& ax, bool zero) {
+    const int n = ax.n;
+    for (int t = threadIdx.x; t < n; t += FFT_THREADS) tw[t] = ax.tw[t];
+    if (zero) {
+        const cd z = make_double2(0.0, 0.0);
+        for (int t = threadIdx.x; t < n * FFT_LS; t += FFT_THREADS) buf[t] = z;
+    }
+}
+
+extern __shared__ __attribute__((aligned(16))) char dftk_smem[];
+
+// ---------------------------------------------------------------------------------------- stage A
+template <bool GEN>
+__global__ __launch_bounds__(FFT_THREADS) void k_xbwd_scatter(FftAxis ax, int nxp, int n_lines,
+                                                              const int* __restrict__ line_start,
+                                                              const int* __restrict__ cpos,
+                                                              const cd* __restrict__ psi, int64_t ldpsi,
+                                                              cd* __restrict__ T1, int64_t T1_stride) {
+    cd* buf = reinterpret_cast<cd*>(dftk_smem);
+    cd* tw = buf + ax.n * FFT_LS;
+    const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
+    const int band = blockIdx.y;
+    const int l0 = blockIdx.x * FFT_L;
+    tile_prologue(buf, tw, ax, true);
+    __syncthreads();
+    const int line = l0 + l;
+    if (line < n_lines) {
+        const int c0 = line_start[line], c1 = line_start[line + 1];
+        const cd* p = psi + (int64_t)band * ldpsi;
+        for (int c = c0 + j; c < c1; c += FFT_TPL) buf[cpos[c] * FFT_LS + l] = p[c];
+    }
+    __syncthreads();
+    fft_tile<false, GEN>(buf, tw, ax, +1.0, l, j);
+    cd* out = T1 + (int64_t)band * T1_stride + (int64_t)l0 * nxp;
+    const int nlv = min(FFT_L, n_lines - l0);
+    const int n = ax.n;
+    for (int idx = tid; idx < nlv * nxp; idx += FFT_THREADS) {
+        const int ll = idx / nxp;
+        const int x = idx - ll * nxp;
+        out[idx] = (x < n) ? buf[x * FFT_LS + ll] : make_double2(0.0, 0.0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- stage B
+template <bool GEN>
+__global__ __launch_bounds__(FFT_THREADS) void k_ybwd(FftAxis ay, int nxp, int ny,
+                                                      const int* __restrict__ zls,
+                                                      const int* __restrict__ line_ypos,
+                                                      const cd* __restrict__ T1, int64_t T1_stride,
+                                                      cd* __restrict__ T2, int64_t T2_stride) {
+    cd* buf = reinterpret_cast<cd*>(dftk_smem);
+    cd* tw = buf + ay.n * FFT_LS;
+    const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
+    const int x = blockIdx.x * FFT_L + l;
+    const int zi = blockIdx.y, band = blockIdx.z;
+    tile_prologue(buf, tw, ay, true);
+    __syncthreads();
+    const cd* t1 = T1 + (int64_t)band * T1_stride;
+    const int ln1 = zls[zi + 1];
+    for (int ln = zls[zi] + j; ln < ln1; ln += FFT_TPL)
+        buf[line_ypos[ln] * FFT_LS + l] = t1[(int64_t)ln * nxp + x];
+    __syncthreads();
+    fft_tile<false, GEN>(buf, tw, ay, +1.0, l, j);
+    cd* t2 = T2 + (int64_t)band * T2_stride + (int64_t)zi * ny * nxp + x;
+    for (int y = j; y < ny; y += FFT_TPL) t2[(int64_t)y * nxp] = buf[y * FFT_LS + l];
+}
+
+// ---------------------------------------------------------------------------------------- stage C
+// MODE 0: backward z, multiply by Vs, forward z (fused local apply), T2 -> T2 in place
+// MODE 1: backward z only, natural-order output to an (nx,ny,nz) cube
+// MODE 2: forward z only from an (nx,ny,nz) cube, sphere planes -> T2
+template <int MODE, bool GEN>
+__global__ __launch_bounds__(FFT_THREADS) void k_zpass(FftAxis az, int nx, int nxp, int ny, int nzx,
+                                                       const int* __restrict__ zpos,
+                                                       const double* __restrict__ Vs,
+                                                       cd* __restrict__ T2, int64_t T2_stride,
+                                                       cd* __restrict__ cube) {
+    cd* buf = reinterpret_cast<cd*>(dftk_smem);
+    cd* tw = buf + az.n * FFT_LS;
+    const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
+    const int x = blockIdx.x * FFT_L + l;
+    const int y = blockIdx.y, band = blockIdx.z;
+    const int nz = az.n;
+    const int64_t plane = (int64_t)ny * nxp;
+    cd* t2 = T2 + (int64_t)band * T2_stride + (int64_t)y * nxp + x;
+    tile_prologue(buf, tw, az, MODE != 2);
+    __syncthreads();
+    if (MODE != 2) {
+        for (int zi = j; zi < nzx; zi += FFT_TPL) buf[zpos[zi] * FFT_LS + l] = t2[(int64_t)zi * plane];
+        __syncthreads();
+        fft_tile<false, GEN>(buf, tw, az, +1.0, l, j);
+    }
+    if (MODE == 0) {
+        const double* v = Vs + (int64_t)y * nxp + x;
+        for (int z = j; z < nz; z += FFT_TPL) {
+            const double s = v[(int64_t)z * plane];
+            cd a = buf[z * FFT_LS + l];
+            a.x *= s;
+            a.y *= s;
+            buf[z * FFT_LS + l] = a;
+        }
+        __syncthreads();
+    }
+    if (MODE == 1) {
+        if (x < nx)
+            for (int z = j; z < nz; z += FFT_TPL) cube[((int64_t)z * ny + y) * nx + x] = buf[z * FFT_LS + l];
+        return;
+    }
+    if (MODE == 2) {
+        for (int z = j; z < nz; z += FFT_TPL)
+            buf[z * FFT_LS + l] = (x < nx) ? cube[((int64_t)z * ny + y) * nx + x] : make_double2(0.0, 0.0);
+        __syncthreads();
+    }
+    fft_tile<true, GEN>(buf, tw, az, -1.0, l, j);
+    for (int zi = j; zi < nzx; zi += FFT_TPL) t2[(int64_t)zi * plane] = buf[zpos[zi] * FFT_LS + l];
+}
+
+// ---------------------------------------------------------------------------------------- stage D
+template <bool GEN>
+__global__ __launch_bounds__(FFT_THREADS) void k_yfwd(FftAxis ay, int nxp, int ny,
+                                                      const int* __restrict__ zls,
+                                                      const int* __restrict__ line_ypos,
+                                                      const cd* __restrict__ T2, int64_t T2_stride,
+                                                      cd* __restrict__ T1, int64_t T1_stride) {
+    cd* buf = reinterpret_cast<cd*>(dftk_smem);
+    cd* tw = buf + ay.n * FFT_LS;
+    const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
+    const int x = blockIdx.x * FFT_L + l;
+    const int zi = blockIdx.y, band = blockIdx.z;
+    tile_prologue(buf, tw, ay, false);
+    const cd* t2 = T2 + (int64_t)band * T2_stride + (int64_t)zi * ny * nxp + x;
+    for (int y = j; y < ny; y += FFT_TPL) buf[y * FFT_LS + l] = t2[(int64_t)y * nxp];
+    __syncthreads();
+    fft_tile<true, GEN>(buf, tw, ay, -1.0, l, j);
+    cd* t1 = T1 + (int64_t)band * T1_stride;
+    const int ln1 = zls[zi + 1];
+    for (int ln = zls[zi] + j; ln < ln1; ln += FFT_TPL)
+        t1[(int64_t)ln * nxp + x] = buf[line_ypos[ln] * FFT_LS + l];
+}
+
+// ---------------------------------------------------------------------------------------- stage E
+// out[c] = FFT_x(line)[ix_c] (+ kin[c] * psi[c]) (+ out[c] if accumulate)
+template <bool GEN>
+__global__ __launch_bounds__(FFT_THREADS) void k_xfwd_gather(FftAxis ax, int nxp, int n_lines,
+                                                             const int* __restrict__ line_start,
+                                                             const int* __restrict__ cpos,
+                                                             const cd* __restrict__ T1, int64_t T1_stride,
+                                                             const double* __restrict__ kin,
+                                                             const cd* __restrict__ psi, int64_t ldpsi,
+                                                             cd* __restrict__ out, int64_t ldout) {
+    cd* buf = reinterpret_cast<cd*>(dftk_smem);
+    cd* tw = buf + ax.n * FFT_LS;
+    const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
+    const int band = blockIdx.y;
+    const int l0 = blockIdx.x * FFT_L;
+    const int n = ax.n;
+    tile_prologue(buf, tw, ax, false);
+    const cd* in = T1 + (int64_t)band * T1_stride + (int64_t)l0 * nxp;
+    const int nlv = min(FFT_L, n_lines - l0);
+    for (int idx = tid; idx < FFT_L * nxp; idx += FFT_THREADS) {
+        const int ll = idx / nxp;
+        const int x = idx - ll * nxp;
+        if (x < n) buf[x * FFT_LS + ll] = (ll < nlv) ? in[idx] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    fft_tile<true, GEN>(buf, tw, ax, -1.0, l, j);
+    const int line = l0 + l;
+    if (line < n_lines) {
+        const int c0 = line_start[line], c1 = line_start[line + 1];
+        cd* o = out + (int64_t)band * ldout;
+        const cd* p = psi + (int64_t)band * ldpsi;
+        for (int c = c0 + j; c < c1; c += FFT_TPL) {
+            cd v = buf[cpos[c] * FFT_LS + l];
+            if (kin != nullptr) {
+                const double k = kin[c];
+                const cd q = p[c];
+                v.x = fma(k, q.x, v.x);
+                v.y = fma(k, q.y, v.y);
+            }
+            o[c] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------- density
+// rho[z,y,x] += sum_band w[band] |BFFT_z(T2[band])|^2 ; one workgroup owns an (x-tile, y) column set.
+template <bool GEN>
+__global__ __launch_bounds__(FFT_THREADS) void k_zdensity(FftAxis az, int nx, int nxp, int ny, int nzx,
+                                                          const int* __restrict__ zpos, int nb,
+                                                          const double* __restrict__ w,
+                                                          const cd* __restrict__ T2, int64_t T2_stride,
+                                                          double* __restrict__ rho) {
+    cd* buf = reinterpret_cast<cd*>(dftk_smem);
+    cd* tw = buf + az.n * FFT_LS;
+    const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
+    const int x = blockIdx.x * FFT_L + l;
+    const int y = blockIdx.y;
+    const int nz = az.n;
+    const int64_t plane = (int64_t)ny * nxp;
+    double acc[DENS_MAXACC];
+#pragma unroll
+    for (int k = 0; k < DENS_MAXACC; ++k) acc[k] = 0.0;
+    for (int t = tid; t < nz; t += FFT_THREADS) tw[t] = az.tw[t];
+    for (int ib = 0; ib < nb; ++ib) {
+        const double wb = w[ib];
+        if (wb == 0.0) continue;   // uniform across the block
+        const cd z0 = make_double2(0.0, 0.0);
+        for (int t = tid; t < nz * FFT_LS; t += FFT_THREADS) buf[t] = z0;
+        __syncthreads();
+        const cd* t2 = T2 + (int64_t)ib * T2_stride + (int64_t)y * nxp + x;
+        for (int zi = j; zi < nzx; zi += FFT_TPL) buf[zpos[zi] * FFT_LS + l] = t2[(int64_t)zi * plane];
+        __syncthreads();
+        fft_tile<false, GEN>(buf, tw, az, +1.0, l, j);
+#pragma unroll
+        for (int k = 0; k < DENS_MAXACC; ++k) {
+            const int z = j + k * FFT_TPL;
+            if (z < nz) {
+                const cd v = buf[z * FFT_LS + l];
+                acc[k] = fma(wb, fma(v.x, v.x, v.y * v.y), acc[k]);
+            }
+        }
+        __syncthreads();
+    }
+    if (x < nx) {
+#pragma unroll
+        for (int k = 0; k < DENS_MAXACC; ++k) {
+            const int z = j + k * FFT_TPL;
+            if (z < nz) rho[((int64_t)z * ny + y) * nx + x] += acc[k];
+        }
+    }
+}
+
+__global__ void k_pad_potential(int nx, int nxp, int64_t rows, double scale, const double* __restrict__ V,
+                                double* __restrict__ Vs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * nxp) return;
+    const int64_t r = i / nxp;
+    const int x = (int)(i - r * nxp);
+    Vs[i] = (x < nx) ? V[r * nx + x] * scale : 0.0;
+}
+
+__global__ void k_kinetic(int64_t n, int nb, const double* __restrict__ kin, const cd* __restrict__ psi,
+                          int64_t ldpsi, cd* __restrict__ out, int64_t ldout, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double k = kin ? kin[i] : 0.0;
+    for (int b = 0; b < nb; ++b) {
+        cd q = psi[(int64_t)b * ldpsi + i];
+        cd v = make_double2(k * q.x, k * q.y);
+        if (accumulate) {
+            cd o = out[(int64_t)b * ldout + i];
+            v.x += o.x;
+            v.y += o.y;
+        }
+        out[(int64_t)b * ldout + i] = v;
+    }
+}
+
+// ======================================================================================== host side
+static size_t lds_bytes(int n) { return (size_t)n * (FFT_LS + 1) * sizeof(cd); }
+
+int fft_ensure_scratch(dftk_mi_basis* b, dftk_mi_kblock* kb, int nb) {
+    const size_t t1 = (size_t)nb * kb->n_lines * b->nxp * sizeof(cd);
+    const size_t t2 = (size_t)nb * kb->nzx * b->ny * b->nxp * sizeof(cd);
+    if (t1 > b->T1_bytes) {
+        if (b->T1) HIPCHK(hipFree(b->T1));
+        b->T1 = nullptr;
+        HIPCHK(hipMalloc(&b->T1, t1));
+        b->T1_bytes = t1;
+    }
+    if (t2 > b->T2_bytes) {
+        if (b->T2) HIPCHK(hipFree(b->T2));
+        b->T2 = nullptr;
+        HIPCHK(hipMalloc(&b->T2, t2));
+        b->T2_bytes = t2;
+    }
+    return 0;
+}
+
+static int check_lds(dftk_mi_basis* b) {
+    const int nmax = b->nx > b->ny ? (b->nx > b->nz ? b->nx : b->nz) : (b->ny > b->nz ? b->ny : b->nz);
+    if (lds_bytes(nmax) > 160 * 1024) {
+        dftk_set_error("FFT axis length %d needs %zu B of LDS (> 160 KiB)", nmax, lds_bytes(nmax));
+        return DFTK_MI_EINVAL;
+    }
+    return 0;
+}
+
+template <typename K>
+static int set_lds_attr(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    }
+    return 0;
+}
+
+static bool axis_generic(const FftAxis& ax) {
+    for (int s = 0; s < ax.nrad; ++s)
+        if (ax.rad[s] > 5) return true;
+    return false;
+}
+
+// launch KERNEL<GEN> with GEN chosen from the axis plan (2-3-5-smooth => lean kernel)
+#define LAUNCH_FFT(KERNEL, AX, GRID, LDS, STREAM, ...)                                               \
+    do {                                                                                             \
+        if (axis_generic(AX)) {                                                                      \
+            CHK(set_lds_attr(KERNEL<true>, LDS));                                                    \
+            hipLaunchKernelGGL((KERNEL<true>), GRID, dim3(FFT_THREADS), LDS, STREAM, __VA_ARGS__);   \
+        } else {                                                                                     \
+            CHK(set_lds_attr(KERNEL<false>, LDS));                                                   \
+            hipLaunchKernelGGL((KERNEL<false>), GRID, dim3(FFT_THREADS), LDS, STREAM, __VA_ARGS__);  \
+        }                                                                                            \
+    } while (0)
+#define LAUNCH_ZPASS(MODE, AX, GRID, LDS, STREAM, ...)                                                      \
+    do {                                                                                                    \
+        if (axis_generic(AX)) {                                                                             \
+            CHK(set_lds_attr(k_zpass<MODE, true>, LDS));                                                    \
+            hipLaunchKernelGGL((k_zpass<MODE, true>), GRID, dim3(FFT_THREADS), LDS, STREAM, __VA_ARGS__);   \
+        } else {                                                                                            \
+            CHK(set_lds_attr(k_zpass<MODE, false>, LDS));                                                   \
+            hipLaunchKernelGGL((k_zpass<MODE, false>), GRID, dim3(FFT_THREADS), LDS, STREAM, __VA_ARGS__);  \
+        }                                                                                                   \
+    } while (0)
+
+struct Strides {
+    int64_t s1, s2;
+};
+static Strides strides(dftk_mi_kblock* kb) {
+    dftk_mi_basis* b = kb->basis;
+    return Strides{(int64_t)kb->n_lines * b->nxp, (int64_t)kb->nzx * b->ny * b->nxp};
+}
+
+static int run_AB(dftk_mi_kblock* kb, int nbb, const cd* psi, int64_t ldpsi) {
+    dftk_mi_basis* b = kb->basis;
+    const Strides st = strides(kb);
+    const int gl = (int)((kb->n_lines + FFT_L - 1) / FFT_L);
+    const int nxt = b->nxp / FFT_L;
+    const double Ncube = (double)b->nx * b->ny * b->nz;
+    int ps = prof_begin(b, PROF_FFT_A, 32.0 * Ncube * nbb + 16.0 * kb->n_G * nbb);
+    LAUNCH_FFT(k_xbwd_scatter, b->ax[0], dim3(gl, nbb), lds_bytes(b->nx), b->stream, b->ax[0],
+                       b->nxp, (int)kb->n_lines, kb->d_line_start, kb->d_cpos, psi, ldpsi, b->T1, st.s1);
+    prof_end(b, ps);
+    ps = prof_begin(b, PROF_FFT_B, 32.0 * Ncube * nbb);
+    LAUNCH_FFT(k_ybwd, b->ax[1], dim3(nxt, kb->nzx, nbb), lds_bytes(b->ny), b->stream, b->ax[1],
+                       b->nxp, b->ny, kb->d_zls, kb->d_line_ypos, b->T1, st.s1, b->T2, st.s2);
+    prof_end(b, ps);
+    return 0;
+}
+
+static int run_DE(dftk_mi_kblock* kb, int nbb, const double* kin, const cd* psi, int64_t ldpsi, cd* out,
+                  int64_t ldout) {
+    dftk_mi_basis* b = kb->basis;
+    const Strides st = strides(kb);
+    const int gl = (int)((kb->n_lines + FFT_L - 1) / FFT_L);
+    const int nxt = b->nxp / FFT_L;
+    const double Ncube = (double)b->nx * b->ny * b->nz;
+    int ps = prof_begin(b, PROF_FFT_D, 32.0 * Ncube * nbb);
+    LAUNCH_FFT(k_yfwd, b->ax[1], dim3(nxt, kb->nzx, nbb), lds_bytes(b->ny), b->stream, b->ax[1],
+                       b->nxp, b->ny, kb->d_zls, kb->d_line_ypos, b->T2, st.s2, b->T1, st.s1);
+    prof_end(b, ps);
+    ps = prof_begin(b, PROF_FFT_E, 32.0 * Ncube * nbb + 40.0 * kb->n_G * nbb);
+    LAUNCH_FFT(k_xfwd_gather, b->ax[0], dim3(gl, nbb), lds_bytes(b->nx), b->stream, b->ax[0],
+                       b->nxp, (int)kb->n_lines, kb->d_line_start, kb->d_cpos, b->T1, st.s1, kin, psi, ldpsi, out,
+                       ldout);
+    prof_end(b, ps);
+    return 0;
+}
+
+int launch_local_apply(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, cd* out, int64_t ldout,
+                       bool add_kinetic, bool have_local) {
+    dftk_mi_basis* b = kb->basis;
+    if (!have_local || kb->d_Vs == nullptr) {
+        // no local potential: out = kinetic * psi (or zero)
+        return launch_kinetic_only(kb, nb, psi, ldpsi, out, ldout, false, add_kinetic);
+    }
+    CHK(check_lds(b));
+    const int batch = b->fft_batch;
+    CHK(fft_ensure_scratch(b, kb, nb < batch ? nb : batch));
+    const Strides st = strides(kb);
+    const int nxt = b->nxp / FFT_L;
+    for (int b0 = 0; b0 < nb; b0 += batch) {
+        const int nbb = (nb - b0) < batch ? (nb - b0) : batch;
+        const cd* p = psi + (int64_t)b0 * ldpsi;
+        CHK(run_AB(kb, nbb, p, ldpsi));
+        const int pc = prof_begin(b, PROF_FFT_C, 72.0 * (double)b->nx * b->ny * b->nz * nbb);
+        LAUNCH_ZPASS(0, b->ax[2], dim3(nxt, b->ny, nbb), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, kb->d_zpos, kb->d_Vs, b->T2, st.s2,
+                           (cd*)nullptr);
+        prof_end(b, pc);
+        CHK(run_DE(kb, nbb, add_kinetic ? kb->d_kin : nullptr, p, ldpsi, out + (int64_t)b0 * ldout, ldout));
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_kinetic_only(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, cd* out, int64_t ldout,
+                        bool accumulate, bool use_kin) {
+    dftk_mi_basis* b = kb->basis;
+    const int threads = 256;
+    const int blocks = (int)((kb->n_G + threads - 1) / threads);
+    hipLaunchKernelGGL(k_kinetic, dim3(blocks), dim3(threads), 0, b->stream, kb->n_G, nb,
+                       use_kin ? kb->d_kin : (const double*)nullptr, psi, ldpsi, out, ldout, accumulate ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_ifft_to_cube(dftk_mi_kblock* kb, const cd* c, cd* cube) {
+    dftk_mi_basis* b = kb->basis;
+    CHK(check_lds(b));
+    CHK(fft_ensure_scratch(b, kb, 1));
+    const Strides st = strides(kb);
+    CHK(run_AB(kb, 1, c, kb->n_G));
+    LAUNCH_ZPASS(1, b->ax[2], dim3(b->nxp / FFT_L, b->ny, 1), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, kb->d_zpos, (const double*)nullptr, b->T2, st.s2,
+                       cube);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_fft_from_cube(dftk_mi_kblock* kb, const cd* cube, cd* c) {
+    dftk_mi_basis* b = kb->basis;
+    CHK(check_lds(b));
+    CHK(fft_ensure_scratch(b, kb, 1));
+    const Strides st = strides(kb);
+    LAUNCH_ZPASS(2, b->ax[2], dim3(b->nxp / FFT_L, b->ny, 1), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, kb->d_zpos, (const double*)nullptr, b->T2, st.s2,
+                       const_cast<cd*>(cube));
+    CHK(run_DE(kb, 1, nullptr, c, kb->n_G, c, kb->n_G));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_density(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, const double* w_h, double* rho) {
+    dftk_mi_basis* b = kb->basis;
+    CHK(check_lds(b));
+    if (b->nz > DENS_MAXACC * FFT_TPL) {
+        dftk_set_error("density kernel supports nz <= %d", DENS_MAXACC * FFT_TPL);
+        return DFTK_MI_EINVAL;
+    }
+    const int batch = b->fft_batch;
+    CHK(fft_ensure_scratch(b, kb, nb < batch ? nb : batch));
+    const Strides st = strides(kb);
+    // weights: stage through the pinned scalar buffer in chunks of <= 256
+    for (int b0 = 0; b0 < nb; b0 += batch) {
+        const int nbb = (nb - b0) < batch ? (nb - b0) : batch;
+        bool any = false;
+        for (int i = 0; i < nbb; ++i) any = any || (w_h[b0 + i] != 0.0);
+        if (!any) continue;
+        if (nbb > 256) return DFTK_MI_EINVAL;
+        // the pinned buffer may still be read by an earlier async copy: synchronise before reuse
+        HIPCHK(hipStreamSynchronize(b->stream));
+        for (int i = 0; i < nbb; ++i) b->h_scalars[i] = w_h[b0 + i];
+        HIPCHK(hipMemcpyAsync(b->d_scalars, b->h_scalars, nbb * sizeof(double), hipMemcpyHostToDevice, b->stream));
+        CHK(run_AB(kb, nbb, psi + (int64_t)b0 * ldpsi, ldpsi));
+        const int pz = prof_begin(b, PROF_DENS_Z, (32.0 * nbb + 16.0) * (double)b->nx * b->ny * b->nz);
+        LAUNCH_FFT(k_zdensity, b->ax[2], dim3(b->nxp / FFT_L, b->ny), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, kb->d_zpos, nbb, b->d_scalars, b->T2, st.s2,
+                           rho);
+        prof_end(b, pz);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_pad_potential(dftk_mi_kblock* kb, const double* V) {
+    dftk_mi_basis* b = kb->basis;
+    const int64_t rows = (int64_t)b->ny * b->nz;
+    const int64_t total = rows * b->nxp;
+    const double scale = 1.0 / ((double)b->nx * b->ny * b->nz);
+    hipLaunchKernelGGL(k_pad_potential, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, b->stream, b->nx,
+                       b->nxp, rows, scale, V, kb->d_Vs);
+    HIPCHK(hipGetLastError());
+    return 0;
+}

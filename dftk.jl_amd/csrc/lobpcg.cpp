@@ -1,0 +1,457 @@
+// lobpcg.cpp -- host driver of the LOBPCG ("hyper") eigensolver, all block algebra on the device.
+//
+// Mirrors LOBPCG(A, X, I, precon, tol, maxiter; miniter, ortho_tol, n_conv_check) of
+// src/eigen/lobpcg_hyper_impl.jl:354-582 (B = I) including rayleigh_ritz (:141-171),
+// safe_cholesky (:190-210), ortho!(X) (:216-261), drop_small! (:264-268), ortho!(X,Y,BY)
+// (:271-323), final_retval (:325-338), compute_lambda (:341-344) and the TPA preconditioner of
+// src/eigen/preconditioners.jl:50-77.  Control flow (locking, active views, adaptive
+// orthogonalisation loops) runs on the host from a handful of reduced scalars per iteration;
+// every n_G-sized operation is a kernel on the basis' stream.
+#include "common.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <random>
+#include <vector>
+
+namespace {
+
+const double EPS = 2.220446049250313e-16;
+const cd ONE = {1.0, 0.0}, ZERO = {0.0, 0.0}, MONE = {-1.0, 0.0};
+
+struct Mat {            // column-major view
+    cd* p;
+    int64_t ld;
+    int64_t rows;
+    int cols;
+    Mat cols_from(int c0, int nc = -1) const {
+        return Mat{p + (int64_t)c0 * ld, ld, rows, nc < 0 ? cols - c0 : nc};
+    }
+    Mat rows_from(int64_t r0, int64_t nr) const { return Mat{p + r0, ld, nr, cols}; }
+};
+
+struct Ctx {
+    dftk_mi_kblock* kb;
+    dftk_mi_basis* b;
+    // small scratch (device)
+    cd *O, *Rw, *invR, *BYX, *tmpS;
+    double *d_a, *d_b;        // M-sized double scratch
+    std::vector<double> h;    // host scratch
+    std::mt19937_64 rng;
+};
+
+int d2h(Ctx& c, const double* d, int n) {
+    if ((int)c.h.size() < n) c.h.resize(n);
+    HIPCHK(hipMemcpyAsync(c.h.data(), d, n * sizeof(double), hipMemcpyDeviceToHost, c.b->stream));
+    HIPCHK(hipStreamSynchronize(c.b->stream));
+    return 0;
+}
+
+// Frobenius norm^2 of a matrix (sum over columns)
+int frob2(Ctx& c, const Mat& A, double* out) {
+    CHK(ew_frob2(c.b, A.rows, A.cols, A.p, A.ld, c.d_a));
+    CHK(d2h(c, c.d_a, A.cols));
+    double s = 0.0;
+    for (int i = 0; i < A.cols; ++i) s += c.h[i];
+    *out = s;
+    return 0;
+}
+
+// safe_cholesky(O): R'R = O with shift-and-retry.  On success Rw holds R (upper), invR its inverse.
+int safe_cholesky(Ctx& c, int m, int* nchol_out, double* nR, double* nI) {
+    int nchol = 0;
+    double alpha = 100.0;
+    for (;;) {
+        if (nchol >= 5) {
+            *nchol_out = 10000;
+            return 0;
+        }
+        nchol += 1;
+        CHK(ew_copy(c.b, m, m, c.O, m, c.Rw, m));
+        int st = dense_potrf_trtri(c.b, m, c.Rw, m, c.invR, m, nR, nI);
+        if (st == 0) break;
+        if (st != DFTK_MI_NUM_CHOLESKY) return st;
+        double f2;
+        CHK(frob2(c, Mat{c.O, m, m, m}, &f2));
+        if (!std::isfinite(f2)) return DFTK_MI_NUM_NONFINITE;
+        CHK(ew_add_diag(c.b, m, c.O, m, alpha * EPS * std::sqrt(f2)));
+        alpha *= 10.0;
+    }
+    *nchol_out = nchol;
+    return 0;
+}
+
+// ortho!(X): Cholesky-QR until the a-posteriori estimate eps*cond(R)^2 < tol.
+// tmp must hold rows x cols elements.
+int ortho_X(Ctx& c, Mat X, cd* tmp, double tol, int* nchol_total_out, double* growth_out) {
+    double growth = 1.0;
+    int nchol_total = 0;
+    const int m = X.cols;
+    if (m == 0) {
+        *growth_out = 1.0;
+        *nchol_total_out = 0;
+        return 0;
+    }
+    for (int pass = 0;; ++pass) {
+        if (pass >= 30) {
+            dftk_set_error("ortho!(X) did not reach the orthogonality tolerance in 30 Cholesky-QR passes");
+            return DFTK_MI_NUM_CHOLESKY;
+        }
+        CHK(zgemm(c.b, 'C', m, m, X.rows, ONE, X.p, X.ld, X.p, X.ld, ZERO, c.O, m));
+        CHK(ew_hermitize_upper(c.b, m, c.O, m));
+        int nchol;
+        double nR = 0, nI = 0;
+        CHK(safe_cholesky(c, m, &nchol, &nR, &nI));
+        nchol_total += nchol;
+        if (nchol > 10) {
+            dftk_set_error("ortho!(X) is failing badly (the reference falls back to an SVD here)");
+            return DFTK_MI_NUM_CHOLESKY;
+        }
+        // X <- X * invR
+        CHK(zgemm(c.b, 'N', X.rows, m, m, ONE, X.p, X.ld, c.invR, m, ZERO, tmp, X.rows));
+        CHK(ew_copy(c.b, X.rows, m, tmp, X.rows, X.p, X.ld));
+        growth *= nI;
+        const double condR = nR * nI;
+        const double est = EPS * condR * condR;
+        if (nchol == 1 && est < tol) break;
+    }
+    *growth_out = growth;
+    *nchol_total_out = nchol_total;
+    return 0;
+}
+
+// X[:, col] = randn (complex) -- host RNG, rare path of drop_small!
+int randomize_column(Ctx& c, Mat X, int col) {
+    std::normal_distribution<double> nd(0.0, 1.0);
+    std::vector<double> v(2 * X.rows);
+    for (auto& x : v) x = nd(c.rng);
+    HIPCHK(hipMemcpyAsync(X.p + (int64_t)col * X.ld, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice,
+                          c.b->stream));
+    HIPCHK(hipStreamSynchronize(c.b->stream));
+    return 0;
+}
+
+// ortho!(X, Y, BY) with Y = hcat(Ys...), B = I
+int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol) {
+    if (X.cols == 0) return 0;
+    CHK(ew_colnorms(c.b, X.rows, X.cols, X.p, X.ld, c.d_a));
+    CHK(ew_scale_cols(c.b, X.rows, X.cols, X.p, X.ld, c.d_a, true));
+    int ny = 0;
+    for (auto& Y : Ys) ny += Y.cols;
+    int niter = 1;
+    for (;;) {
+        // BYX = Y' X ; X -= Y BYX
+        int off = 0;
+        for (auto& Y : Ys) {
+            if (Y.cols == 0) continue;
+            CHK(zgemm(c.b, 'C', Y.cols, X.cols, X.rows, ONE, Y.p, Y.ld, X.p, X.ld, ZERO, c.BYX + off, ny));
+            off += Y.cols;
+        }
+        off = 0;
+        for (auto& Y : Ys) {
+            if (Y.cols == 0) continue;
+            CHK(zgemm(c.b, 'N', X.rows, X.cols, Y.cols, MONE, Y.p, Y.ld, c.BYX + off, ny, ONE, X.p, X.ld));
+            off += Y.cols;
+        }
+        // drop_small!
+        CHK(ew_colnorms(c.b, X.rows, X.cols, X.p, X.ld, c.d_a));
+        CHK(d2h(c, c.d_a, X.cols));
+        std::vector<int> dropped;
+        for (int j = 0; j < X.cols; ++j) {
+            if (!std::isfinite(c.h[j])) return DFTK_MI_NUM_NONFINITE;
+            if (c.h[j] <= tol) dropped.push_back(j);
+        }
+        for (int j : dropped) {
+            CHK(randomize_column(c, X, j));
+            Mat xj = X.cols_from(j, 1);
+            int o2 = 0;
+            // X[:, j] -= Y (Y' X[:, j])   (uses the tail of BYX as scratch: ny x 1 beyond the block)
+            cd* scr = c.BYX + (int64_t)ny * X.cols;
+            for (auto& Y : Ys) {
+                if (Y.cols == 0) continue;
+                CHK(zgemm(c.b, 'C', Y.cols, 1, X.rows, ONE, Y.p, Y.ld, xj.p, xj.ld, ZERO, scr + o2, ny));
+                o2 += Y.cols;
+            }
+            o2 = 0;
+            for (auto& Y : Ys) {
+                if (Y.cols == 0) continue;
+                CHK(zgemm(c.b, 'N', X.rows, 1, Y.cols, MONE, Y.p, Y.ld, scr + o2, ny, ONE, xj.p, xj.ld));
+                o2 += Y.cols;
+            }
+        }
+        double byx2;
+        CHK(frob2(c, Mat{c.BYX, ny, ny, X.cols}, &byx2));
+        if (std::sqrt(byx2) < tol && niter > 1) break;
+        int ninner;
+        double growth;
+        CHK(ortho_X(c, X, tmp, tol, &ninner, &growth));
+        if (growth * EPS < tol) break;
+        if (niter > 10) {
+            dftk_set_error("ortho!(X, Y) is failing badly (the reference falls back to an SVD here)");
+            return DFTK_MI_NUM_CHOLESKY;
+        }
+        niter += 1;
+    }
+    return 0;
+}
+
+// C = sum_b Yb * coef[rows of b]   (LazyHcat * Matrix, lobpcg_hyper_impl.jl:124-132)
+int hcat_mul(Ctx& c, const std::vector<Mat>& Ys, const cd* coef, int64_t ldcoef, int ncols, Mat C) {
+    int64_t off = 0;
+    bool first = true;
+    for (auto& Y : Ys) {
+        if (Y.cols == 0) continue;
+        CHK(zgemm(c.b, 'N', Y.rows, ncols, Y.cols, ONE, Y.p, Y.ld, coef + off, ldcoef, first ? ZERO : ONE, C.p, C.ld));
+        first = false;
+        off += Y.cols;
+    }
+    return 0;
+}
+
+}  // namespace
+
+int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int miniter, int maxiter,
+               int n_conv_check, int use_tpa, uint64_t seed, double* lambda_h, double* resid_h, int* n_iter_out,
+               int* converged_out, int64_t* n_matvec_out) {
+    dftk_mi_basis* b = kb->basis;
+    const int64_t N = kb->n_G;
+    if (!(N > 3 * (int64_t)M)) {
+        dftk_set_error("The eigenproblem is too small (n_G=%lld, M=%d): N > 3M required", (long long)N, M);
+        return DFTK_MI_NUM_TOO_SMALL;
+    }
+    if (n_conv_check <= 0 || n_conv_check > M) n_conv_check = M;
+    const double ortho_tol = 2 * EPS;
+
+    // ---- workspace -------------------------------------------------------------------------
+    const size_t blk = (size_t)N * M;                   // elements of one n_G x M block
+    const size_t nbig = 11;                             // AX R AR P AP newX newAX newR newP newAP tmp
+    const size_t m3 = 3 * (size_t)M;
+    const size_t small_elems = m3 * m3 * 2              // G, V
+                               + m3 * M * 2             // cP, tmpS
+                               + (size_t)M * M * 3      // O, Rw, invR
+                               + (2 * (size_t)M + m3) * (M + 1);   // BYX (+1 scratch column)
+    const size_t dbl = 8 * (size_t)(M + 8);
+    const size_t need = (nbig * blk + small_elems) * sizeof(cd) + dbl * sizeof(double) + m3 * sizeof(int) + 1024;
+    if (need > kb->lob_bytes) {
+        HIPCHK(hipStreamSynchronize(b->stream));
+        if (kb->lob_buf) HIPCHK(hipFree(kb->lob_buf));
+        kb->lob_buf = nullptr;
+        kb->lob_bytes = 0;
+        HIPCHK(hipMalloc((void**)&kb->lob_buf, need));
+        kb->lob_bytes = need;
+    }
+    cd* w = kb->lob_buf;
+    auto take = [&](size_t n) {
+        cd* r = w;
+        w += n;
+        return r;
+    };
+    Mat AX{take(blk), N, N, M}, R{take(blk), N, N, M}, AR{take(blk), N, N, M}, P{take(blk), N, N, M},
+        AP{take(blk), N, N, M}, newX{take(blk), N, N, M}, newAX{take(blk), N, N, M}, newR{take(blk), N, N, M},
+        newP{take(blk), N, N, M}, newAP{take(blk), N, N, M};
+    cd* tmp = take(blk);
+    cd* G = take(m3 * m3);
+    cd* V = take(m3 * m3);
+    cd* cP = take(m3 * M);
+    Ctx c;
+    c.kb = kb;
+    c.b = b;
+    c.tmpS = take(m3 * M);
+    c.O = take((size_t)M * M);
+    c.Rw = take((size_t)M * M);
+    c.invR = take((size_t)M * M);
+    c.BYX = take((2 * (size_t)M + m3) * (M + 1));
+    double* dd = reinterpret_cast<double*>(w);
+    c.d_a = dd;
+    c.d_b = dd + (M + 8);
+    double* d_lam = dd + 2 * (M + 8);
+    double* d_norms = dd + 3 * (M + 8);
+    double* d_mk = dd + 4 * (M + 8);
+    c.rng.seed(seed ? seed : 0x9E3779B97F4A7C15ull);
+    kb->last_AX = AX.p;
+
+    Mat X{Xp, ldX, N, M};
+    std::vector<double> resid_history((size_t)M * (maxiter + 1), 0.0);
+    auto RH = [&](int i, int it) -> double& { return resid_history[(size_t)i + (size_t)M * it]; };
+    std::vector<double> full_lam(M, 0.0);
+
+    // ---- X = ortho!(copy(X)); AX = A X --------------------------------------------------------
+    {
+        int nch;
+        double gr;
+        CHK(ortho_X(c, X, tmp, ortho_tol, &nch, &gr));
+    }
+    int64_t n_matvec = M;
+    CHK(dftk_mi_apply_H(kb, M, reinterpret_cast<const dftk_mi_cplx*>(X.p), X.ld,
+                        reinterpret_cast<dftk_mi_cplx*>(AX.p), AX.ld));
+    CHK(ew_has_nonfinite(b, N, M, AX.p, AX.ld, c.d_a));
+    CHK(d2h(c, c.d_a, M));
+    for (int i = 0; i < M; ++i)
+        if (c.h[i] != 0.0) {
+            dftk_set_error("non-finite values in H*X");
+            return DFTK_MI_NUM_NONFINITE;
+        }
+    CHK(ew_fill_zero(b, P.p, blk));
+    CHK(ew_fill_zero(b, AP.p, blk));
+    CHK(ew_fill_zero(b, R.p, blk));
+    // lambda = Re(X'AX)/(X'X) column-wise
+    CHK(ew_coldots(b, N, M, X.p, X.ld, AX.p, AX.ld, c.d_a));
+    CHK(ew_coldots(b, N, M, X.p, X.ld, X.p, X.ld, c.d_b));
+    CHK(d2h(c, c.d_a, 2 * (M + 8)));
+    for (int i = 0; i < M; ++i) full_lam[i] = c.h[i] / c.h[(M + 8) + i];
+
+    int nlocked = 0, niter = 0, lo = 0;
+    int status_final = 0;
+    bool finished = false;
+    int final_iter = maxiter;
+    int ncx = 0;   // columns of cX of the current iteration
+
+    while (true) {
+        const int nact = M - lo;
+        Mat Xa = X.cols_from(lo), AXa = AX.cols_from(lo);
+        Mat Ra = R.cols_from(0, nact), ARa = AR.cols_from(0, nact), Pa = P.cols_from(0, nact),
+            APa = AP.cols_from(0, nact);
+        Mat nX = newX.cols_from(0, nact), nAX = newAX.cols_from(0, nact), nR = newR.cols_from(0, nact);
+        std::vector<Mat> Ys, AYs;
+        int nY = 0;
+        cd* cX = V;
+        if (niter > 0) {
+            CHK(dftk_mi_apply_H(kb, nact, reinterpret_cast<const dftk_mi_cplx*>(Ra.p), Ra.ld,
+                                reinterpret_cast<dftk_mi_cplx*>(ARa.p), ARa.ld));
+            n_matvec += nact;
+            Ys = {Xa, Ra};
+            AYs = {AXa, ARa};
+            if (niter > 1) {
+                Ys.push_back(Pa);
+                AYs.push_back(APa);
+            }
+            nY = (int)Ys.size() * nact;
+            // rayleigh_ritz: G = Y' AY (upper block triangle), eigen, take the lowest nact
+            for (size_t ib = 0; ib < Ys.size(); ++ib)
+                for (size_t ia = 0; ia <= ib; ++ia)
+                    CHK(zgemm(b, 'C', nact, nact, N, ONE, Ys[ia].p, Ys[ia].ld, AYs[ib].p, AYs[ib].ld, ZERO,
+                              G + (int64_t)ia * nact + (int64_t)ib * nact * nY, nY));
+            CHK(ew_hermitize_upper(b, nY, G, nY));
+            std::vector<double> wv(nY);
+            {
+                int st = dense_heev(b, nY, G, nY, wv.data(), V, nY);
+                if (st != 0) return st;
+            }
+            ncx = nact;
+            // re-orthonormalise the Ritz coefficient block (lobpcg_hyper_impl.jl:165-169)
+            {
+                int nch;
+                double gr;
+                CHK(ortho_X(c, Mat{cX, nY, nY, ncx}, c.tmpS, ortho_tol, &nch, &gr));
+            }
+            for (int i = 0; i < nact; ++i) full_lam[lo + i] = wv[i];
+            CHK(hcat_mul(c, Ys, cX, nY, nact, nX));
+            CHK(hcat_mul(c, AYs, cX, nY, nact, nAX));
+        } else {
+            CHK(ew_copy(b, N, nact, Xa.p, Xa.ld, nX.p, nX.ld));
+            CHK(ew_copy(b, N, nact, AXa.p, AXa.ld, nAX.p, nAX.ld));
+        }
+
+        // residuals
+        HIPCHK(hipMemcpyAsync(d_lam, full_lam.data() + lo, nact * sizeof(double), hipMemcpyHostToDevice, b->stream));
+        CHK(ew_residual(b, N, nact, nAX.p, nAX.ld, nX.p, nX.ld, d_lam, nR.p, nR.ld, d_norms));
+        CHK(d2h(c, d_norms, nact));
+        for (int i = 0; i < nact; ++i) {
+            if (!std::isfinite(c.h[i])) {
+                dftk_set_error("non-finite residual norm in LOBPCG iteration %d", niter);
+                return DFTK_MI_NUM_NONFINITE;
+            }
+            RH(nlocked + i, niter) = c.h[i];
+        }
+        // preconditioning: precondprep!(new_X); ldiv!(precon, new_R)
+        if (use_tpa) {
+            CHK(ew_weighted_colnorm2(b, N, nact, nX.p, nX.ld, kb->d_kin, d_mk));
+            CHK(ew_tpa(b, N, nact, nR.p, nR.ld, kb->d_kin, d_mk));
+        }
+        // locking
+        const int prev_nlocked = nlocked;
+        if (niter >= miniter) {
+            for (int i = nlocked; i < M; ++i) {
+                if (RH(i, niter) < tol)
+                    nlocked += 1;
+                else
+                    break;
+            }
+        }
+        if (nlocked >= n_conv_check) {
+            CHK(ew_copy(b, N, nact, nX.p, nX.ld, Xa.p, Xa.ld));
+            CHK(ew_copy(b, N, nact, nAX.p, nAX.ld, AXa.p, AXa.ld));
+            final_iter = niter;
+            finished = true;
+            break;
+        }
+        const int newly_locked = nlocked - prev_nlocked;
+        const int lenXn = nact - newly_locked;   // == M - nlocked
+
+        Mat nP = newP.cols_from(0, lenXn), nAP = newAP.cols_from(0, lenXn);
+        if (niter > 0) {
+            // cP = (cX - e)[:, newly_locked:], then orthogonalise against all of cX
+            Mat cPm{cP, nY, nY, lenXn};
+            CHK(ew_copy(b, nY, lenXn, cX + (int64_t)newly_locked * nY, nY, cP, nY));
+            CHK(ew_sub_identity_shifted(b, nY, lenXn - newly_locked, cP, nY, 2 * newly_locked));
+            std::vector<Mat> cXs = {Mat{cX, nY, nY, ncx}};
+            CHK(ortho_XY(c, cPm, cXs, c.tmpS, ortho_tol));
+            CHK(hcat_mul(c, Ys, cP, nY, lenXn, nP));
+            CHK(hcat_mul(c, AYs, cP, nY, lenXn, nAP));
+        }
+        // update all X (even newly locked), AX
+        CHK(ew_copy(b, N, nact, nX.p, nX.ld, Xa.p, Xa.ld));
+        CHK(ew_copy(b, N, nact, nAX.p, nAX.ld, AXa.p, AXa.ld));
+        // sanity: |<x,x> - 1| < sqrt(eps)
+        CHK(ew_coldots(b, N, nact, Xa.p, Xa.ld, Xa.p, Xa.ld, c.d_a));
+        CHK(d2h(c, c.d_a, nact));
+        for (int i = 0; i < nact; ++i)
+            if (!(std::fabs(c.h[i] - 1.0) < std::sqrt(EPS))) {
+                dftk_set_error("LOBPCG is badly failing to keep the vectors normalized (column %d: %g)", lo + i,
+                               c.h[i]);
+                return DFTK_MI_NUM_NORMALIZATION;
+            }
+        // restrict to active
+        lo = nlocked;
+        CHK(ew_copy(b, N, lenXn, nR.p + (int64_t)newly_locked * nR.ld, nR.ld, R.p, R.ld));
+        std::vector<Mat> Zs = {X};
+        if (niter > 0) {
+            CHK(ew_copy(b, N, lenXn, nP.p, nP.ld, P.p, P.ld));
+            CHK(ew_copy(b, N, lenXn, nAP.p, nAP.ld, AP.p, AP.ld));
+            Zs.push_back(P.cols_from(0, lenXn));
+        }
+        CHK(ortho_XY(c, R.cols_from(0, lenXn), Zs, tmp, ortho_tol));
+
+        if (niter >= maxiter) break;
+        niter += 1;
+    }
+    if (!finished) final_iter = maxiter;
+    (void)status_final;
+
+    // final_retval: sort by lambda if needed
+    std::vector<int> perm(M);
+    std::iota(perm.begin(), perm.end(), 0);
+    bool sorted = std::is_sorted(full_lam.begin(), full_lam.end());
+    if (!sorted) {
+        std::stable_sort(perm.begin(), perm.end(), [&](int a, int d) { return full_lam[a] < full_lam[d]; });
+        int* d_perm = reinterpret_cast<int*>(dd + 5 * (M + 8));
+        HIPCHK(hipMemcpyAsync(d_perm, perm.data(), M * sizeof(int), hipMemcpyHostToDevice, b->stream));
+        CHK(ew_gather_cols(b, N, M, X.p, X.ld, d_perm, tmp, N));
+        CHK(ew_copy(b, N, M, tmp, N, X.p, X.ld));
+        CHK(ew_gather_cols(b, N, M, AX.p, AX.ld, d_perm, tmp, N));
+        CHK(ew_copy(b, N, M, tmp, N, AX.p, AX.ld));
+        HIPCHK(hipStreamSynchronize(b->stream));
+    }
+    double maxres = 0.0;
+    for (int i = 0; i < M; ++i) {
+        lambda_h[i] = full_lam[perm[i]];
+        resid_h[i] = RH(perm[i], final_iter);
+    }
+    for (int i = 0; i < n_conv_check; ++i) maxres = std::max(maxres, resid_h[i]);
+    *converged_out = (maxres < tol) ? 1 : 0;
+    *n_iter_out = final_iter;
+    *n_matvec_out = n_matvec;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}

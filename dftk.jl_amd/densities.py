@@ -1,0 +1,30 @@
+"""``compute_density`` (src/densities.jl:13-57): per-band pruned iFFT + |psi|^2 accumulation on the
+device, one RCCL all-reduce over ``comm_kpts``; no symmetrisation (identity symmetry only, as
+``symmetries=false`` / Gamma-only supercells, symmetry.jl:292-295)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def compute_density(basis, psi, occupation, occupation_threshold: float = 0.0) -> torch.Tensor:
+    basis._require_gpu()
+    nx, ny, nz = basis.fft_size
+    rho = torch.zeros((nz, ny, nx), dtype=torch.float64, device=basis.device)
+    torch.cuda.current_stream(basis.device).synchronize()
+    for ik, kpt in enumerate(basis.kpoints):
+        occ = np.asarray(occupation[ik], dtype=np.float64)          # occupations live on the host (:16)
+        w = np.where(np.abs(occ) >= occupation_threshold, occ, 0.0) * basis.kweights[ik] * basis.ifft_normalization ** 2
+        w = np.ascontiguousarray(w)
+        psik = psi[ik]
+        if not (psik.is_cuda and psik.dtype == torch.complex128 and psik.stride(1) == 1):
+            raise TypeError("compute_density: complex128 CUDA band-major blocks required")
+        _lib.check(basis.lib.dftk_mi_density_accumulate(kpt.handle, len(w), psik.data_ptr(), psik.stride(0),
+                                                        w.ctypes.data, rho.data_ptr()))
+    basis.sync()
+    basis.comm_kpts.sum_(rho, None)                                  # mpi_sum!(rho, comm_kpts) (:46)
+    if basis.comm_kpts.size > 1:
+        torch.cuda.synchronize(basis.device)
+    return rho

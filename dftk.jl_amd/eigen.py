@@ -1,0 +1,100 @@
+"""Eigensolver seam: ``lobpcg_hyper`` and ``diagonalize_all_kblocks``.
+
+Contract of the reference (src/eigen/diag.jl:1-8,50-64, src/eigen/diag_lobpcg_hyper.jl:5-18):
+``eigensolver(A::HamiltonianBlock, X0; prec, tol, miniter, maxiter, n_conv_check) ->
+(; lambda, X, residual_norms, n_iter, converged, n_matvec)``, lambda ascending on the host,
+X orthonormal on the device.  The whole LOBPCG iteration (src/eigen/lobpcg_hyper_impl.jl:354-582)
+runs inside the library (``dftk_mi_lobpcg``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from .hamiltonian import DftHamiltonianBlock
+
+EPS = float(np.finfo(np.float64).eps)
+
+
+class PreconditionerTPA:
+    """Marker for the Teter-Payne-Allan preconditioner (src/eigen/preconditioners.jl:27-78); the
+    kinetic vector it needs already lives in the k-block, so the object carries no data."""
+
+    def __init__(self, ham_block: DftHamiltonianBlock | None = None, default_shift: float = 1.0):
+        self.ham_block = ham_block
+        self.default_shift = default_shift
+
+
+@dataclass
+class EigResult:
+    λ: np.ndarray
+    X: torch.Tensor
+    residual_norms: np.ndarray
+    n_iter: int
+    converged: bool
+    n_matvec: int
+
+
+def lobpcg_hyper(A: DftHamiltonianBlock, X0: torch.Tensor, maxiter: int = 100, prec=None, tol: float | None = None,
+                 n_conv_check: int | None = None, miniter: int = 1, seed: int = 0) -> EigResult:
+    """``lobpcg_hyper(A, X0; prec, tol, maxiter, miniter, n_conv_check)``.  X0: (M, n_G) complex128
+    CUDA tensor (rows = bands); it is not modified."""
+    basis = A.basis
+    if not (X0.is_cuda and X0.dtype == torch.complex128):
+        raise TypeError("lobpcg_hyper: complex128 CUDA block required (no CPU fallback)")
+    M, n_G = X0.shape
+    if n_G != A.n_G:
+        raise ValueError(f"Mismatch in dimension between guess ({n_G}) and Hamiltonian ({A.n_G})")
+    if tol is None:
+        tol = 20 * n_G * EPS                    # diag_lobpcg_hyper.jl:6
+    X = X0.clone().contiguous()
+    lam = np.zeros(M)
+    res = np.zeros(M)
+    n_iter, conv, nmv = C.c_int(), C.c_int(), C.c_int64()
+    torch.cuda.current_stream(basis.device).synchronize()
+    _lib.check(basis.lib.dftk_mi_lobpcg(A.kpoint.handle, M, X.data_ptr(), X.stride(0), float(tol), int(miniter),
+                                        int(maxiter), int(n_conv_check or 0), 1 if prec is not None else 0,
+                                        int(seed) & (2 ** 64 - 1), lam.ctypes.data, res.ctypes.data,
+                                        C.byref(n_iter), C.byref(conv), C.byref(nmv)))
+    return EigResult(lam, X, res, n_iter.value, bool(conv.value), int(nmv.value))
+
+
+def random_orbitals(basis, kpt, howmany: int, generator: torch.Generator | None = None) -> torch.Tensor:
+    """orbitals.jl:82-86: complex normal entries; orthonormalisation is left to LOBPCG's first
+    Cholesky-QR (``X = ortho!(copy(X))``, lobpcg_hyper_impl.jl:370), which spans the same space."""
+    re = torch.randn((howmany, kpt.n_G), dtype=torch.float64, device=basis.device, generator=generator)
+    im = torch.randn((howmany, kpt.n_G), dtype=torch.float64, device=basis.device, generator=generator)
+    return torch.complex(re, im) / np.sqrt(2 * kpt.n_G)
+
+
+def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None, prec_type=PreconditionerTPA,
+                            tol: float = 1e-6, miniter: int = 1, maxiter: int = 100, n_conv_check=None,
+                            generator: torch.Generator | None = None, seed: int = 0):
+    """diag.jl:9-65 with ``interpolate_kpoints=false``."""
+    results = []
+    for ik, Hk in enumerate(ham):
+        kpt, basis = Hk.kpoint, Hk.basis
+        if kpt.n_G < nev_per_kpoint:
+            raise ValueError(f"The size of the plane wave basis is {kpt.n_G}, and you are asking for "
+                             f"{nev_per_kpoint} eigenvalues. Increase Ecut.")
+        if psiguess is not None:
+            g = psiguess[ik]
+            if g.shape[1] != kpt.n_G:
+                raise ValueError(f"Mismatch in dimension between guess ({g.shape[1]}) and Hamiltonian ({kpt.n_G})")
+            if g.shape[0] > nev_per_kpoint:
+                g = g[:nev_per_kpoint]
+            elif g.shape[0] < nev_per_kpoint:
+                extra = random_orbitals(basis, kpt, nev_per_kpoint - g.shape[0], generator)
+                g = torch.cat([g, extra * np.sqrt(2 * kpt.n_G)], dim=0)
+        else:
+            g = random_orbitals(basis, kpt, nev_per_kpoint, generator)
+        prec = prec_type(Hk) if prec_type is not None else None
+        results.append(eigensolver(Hk, g, prec=prec, tol=tol, miniter=miniter, maxiter=maxiter,
+                                   n_conv_check=n_conv_check, seed=seed + ik))
+    return dict(λ=[r.λ for r in results], X=[r.X for r in results],
+                residual_norms=[r.residual_norms for r in results], n_iter=[r.n_iter for r in results],
+                converged=all(r.converged for r in results), n_matvec=sum(r.n_matvec for r in results))

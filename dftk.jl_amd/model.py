@@ -1,0 +1,141 @@
+"""Physics specification: ``Model``, ``ElementPsp``, standard models, supercells, k-grids.
+
+Mirrors the parts of src/Model.jl, src/elements.jl, src/standard_models.jl:45-61,116-131,220,
+src/supercell.jl:5-20 and src/bzmesh.jl:4-48 that the SCF hot path consumes.  Symmetry
+detection (Spglib) is out of scope: k-points are explicit lists or unreduced Monkhorst-Pack
+meshes (``symmetries=false`` in the reference's terms).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+from .psp import ATOMIC_NUMBER, PspHgh, load_psp
+
+
+@dataclass(eq=False)
+class ElementPsp:
+    symbol: str
+    psp: PspHgh
+
+    @property
+    def charge_nuclear(self):
+        return ATOMIC_NUMBER[self.symbol]
+
+    @property
+    def charge_ionic(self):
+        return self.psp.Zion
+
+    n_elec_valence = charge_ionic
+
+    @property
+    def n_elec_core(self):
+        return self.charge_nuclear - self.psp.Zion
+
+
+def compute_recip_lattice(lattice):
+    """structure.jl:24-26 (lattice vectors are columns)."""
+    return 2 * math.pi * np.linalg.inv(np.asarray(lattice, dtype=float).T)
+
+
+class Model:
+    """Spin-unpolarised ``Model`` (src/Model.jl): lattice (columns), atoms, fractional positions,
+    term list, XC functionals, temperature/smearing."""
+
+    def __init__(self, lattice, atoms, positions, terms, functionals=("lda_x", "lda_c_pw"),
+                 temperature=0.0, smearing=None, n_electrons=None):
+        self.lattice = np.asarray(lattice, dtype=float)
+        self.atoms = list(atoms)
+        self.positions = [np.asarray(p, dtype=float) for p in positions]
+        if len(self.atoms) != len(self.positions):
+            raise ValueError("Length of atoms and positions vectors need to agree.")
+        self.term_types = tuple(terms)
+        if not self.term_types:
+            raise ValueError("Model without terms not supported.")
+        self.functionals = tuple(functionals)
+        self.temperature = float(temperature)
+        self.smearing = smearing if smearing is not None else ("fermi_dirac" if temperature > 0 else "none")
+        self.recip_lattice = compute_recip_lattice(self.lattice)
+        self.unit_cell_volume = abs(np.linalg.det(self.lattice))
+        self.n_electrons = int(sum(a.charge_ionic for a in self.atoms)) if n_electrons is None else n_electrons
+        self.n_spin_components = 1
+        self.spin_polarization = "none"
+        # atom_groups (Model.jl:169): indices of identical elements, in order of first appearance
+        self.atom_groups = []
+        reps = []
+        for i, a in enumerate(self.atoms):
+            for g, r in zip(self.atom_groups, reps):
+                if r is a or (r.symbol == a.symbol and r.psp.identifier == a.psp.identifier):
+                    g.append(i)
+                    break
+            else:
+                self.atom_groups.append([i])
+                reps.append(a)
+
+    @property
+    def filled_occupation(self):   # Model.jl:352-360
+        return 2
+
+
+def model_atomic(lattice, atoms, positions, extra_terms=(), **kw):
+    """standard_models.jl:45-61."""
+    terms = ("Kinetic", "AtomicLocal", "AtomicNonlocal", "Ewald", "PspCorrection") + tuple(extra_terms)
+    return Model(lattice, atoms, positions, terms, **kw)
+
+
+def model_DFT(lattice, atoms, positions, functionals=("lda_x", "lda_c_pw"), **kw):
+    """standard_models.jl:116-131; default functionals = ``LDA()`` (:220)."""
+    return model_atomic(lattice, atoms, positions, extra_terms=("Hartree", "Xc"),
+                        functionals=tuple(functionals), **kw)
+
+
+def create_supercell(lattice, atoms, positions, supercell_size):
+    """supercell.jl:5-20 (species-major, then (i,j,k) with i fastest)."""
+    nx, ny, nz = supercell_size
+    size = np.array([nx, ny, nz], dtype=float)
+    lat = np.asarray(lattice, dtype=float) * size[None, :]
+    new_atoms, new_pos = [], []
+    for atom, pos in zip(atoms, positions):
+        for k in range(nz):
+            for j in range(ny):
+                for i in range(nx):
+                    new_pos.append((np.asarray(pos, dtype=float) + np.array([i, j, k])) / size)
+                    new_atoms.append(atom)
+    return lat, new_atoms, new_pos
+
+
+def silicon_cell(supercell=(1, 1, 1), a=10.26, functional="lda"):
+    """fcc silicon of examples/silicon.jl:5-11 with the vendored HGH pseudopotential."""
+    lattice = a / 2 * np.array([[0, 1, 1.0], [1, 0, 1.0], [1, 1, 0.0]])
+    Si = ElementPsp("Si", load_psp("Si", functional))
+    atoms, positions = [Si, Si], [np.ones(3) / 8, -np.ones(3) / 8]
+    if tuple(supercell) != (1, 1, 1):
+        lattice, atoms, positions = create_supercell(lattice, atoms, positions, supercell)
+    return lattice, atoms, positions
+
+
+@dataclass
+class ExplicitKpoints:
+    kcoords: list
+    kweights: list
+
+
+@dataclass
+class MonkhorstPack:
+    kgrid_size: tuple
+    kshift: tuple = (0, 0, 0)
+
+    def reducible(self) -> ExplicitKpoints:
+        """bzmesh.jl:41-48; uniform weights (no symmetry reduction)."""
+        size = np.array(self.kgrid_size)
+        start = -np.floor((size - 1) / 2).astype(int)
+        stop = np.ceil((size - 1) / 2).astype(int)
+        ks = []
+        for k in range(start[2], stop[2] + 1):
+            for j in range(start[1], stop[1] + 1):
+                for i in range(start[0], stop[0] + 1):
+                    kc = (np.array(self.kshift, dtype=float) + np.array([i, j, k])) / size
+                    ks.append(kc - np.floor(kc + 0.5))
+        return ExplicitKpoints(ks, [1.0 / len(ks)] * len(ks))

@@ -1,0 +1,302 @@
+"""SCF driver glue around the device hot path (host mirror of src/scf/*.jl, src/occupation.jl).
+
+``self_consistent_field`` (self_consistent_field.jl:164-289) with ``ScfAndersonDensitySolver``
+(scf_solvers.jl:68-102, anderson.jl:36-130), simple mixing (what ``LdosMixing`` reduces to at
+T = 0, chi0models.jl:32, mixing.jl:264-266), ``AdaptiveDiagtol`` (scf_callbacks.jl:191-212),
+``AdaptiveBands`` (nbands_algorithm.jl:52-110), ``next_density`` (:80-129) and the Fermi-level
+search (occupation.jl:53-211; None / Fermi-Dirac / Gaussian smearing).  Everything cube- or
+block-sized stays in HBM; the host only sees eigenvalues, occupations and scalars.
+"""
+from __future__ import annotations
+
+import math
+import time
+
+import numpy as np
+import torch
+from scipy.special import erfc
+
+from .densities import compute_density
+from .eigen import diagonalize_all_kblocks, lobpcg_hyper
+from .terms import energy_hamiltonian, guess_density
+
+EPS = float(np.finfo(np.float64).eps)
+
+
+# ---------------------------------------------------------------------------------- occupations
+def _smear(kind, x):
+    if kind == "none":
+        return np.where(x > 0, 0.0, 1.0)
+    if kind == "fermi_dirac":      # Smearing.jl:66-76 (overflow-safe form)
+        out = np.empty_like(x)
+        pos = x > 0
+        y = np.exp(-x[pos])
+        out[pos] = y / (1 + y)
+        out[~pos] = 1 / (1 + np.exp(x[~pos]))
+        return out
+    if kind == "gaussian":
+        return erfc(x) / 2
+    raise NotImplementedError(f"smearing {kind}")
+
+
+def _occupations(model, eigenvalues, eF):
+    T = model.temperature
+    out = []
+    for ek in eigenvalues:
+        ek = np.asarray(ek, dtype=float)
+        x = np.where(ek > eF, np.inf, -np.inf) if T == 0 else (ek - eF) / T
+        out.append(model.filled_occupation * _smear(model.smearing if T > 0 else "none", x))
+    return out
+
+
+def compute_occupation(basis, eigenvalues, tol_n_elec: float = 1e-6):
+    """occupation.jl:53-132,160-211.  ``eigenvalues`` are this rank's k-points; the electron count
+    is reduced over ``comm_kpts`` (weighted_ksum, PlaneWaveBasis.jl:509-512)."""
+    model, comm = basis.model, basis.comm_kpts
+    kw = np.asarray(basis.kweights)
+
+    def excess(eF):
+        occ = _occupations(model, eigenvalues, eF)
+        return comm.sum_scalar(float(sum(w * o.sum() for w, o in zip(kw, occ)))) - model.n_electrons
+
+    n_fill = -(-model.n_electrons // (model.n_spin_components * model.filled_occupation))
+    homo = comm.max_scalar(max(float(e[n_fill - 1]) for e in eigenvalues))
+    lumo_local = min((float(np.min(e[n_fill:])) if len(e) > n_fill else math.inf) for e in eigenvalues)
+    lumo = -comm.max_scalar(-lumo_local)
+    eF = homo + 1 if lumo == math.inf else (homo + lumo) / 2           # guess_fermi_level_intocc_
+    if model.temperature == 0:
+        if abs(excess(eF)) > tol_n_elec:
+            raise RuntimeError("Unable to find non-fractional occupations that have the correct number of "
+                               "electrons. You should add a temperature.")
+    elif abs(excess(eF)) >= tol_n_elec / 10:                           # FermiBisection (:99-132)
+        if excess(eF) < 0:
+            lo, hi = eF, comm.max_scalar(max(float(np.max(e)) for e in eigenvalues)) + 1
+        else:
+            lo, hi = -comm.max_scalar(-min(float(np.min(e)) for e in eigenvalues)) - 1, eF
+        for _ in range(200):
+            mid = 0.5 * (lo + hi)
+            if mid == lo or mid == hi:
+                break
+            if excess(mid) < 0:
+                lo = mid
+            else:
+                hi = mid
+        eF = 0.5 * (lo + hi)
+    return _occupations(model, eigenvalues, eF), eF
+
+
+# ---------------------------------------------------------------------------------- band counts
+def default_n_bands(model, temperature_factor=1.05):
+    min_n = -(-model.n_electrons // (model.n_spin_components * model.filled_occupation))
+    return int(math.ceil(min_n * (1.0 if model.temperature == 0 else temperature_factor)))
+
+
+class AdaptiveBands:
+    """nbands_algorithm.jl:52-110."""
+
+    def __init__(self, model, n_bands_converge=None, occupation_threshold=1e-6, gap_min=1e-2):
+        self.n_bands_converge = default_n_bands(model, 1.05) if n_bands_converge is None else int(n_bands_converge)
+        self.n_bands_compute = max(3 + self.n_bands_converge, default_n_bands(model, 1.20))
+        self.occupation_threshold = occupation_threshold
+        self.gap_min = gap_min
+
+    def determine_n_bands(self, occupation, eigenvalues, psi):
+        n_psi = max(p.shape[0] for p in psi) if psi is not None else 0
+        if occupation is None:
+            return (self.n_bands_converge + self.n_bands_compute) // 2, max(self.n_bands_compute, n_psi)
+        n_occ = 0
+        for occk in occupation:
+            idx = np.nonzero(np.abs(occk) >= self.occupation_threshold)[0]
+            n_occ = max(n_occ, int(idx[-1]) + 1 if len(idx) else len(occk) + 1)
+        n_conv = max(self.n_bands_converge, n_occ)
+        n_eps = 0
+        if eigenvalues is not None:
+            for ek in eigenvalues:
+                if n_conv > len(ek):
+                    n_eps = max(n_eps, len(ek) + 1)
+                    continue
+                idx = np.nonzero(ek <= ek[n_conv - 1] + self.gap_min)[0]
+                n_eps = max(n_eps, int(idx[-1]) + 1 if len(idx) else len(ek) + 1)
+        return n_conv, max(self.n_bands_compute, n_eps, n_conv + 3, n_psi)
+
+
+class FixedBands:
+    """nbands_algorithm.jl:21-37."""
+
+    def __init__(self, n_bands_converge, n_bands_compute=None, occupation_threshold=1e-6):
+        self.n_bands_converge = n_bands_converge
+        self.n_bands_compute = n_bands_compute if n_bands_compute is not None else n_bands_converge + 3
+        self.occupation_threshold = occupation_threshold
+
+    def determine_n_bands(self, occupation, eigenvalues, psi):
+        return self.n_bands_converge, self.n_bands_compute
+
+
+def next_density(ham, nbandsalg, eigensolver=lobpcg_hyper, psi=None, eigenvalues=None, occupation=None,
+                 tol=1e-6, generator=None, seed=0):
+    """self_consistent_field.jl:80-129."""
+    basis = ham[0].basis
+    n_conv, n_comp = nbandsalg.determine_n_bands(occupation, eigenvalues, psi)
+    if psi is not None:
+        n_comp = max(n_comp, max(p.shape[0] for p in psi))
+    n_comp = int(basis.comm_kpts.max_scalar(n_comp))                       # mpi_max(n_bands_compute)
+    eig = diagonalize_all_kblocks(eigensolver, ham, n_comp, psiguess=psi, n_conv_check=n_conv, tol=tol,
+                                  miniter=1, generator=generator, seed=seed)
+    occ, eF = compute_occupation(basis, eig["λ"], tol_n_elec=nbandsalg.occupation_threshold)
+    rho = compute_density(basis, eig["X"], occ, nbandsalg.occupation_threshold)
+    n_matvec = int(basis.comm_kpts.sum_scalar(eig["n_matvec"]))
+    return dict(psi=eig["X"], eigenvalues=eig["λ"], occupation=occ, eF=eF, rho=rho, diagonalization=eig,
+                n_bands_converge=n_conv, n_matvec=n_matvec)
+
+
+# ---------------------------------------------------------------------------------- Anderson
+class AndersonAcceleration:
+    """anderson.jl:36-130.  The history (<= m cube-sized vectors) stays in HBM; the m x m
+    least-squares problem min |Pf_n + M beta| is solved on the host from the Gram matrix
+    M'M (cond(R)^2 = cond(M'M) gives the reference's conditioning test on the QR factor)."""
+
+    def __init__(self, m=10, maxcond=1e6, errorfactor=1e5):
+        self.iterates, self.residuals, self.errors = [], [], []
+        self.m, self.maxcond, self.errorfactor = m, maxcond, errorfactor
+
+    def _push(self, x, r):
+        self.iterates.append(x.reshape(-1).clone())
+        self.residuals.append(r.reshape(-1).clone())
+        self.errors.append(float(torch.linalg.norm(r).item()))
+        if len(self.iterates) > self.m:
+            self._delete([0])
+
+    def _delete(self, idxs):
+        for i in sorted(idxs, reverse=True):
+            for lst in (self.iterates, self.residuals, self.errors):
+                lst.pop(i)
+
+    def __call__(self, x, alpha, Pfx):
+        if self.m == 0:
+            return x + alpha * Pfx
+        if not self.iterates:
+            self._push(x, Pfx)
+            return x + alpha * Pfx
+        err_n = float(torch.linalg.norm(Pfx).item())
+        min_error = min(self.errors + [err_n])
+        drop = [i for i, e in enumerate(self.errors[:-1]) if e > self.errorfactor * min_error]
+        if drop:
+            self._delete(drop)
+        pf = Pfx.reshape(-1)
+        while True:
+            Mmat = torch.stack(self.residuals, dim=0) - pf[None, :]          # (m, N): rows M[:, j]
+            G = (Mmat @ Mmat.T).cpu().numpy()
+            b = (Mmat @ pf).cpu().numpy()
+            ev = np.linalg.eigvalsh(G)
+            cond_R = math.sqrt(max(ev[-1], 0.0) / max(ev[0], 1e-300)) if ev[-1] > 0 else 1.0
+            if Mmat.shape[0] > 1 and cond_R > self.maxcond:
+                self._delete([int(np.argmax(self.errors[:-1]))])
+                continue
+            break
+        betas = -np.linalg.lstsq(G, b, rcond=None)[0]
+        xn = x.reshape(-1) + alpha * pf
+        for ib, beta in enumerate(betas):
+            xn = xn + float(beta) * (self.iterates[ib] - x.reshape(-1) + alpha * (self.residuals[ib] - pf))
+        self._push(x, Pfx)
+        return xn.reshape(x.shape)
+
+
+def determine_diagtol(n_iter, history_drho, ratio=0.2, diagtol_max=0.005, diagtol_first=None):
+    """AdaptiveDiagtol (scf_callbacks.jl:191-212)."""
+    if diagtol_first is None:
+        diagtol_first = 6 * diagtol_max
+    if n_iter <= 1:
+        return min(diagtol_first, 5 * diagtol_max)
+    return float(np.clip(min(history_drho) * ratio, 100 * EPS, diagtol_max))
+
+
+class ScfStepper:
+    """One object = the state of ``self_consistent_field`` between fixed-point iterations
+    (``fixpoint_map`` + ``ScfAndersonDensitySolver`` step, self_consistent_field.jl:200-257,
+    scf_solvers.jl:85-98).  ``step()`` performs exactly one SCF iteration."""
+
+    def __init__(self, basis, rho=None, psi=None, tol=1e-6, damping=0.8, nbandsalg=None, is_converged=None,
+                 eigensolver=lobpcg_hyper, anderson_m=10, seed=0, determine_tol=determine_diagtol):
+        basis._require_gpu()
+        self.basis = basis
+        self.gen = torch.Generator(device=basis.device)
+        self.gen.manual_seed(seed + 7919 * basis.comm_kpts.rank)
+        self.seed = seed
+        self.rho_in = guess_density(basis) if rho is None else rho
+        self.nbandsalg = nbandsalg if nbandsalg is not None else AdaptiveBands(basis.model)
+        self.is_converged = is_converged or (lambda info: info["history_drho"][-1] < tol)   # ScfConvergenceDensity
+        self.eigensolver, self.damping, self.determine_tol = eigensolver, damping, determine_tol
+        self.accel = AndersonAcceleration(m=anderson_m)
+        self.sqrt_dvol = math.sqrt(basis.dvol)
+        self.info = dict(psi=psi, occupation=None, eigenvalues=None, eF=None, n_iter=0, n_matvec=0, converged=False,
+                         history_Etot=[], history_drho=[], rho=self.rho_in, timings=[])
+
+    def step(self):
+        basis, info = self.basis, self.info
+        t_it = time.time()
+        _, ham = energy_hamiltonian(basis, info["psi"], info["occupation"], rho=self.rho_in)
+        diagtol = self.determine_tol(info["n_iter"], info["history_drho"])
+        nxt = next_density(ham, self.nbandsalg, self.eigensolver, psi=info["psi"], eigenvalues=info["eigenvalues"],
+                           occupation=info["occupation"], tol=diagtol, generator=self.gen, seed=self.seed)
+        energies, _ = energy_hamiltonian(basis, nxt["psi"], nxt["occupation"], rho=nxt["rho"], only_energies=True)
+        drho = nxt["rho"] - self.rho_in
+        n_matvec_total = info["n_matvec"] + nxt["n_matvec"]
+        info = dict(info, **nxt)
+        info.update(n_iter=info["n_iter"] + 1, n_matvec=n_matvec_total, n_matvec_step=nxt["n_matvec"],
+                    energies=energies, ham=ham, rho_in=self.rho_in, diagtol=diagtol,
+                    history_Etot=info["history_Etot"] + [energies.total],
+                    history_drho=info["history_drho"] + [float(torch.linalg.norm(drho).item()) * self.sqrt_dvol])
+        info["converged"] = bool(self.is_converged(info))
+        info["timings"] = info["timings"] + [time.time() - t_it]
+        if not info["converged"]:
+            # rho_next = Anderson(rho_in, beta, rho_out - rho_in); simple mixing: P^-1 = 1
+            self.rho_in = self.accel(self.rho_in, self.damping, drho)
+        self.info = info
+        return info
+
+    def finalize(self):
+        info = self.info
+        energies, ham = energy_hamiltonian(self.basis, info["psi"], info["occupation"], rho=info["rho"])
+        info.update(energies=energies, ham=ham)
+        return info
+
+
+def self_consistent_field(basis, rho=None, psi=None, tol=1e-6, maxiter=100, damping=0.8, nbandsalg=None,
+                          is_converged=None, callback=None, eigensolver=lobpcg_hyper, anderson_m=10, seed=0,
+                          determine_tol=determine_diagtol):
+    """``self_consistent_field(basis; rho, psi, tol, maxiter, damping, nbandsalg, is_converged, callback,
+    eigensolver)`` (self_consistent_field.jl:164-289)."""
+    t0 = time.time()
+    stepper = ScfStepper(basis, rho=rho, psi=psi, tol=tol, damping=damping, nbandsalg=nbandsalg,
+                         is_converged=is_converged, eigensolver=eigensolver, anderson_m=anderson_m, seed=seed,
+                         determine_tol=determine_tol)
+    for _ in range(maxiter):
+        info = stepper.step()
+        if callback is not None:
+            callback(info)
+        if info["converged"]:
+            break
+    info = stepper.finalize()
+    info["runtime"] = time.time() - t0
+    return info
+
+
+class ScfDefaultCallback:
+    """scf_callbacks.jl:30-124 (table of n, Energy, log10 dE, log10 drho, Diag, dtime)."""
+
+    def __init__(self, stream=None):
+        self.prev_E = None
+        self.stream = stream
+
+    def __call__(self, info):
+        import sys
+        out = self.stream or sys.stdout
+        if info["n_iter"] == 1:
+            print("n     Energy            log10(ΔE)   log10(Δρ)   Diag   Δtime", file=out)
+            print("---   ---------------   ---------   ---------   ----   ------", file=out)
+        E = info["energies"].total
+        dE = "         " if self.prev_E is None else f"{math.log10(abs(E - self.prev_E) + 1e-300):9.2f}"
+        self.prev_E = E
+        diag = float(np.mean(info["diagonalization"]["n_iter"]))
+        print(f"{info['n_iter']:3d}   {E:+15.12f}   {dE}   {math.log10(info['history_drho'][-1] + 1e-300):9.2f}   "
+              f"{diag:4.1f}   {info['timings'][-1]:6.2f}s", file=out, flush=True)

@@ -1,0 +1,379 @@
+"""Energy terms -> operators, on the device (host mirror of src/terms/*.jl for the hot path).
+
+Set-up (once per basis): kinetic multipliers (kinetic.jl:31-35), V_loc(r) (local.jl:108-138), the
+Kleinman-Bylander projector matrix P and coupling D (nonlocal.jl:107-141,166-244), the Poisson
+kernel (hartree.jl:29-45), Ewald (ewald.jl:64-168) and pseudopotential-correction
+(psp_correction.jl:26-32) energies, Gaussian guess density (density_methods.jl).
+Per SCF step: ``energy_hamiltonian`` (Hamiltonian.jl:200-236) builds V = V_loc + V_H + V_xc on
+the cube (hand-written cube FFTs of the library + torch elementwise ops) and hands it to each
+k-block; LDA exchange-correlation uses closed forms (Slater, VWN5, PW92).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+from scipy.special import erfc
+
+from . import _lib
+from .hamiltonian import DftHamiltonianBlock
+from .psp import (eval_psp_energy_correction, eval_psp_local_fourier, eval_psp_projector_fourier,
+                  solid_harmonic_real)
+
+TWO_PI = 2 * math.pi
+
+
+def _structure_factor_cube(basis, r):
+    """e^{-2 pi i G.r} on the cube as an outer product of three 1-D phase vectors."""
+    from .basis import G_axis
+    nx, ny, nz = basis.fft_size
+    dev = basis.device
+    px = torch.exp(-1j * TWO_PI * r[0] * torch.tensor(G_axis(nx), dtype=torch.float64, device=dev))
+    py = torch.exp(-1j * TWO_PI * r[1] * torch.tensor(G_axis(ny), dtype=torch.float64, device=dev))
+    pz = torch.exp(-1j * TWO_PI * r[2] * torch.tensor(G_axis(nz), dtype=torch.float64, device=dev))
+    return pz[:, None, None] * py[None, :, None] * px[None, None, :]
+
+
+def compute_local_potential(basis):
+    """local.jl:108-138."""
+    model = basis.model
+    Gnorm = torch.linalg.norm(basis.G_vectors_cart_cube(), dim=-1)
+    pot = torch.zeros(Gnorm.shape, dtype=torch.complex128, device=basis.device)
+    for group in model.atom_groups:
+        ff = eval_psp_local_fourier(model.atoms[group[0]].psp, Gnorm) / math.sqrt(model.unit_cell_volume)
+        sf = torch.zeros_like(pot)
+        for ia in group:
+            sf += _structure_factor_cube(basis, model.positions[ia])
+        pot += sf * ff
+    pot = pot * basis.enforce_real_mask()
+    return basis.irfft(pot)
+
+
+def build_projector_form_factors(psp, Gpk_cart):
+    """nonlocal.jl:205-244; rows ordered (l, m, i): offset_l + n_proj_l (m + l) + i."""
+    n_G = Gpk_cart.shape[0]
+    pnorm = torch.linalg.norm(Gpk_cart, dim=1)
+    out = torch.zeros((psp.count_n_proj(), n_G), dtype=torch.complex128, device=Gpk_cart.device)
+    for l in range(psp.lmax + 1):
+        n_l = psp.count_n_proj_radial(l)
+        off = sum(psp.count_n_proj(ll) for ll in range(l))
+        for i in range(1, n_l + 1):
+            radial = eval_psp_projector_fourier(psp, i, l, pnorm)
+            for m in range(-l, l + 1):
+                out[off + n_l * (m + l) + (i - 1)] = radial * ((-1j) ** l) * solid_harmonic_real(l, m, Gpk_cart)
+    return out      # (n_proj_psp, n_G)
+
+
+def build_projection_vectors(basis, kpt):
+    """nonlocal.jl:166-199.  Returns P as a (n_p, n_G) tensor == column-major n_G x n_p."""
+    model = basis.model
+    Gpk = (kpt.G_vectors.to(torch.float64)
+           + torch.tensor(kpt.coordinate, dtype=torch.float64, device=basis.device)[None, :])
+    rows = []
+    for group in model.atom_groups:
+        psp = model.atoms[group[0]].psp
+        if psp.count_n_proj() == 0:
+            continue
+        ff = build_projector_form_factors(psp, kpt.Gplusk_cart) / math.sqrt(model.unit_cell_volume)
+        for ia in group:
+            r = torch.tensor(model.positions[ia], dtype=torch.float64, device=basis.device)
+            sf = torch.exp(-1j * TWO_PI * (Gpk @ r))
+            rows.append(ff * sf[None, :])
+    if not rows:
+        return None
+    return torch.cat(rows, dim=0).contiguous()
+
+
+def build_projection_coefficients(model):
+    """Dense block-diagonal D (nonlocal.jl:107-141), numpy on the host."""
+    blocks = []
+    for group in model.atom_groups:
+        psp = model.atoms[group[0]].psp
+        n = psp.count_n_proj()
+        Dp = np.zeros((n, n))
+        c = 0
+        for l in range(psp.lmax + 1):
+            for _m in range(-l, l + 1):
+                nl = psp.count_n_proj_radial(l)
+                Dp[c:c + nl, c:c + nl] = psp.h[l]
+                c += nl
+        blocks += [Dp] * len(group)
+    n = sum(b.shape[0] for b in blocks)
+    D = np.zeros((n, n))
+    c = 0
+    for b in blocks:
+        D[c:c + b.shape[0], c:c + b.shape[0]] = b
+        c += b.shape[0]
+    return D
+
+
+def compute_poisson_green_coeffs(basis):
+    """hartree.jl:29-45."""
+    Gc = basis.G_vectors_cart_cube()
+    G2 = (Gc * Gc).sum(dim=-1)
+    G2[0, 0, 0] = 1.0
+    coeffs = 4 * math.pi / G2
+    coeffs[0, 0, 0] = 0.0
+    return coeffs * basis.enforce_real_mask()
+
+
+def energy_ewald(lattice, charges, positions, eta=None):
+    """ewald.jl:64-168, energy only (host, numpy + scipy.erfc)."""
+    from .basis import estimate_integer_lattice_bounds
+    lattice = np.asarray(lattice, dtype=float)
+    q = np.asarray(charges, dtype=float)
+    pos = np.asarray(positions, dtype=float).reshape(-1, 3)
+    if q.size == 0:
+        return 0.0
+    recip = TWO_PI * np.linalg.inv(lattice.T)
+    if eta is None:   # default_eta, ewald.jl:40-44
+        eta = math.sqrt(math.sqrt(1.69 * np.linalg.norm(recip / TWO_PI) / np.linalg.norm(lattice))) / 2
+    max_exp = -math.log(np.finfo(float).eps) + 5
+    max_erfc = math.sqrt(max_exp)
+    Glims = estimate_integer_lattice_bounds(recip, math.sqrt(max_exp) * 2 * eta)
+    poslims = [float(np.max(pos[:, i][:, None] - pos[:, i][None, :])) for i in range(3)]
+    Rlims = estimate_integer_lattice_bounds(lattice, max_erfc / eta, poslims)
+    vol = abs(np.linalg.det(lattice))
+    # reciprocal part
+    rng = [np.arange(-g, g + 1) for g in Glims]
+    G = np.stack(np.meshgrid(*rng, indexing="ij"), axis=-1).reshape(-1, 3)
+    G = G[np.any(G != 0, axis=1)]
+    Gsq = np.sum((G @ recip.T) ** 2, axis=1)
+    sel = Gsq / (4 * eta ** 2) < max_exp + 40
+    G, Gsq = G[sel], Gsq[sel]
+    s_recip = -(q.sum() ** 2) / (4 * eta ** 2)
+    for c0 in range(0, len(G), 32768):
+        ph = TWO_PI * (G[c0:c0 + 32768] @ pos.T)
+        sf2 = (np.cos(ph) @ q) ** 2 + (np.sin(ph) @ q) ** 2
+        s_recip += float(np.sum(sf2 * np.exp(-Gsq[c0:c0 + 32768] / (4 * eta ** 2)) / Gsq[c0:c0 + 32768]))
+    s_recip *= 4 * math.pi / vol
+    # real-space part
+    s_real = -2 * eta / math.sqrt(math.pi) * float(np.sum(q * q))
+    rr = [np.arange(-g, g + 1) for g in Rlims]
+    R = np.stack(np.meshgrid(*rr, indexing="ij"), axis=-1).reshape(-1, 3).astype(float)
+    qq = q[:, None] * q[None, :]
+    n = len(q)
+    eye = np.eye(n, dtype=bool)
+    for Rv in R:
+        d = (pos[:, None, :] - pos[None, :, :] - Rv[None, None, :]) @ lattice.T
+        dist = np.linalg.norm(d, axis=-1)
+        if not Rv.any():
+            dist = np.where(eye, np.inf, dist)
+        m = dist * eta < max_erfc + 8
+        if m.any():
+            s_real += float(np.sum(qq[m] * erfc(eta * dist[m]) / dist[m]))
+    return (s_recip + s_real) / 2
+
+
+def energy_psp_correction(model):
+    """psp_correction.jl:26-32."""
+    corr = sum(len(g) * eval_psp_energy_correction(model.atoms[g[0]].psp) for g in model.atom_groups)
+    return corr * sum(a.charge_ionic for a in model.atoms) / model.unit_cell_volume
+
+
+# ---------------------------------------------------------------------------------- XC, closed forms
+def _lda_x(rho):
+    cx = -0.75 * (3 / math.pi) ** (1 / 3)
+    r13 = rho ** (1 / 3)
+    return cx * rho * r13, (4 / 3) * cx * r13
+
+
+def _lda_c_vwn(rho):
+    A, b, c, x0 = 0.0310907, 3.72744, 12.9352, -0.10498
+    rs = (3 / (4 * math.pi * rho)) ** (1 / 3)
+    x = torch.sqrt(rs)
+    X = x * x + b * x + c
+    X0 = x0 * x0 + b * x0 + c
+    Q = math.sqrt(4 * c - b * b)
+    at = torch.atan(Q / (2 * x + b))
+    eps = A * (torch.log(x * x / X) + 2 * b / Q * at
+               - b * x0 / X0 * (torch.log((x - x0) ** 2 / X) + 2 * (b + 2 * x0) / Q * at))
+    dat = -2 * Q / (Q * Q + (2 * x + b) ** 2)
+    deps_dx = A * (2 / x - (2 * x + b) / X + 2 * b / Q * dat
+                   - b * x0 / X0 * (2 / (x - x0) - (2 * x + b) / X + 2 * (b + 2 * x0) / Q * dat))
+    return rho * eps, eps - rs / 3 * deps_dx / (2 * x)
+
+
+def _lda_c_pw(rho):
+    a, a1, b1, b2, b3, b4 = 0.031091, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294
+    rs = (3 / (4 * math.pi * rho)) ** (1 / 3)
+    sq = torch.sqrt(rs)
+    den = 2 * a * (b1 * sq + b2 * rs + b3 * rs * sq + b4 * rs * rs)
+    lg = torch.log1p(1 / den)
+    eps = -2 * a * (1 + a1 * rs) * lg
+    dden = 2 * a * (b1 / (2 * sq) + b2 + 1.5 * b3 * sq + 2 * b4 * rs)
+    deps = -2 * a * a1 * lg + 2 * a * (1 + a1 * rs) * dden / (den * den + den)
+    return rho * eps, eps - rs / 3 * deps
+
+
+_FUNCTIONALS = {"lda_x": _lda_x, "lda_c_vwn": _lda_c_vwn, "lda_c_pw": _lda_c_pw}
+
+
+def xc_energy_potential(basis, rho):
+    """LDA branch of xc_potential_real (xc.jl:84-160): E = sum e dvol, V = de/drho."""
+    rc = torch.clamp(rho, min=1e-300)
+    e = torch.zeros_like(rho)
+    v = torch.zeros_like(rho)
+    for name in basis.model.functionals:
+        if name not in _FUNCTIONALS:
+            raise NotImplementedError(f"XC functional {name}: only LDA (lda_x, lda_c_vwn, lda_c_pw) on this path")
+        ei, vi = _FUNCTIONALS[name](rc)
+        e += ei
+        v += vi
+    tiny = rho <= 1e-300
+    e = torch.where(tiny, torch.zeros_like(e), e)
+    v = torch.where(tiny, torch.zeros_like(v), v)
+    return float(e.sum().item() * basis.dvol), v
+
+
+# ---------------------------------------------------------------------------------- guess density
+_DECAY = [(0.5, [0.6, 0.4, 0.3, 0.25, 0.2]),
+          (2.5, [1.8, 1.4, 1.0, 0.7, 0.6, 0.5, 0.4, 0.35, 0.3]),
+          (10.5, [2.0, 1.6, 1.25, 1.1, 1.0, 0.9, 0.8, 0.7, 0.7, 0.7, 0.6]),
+          (12.5, [1.9, 1.5, 1.15, 1.0, 0.9, 0.8, 0.7, 0.6, 0.6, 0.6, 0.5]),
+          (18.5, [2.0, 1.8, 1.5, 1.2, 1.0, 0.9, 0.85, 0.8, 0.75, 0.7, 0.65, 0.65, 0.6]),
+          (28.5, [1.5, 1.25, 1.15, 1.05, 1.00, 0.95, 0.95, 0.9, 0.9, 0.85, 0.85, 0.80, 0.8, 0.75, 0.7]),
+          (36.5, [2.0, 2.00, 1.60, 1.40, 1.25, 1.10, 1.00, 0.95, 0.90, 0.85, 0.80, 0.75, 0.7]),
+          (math.inf, [2.0, 2.00, 1.55, 1.25, 1.15, 1.10, 1.05, 1.0, 0.95, 0.9, 0.85, 0.85, 0.8])]
+
+
+def atom_decay_length(n_core, n_val):
+    """ABINIT table (density_methods.jl:286-322)."""
+    n_val = int(round(n_val))
+    if n_val == 0:
+        return 0.0
+    for bound, data in _DECAY:
+        if n_core < bound:
+            return data[min(n_val, len(data)) - 1]
+    raise AssertionError
+
+
+def guess_density(basis):
+    """``guess_density(basis, ValenceDensityGaussian())`` (density_methods.jl:111-125,158-181,236-244)."""
+    model = basis.model
+    Gnorm = torch.linalg.norm(basis.G_vectors_cart_cube(), dim=-1)
+    rho_G = torch.zeros(Gnorm.shape, dtype=torch.complex128, device=basis.device)
+    for group in model.atom_groups:
+        el = model.atoms[group[0]]
+        ff = el.charge_ionic * torch.exp(-(Gnorm * atom_decay_length(el.n_elec_core, el.charge_ionic)) ** 2)
+        sf = torch.zeros_like(rho_G)
+        for ia in group:
+            sf += _structure_factor_cube(basis, model.positions[ia])
+        rho_G += sf * ff / math.sqrt(model.unit_cell_volume)
+    rho = basis.irfft(rho_G * basis.enforce_real_mask())
+    N = float(rho.sum().item()) * model.unit_cell_volume / basis.N
+    if N > 0:
+        rho = rho * (model.n_electrons / N)
+    return rho
+
+
+# ---------------------------------------------------------------------------------- containers
+class Terms:
+    """What ``basis.terms`` holds after PlaneWaveBasis.jl:256-259."""
+
+
+def instantiate_terms(basis):
+    model = basis.model
+    T = Terms()
+    T.names = list(model.term_types)
+    T.kinetic = [k.kinetic for k in basis.kpoints] if "Kinetic" in T.names else None
+    T.P, T.D = None, None
+    if "AtomicNonlocal" in T.names:
+        P = [build_projection_vectors(basis, k) for k in basis.kpoints]
+        if P and P[0] is not None:
+            T.P, T.D = P, build_projection_coefficients(model)
+    T.E_ewald = (energy_ewald(model.lattice, [a.charge_ionic for a in model.atoms], model.positions)
+                 if "Ewald" in T.names else None)
+    T.E_pspcorr = energy_psp_correction(model) if "PspCorrection" in T.names else None
+    # terms that need cube FFTs can only be instantiated with the device library
+    T.V_loc = T.poisson = None
+    if basis.handle is not None:
+        if "AtomicLocal" in T.names:
+            T.V_loc = compute_local_potential(basis)
+        if "Hartree" in T.names:
+            T.poisson = compute_poisson_green_coeffs(basis)
+        for ik, kpt in enumerate(basis.kpoints):
+            if T.P is not None:
+                Dh = np.asfortranarray(T.D)
+                kpt._keep["D"] = Dh
+                torch.cuda.current_stream(basis.device).synchronize()
+                _lib.check(basis.lib.dftk_mi_kblock_set_projectors(kpt.handle, T.P[ik].shape[0],
+                                                                   T.P[ik].data_ptr(), kpt.n_G, Dh.ctypes.data))
+    return T
+
+
+def _PH_psi(basis, Pt, psik):
+    """P' psi through the library's f64-MFMA zgemm; returns a (n_bands, n_p) tensor."""
+    n_p, n_G = Pt.shape
+    nb = psik.shape[0]
+    out = torch.empty((nb, n_p), dtype=torch.complex128, device=basis.device)
+    torch.cuda.current_stream(basis.device).synchronize()
+    _lib.check(basis.lib.dftk_mi_zgemm(basis.handle, b"C", n_p, nb, n_G, _lib.cplx(1.0), Pt.data_ptr(), Pt.stride(0),
+                                       psik.data_ptr(), psik.stride(0), _lib.cplx(0.0), out.data_ptr(), n_p))
+    basis.sync()
+    return out
+
+
+class Energies(dict):
+    @property
+    def total(self):
+        return float(sum(self.values()))
+
+
+def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False):
+    """``energy_hamiltonian(basis, psi, occupation; rho)`` (Hamiltonian.jl:200-227); with
+    ``only_energies`` it is ``energy(...)`` (:232-236).  Returns (Energies, [DftHamiltonianBlock])."""
+    basis._require_gpu()
+    T = basis.terms
+    E = Energies()
+    pot = None
+    have_psi = psi is not None and occupation is not None
+    for name in T.names:
+        if name == "Kinetic":
+            if have_psi:
+                e = 0.0
+                for ik, psik in enumerate(psi):
+                    dots = (psik.real ** 2 + psik.imag ** 2) @ T.kinetic[ik]      # (n_bands,)
+                    occ = torch.as_tensor(occupation[ik], dtype=torch.float64, device=basis.device)
+                    e += basis.kweights[ik] * float((occ * dots).sum().item())
+                E[name] = basis.comm_kpts.sum_scalar(e)
+            else:
+                E[name] = math.inf
+        elif name == "AtomicLocal":
+            pot = T.V_loc.clone() if pot is None else pot + T.V_loc
+            E[name] = float((rho * T.V_loc).sum().item() * basis.dvol) if rho is not None else math.inf
+        elif name == "AtomicNonlocal":
+            if T.P is None:
+                E[name] = 0.0
+            elif have_psi:
+                e = 0.0
+                Dd = torch.as_tensor(T.D, dtype=torch.complex128, device=basis.device)
+                for ik, psik in enumerate(psi):
+                    Ppsi = _PH_psi(basis, T.P[ik], psik)           # (n_bands, n_p) rows = (P' psi)[:, band]
+                    band = (torch.conj(Ppsi) * (Ppsi @ Dd.T)).real.sum(dim=1)
+                    occ = torch.as_tensor(occupation[ik], dtype=torch.float64, device=basis.device)
+                    e += basis.kweights[ik] * float((band * occ).sum().item())
+                E[name] = basis.comm_kpts.sum_scalar(e)
+            else:
+                E[name] = math.inf
+        elif name == "Ewald":
+            E[name] = T.E_ewald
+        elif name == "PspCorrection":
+            E[name] = T.E_pspcorr
+        elif name == "Hartree":
+            rho_G = basis.fft(rho)
+            pot_G = T.poisson * rho_G
+            vh = basis.irfft(pot_G)
+            pot = vh if pot is None else pot + vh
+            E[name] = float(torch.vdot(pot_G.reshape(-1), rho_G.reshape(-1)).real.item()) / 2
+        elif name == "Xc":
+            exc, vxc = xc_energy_potential(basis, rho)
+            pot = vxc if pot is None else pot + vxc
+            E[name] = exc
+        else:
+            raise NotImplementedError(f"term {name} is outside the MI355X hot path")
+    if only_energies:
+        return E, None
+    ham = [DftHamiltonianBlock(basis, kpt, pot) for kpt in basis.kpoints]
+    return E, ham

@@ -1,0 +1,167 @@
+/* dftk_mi355x.h -- C ABI of the MI355X-native plane-wave Kohn-Sham hot path.
+ *
+ * Drop-in boundary for DFTK.jl's SCF hot path.  The reference has no
+ * FFI; its seams are Julia-level (the `architecture` kwarg, `HamiltonianBlock` + `mul!`, the
+ * `eigensolver=` kwarg of `self_consistent_field`, `compute_density`).  Each entry point below
+ * names the reference function it replaces (file:line under the DFTK.jl checkout); the Julia
+ * `ccall` shim a maintainer would add is in INTEGRATION.md, the Python (ctypes) binding used
+ * by this repo's host mirror is dftk.jl_amd/_lib.py.
+ *
+ * Conventions
+ *  - complex = interleaved (re, im) IEEE fp64 (`dftk_mi_cplx`, 16 B); all arithmetic is fp64.
+ *  - matrices are column-major with an explicit leading dimension counted in elements;
+ *    orbital blocks psi are n_G x n_bands (one column per band), as in DFTK.
+ *  - cubes are (nx, ny, nz) with x fastest: linear index i = ix + nx*(iy + ny*iz) -- exactly
+ *    Julia's column-major linear index minus one.  `mapping0` is that 0-based index.
+ *  - pointers suffixed `_h` are host pointers, `_d` device pointers (same device as the basis).
+ *    Device buffers are owned by the caller; the library never frees them and only keeps the
+ *    pointers explicitly documented as "borrowed".
+ *  - every call returns an int status: 0 ok; <0 invalid argument / runtime (HIP, RCCL) error;
+ *    >0 numerical failure (non-finite values, Cholesky breakdown, eigen-solver not converged).
+ *    `dftk_mi_last_error()` gives a thread-local message for the last non-zero status.
+ *  - calls are asynchronous on the basis' HIP stream unless they return host data
+ *    (`dftk_mi_lobpcg`); `dftk_mi_basis_sync` blocks.
+ *  - no call falls back to the CPU: a missing GPU is an error (status -100).
+ */
+#ifndef DFTK_MI355X_H
+#define DFTK_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { double re, im; } dftk_mi_cplx;
+
+typedef struct dftk_mi_basis  dftk_mi_basis;   /* FFTGrid + device/stream          */
+typedef struct dftk_mi_kblock dftk_mi_kblock;  /* Kpoint + DftHamiltonianBlock     */
+typedef struct dftk_mi_comm   dftk_mi_comm;    /* comm_kpts (RCCL communicator)    */
+
+/* ---- status codes -------------------------------------------------------------------------- */
+#define DFTK_MI_OK                 0
+#define DFTK_MI_EINVAL            (-1)
+#define DFTK_MI_EHIP              (-2)
+#define DFTK_MI_ERCCL             (-3)
+#define DFTK_MI_ENOGPU            (-100)
+#define DFTK_MI_NUM_NONFINITE       1   /* NaN/Inf met (reference: @assert !any(isnan, AX))      */
+#define DFTK_MI_NUM_CHOLESKY        2   /* ortho!: Cholesky kept failing (reference: SVD fallback)*/
+#define DFTK_MI_NUM_NORMALIZATION   3   /* "LOBPCG is badly failing to keep the vectors normalized"*/
+#define DFTK_MI_NUM_EIGEN           4   /* dense Hermitian eigensolver did not converge          */
+#define DFTK_MI_NUM_TOO_SMALL       5   /* N > 3M violated (lobpcg_hyper_impl.jl:363)            */
+
+const char* dftk_mi_last_error(void);
+/* Library / build identification: "dftk_mi355x <version> gfx950 ..." */
+const char* dftk_mi_version(void);
+
+/* ---- basis: replaces FFTGrid(fft_size, unit_cell_volume, arch)  (src/fft.jl:76-98) -----------
+ * Holds the 3 one-dimensional mixed-radix plans (radices 2,3,4,5 + generic primes), twiddle
+ * tables, the HIP stream and the scratch pool.  `device` is the HIP device ordinal.          */
+int dftk_mi_basis_create(int nx, int ny, int nz, double unit_cell_volume, int device,
+                         dftk_mi_basis** basis_out);
+int dftk_mi_basis_destroy(dftk_mi_basis* basis);
+int dftk_mi_basis_sync(dftk_mi_basis* basis);              /* synchronize_device (architecture.jl) */
+/* Bands processed per FFT launch group (scratch = n * (T1 + T2) bytes); default 8. */
+int dftk_mi_basis_set_fft_batch(dftk_mi_basis* basis, int n_bands_per_batch);
+/* HIP stream used by this basis (hipStream_t as void*) -- lets the caller order its own work. */
+void* dftk_mi_basis_stream(dftk_mi_basis* basis);
+
+/* ---- k-block: replaces Kpoint(...) (src/Kpoint.jl:20-41) + DftHamiltonianBlock
+ *      (src/terms/Hamiltonian.jl:22-57).  `mapping0_h` must be ascending (as Kpoint builds it). */
+int dftk_mi_kblock_create(dftk_mi_basis* basis, int64_t n_G, const int64_t* mapping0_h,
+                          const double* kinetic_h /* n_G: fourier_op.multiplier, kinetic.jl:31-35 */,
+                          dftk_mi_kblock** kb_out);
+int dftk_mi_kblock_destroy(dftk_mi_kblock* kb);
+/* nonlocal_op (src/terms/operators.jl:119-129): P is n_G x n_p (borrowed device pointer, must
+ * outlive the k-block or the next call), D is the dense real n_p x n_p coupling matrix
+ * (nonlocal.jl:107-141) on the host; its band structure is detected and exploited. n_p = 0 clears. */
+int dftk_mi_kblock_set_projectors(dftk_mi_kblock* kb, int n_p, const dftk_mi_cplx* P_d, int64_t ldP,
+                                  const double* D_h);
+/* local_op.potential (operators.jl:71-78, :213-222): the SUM of all local terms on the cube,
+ * un-normalised (the 1/N of Hamiltonian.jl:152-153 is applied inside).  Copied. NULL clears. */
+int dftk_mi_kblock_set_potential(dftk_mi_kblock* kb, const double* V_d);
+
+/* ---- mul!(Hpsi, H::DftHamiltonianBlock, psi)  (src/terms/Hamiltonian.jl:137-192) ------------- */
+int dftk_mi_apply_H(dftk_mi_kblock* kb, int n_bands, const dftk_mi_cplx* psi_d, int64_t ld_psi,
+                    dftk_mi_cplx* Hpsi_d, int64_t ld_Hpsi);
+/* Pieces, for tests and profiling: which = 1 local (K1-K5: scatter, iFFT, V, FFT, gather),
+ * 2 kinetic (K6), 4 nonlocal (K7-K9); OR-able.  dftk_mi_apply_H == which 7. */
+int dftk_mi_apply_H_parts(dftk_mi_kblock* kb, int which, int n_bands, const dftk_mi_cplx* psi_d,
+                          int64_t ld_psi, dftk_mi_cplx* Hpsi_d, int64_t ld_Hpsi);
+
+/* ---- sphere <-> cube transforms  (src/fft.jl:110-122 ifft!, :162-172 fft!; normalize=false) --
+ * cube_d is nx*ny*nz complex, x fastest.  Test/diagnostic entry points (the hot path never
+ * materialises the full cube in the caller's layout). */
+int dftk_mi_ifft_sphere(dftk_mi_kblock* kb, const dftk_mi_cplx* c_d, dftk_mi_cplx* cube_d);
+int dftk_mi_fft_sphere(dftk_mi_kblock* kb, const dftk_mi_cplx* cube_d, dftk_mi_cplx* c_d);
+
+/* ---- compute_density inner loop (src/densities.jl:35-43) -------------------------------------
+ * rho_d[nx*ny*nz] += sum_n weight_h[n] * |BFFT(pad(psi[:,n]))|^2, weight_h[n] =
+ * occupation[n] * kweight * ifft_normalization^2 (bands with weight 0 are skipped). */
+int dftk_mi_density_accumulate(dftk_mi_kblock* kb, int n_bands, const dftk_mi_cplx* psi_d,
+                               int64_t ld_psi, const double* weight_h, double* rho_d);
+
+/* ---- lobpcg_hyper(A, X0; prec=PreconditionerTPA, tol, miniter, maxiter, n_conv_check)
+ *      (src/eigen/diag_lobpcg_hyper.jl:5-18 -> LOBPCG, src/eigen/lobpcg_hyper_impl.jl:354-582;
+ *       PreconditionerTPA src/eigen/preconditioners.jl:27-78) ----------------------------------
+ * X_d: in = guess (need not be orthonormal), out = Ritz vectors (orthonormal), n_G x M.
+ * use_tpa: 1 = TPA preconditioner from the block's kinetic vector, 0 = none.
+ * n_conv_check <= 0 means M.  seed drives the (rare) re-randomisation of null columns.
+ * Outputs (host): lambda_h[M] ascending, resid_h[M] final residual norms, *n_iter, *converged,
+ * *n_matvec (the "H psi applies" counter, lobpcg_hyper_impl.jl:377,417). */
+int dftk_mi_lobpcg(dftk_mi_kblock* kb, int M, dftk_mi_cplx* X_d, int64_t ldX, double tol,
+                   int miniter, int maxiter, int n_conv_check, int use_tpa, uint64_t seed,
+                   double* lambda_h, double* resid_h, int* n_iter, int* converged,
+                   int64_t* n_matvec);
+/* Optional: device pointer to H*X of the last dftk_mi_lobpcg call on this block (n_G x M,
+ * leading dimension n_G; valid until the next lobpcg call on the block). */
+const dftk_mi_cplx* dftk_mi_lobpcg_last_AX(dftk_mi_kblock* kb);
+
+/* ---- dense helpers exposed for tests (the LOBPCG building blocks) ----------------------------
+ * zgemm: C = alpha*op(A)*B + beta*C, op(A) = A ('N') or A^H ('C'); f64 MFMA, deterministic split-K. */
+int dftk_mi_zgemm(dftk_mi_basis* basis, char transA, int64_t m, int64_t n, int64_t k,
+                  dftk_mi_cplx alpha, const dftk_mi_cplx* A_d, int64_t lda,
+                  const dftk_mi_cplx* B_d, int64_t ldb, dftk_mi_cplx beta,
+                  dftk_mi_cplx* C_d, int64_t ldc);
+/* Hermitian eigen-decomposition (blocked parallel Jacobi): A (n x n, full storage, destroyed),
+ * W_h[n] ascending eigenvalues (host), V_d n x n eigenvectors (columns, sorted like W). */
+int dftk_mi_heev(dftk_mi_basis* basis, int n, dftk_mi_cplx* A_d, int64_t lda, double* W_h,
+                 dftk_mi_cplx* V_d, int64_t ldv);
+/* Upper Cholesky A = R^H R in place (strict lower part left untouched) + inverse of R.
+ * Returns DFTK_MI_NUM_CHOLESKY when a pivot is not positive / finite. */
+int dftk_mi_potrf_trtri(dftk_mi_basis* basis, int n, dftk_mi_cplx* A_d, int64_t lda,
+                        dftk_mi_cplx* invR_d, int64_t ldi);
+
+/* ---- comm_kpts: replaces MPI.Init / mpi_sum!(rho, comm_kpts)
+ *      (src/common/mpi.jl:19-32 at src/densities.jl:46) with RCCL over xGMI ---------------------
+ * Rank 0 calls get_unique_id and ships the 128 bytes to the other ranks by any side channel. */
+int dftk_mi_comm_get_unique_id(char id_out[128]);
+int dftk_mi_comm_init_rank(const char id[128], int n_ranks, int rank, int device,
+                           dftk_mi_comm** comm_out);
+int dftk_mi_comm_destroy(dftk_mi_comm* comm);
+/* In-place sum all-reduce of n doubles on `stream` (hipStream_t as void*, NULL = default). */
+int dftk_mi_allreduce_sum_f64(dftk_mi_comm* comm, double* buf_d, size_t n, void* stream);
+
+/* ---- per-family kernel timing with HIP events on the basis' stream (used by bench.py) ----------
+ * family: 0 zgemm (work = flops), 1..5 FFT stages A..E (work = algorithmic bytes, dense 3-pass
+ * convention of SURVEY.md section 8d), 6 density z-pass, 7 heev, 8 potrf+trtri, 9 whole apply_H
+ * (work = bands).  enable(1) resets the counters. */
+int dftk_mi_prof_enable(dftk_mi_basis* basis, int on);
+int dftk_mi_prof_get(dftk_mi_basis* basis, int family, double* total_ms, double* work, int64_t* launches);
+
+/* ---- host-only introspection (no GPU needed; used by the CPU test-suite) ---------------------
+ * 1-D plan for length n: radices (<= 32 entries) and the in-place permutation `pos[e]` such
+ * that a decimation-in-time pass wants input element e at position pos[e] and a
+ * decimation-in-frequency pass leaves output frequency k at position pos[k]. */
+int dftk_mi_fft_plan_host(int n, int* n_radices, int* radices /* [32] */, int* pos /* [n] */);
+/* Sphere pruning tables derived from a mapping: number of non-empty x-lines, number of distinct
+ * z planes, and (optionally, may be NULL) the line ids (iy + ny*iz) / first-coefficient offsets. */
+int dftk_mi_sphere_tables_host(int nx, int ny, int nz, int64_t n_G, const int64_t* mapping0_h,
+                               int64_t* n_lines, int* n_zplanes, int64_t* line_id /* [n_lines] */,
+                               int64_t* line_start /* [n_lines+1] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFTK_MI355X_H */

@@ -1,0 +1,308 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every symbol of the header, the
+host planning logic (1-D plans, sphere pruning tables) drives a NumPy emulation of the kernel
+pipeline to the exact FFT answer, the host mirror's set-up arrays equal the oracle's, the hot
+path refuses to run without a GPU, and the k-point sharding works under gloo with 2 ranks."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import dftk_jl_amd as dftk
+from dftk_jl_amd._lib import check
+
+import oracle
+from oracle.basis import G_axis
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return dftk.load_library()
+
+
+def test_library_exports_every_header_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "dftk_mi355x.h")).read()
+    names = set(re.findall(r"\b(dftk_mi_[A-Za-z0-9_]+)\s*\(", header))
+    assert names, "no prototypes found in the header"
+    for name in sorted(names):
+        assert hasattr(lib, name), f"{name} declared in include/dftk_mi355x.h but not exported"
+    assert names == set(dftk.EXPORTED_SYMBOLS), names ^ set(dftk.EXPORTED_SYMBOLS)
+    assert b"gfx950" in lib.dftk_mi_version()
+
+
+def test_no_gpu_fails_loudly(lib):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    st = lib.dftk_mi_basis_create(8, 8, 8, 1.0, 0, C.byref(h))
+    assert st == -100 and b"no CPU fallback" in lib.dftk_mi_last_error()
+    lat, atoms, pos = dftk.silicon_cell()
+    basis = dftk.PlaneWaveBasis(dftk.model_DFT(lat, atoms, pos), 5, device="cpu")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dftk.energy_hamiltonian(basis, None, None, rho=None)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dftk.compute_density(basis, [], [])
+
+
+def get_plan(lib, n):
+    nr = C.c_int()
+    rad = (C.c_int * 32)()
+    pos = (C.c_int * n)()
+    check(lib.dftk_mi_fft_plan_host(n, C.byref(nr), rad, pos))
+    return list(rad[:nr.value]), np.array(pos[:n])
+
+
+def dit(buf, n, rad, sgn):
+    """NumPy twin of fft_tile<DIF=false> (dftk.jl_amd/csrc/fft_kernels.hip)."""
+    tw = np.exp(sgn * 2j * np.pi * np.arange(n) / n)
+    m = 1
+    for r in rad:
+        out = buf.copy()
+        for b in range(n // r):
+            jj, g = b % m, b // m
+            base = g * r * m + jj
+            a = [buf[base + q * m] * tw[q * jj * (n // (r * m))] for q in range(r)]
+            for p in range(r):
+                out[base + p * m] = sum(a[q] * tw[((p * q) % r) * (n // r)] for q in range(r))
+        buf, m = out, m * r
+    return buf
+
+
+def dif(buf, n, rad, sgn):
+    """NumPy twin of fft_tile<DIF=true>."""
+    tw = np.exp(sgn * 2j * np.pi * np.arange(n) / n)
+    m = n
+    for r in reversed(rad):
+        m //= r
+        out = buf.copy()
+        for b in range(n // r):
+            jj, g = b % m, b // m
+            base = g * r * m + jj
+            a = [buf[base + q * m] for q in range(r)]
+            for p in range(r):
+                out[base + p * m] = (sum(a[q] * tw[((p * q) % r) * (n // r)] for q in range(r))
+                                     * tw[p * jj * (n // (r * m))])
+        buf = out
+    return buf
+
+
+@pytest.mark.parametrize("n", [1, 2, 8, 12, 15, 17, 21, 27, 30, 33, 36, 40, 120, 150, 192])
+def test_fft_plan_tables(lib, n):
+    rad, pos = get_plan(lib, n)
+    assert int(np.prod(rad)) == n or (n == 1 and rad == [])
+    assert sorted(pos) == list(range(n))
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    buf = np.zeros(n, complex)
+    buf[pos] = x
+    np.testing.assert_allclose(dit(buf, n, rad, +1), np.fft.ifft(x) * n, atol=1e-12 * n)
+    np.testing.assert_allclose(dif(x.copy(), n, rad, -1)[pos], np.fft.fft(x), atol=1e-12 * n)
+
+
+def test_fft_plan_rejects_large_primes(lib):
+    nr, rad, pos = C.c_int(), (C.c_int * 32)(), (C.c_int * 67)()
+    assert lib.dftk_mi_fft_plan_host(67, C.byref(nr), rad, pos) == -1
+
+
+def test_pruned_pipeline_emulation(lib):
+    """Stages A-E of the kernel pipeline, emulated with the library's own tables, reproduce
+    FFT[V * iFFT[pad(c)]] restricted to the sphere (Hamiltonian.jl:155-163)."""
+    a = 5.13
+    lat = a * np.array([[0, 1, 1.0], [1, 0, 1.0], [1, 1, 0.0]])
+    model = oracle.Model(lat, [], [], terms=("Kinetic",), n_electrons=2)
+    fft_size = (12, 15, 10)
+    ob = oracle.PlaneWaveBasis(model, 4.0, oracle.ExplicitKpoints([[0.1, -0.2, 0.3]], [1.0]), fft_size=fft_size)
+    kpt = ob.kpoints[0]
+    nx, ny, nz = fft_size
+    n_G = len(kpt.mapping)
+    nl, nzp = C.c_int64(), C.c_int()
+    m = np.ascontiguousarray(kpt.mapping)
+    check(lib.dftk_mi_sphere_tables_host(nx, ny, nz, n_G, m.ctypes.data, C.byref(nl), C.byref(nzp), None, None))
+    line_id = np.zeros(nl.value, dtype=np.int64)
+    line_start = np.zeros(nl.value + 1, dtype=np.int64)
+    check(lib.dftk_mi_sphere_tables_host(nx, ny, nz, n_G, m.ctypes.data, C.byref(nl), C.byref(nzp),
+                                         line_id.ctypes.data, line_start.ctypes.data))
+    assert line_start[-1] == n_G and np.all(np.diff(line_id) > 0)
+    plans = [get_plan(lib, n) for n in fft_size]
+    rng = np.random.default_rng(0)
+    c = rng.standard_normal(n_G) + 1j * rng.standard_normal(n_G)
+    V = rng.standard_normal((nz, ny, nx))
+    zvals = sorted(set(line_id // ny))
+    assert len(zvals) == nzp.value
+    # A: x-lines
+    T1 = np.zeros((nl.value, nx), complex)
+    for l in range(nl.value):
+        buf = np.zeros(nx, complex)
+        for j in range(line_start[l], line_start[l + 1]):
+            buf[plans[0][1][kpt.mapping[j] - line_id[l] * nx]] = c[j]
+        T1[l] = dit(buf, nx, plans[0][0], +1)
+    # B: y-lines per z plane
+    T2 = np.zeros((len(zvals), ny, nx), complex)
+    for zi, iz in enumerate(zvals):
+        buf = np.zeros((ny, nx), complex)
+        for l in np.nonzero(line_id // ny == iz)[0]:
+            buf[plans[1][1][line_id[l] % ny]] = T1[l]
+        for x in range(nx):
+            T2[zi, :, x] = dit(buf[:, x].copy(), ny, plans[1][0], +1)
+    # C: z backward, multiply, z forward
+    for y in range(ny):
+        for x in range(nx):
+            buf = np.zeros(nz, complex)
+            for zi, iz in enumerate(zvals):
+                buf[plans[2][1][iz]] = T2[zi, y, x]
+            col = dit(buf, nz, plans[2][0], +1) * V[:, y, x] / (nx * ny * nz)
+            col = dif(col, nz, plans[2][0], -1)
+            for zi, iz in enumerate(zvals):
+                T2[zi, y, x] = col[plans[2][1][iz]]
+    # D: y forward, keep sphere lines ; E: x forward + gather
+    out = np.zeros(n_G, complex)
+    for zi, iz in enumerate(zvals):
+        planes = np.stack([dif(T2[zi, :, x].copy(), ny, plans[1][0], -1) for x in range(nx)], axis=1)
+        for l in np.nonzero(line_id // ny == iz)[0]:
+            row = dif(planes[plans[1][1][line_id[l] % ny]].copy(), nx, plans[0][0], -1)
+            for j in range(line_start[l], line_start[l + 1]):
+                out[j] = row[plans[0][1][kpt.mapping[j] - line_id[l] * nx]]
+    ref = ob.fft(kpt, ob.ifft(kpt, c, normalize=False) * V / (nx * ny * nz), normalize=False)
+    np.testing.assert_allclose(out, ref, atol=1e-12 * np.abs(ref).max())
+
+
+def test_host_mirror_setup_matches_oracle():
+    """Package set-up (torch) vs oracle (NumPy): k-sphere, kinetic, projectors P, coupling D,
+    Ewald, psp correction -- parity level P0 of SURVEY.md appendix B."""
+    lat, atoms, pos = dftk.silicon_cell((2, 1, 1))
+    model = dftk.model_DFT(lat, atoms, pos)
+    kg = dftk.ExplicitKpoints([[0, 0, 0], [0.25, -0.125, 0.5]], [0.5, 0.5])
+    basis = dftk.PlaneWaveBasis(model, 8.0, kg, device="cpu")
+    oSi = oracle.ElementPsp("Si", oracle.load_psp_hgh("Si", "lda"))
+    omodel = oracle.model_DFT(lat, [oSi] * len(atoms), pos)
+    ob = oracle.PlaneWaveBasis(omodel, 8.0, oracle.ExplicitKpoints(kg.kcoords, kg.kweights))
+    assert basis.fft_size == ob.fft_size
+    for k, ok in zip(basis.kpoints, ob.kpoints):
+        np.testing.assert_array_equal(k.mapping, ok.mapping)
+        np.testing.assert_array_equal(k.G_vectors.numpy(), ok.G_vectors)
+    for ik in range(2):
+        np.testing.assert_allclose(basis.terms.kinetic[ik].numpy(), ob.terms.kinetic[ik], rtol=1e-14)
+        np.testing.assert_allclose(basis.terms.P[ik].numpy().T, ob.terms.P[ik], rtol=0, atol=1e-13)
+    np.testing.assert_array_equal(basis.terms.D, ob.terms.D)
+    assert basis.terms.E_ewald == pytest.approx(ob.terms.E_ewald, abs=1e-11)
+    assert basis.terms.E_pspcorr == pytest.approx(ob.terms.E_pspcorr, rel=1e-14)
+    # golden values (test/ewald.jl:14-26; test/PspHgh.jl:41-52) through the package's own code
+    from dftk_jl_amd.terms import energy_ewald
+    from dftk_jl_amd.psp import eval_psp_local_fourier, load_psp
+    a = 5.131570667152971
+    lat0 = np.array([[0, a, a], [a, 0, a], [a, a, 0.0]])
+    assert energy_ewald(lat0, [14, 14], [np.ones(3) / 8, -np.ones(3) / 8]) == pytest.approx(-102.8741963352893, abs=1e-8)
+    v = eval_psp_local_fourier(load_psp("Si"), torch.tensor([0.1], dtype=torch.float64)).item()
+    assert v == pytest.approx(-400.395448865164 * 4 * np.pi, rel=1e-12)
+    assert dftk.compute_fft_size(lat0, 15) == (27, 27, 27) and dftk.compute_fft_size(lat0, 30) == (40, 40, 40)
+
+
+def test_supercell_sizes_match_survey_table():
+    """SURVEY.md section 8 size table: cfg 2 = 150^3 / n_G 135 491, cfg 5 = 192^3."""
+    lat, atoms, pos = dftk.silicon_cell((4, 4, 4))
+    assert len(atoms) == 128 and dftk.compute_fft_size(lat, 30) == (150, 150, 150)
+    lat5, atoms5, _ = dftk.silicon_cell((5, 5, 5))
+    assert len(atoms5) == 250 and dftk.compute_fft_size(lat5, 30) == (192, 192, 192)
+
+
+def test_split_and_duplicate_kpoints():
+    """PlaneWaveBasis.jl:183-235: contiguous split; more ranks than k-points duplicates the heaviest."""
+    assert [list(r) for r in dftk.split_evenly(7, 3)] == [[0, 1, 2], [3, 4], [5, 6]]
+    comm = dftk.KptComm(rank=2, size=3)
+    kc, kw, allk, allw, ranges = dftk.distribute_kpoints([[0, 0, 0], [0.5, 0, 0]], [0.25, 0.75], comm)
+    assert len(allk) == 3 and allw == [0.25, 0.375, 0.375] and abs(sum(allw) - 1) < 1e-15
+    assert list(ranges[2]) == [2] and np.allclose(kc[0], [0.5, 0, 0]) and kw == [0.375]
+
+
+def test_anderson_and_occupation_match_oracle():
+    from oracle.scf import AndersonAcceleration as OA
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((40, 40))
+    A = A @ A.T / 40 + np.eye(40)
+    bvec = rng.standard_normal(40)
+    x_t = torch.zeros(40, dtype=torch.float64)
+    x_n = np.zeros(40)
+    acc_t, acc_n = dftk.AndersonAcceleration(m=5), OA(m=5)
+    for _ in range(25):
+        x_t = acc_t(x_t, 0.5, torch.from_numpy(bvec - A @ x_t.numpy()))
+        x_n = acc_n(x_n, 0.5, bvec - A @ x_n)
+        np.testing.assert_allclose(x_t.numpy(), x_n, atol=1e-7)
+    assert np.linalg.norm(A @ x_n - bvec) < 1e-4
+    # Fermi level / occupations: insulator at T = 0 and Gaussian smearing
+    lat, atoms, pos = dftk.silicon_cell()
+    for T, sm in ((0.0, None), (0.01, "gaussian"), (0.02, "fermi_dirac")):
+        model = dftk.model_DFT(lat, atoms, pos, temperature=T, smearing=sm)
+        basis = dftk.PlaneWaveBasis(model, 5, dftk.MonkhorstPack((2, 1, 1)), device="cpu", build_terms=False)
+        ev = [np.sort(rng.standard_normal(8)) * 0.3 for _ in basis.kpoints]
+        occ, eF = dftk.compute_occupation(basis, ev)
+        om = oracle.Model(lat, [oracle.ElementPsp("Si", oracle.load_psp_hgh("Si"))] * 2, pos, temperature=T,
+                          smearing=sm or "none")
+        ob = oracle.PlaneWaveBasis(om, 5, oracle.MonkhorstPack((2, 1, 1)), build_terms=False)
+        oocc, oeF = oracle.compute_occupation(ob, ev)
+        assert eF == pytest.approx(oeF, abs=1e-12)
+        for o1, o2 in zip(occ, oocc):
+            np.testing.assert_allclose(o1, o2, atol=1e-12)
+        assert sum(w * o.sum() for w, o in zip(basis.kweights, occ)) == pytest.approx(8.0, abs=1e-6)
+
+
+GLOO_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["REPO"])
+import numpy as np, torch, torch.distributed as dist
+import dftk_jl_amd as dftk
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["PORT"],
+                        rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+comm = dftk.KptComm.from_torch()
+lat, atoms, pos = dftk.silicon_cell()
+model = dftk.model_DFT(lat, atoms, pos)
+basis = dftk.PlaneWaveBasis(model, 5, dftk.MonkhorstPack((1, 1, 3)), device="cpu", comm_kpts=comm, build_terms=False)
+# every k-point is owned by exactly one rank and the weights sum to one over the communicator
+assert abs(comm.sum_scalar(sum(basis.kweights)) - 1.0) < 1e-14
+n_local = len(basis.kpoints)
+assert comm.sum_scalar(n_local) == 3 and n_local == len(basis.krange_thisproc)
+# density-style reduction: each rank contributes its k-points' partial sums (the path compute_density takes)
+nx, ny, nz = basis.fft_size
+part = torch.zeros((nz, ny, nx), dtype=torch.float64)
+for w, k in zip(basis.kweights, basis.kpoints):
+    part += w * float(k.n_G)
+comm.sum_(part)
+tot = float(part[0, 0, 0])
+all_nG = comm.gather_lists([k.n_G for k in basis.kpoints])
+flat = [n for sub in all_nG for n in sub]
+assert len(flat) == 3 and abs(tot - sum(flat) / 3) < 1e-12
+# Fermi level over sharded eigenvalues equals the serial answer
+rng = np.random.default_rng(0)
+ev_all = [np.concatenate([np.sort(rng.uniform(-1, -0.5, 4)), np.sort(rng.uniform(0.5, 1, 2))]) for _ in range(3)]
+mine = [ev_all[i] for i in basis.krange_thisproc]
+occ, eF = dftk.compute_occupation(basis, mine)
+serial = dftk.PlaneWaveBasis(model, 5, dftk.MonkhorstPack((1, 1, 3)), device="cpu", build_terms=False)
+occ_s, eF_s = dftk.compute_occupation(serial, ev_all)
+assert abs(eF - eF_s) < 1e-14
+for i, o in zip(basis.krange_thisproc, occ):
+    assert np.allclose(o, occ_s[i])
+assert comm.max_scalar(float(comm.rank)) == comm.size - 1
+dist.barrier(); dist.destroy_process_group()
+print("rank", comm.rank, "ok")
+'''
+
+
+def test_kpoint_sharding_gloo_world2(tmp_path):
+    """N > 1 path on CPU: 2 ranks over gloo (k-point split, weights, reductions, Fermi level)."""
+    script = tmp_path / "worker.py"
+    script.write_text(GLOO_WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", PORT=port, REPO=ROOT, MASTER_ADDR="127.0.0.1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o}"
+        assert f"rank {r} ok" in o

@@ -39,12 +39,12 @@ FAMILIES = {0: "zgemm_f64_mfma", 1: "fft_A_xbwd_scatter", 2: "fft_B_ybwd", 3: "f
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--supercell", type=int, default=4, help="n for the n x n x n Si supercell (4 = configs[1])")
     ap.add_argument("--ecut", type=float, default=30.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-bands", type=int, default=8)
+    ap.add_argument("--cpu-sample-bands", type=int, default=48)
     return ap.parse_args()
 
 

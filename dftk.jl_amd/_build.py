@@ -30,6 +30,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError("hipcc not found: cannot build libdftk_mi355x.so")
     os.makedirs(LIBDIR, exist_ok=True)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           # keep MFMA accumulators in VGPRs: without it hipcc (ROCm 7.2) shuttles every loop-carried
+           # accumulator VGPR<->AGPR around each k-step (256 v_accvgpr moves per 32 f64 MFMAs)
+           "-mllvm", "-amdgpu-mfma-vgpr-form=1",
            "-o", LIBPATH] + [os.path.join(CSRC, f) for f in SOURCES] + ["-ldl"]
     if verbose:
         print(" ".join(cmd))

@@ -176,52 +176,88 @@ __global__ void k_apply_D(int n_p, int nb, int bw, const double* __restrict__ D,
 }
 
 // ---------------------------------------------------------------------------- Cholesky + inverse
-// Right-looking unblocked upper Cholesky by ONE workgroup of 1024 threads working in global
-// memory (the matrix is L2 resident).  info[0] = 0 on success, else 1-based failing column.
-__global__ __launch_bounds__(1024) void k_potrf_upper(int n, cd* __restrict__ A, int64_t lda, int* __restrict__ info) {
-    __shared__ double s_d;
-    __shared__ int s_fail;
-    const int tid = threadIdx.x;
-    if (tid == 0) s_fail = 0;
+// Blocked right-looking upper Cholesky (A = R^H R), panel width PB = 32:
+//   k_potrf_diag : one wave factors the PB x PB diagonal block in LDS
+//   k_trsm_row   : R12 = R11^{-H} A12, one thread per column of the row panel (forward substitution)
+//   trailing     : A22 -= R12^H R12 through the f64-MFMA zgemm ('C', alpha = -1, beta = 1)
+// info[0] = 0 on success, else the 1-based failing column (non-positive / non-finite pivot).
+#define PB 32
+__global__ __launch_bounds__(64) void k_potrf_diag(int jb, int j0, cd* __restrict__ A, int64_t lda,
+                                                   int* __restrict__ info) {
+    __shared__ cd T[PB][PB + 1];
+    __shared__ int fail;
+    const int c = threadIdx.x;
+    if (c == 0) fail = info[0];
+    for (int e = c; e < PB * PB; e += 64) {
+        const int cc = e / PB, r = e - cc * PB;
+        T[r][cc] = (r < jb && cc < jb && r <= cc) ? A[(j0 + r) + (int64_t)(j0 + cc) * lda] : make_double2(0.0, 0.0);
+    }
     __syncthreads();
-    for (int j = 0; j < n; ++j) {
-        if (tid == 0) {
-            const double d = A[j + (int64_t)j * lda].x;
-            if (!(d > 0.0) || !isfinite(d)) {
-                s_fail = j + 1;
-                s_d = 1.0;
-            } else {
-                s_d = sqrt(d);
-            }
-            A[j + (int64_t)j * lda] = make_double2(s_d, 0.0);
+    if (fail != 0) return;   // an earlier panel already failed
+    for (int j = 0; j < jb; ++j) {
+        const double d = T[j][j].x;
+        if (!(d > 0.0) || !isfinite(d)) {
+            if (c == 0) info[0] = j0 + j + 1;
+            return;   // uniform: every lane read the same d
         }
+        const double sd = sqrt(d), inv = 1.0 / sd;
         __syncthreads();
-        if (s_fail) break;
-        const double inv = 1.0 / s_d;
-        for (int c = j + 1 + tid; c < n; c += 1024) {
-            cd v = A[j + (int64_t)c * lda];
+        if (c == j) T[j][j] = make_double2(sd, 0.0);
+        if (c > j && c < jb) {
+            cd v = T[j][c];
             v.x *= inv;
             v.y *= inv;
-            A[j + (int64_t)c * lda] = v;
+            T[j][c] = v;
         }
         __syncthreads();
-        // trailing update of the upper triangle: A[r,c] -= conj(R[j,r]) * R[j,c], j < r <= c
-        const int t = n - j - 1;
-        const int64_t total = (int64_t)t * t;
-        for (int64_t e = tid; e < total; e += 1024) {
-            const int cc = (int)(e / t), rr = (int)(e - (int64_t)cc * t);
-            if (rr > cc) continue;
-            const int r = j + 1 + rr, c = j + 1 + cc;
-            const cd a = A[j + (int64_t)r * lda];
-            const cd bb = A[j + (int64_t)c * lda];
-            cd v = A[r + (int64_t)c * lda];
-            v.x -= a.x * bb.x + a.y * bb.y;
-            v.y -= a.x * bb.y - a.y * bb.x;
-            A[r + (int64_t)c * lda] = v;
+        if (c > j && c < jb) {
+            const cd bb = T[j][c];
+            for (int r = j + 1; r <= c; ++r) {
+                const cd a = T[j][r];
+                cd v = T[r][c];
+                v.x -= a.x * bb.x + a.y * bb.y;
+                v.y -= a.x * bb.y - a.y * bb.x;
+                T[r][c] = v;
+            }
         }
         __syncthreads();
     }
-    if (tid == 0) info[0] = s_fail;
+    for (int e = c; e < PB * PB; e += 64) {
+        const int cc = e / PB, r = e - cc * PB;
+        if (r < jb && cc < jb && r <= cc) A[(j0 + r) + (int64_t)(j0 + cc) * lda] = T[r][cc];
+    }
+}
+
+// columns c in [j0+PB, n): solve R11^H y = A[j0:j0+PB, c] in place (R11 = A[j0:j0+PB, j0:j0+PB], upper)
+__global__ __launch_bounds__(64) void k_trsm_row(int n, int j0, cd* __restrict__ A, int64_t lda,
+                                                 const int* __restrict__ info) {
+    __shared__ cd R[PB][PB + 1];
+    for (int e = threadIdx.x; e < PB * PB; e += 64) {
+        const int cc = e / PB, r = e - cc * PB;
+        R[r][cc] = A[(j0 + r) + (int64_t)(j0 + cc) * lda];
+    }
+    __syncthreads();
+    if (info[0] != 0) return;
+    const int c = j0 + PB + blockIdx.x * 64 + threadIdx.x;
+    if (c >= n) return;
+    cd y[PB];
+    cd* col = A + j0 + (int64_t)c * lda;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) y[i] = col[i];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        double sr = y[i].x, si = y[i].y;
+#pragma unroll
+        for (int k = 0; k < i; ++k) {
+            const cd r = R[k][i];   // conj(R[k][i]) * y[k]
+            sr -= r.x * y[k].x + r.y * y[k].y;
+            si -= r.x * y[k].y - r.y * y[k].x;
+        }
+        const double inv = 1.0 / R[i][i].x;
+        y[i] = make_double2(sr * inv, si * inv);
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) col[i] = y[i];
 }
 
 // Z = inv(R) for upper-triangular R: one wave per column (back substitution, lane-parallel dots).
@@ -292,7 +328,12 @@ __global__ __launch_bounds__(256) void k_normest_upper(int n, const cd* __restri
 #define J2B (2 * JB)
 
 __device__ __forceinline__ void tournament_pair(int nb, int round, int k, int& p, int& q) {
-    // nb even, round in [0, nb-1), k in [0, nb/2): pair k of the round
+    // nb even, round in [0, nb-1), k in [0, nb/2): pair k of the round; round < 0: the fixed pairing (2k, 2k+1)
+    if (round < 0) {
+        p = 2 * k;
+        q = 2 * k + 1;
+        return;
+    }
     int a, b2;
     if (k == 0) {
         a = nb - 1;
@@ -305,15 +346,24 @@ __device__ __forceinline__ void tournament_pair(int nb, int round, int k, int& p
     q = a < b2 ? b2 : a;
 }
 
+// mode 0 ("cross", round in [0, nb-1)): tournament block pair (bp, bq); rotates the JB*JB cross pairs
+//        (i, JB + (i + r) % JB), r = 0..JB-1 -- every (i, j) with i in block p and j in block q once.
+// mode 1 ("diag", one launch per sweep): block pair (2k, 2k+1); rotates the within-block pairs of both
+//        blocks (tournament of JB) -- together with the cross rounds each index pair is met once per sweep.
 __global__ __launch_bounds__(256) void k_jacobi_pair(int n, int nb, int round, cd* __restrict__ A, int64_t lda,
-                                                     cd* __restrict__ Ubuf, int inner_sweeps) {
+                                                     cd* __restrict__ Ubuf, int mode) {
     __shared__ cd S[J2B][J2B + 1];
     __shared__ cd U[J2B][J2B + 1];
     __shared__ cd rot_s[JB];
     __shared__ double rot_c[JB];
     __shared__ int rot_p[JB], rot_q[JB];
     int bp, bq;
-    tournament_pair(nb, round, blockIdx.x, bp, bq);
+    if (mode == 0) {
+        tournament_pair(nb, round, blockIdx.x, bp, bq);
+    } else {
+        bp = 2 * blockIdx.x;
+        bq = bp + 1;
+    }
     const int tid = threadIdx.x;
     // load the 2x2 block sub-matrix (global index of local i)
     for (int e = tid; e < J2B * J2B; e += 256) {
@@ -324,11 +374,21 @@ __global__ __launch_bounds__(256) void k_jacobi_pair(int n, int nb, int round, c
         U[r][c] = make_double2(r == c ? 1.0 : 0.0, 0.0);
     }
     __syncthreads();
-    for (int sw = 0; sw < inner_sweeps; ++sw) {
-        for (int rd = 0; rd < J2B - 1; ++rd) {
+    {
+        const int nrounds = mode == 0 ? JB : JB - 1;
+        for (int rd = 0; rd < nrounds; ++rd) {
             if (tid < JB) {
                 int p, q;
-                tournament_pair(J2B, rd, tid, p, q);
+                if (mode == 0) {
+                    p = tid;
+                    q = JB + ((tid + rd) & (JB - 1));
+                } else {
+                    tournament_pair(JB, rd, tid & (JB / 2 - 1), p, q);
+                    if (tid >= JB / 2) {
+                        p += JB;
+                        q += JB;
+                    }
+                }
                 const cd beta = S[p][q];
                 const double ab = sqrt(beta.x * beta.x + beta.y * beta.y);
                 const double al = S[p][p].x, ga = S[q][q].x;
@@ -347,30 +407,34 @@ __global__ __launch_bounds__(256) void k_jacobi_pair(int n, int nb, int round, c
                 rot_q[tid] = q;
             }
             __syncthreads();
-            // column rotations of S and U: (x_p, x_q) <- (c x_p - conj(s) x_q, s x_p + c x_q)
-            for (int e = tid; e < 2 * J2B * JB; e += 256) {
-                const int which = e / (J2B * JB);
-                const int rem = e - which * (J2B * JB);
-                const int k = rem / J2B, r = rem - k * J2B;
-                const int p = rot_p[k], q = rot_q[k];
-                const double c = rot_c[k];
-                const cd s = rot_s[k];
-                cd(*Mx)[J2B + 1] = which ? U : S;
-                const cd xp = Mx[r][p], xq = Mx[r][q];
-                // conj(s) * xq = (s.x xq.x + s.y xq.y, s.x xq.y - s.y xq.x)
-                Mx[r][p] = make_double2(c * xp.x - (s.x * xq.x + s.y * xq.y), c * xp.y - (s.x * xq.y - s.y * xq.x));
-                Mx[r][q] = make_double2(s.x * xp.x - s.y * xp.y + c * xq.x, s.x * xp.y + s.y * xp.x + c * xq.y);
+            // two-sided update of S in 2x2 blocks: thread (k1, k2) owns S[{p1,q1}][{p2,q2}] and applies
+            // the row rotation of pair k1 and the column rotation of pair k2 in one pass
+            {
+                const int k1 = tid >> 4, k2 = tid & 15;
+                const int p1 = rot_p[k1], q1 = rot_q[k1], p2 = rot_p[k2], q2 = rot_q[k2];
+                const double c1 = rot_c[k1], c2 = rot_c[k2];
+                const cd s1 = rot_s[k1], s2 = rot_s[k2];
+                const cd a = S[p1][p2], b2 = S[p1][q2], c3 = S[q1][p2], d = S[q1][q2];
+                // rows: (row_p, row_q) <- (c row_p - s row_q, conj(s) row_p + c row_q)
+                const cd ra = make_double2(c1 * a.x - (s1.x * c3.x - s1.y * c3.y), c1 * a.y - (s1.x * c3.y + s1.y * c3.x));
+                const cd rb = make_double2(c1 * b2.x - (s1.x * d.x - s1.y * d.y), c1 * b2.y - (s1.x * d.y + s1.y * d.x));
+                const cd rc = make_double2(s1.x * a.x + s1.y * a.y + c1 * c3.x, s1.x * a.y - s1.y * a.x + c1 * c3.y);
+                const cd rd = make_double2(s1.x * b2.x + s1.y * b2.y + c1 * d.x, s1.x * b2.y - s1.y * b2.x + c1 * d.y);
+                // cols: (x_p, x_q) <- (c x_p - conj(s) x_q, s x_p + c x_q)
+                S[p1][p2] = make_double2(c2 * ra.x - (s2.x * rb.x + s2.y * rb.y), c2 * ra.y - (s2.x * rb.y - s2.y * rb.x));
+                S[p1][q2] = make_double2(s2.x * ra.x - s2.y * ra.y + c2 * rb.x, s2.x * ra.y + s2.y * ra.x + c2 * rb.y);
+                S[q1][p2] = make_double2(c2 * rc.x - (s2.x * rd.x + s2.y * rd.y), c2 * rc.y - (s2.x * rd.y - s2.y * rd.x));
+                S[q1][q2] = make_double2(s2.x * rc.x - s2.y * rc.y + c2 * rd.x, s2.x * rc.y + s2.y * rc.x + c2 * rd.y);
             }
-            __syncthreads();
-            // row rotations of S: (row_p, row_q) <- (c row_p - s row_q, conj(s) row_p + c row_q)
+            // column rotations of U
             for (int e = tid; e < J2B * JB; e += 256) {
-                const int k = e / J2B, cidx = e - k * J2B;
+                const int k = e / J2B, r = e - k * J2B;
                 const int p = rot_p[k], q = rot_q[k];
                 const double c = rot_c[k];
                 const cd s = rot_s[k];
-                const cd xp = S[p][cidx], xq = S[q][cidx];
-                S[p][cidx] = make_double2(c * xp.x - (s.x * xq.x - s.y * xq.y), c * xp.y - (s.x * xq.y + s.y * xq.x));
-                S[q][cidx] = make_double2(s.x * xp.x + s.y * xp.y + c * xq.x, s.x * xp.y - s.y * xp.x + c * xq.y);
+                const cd xp = U[r][p], xq = U[r][q];
+                U[r][p] = make_double2(c * xp.x - (s.x * xq.x + s.y * xq.y), c * xp.y - (s.x * xq.y - s.y * xq.x));
+                U[r][q] = make_double2(s.x * xp.x - s.y * xp.y + c * xq.x, s.x * xp.y + s.y * xp.x + c * xq.y);
             }
             __syncthreads();
         }
@@ -382,70 +446,89 @@ __global__ __launch_bounds__(256) void k_jacobi_pair(int n, int nb, int round, c
     }
 }
 
-// columns: M[:, cols(pair)] <- M[:, cols(pair)] * U  for M = A (rows [0,n)) and V (rows [0,n))
-// grid (npairs, ceil(2n / 256)); thread = one row of the stacked [A; V]
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int pair_index(int bp, int bq, int kk) {
+    return kk < JB ? bp * JB + kk : bq * JB + (kk - JB);
+}
+
+// columns: M[:, cols(pair)] <- M[:, cols(pair)] * U  for M = A (rows [0,n)) and V (rows [0,n)).
+// f64 MFMA: one wave owns a 16-row strip of the stacked [A; V] and its 32 pair columns
+// (2 output tiles x 8 k-steps x 4 real products = 64 v_mfma_f64_16x16x4_f64).
+// grid (npairs, ceil(2n/16/4)); n is a multiple of 16.
 __global__ __launch_bounds__(256) void k_jacobi_cols(int n, int nb, int round, cd* __restrict__ A, int64_t lda,
                                                      cd* __restrict__ V, int64_t ldv, const cd* __restrict__ Ubuf) {
-    __shared__ cd U[J2B * J2B];
     int bp, bq;
     tournament_pair(nb, round, blockIdx.x, bp, bq);
-    const cd* Ui = Ubuf + (int64_t)blockIdx.x * J2B * J2B;
-    for (int e = threadIdx.x; e < J2B * J2B; e += 256) U[e] = Ui[e];
-    __syncthreads();
-    const int row = blockIdx.y * 256 + threadIdx.x;
-    if (row >= 2 * n) return;
-    cd* M = row < n ? A : V;
-    const int64_t ld = row < n ? lda : ldv;
-    const int r = row < n ? row : row - n;
-    cd x[J2B];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int r0 = (blockIdx.y * 4 + wave) * 16;
+    if (r0 >= 2 * n) return;
+    cd* M = r0 < n ? A : V;
+    const int64_t ld = r0 < n ? lda : ldv;
+    const int rr0 = r0 < n ? r0 : r0 - n;
+    const cd* U = Ubuf + (int64_t)blockIdx.x * J2B * J2B;
+    v4d_t accR[2], accI[2];
+    accR[0] = accR[1] = accI[0] = accI[1] = (v4d_t){0.0, 0.0, 0.0, 0.0};
+    cd fa[8];
 #pragma unroll
-    for (int k = 0; k < J2B; ++k) {
-        const int gc = (k < JB ? bp * JB + k : bq * JB + (k - JB));
-        x[k] = M[r + (int64_t)gc * ld];
-    }
-#pragma unroll 4
-    for (int c = 0; c < J2B; ++c) {
-        double sr = 0.0, si = 0.0;
+    for (int t = 0; t < 8; ++t) fa[t] = M[rr0 + li + (int64_t)pair_index(bp, bq, 4 * t + lk) * ld];
 #pragma unroll
-        for (int k = 0; k < J2B; ++k) {
-            const cd u = U[k + c * J2B];
-            sr += x[k].x * u.x - x[k].y * u.y;
-            si += x[k].x * u.y + x[k].y * u.x;
+    for (int t = 0; t < 8; ++t) {
+        const double ar = fa[t].x, ai = fa[t].y, nai = -ai;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const cd u = U[(4 * t + lk) + (16 * c + li) * J2B];
+            accR[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, u.x, accR[c], 0, 0, 0);
+            accR[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, u.y, accR[c], 0, 0, 0);
+            accI[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, u.y, accI[c], 0, 0, 0);
+            accI[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, u.x, accI[c], 0, 0, 0);
         }
-        const int gc = (c < JB ? bp * JB + c : bq * JB + (c - JB));
-        M[r + (int64_t)gc * ld] = make_double2(sr, si);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int64_t gc = pair_index(bp, bq, 16 * c + li);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            M[rr0 + lk + 4 * r + gc * ld] = make_double2(accR[c][r], accI[c][r]);
     }
 }
 
-// rows: A[rows(pair), :] <- U^H * A[rows(pair), :]; thread = one column of A
+// rows: A[rows(pair), :] <- U^H * A[rows(pair), :]; one wave owns the 32 pair rows of a 16-column strip.
+// grid (npairs, ceil(n/16/4))
 __global__ __launch_bounds__(256) void k_jacobi_rows(int n, int nb, int round, cd* __restrict__ A, int64_t lda,
                                                      const cd* __restrict__ Ubuf) {
-    __shared__ cd U[J2B * J2B];
     int bp, bq;
     tournament_pair(nb, round, blockIdx.x, bp, bq);
-    const cd* Ui = Ubuf + (int64_t)blockIdx.x * J2B * J2B;
-    for (int e = threadIdx.x; e < J2B * J2B; e += 256) U[e] = Ui[e];
-    __syncthreads();
-    const int col = blockIdx.y * 256 + threadIdx.x;
-    if (col >= n) return;
-    cd x[J2B];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int c0 = (blockIdx.y * 4 + wave) * 16;
+    if (c0 >= n) return;
+    const cd* U = Ubuf + (int64_t)blockIdx.x * J2B * J2B;
+    v4d_t accR[2], accI[2];
+    accR[0] = accR[1] = accI[0] = accI[1] = (v4d_t){0.0, 0.0, 0.0, 0.0};
+    cd fb[8];
 #pragma unroll
-    for (int k = 0; k < J2B; ++k) {
-        const int gr = (k < JB ? bp * JB + k : bq * JB + (k - JB));
-        x[k] = A[gr + (int64_t)col * lda];
-    }
-#pragma unroll 4
-    for (int r = 0; r < J2B; ++r) {
-        double sr = 0.0, si = 0.0;
+    for (int t = 0; t < 8; ++t) fb[t] = A[pair_index(bp, bq, 4 * t + lk) + (int64_t)(c0 + li) * lda];
 #pragma unroll
-        for (int k = 0; k < J2B; ++k) {
-            const cd u = U[k + r * J2B];   // conj(U[k, r])
-            sr += u.x * x[k].x + u.y * x[k].y;
-            si += u.x * x[k].y - u.y * x[k].x;
+    for (int t = 0; t < 8; ++t) {
+        const double br = fb[t].x, bi = fb[t].y;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const cd u = U[(4 * t + lk) + (16 * it + li) * J2B];   // A operand: conj(U[k][i])
+            const double nui = -u.y;
+            accR[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(u.x, br, accR[it], 0, 0, 0);
+            accR[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(u.y, bi, accR[it], 0, 0, 0);
+            accI[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(u.x, bi, accI[it], 0, 0, 0);
+            accI[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(nui, br, accI[it], 0, 0, 0);
         }
-        const int gr = (r < JB ? bp * JB + r : bq * JB + (r - JB));
-        A[gr + (int64_t)col * lda] = make_double2(sr, si);
     }
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gr = pair_index(bp, bq, 16 * it + lk + 4 * r);
+            A[gr + (int64_t)(c0 + li) * lda] = make_double2(accR[it][r], accI[it][r]);
+        }
 }
 
 // out[0] = sum |offdiag|^2, out[1] = sum |diag|^2   (whole matrix)
@@ -522,7 +605,19 @@ int dense_potrf_trtri(dftk_mi_basis* b, int n, cd* A, int64_t lda, cd* invR, int
                       double* normest_invR) {
     const int ps = prof_begin(b, PROF_CHOL, (double)n);
     int* d_info = reinterpret_cast<int*>(b->d_scalars + 200);
-    hipLaunchKernelGGL(k_potrf_upper, dim3(1), dim3(1024), 0, b->stream, n, A, lda, d_info);
+    HIPCHK(hipMemsetAsync(d_info, 0, sizeof(int), b->stream));
+    for (int j0 = 0; j0 < n; j0 += PB) {
+        const int jb = (n - j0) < PB ? (n - j0) : PB;
+        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(64), 0, b->stream, jb, j0, A, lda, d_info);
+        const int n2 = n - j0 - jb;
+        if (n2 > 0) {
+            hipLaunchKernelGGL(k_trsm_row, dim3((n2 + 63) / 64), dim3(64), 0, b->stream, n, j0, A, lda, d_info);
+            cd* R12 = A + j0 + (int64_t)(j0 + jb) * lda;
+            cd* A22 = A + (j0 + jb) + (int64_t)(j0 + jb) * lda;
+            const cd mone = make_double2(-1.0, 0.0), one = make_double2(1.0, 0.0);
+            CHK(zgemm(b, 'C', n2, n2, jb, mone, R12, lda, R12, lda, one, A22, lda));
+        }
+    }
     hipLaunchKernelGGL(k_trtri_upper, dim3(n), dim3(64), (size_t)n * sizeof(cd), b->stream, n, A, lda, invR, ldi);
     hipLaunchKernelGGL(k_normest_upper, dim3(1), dim3(256), 0, b->stream, n, A, lda, b->d_scalars);
     hipLaunchKernelGGL(k_normest_upper, dim3(1), dim3(256), 0, b->stream, n, invR, ldi, b->d_scalars + 3);
@@ -590,12 +685,14 @@ int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, 
     const int maxsweeps = 40;
     bool done = (off2 <= tol * tol * (dg2 + off2)) && off2 == 0.0;
     for (; sweep < maxsweeps && !done; ++sweep) {
-        for (int round = 0; round < nb - 1; ++round) {
+        for (int round = -1; round < nb - 1; ++round) {
+            // round -1: within-block rotations on the block pairs (2k, 2k+1); the update kernels see the
+            // same pairing through a negative round index
             hipLaunchKernelGGL(k_jacobi_pair, dim3(npairs), dim3(256), 0, b->stream, np, nb, round, W, (int64_t)np,
-                               Ubuf, 1);
-            hipLaunchKernelGGL(k_jacobi_cols, dim3(npairs, (2 * np + 255) / 256), dim3(256), 0, b->stream, np, nb,
+                               Ubuf, round < 0 ? 1 : 0);
+            hipLaunchKernelGGL(k_jacobi_cols, dim3(npairs, (2 * np / 16 + 3) / 4), dim3(256), 0, b->stream, np, nb,
                                round, W, (int64_t)np, Vw, (int64_t)np, Ubuf);
-            hipLaunchKernelGGL(k_jacobi_rows, dim3(npairs, (np + 255) / 256), dim3(256), 0, b->stream, np, nb, round,
+            hipLaunchKernelGGL(k_jacobi_rows, dim3(npairs, (np / 16 + 3) / 4), dim3(256), 0, b->stream, np, nb, round,
                                W, (int64_t)np, Ubuf);
         }
         hipLaunchKernelGGL(k_offdiag_norm, dim3(redblocks), dim3(256), 0, b->stream, np, W, (int64_t)np, d_red);

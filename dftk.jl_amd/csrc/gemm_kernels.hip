@@ -14,6 +14,7 @@
 // stacked along m.  Long-K products (Gram matrices over n_G) are split along K into slabs that
 // a second kernel reduces in a fixed order => bitwise reproducible results.
 #include "common.h"
+#include <cstdio>
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -26,19 +27,38 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // lane mapping of v_mfma_f64_16x16x4_f64:
 //   A operand: lane l holds A[i = l & 15][k = l >> 4];  B operand: lane l holds B[k = l >> 4][j = l & 15]
 //   C/D: 4 values per lane, value r is C[row = (l >> 4) + 4 r][col = l & 15]
+// The four k slots of one MFMA need not be consecutive k values: each lane loads TWO consecutive k
+// (32 B, so the four lanes of a column cover a whole 128-B line of a K-major operand) and feeds
+// them to two MFMAs; a k-step is therefore 8 deep.
+//
+// Grid: 1-D, XCD-aware.  Workgroup id -> (xcd = id % 8, slot = id / 8); the column tiles of one
+// (k-slice, row-panel) pair are consecutive slots of the SAME XCD, so the A panel they share is
+// served by that XCD's L2 instead of being re-fetched through eight different L2s.
+// Tiles that lie completely outside the matrix (m, n not multiples of the tile) are skipped.
 template <bool CONJA>
-__global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_mfma(int m, int n, int K, int kchunk,
-                                                                const cd* __restrict__ A, int64_t lda,
+__global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_mfma(int m, int n, int K, int kchunk, int gm, int gn,
+                                                                int nsplit, const cd* __restrict__ A, int64_t lda,
                                                                 const cd* __restrict__ B, int64_t ldb,
                                                                 cd* __restrict__ C, int64_t ldc, cd alpha, cd beta,
                                                                 cd* __restrict__ slab) {
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int col_t = slot % gn;
+    const int R = (slot / gn) * 8 + xcd;
+    if (R >= gm * nsplit) return;
+    const int z = R / gm, row_t = R - z * gm;
+
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const int i0 = blockIdx.x * GEMM_BM + wave * (GEMM_RM * 16);
-    const int j0 = blockIdx.y * GEMM_BN;
-    const int kbeg = blockIdx.z * kchunk;
+    const int i0 = row_t * GEMM_BM + wave * (GEMM_RM * 16);
+    const int j0 = col_t * GEMM_BN;
+    const int kbeg = z * kchunk;
     const int kend = min(K, kbeg + kchunk);
+    // number of 16-wide tiles of this wave that intersect the matrix (wave-uniform)
+    const int rmv = min(GEMM_RM, max(0, (m - i0 + 15) >> 4));
+    const int rnv = min(GEMM_RN, max(0, (n - j0 + 15) >> 4));
+    if (rmv == 0 || rnv == 0) return;
 
     v4d accR[GEMM_RM][GEMM_RN], accI[GEMM_RM][GEMM_RN];
 #pragma unroll
@@ -65,39 +85,91 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_mfma(int m, int n, in
         pb[b] = B + (int64_t)j * ldb;
     }
 
-    for (int k0 = kbeg; k0 < kend; k0 += 4) {
-        const int kk = k0 + lk;
-        const bool valid = kk < kend;
-        const int kc = valid ? kk : (kend - 1);
-        cd fa[GEMM_RM], fb[GEMM_RN];
+    // ---- main loop: full 8-deep k-steps, register double-buffered (loads of step s+1 are in
+    //      flight while the 64 MFMAs of step s issue); every load is unconditional (clamped
+    //      addresses) so that the compiler emits them back to back with a single counted wait.
+    struct Frags {
+        cd a[GEMM_RM][2];
+        cd b[GEMM_RN][2];
+    };
+    auto load_frags = [&](Frags& f, int k0) {
+        const int ka = k0 + 2 * lk;
 #pragma unroll
         for (int a = 0; a < GEMM_RM; ++a) {
-            cd v = CONJA ? pa[a][kc] : pa[a][(int64_t)kc * lda];
-            fa[a] = valid ? v : make_double2(0.0, 0.0);
+            f.a[a][0] = CONJA ? pa[a][ka] : pa[a][(int64_t)ka * lda];
+            f.a[a][1] = CONJA ? pa[a][ka + 1] : pa[a][(int64_t)(ka + 1) * lda];
         }
 #pragma unroll
         for (int b = 0; b < GEMM_RN; ++b) {
-            cd v = pb[b][kc];
-            fb[b] = valid ? v : make_double2(0.0, 0.0);
+            f.b[b][0] = pb[b][ka];
+            f.b[b][1] = pb[b][ka + 1];
         }
+    };
+    auto mfma_step = [&](const Frags& f) {
 #pragma unroll
         for (int a = 0; a < GEMM_RM; ++a) {
-            const double ar = fa[a].x;
-            const double ai = fa[a].y;
-            const double nai = -ai;
+            if (a < rmv) {
 #pragma unroll
-            for (int b = 0; b < GEMM_RN; ++b) {
-                accR[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, fb[b].x, accR[a][b], 0, 0, 0);
-                accR[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(CONJA ? ai : nai, fb[b].y, accR[a][b], 0, 0, 0);
-                accI[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, fb[b].y, accI[a][b], 0, 0, 0);
-                accI[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(CONJA ? nai : ai, fb[b].x, accI[a][b], 0, 0, 0);
+                for (int h = 0; h < 2; ++h) {
+                    const double ar = f.a[a][h].x;
+                    const double ai = f.a[a][h].y;
+                    const double nai = -ai;
+#pragma unroll
+                    for (int b = 0; b < GEMM_RN; ++b)
+                        if (b < rnv) accR[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, f.b[b][h].x, accR[a][b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < GEMM_RN; ++b)
+                        if (b < rnv) accI[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, f.b[b][h].y, accI[a][b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < GEMM_RN; ++b)
+                        if (b < rnv)
+                            accR[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(CONJA ? ai : nai, f.b[b][h].y, accR[a][b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < GEMM_RN; ++b)
+                        if (b < rnv)
+                            accI[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(CONJA ? nai : ai, f.b[b][h].x, accI[a][b], 0, 0, 0);
+                }
             }
         }
+    };
+    const int kfull = kbeg + ((kend - kbeg) & ~7);
+    if (kfull > kbeg) {
+        Frags cur, nxt;
+        load_frags(cur, kbeg);
+        for (int k0 = kbeg; k0 < kfull; k0 += 8) {
+            const bool more = (k0 + 8) < kfull;
+            if (more) load_frags(nxt, k0 + 8);
+            mfma_step(cur);
+            if (more) cur = nxt;
+        }
+    }
+    // ---- tail: fewer than 8 k left, masked
+    if (kfull < kend) {
+        const cd czero = make_double2(0.0, 0.0);
+        const int ka = kfull + 2 * lk, kb2 = ka + 1;
+        const bool va = ka < kend, vb = kb2 < kend;
+        const int kca = va ? ka : (kend - 1), kcb = vb ? kb2 : (kend - 1);
+        Frags f;
+#pragma unroll
+        for (int a = 0; a < GEMM_RM; ++a) {
+            const cd v0 = CONJA ? pa[a][kca] : pa[a][(int64_t)kca * lda];
+            const cd v1 = CONJA ? pa[a][kcb] : pa[a][(int64_t)kcb * lda];
+            f.a[a][0] = va ? v0 : czero;
+            f.a[a][1] = vb ? v1 : czero;
+        }
+#pragma unroll
+        for (int b = 0; b < GEMM_RN; ++b) {
+            const cd v0 = pb[b][kca];
+            const cd v1 = pb[b][kcb];
+            f.b[b][0] = va ? v0 : czero;
+            f.b[b][1] = vb ? v1 : czero;
+        }
+        mfma_step(f);
     }
 
     // epilogue
     const bool direct = (slab == nullptr);
-    cd* sl = direct ? nullptr : slab + (int64_t)blockIdx.z * m * n;
+    cd* sl = direct ? nullptr : slab + (int64_t)z * m * n;
 #pragma unroll
     for (int a = 0; a < GEMM_RM; ++a)
 #pragma unroll
@@ -174,6 +246,78 @@ __global__ void k_zgemm_naive(int m, int n, int K, const cd* __restrict__ A, int
     *c = o;
 }
 
+// ---- diagnostic: pure v_mfma_f64_16x16x4_f64 issue rate (no memory traffic) -> measured ceiling
+__global__ __launch_bounds__(256) void k_mfma_peak(int iters, double* out) {
+    v4d acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + threadIdx.x * 1e-9, bb = 1.0 - threadIdx.x * 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[i], 0, 0, 0);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678) out[0] = s;   // keep the chain alive
+}
+
+// cycles per MFMA on one wave: out[1] = shader clocks, out[2] = 100 MHz wall ticks for `iters` x 8 MFMAs
+template <int NACC>
+__global__ __launch_bounds__(256) void k_mfma_cycles(int iters, double* out) {
+    v4d acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + threadIdx.x * 1e-9, bb = 1.0 - threadIdx.x * 1e-9;
+    const long long c0 = clock64();
+    const long long w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            acc[i % NACC] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[i % NACC], 0, 0, 0);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    const long long c1 = clock64();
+    const long long w1 = wall_clock64();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[1] = (double)(c1 - c0);
+        out[2] = (double)(w1 - w0);
+        out[3] = s;
+    }
+}
+
+extern "C" int dftk_mi_diag_mfma_peak(dftk_mi_basis* b, int waves_per_simd, int iters, double* tflops) {
+    if (!b || !tflops || waves_per_simd < 1 || iters < 1) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(b->device));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    const int blocks = 256 * waves_per_simd;       // 256 CUs x (4 waves per block = 1 per SIMD)
+    hipLaunchKernelGGL(k_mfma_peak, dim3(blocks), dim3(256), 0, b->stream, 10, b->d_scalars);
+    HIPCHK(hipEventRecord(e0, b->stream));
+    hipLaunchKernelGGL(k_mfma_peak, dim3(blocks), dim3(256), 0, b->stream, iters, b->d_scalars);
+    HIPCHK(hipEventRecord(e1, b->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    const double flops = (double)blocks * 4.0 * iters * 8.0 * 2048.0;
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    for (int nacc : {8, 2, 1}) {
+        if (nacc == 8) hipLaunchKernelGGL(k_mfma_cycles<8>, dim3(blocks), dim3(256), 0, b->stream, iters, b->d_scalars);
+        if (nacc == 2) hipLaunchKernelGGL(k_mfma_cycles<2>, dim3(blocks), dim3(256), 0, b->stream, iters, b->d_scalars);
+        if (nacc == 1) hipLaunchKernelGGL(k_mfma_cycles<1>, dim3(blocks), dim3(256), 0, b->stream, iters, b->d_scalars);
+        HIPCHK(hipMemcpyAsync(b->h_scalars, b->d_scalars, 4 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        fprintf(stderr, "[diag] %d wave(s)/SIMD, %d independent accumulators: %.1f shader clocks per MFMA, clock %.0f MHz\n",
+                waves_per_simd, nacc, b->h_scalars[1] / (8.0 * iters), b->h_scalars[1] / (b->h_scalars[2] / 100.0));
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return 0;
+}
+
 int ensure_ws(dftk_mi_basis* b, size_t bytes) {
     if (bytes <= b->ws_bytes) return 0;
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -231,20 +375,23 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
         if (nsplit < 1) nsplit = 1;
     }
     int kchunk = (int)((k + nsplit - 1) / nsplit);
-    kchunk = (kchunk + 3) & ~3;
+    kchunk = (kchunk + 7) & ~7;
     nsplit = (int)((k + kchunk - 1) / kchunk);
     cd* slab = nullptr;
     if (nsplit > 1) {
         CHK(ensure_ws(b, (size_t)nsplit * m * n * sizeof(cd)));
         slab = (cd*)b->ws;
     }
-    dim3 grid(gm, gn, nsplit);
+    const int64_t rows_total = (int64_t)gm * nsplit;
+    const int64_t nblocks = ((rows_total + 7) / 8) * 8 * gn;
+    if (nblocks > INT32_MAX) return DFTK_MI_EINVAL;
+    dim3 grid((unsigned)nblocks);
     if (conja)
         hipLaunchKernelGGL(k_zgemm_mfma<true>, grid, dim3(GEMM_WAVES * 64), 0, b->stream, (int)m, (int)n, (int)k,
-                           kchunk, A, lda, B, ldb, C, ldc, alpha, beta, slab);
+                           kchunk, gm, gn, nsplit, A, lda, B, ldb, C, ldc, alpha, beta, slab);
     else
         hipLaunchKernelGGL(k_zgemm_mfma<false>, grid, dim3(GEMM_WAVES * 64), 0, b->stream, (int)m, (int)n, (int)k,
-                           kchunk, A, lda, B, ldb, C, ldc, alpha, beta, slab);
+                           kchunk, gm, gn, nsplit, A, lda, B, ldb, C, ldc, alpha, beta, slab);
     if (nsplit > 1) {
         hipLaunchKernelGGL(k_zgemm_reduce, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, b->stream, (int)m,
                            (int)n, nsplit, slab, C, ldc, alpha, beta);

@@ -150,6 +150,9 @@ int dftk_mi_allreduce_sum_f64(dftk_mi_comm* comm, double* buf_d, size_t n, void*
 int dftk_mi_prof_enable(dftk_mi_basis* basis, int on);
 int dftk_mi_prof_get(dftk_mi_basis* basis, int family, double* total_ms, double* work, int64_t* launches);
 
+/* Diagnostic: measured issue-rate ceiling of v_mfma_f64_16x16x4_f64 (TFLOP/s, no memory traffic). */
+int dftk_mi_diag_mfma_peak(dftk_mi_basis* basis, int waves_per_simd, int iters, double* tflops);
+
 /* ---- host-only introspection (no GPU needed; used by the CPU test-suite) ---------------------
  * 1-D plan for length n: radices (<= 32 entries) and the in-place permutation `pos[e]` such
  * that a decimation-in-time pass wants input element e at position pos[e] and a

@@ -150,10 +150,13 @@ def main():
     check(lib.dftk_mi_prof_enable(basis.handle, 1))
     nmv0 = stepper.info["n_matvec"]
     iters = []
+    host_timers = {}
     t0 = time.time()
     for _ in range(args.steps):
         info = stepper.step()
         iters.append(float(np.mean(info["diagonalization"]["n_iter"])))
+        for k_, v_ in info["timers"].items():
+            host_timers[k_] = host_timers.get(k_, 0.0) + v_
     barrier()
     elapsed = time.time() - t0
     check(lib.dftk_mi_prof_enable(basis.handle, 0))
@@ -196,7 +199,8 @@ def main():
                        "n_G": basis.kpoints[0].n_G, "n_bands": int(info["psi"][0].shape[0]),
                        "n_proj": int(basis.terms.D.shape[0]) if basis.terms.D is not None else 0,
                        "parallelism": f"kpt{n_gpus}", "setup_s": round(t_setup, 2),
-                       "lobpcg_iters_per_step": iters, "E_total": info["energies"].total,
+                       "lobpcg_iters_per_step": iters,
+                       "host_timers_ms_per_step": {k_: round(1e3 * v_ / args.steps, 2) for k_, v_ in host_timers.items()}, "E_total": info["energies"].total,
                        "drho": info["history_drho"][-1]},
             "roofline": roof,
         }

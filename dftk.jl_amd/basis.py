@@ -67,7 +67,9 @@ class Kpoint:
         B = torch.tensor(basis.model.recip_lattice, dtype=torch.float64, device=dev)
         k = torch.tensor(self.coordinate, dtype=torch.float64, device=dev)
         G = torch.stack([gx.reshape(-1), gy.reshape(-1), gz.reshape(-1)], dim=1).to(torch.float64)
-        Gk = (G + k[None, :]) @ B.T
+        Gp = G + k[None, :]
+        # B (G + k) spelled out (keeps the set-up free of BLAS calls with degenerate 3-wide shapes)
+        Gk = Gp[:, 0:1] * B[:, 0][None, :] + Gp[:, 1:2] * B[:, 1][None, :] + Gp[:, 2:3] * B[:, 2][None, :]
         kin_all = (Gk * Gk).sum(dim=1) / 2
         mapping = torch.nonzero(kin_all <= basis.Ecut).reshape(-1)
         self.mapping = mapping.cpu().numpy().astype(np.int64)            # 0-based, ascending
@@ -151,8 +153,8 @@ class PlaneWaveBasis:
     def G_vectors_cart_cube(self):
         gx, gy, gz = self.G_vectors_cube()
         B = torch.tensor(self.model.recip_lattice, dtype=torch.float64, device=self.device)
-        G = torch.stack([gx, gy, gz], dim=-1).to(torch.float64)
-        return G @ B.T
+        gx, gy, gz = gx.to(torch.float64), gy.to(torch.float64), gz.to(torch.float64)
+        return gx[..., None] * B[:, 0] + gy[..., None] * B[:, 1] + gz[..., None] * B[:, 2]
 
     def enforce_real_mask(self):
         """1 where the -G partner exists on the grid (symmetry.jl:318-337,550-552), else 0."""

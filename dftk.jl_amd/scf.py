@@ -133,17 +133,22 @@ class FixedBands:
 
 
 def next_density(ham, nbandsalg, eigensolver=lobpcg_hyper, psi=None, eigenvalues=None, occupation=None,
-                 tol=1e-6, generator=None, seed=0):
+                 tol=1e-6, generator=None, seed=0, timers=None):
     """self_consistent_field.jl:80-129."""
     basis = ham[0].basis
     n_conv, n_comp = nbandsalg.determine_n_bands(occupation, eigenvalues, psi)
     if psi is not None:
         n_comp = max(n_comp, max(p.shape[0] for p in psi))
     n_comp = int(basis.comm_kpts.max_scalar(n_comp))                       # mpi_max(n_bands_compute)
+    t0 = time.time()
     eig = diagonalize_all_kblocks(eigensolver, ham, n_comp, psiguess=psi, n_conv_check=n_conv, tol=tol,
                                   miniter=1, generator=generator, seed=seed)
+    t1 = time.time()
     occ, eF = compute_occupation(basis, eig["λ"], tol_n_elec=nbandsalg.occupation_threshold)
     rho = compute_density(basis, eig["X"], occ, nbandsalg.occupation_threshold)
+    if timers is not None:
+        timers["diagonalization"] = timers.get("diagonalization", 0.0) + t1 - t0
+        timers["occupation+density"] = timers.get("occupation+density", 0.0) + time.time() - t1
     n_matvec = int(basis.comm_kpts.sum_scalar(eig["n_matvec"]))
     return dict(psi=eig["X"], eigenvalues=eig["λ"], occupation=occ, eF=eF, rho=rho, diagonalization=eig,
                 n_bands_converge=n_conv, n_matvec=n_matvec)
@@ -153,7 +158,8 @@ def next_density(ham, nbandsalg, eigensolver=lobpcg_hyper, psi=None, eigenvalues
 class AndersonAcceleration:
     """anderson.jl:36-130.  The history (<= m cube-sized vectors) stays in HBM; the m x m
     least-squares problem min |Pf_n + M beta| is solved on the host from the Gram matrix
-    M'M (cond(R)^2 = cond(M'M) gives the reference's conditioning test on the QR factor)."""
+    M'M (cond(R)^2 = cond(M'M) gives the reference's conditioning test on the QR factor).
+    Only elementwise products / row sums / axpys touch the cube-sized vectors."""
 
     def __init__(self, m=10, maxcond=1e6, errorfactor=1e5):
         self.iterates, self.residuals, self.errors = [], [], []
@@ -183,20 +189,40 @@ class AndersonAcceleration:
         if drop:
             self._delete(drop)
         pf = Pfx.reshape(-1)
+        xf = x.reshape(-1)
+        # inner products <r_i, r_j>, <r_i, pf>, <pf, pf> (one fused reduction per history entry)
+        nh = len(self.residuals)
+        rr = np.zeros((nh, nh))
+        rp = np.zeros(nh)
+        for i in range(nh):
+            ri = self.residuals[i]
+            vals = torch.stack([(ri * self.residuals[j]).sum() for j in range(i, nh)] + [(ri * pf).sum()]).cpu().numpy()
+            rr[i, i:] = vals[:-1]
+            rr[i:, i] = vals[:-1]
+            rp[i] = vals[-1]
+        pp = float((pf * pf).sum().item())
+        keep = list(range(nh))
         while True:
-            Mmat = torch.stack(self.residuals, dim=0) - pf[None, :]          # (m, N): rows M[:, j]
-            G = (Mmat @ Mmat.T).cpu().numpy()
-            b = (Mmat @ pf).cpu().numpy()
+            # M[:, j] = r_j - pf  =>  G = M'M, b = M'pf
+            G = rr[np.ix_(keep, keep)] - rp[keep][:, None] - rp[keep][None, :] + pp
+            bvec = rp[keep] - pp
             ev = np.linalg.eigvalsh(G)
             cond_R = math.sqrt(max(ev[-1], 0.0) / max(ev[0], 1e-300)) if ev[-1] > 0 else 1.0
-            if Mmat.shape[0] > 1 and cond_R > self.maxcond:
-                self._delete([int(np.argmax(self.errors[:-1]))])
+            if len(keep) > 1 and cond_R > self.maxcond:
+                worst = int(np.argmax([self.errors[k] for k in keep[:-1]]))
+                keep.pop(worst)
                 continue
             break
-        betas = -np.linalg.lstsq(G, b, rcond=None)[0]
-        xn = x.reshape(-1) + alpha * pf
+        if len(keep) < nh:
+            self._delete([k for k in range(nh) if k not in keep])
+        betas = -np.linalg.lstsq(G, bvec, rcond=None)[0]
+        xn = xf + alpha * pf
+        sb = float(np.sum(betas))
+        # sum_i beta_i (x_i - x + alpha (r_i - pf))
+        xn = xn - sb * (xf + alpha * pf)
         for ib, beta in enumerate(betas):
-            xn = xn + float(beta) * (self.iterates[ib] - x.reshape(-1) + alpha * (self.residuals[ib] - pf))
+            xn.add_(self.iterates[ib], alpha=float(beta))
+            xn.add_(self.residuals[ib], alpha=float(beta) * alpha)
         self._push(x, Pfx)
         return xn.reshape(x.shape)
 
@@ -234,11 +260,23 @@ class ScfStepper:
     def step(self):
         basis, info = self.basis, self.info
         t_it = time.time()
+        timers = {}
+
+        def lap(name, t0):
+            torch.cuda.synchronize(basis.device)
+            timers[name] = timers.get(name, 0.0) + time.time() - t0
+            return time.time()
+
+        t = time.time()
         _, ham = energy_hamiltonian(basis, info["psi"], info["occupation"], rho=self.rho_in)
+        t = lap("energy_hamiltonian", t)
         diagtol = self.determine_tol(info["n_iter"], info["history_drho"])
         nxt = next_density(ham, self.nbandsalg, self.eigensolver, psi=info["psi"], eigenvalues=info["eigenvalues"],
-                           occupation=info["occupation"], tol=diagtol, generator=self.gen, seed=self.seed)
+                           occupation=info["occupation"], tol=diagtol, generator=self.gen, seed=self.seed,
+                           timers=timers)
+        t = time.time()
         energies, _ = energy_hamiltonian(basis, nxt["psi"], nxt["occupation"], rho=nxt["rho"], only_energies=True)
+        t = lap("energies", t)
         drho = nxt["rho"] - self.rho_in
         n_matvec_total = info["n_matvec"] + nxt["n_matvec"]
         info = dict(info, **nxt)
@@ -250,7 +288,10 @@ class ScfStepper:
         info["timings"] = info["timings"] + [time.time() - t_it]
         if not info["converged"]:
             # rho_next = Anderson(rho_in, beta, rho_out - rho_in); simple mixing: P^-1 = 1
+            t = time.time()
             self.rho_in = self.accel(self.rho_in, self.damping, drho)
+            lap("mixing", t)
+        info["timers"] = timers
         self.info = info
         return info
 

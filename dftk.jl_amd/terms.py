@@ -78,7 +78,7 @@ def build_projection_vectors(basis, kpt):
         ff = build_projector_form_factors(psp, kpt.Gplusk_cart) / math.sqrt(model.unit_cell_volume)
         for ia in group:
             r = torch.tensor(model.positions[ia], dtype=torch.float64, device=basis.device)
-            sf = torch.exp(-1j * TWO_PI * (Gpk @ r))
+            sf = torch.exp(-1j * TWO_PI * (Gpk[:, 0] * r[0] + Gpk[:, 1] * r[1] + Gpk[:, 2] * r[2]))
             rows.append(ff * sf[None, :])
     if not rows:
         return None
@@ -303,6 +303,21 @@ def instantiate_terms(basis):
     return T
 
 
+def _band_nonlocal_energy(Ppsi, D):
+    """Re sum_ij conj(p_i) D_ij p_j per band, using only the non-zero (banded) entries of D."""
+    n_p = D.shape[0]
+    bw = 0
+    nz = np.nonzero(D)
+    if len(nz[0]):
+        bw = int(np.max(np.abs(nz[0] - nz[1])))
+    out = torch.zeros(Ppsi.shape[0], dtype=torch.float64, device=Ppsi.device)
+    for off in range(-bw, bw + 1):
+        i0, i1 = max(0, -off), min(n_p, n_p - off)
+        d = torch.as_tensor(np.ascontiguousarray(np.diagonal(D, offset=off)), dtype=torch.float64, device=Ppsi.device)
+        out += ((torch.conj(Ppsi[:, i0:i1]) * Ppsi[:, i0 + off:i1 + off]).real * d[None, :]).sum(dim=1)
+    return out
+
+
 def _PH_psi(basis, Pt, psik):
     """P' psi through the library's f64-MFMA zgemm; returns a (n_bands, n_p) tensor."""
     n_p, n_G = Pt.shape
@@ -334,7 +349,7 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False):
             if have_psi:
                 e = 0.0
                 for ik, psik in enumerate(psi):
-                    dots = (psik.real ** 2 + psik.imag ** 2) @ T.kinetic[ik]      # (n_bands,)
+                    dots = ((psik.real ** 2 + psik.imag ** 2) * T.kinetic[ik][None, :]).sum(dim=1)   # (n_bands,)
                     occ = torch.as_tensor(occupation[ik], dtype=torch.float64, device=basis.device)
                     e += basis.kweights[ik] * float((occ * dots).sum().item())
                 E[name] = basis.comm_kpts.sum_scalar(e)
@@ -348,10 +363,9 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False):
                 E[name] = 0.0
             elif have_psi:
                 e = 0.0
-                Dd = torch.as_tensor(T.D, dtype=torch.complex128, device=basis.device)
                 for ik, psik in enumerate(psi):
                     Ppsi = _PH_psi(basis, T.P[ik], psik)           # (n_bands, n_p) rows = (P' psi)[:, band]
-                    band = (torch.conj(Ppsi) * (Ppsi @ Dd.T)).real.sum(dim=1)
+                    band = _band_nonlocal_energy(Ppsi, T.D)
                     occ = torch.as_tensor(occupation[ik], dtype=torch.float64, device=basis.device)
                     e += basis.kweights[ik] * float((band * occ).sum().item())
                 E[name] = basis.comm_kpts.sum_scalar(e)

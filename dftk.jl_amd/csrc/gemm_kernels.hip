@@ -196,6 +196,227 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_mfma(int m, int n, in
             }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-staged variant (default).  Same tiling / grid / epilogue as k_zgemm_mfma, but the K-tile
+// (8 deep) of both operands is staged through LDS:
+//   * global reads are fully coalesced (8 lanes x 16 B = one 128-B line per column of a K-major
+//     operand; 128 consecutive rows of an M-major one) and each element is fetched ONCE per
+//     workgroup instead of once per wave that needs it;
+//   * LDS image is [k][column] with a 16-element-aligned pitch, so a wave's MFMA fragment read
+//     (16 columns x 2 k per lane group) touches 16 distinct 16-B slots: conflict-free
+//     ds_read_b128; K-major operands are stored with the column index XOR (k & 7) so that the
+//     transposing ds_write_b128 of 8 consecutive-k lanes also hits 8 distinct slots;
+//   * register-staged software pipeline: the global loads of tile t+1 are in flight while the 64
+//     MFMAs of tile t issue; one barrier per tile, two LDS buffers.
+#define LT_KT 8
+template <bool CONJA>
+__global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_lds(int m, int n, int K, int kchunk, int gm, int gn,
+                                                               int nsplit, const cd* __restrict__ A, int64_t lda,
+                                                               const cd* __restrict__ B, int64_t ldb,
+                                                               cd* __restrict__ C, int64_t ldc, cd alpha, cd beta,
+                                                               cd* __restrict__ slab) {
+    __shared__ cd sA[2][LT_KT][GEMM_BM];
+    __shared__ cd sB[2][LT_KT][GEMM_BN];
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int col_t = slot % gn;
+    const int R = (slot / gn) * 8 + xcd;
+    if (R >= gm * nsplit) return;   // whole workgroup
+    const int z = R / gm, row_t = R - z * gm;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int I0 = row_t * GEMM_BM, J0 = col_t * GEMM_BN;
+    const int i0 = I0 + wave * (GEMM_RM * 16);
+    const int kbeg = z * kchunk;
+    const int kend = min(K, kbeg + kchunk);
+    const int rmv = min(GEMM_RM, max(0, (m - i0 + 15) >> 4));
+    const int rnv = min(GEMM_RN, max(0, (n - J0 + 15) >> 4));
+    const bool active = rmv > 0 && rnv > 0;
+
+    v4d accR[GEMM_RM][GEMM_RN], accI[GEMM_RM][GEMM_RN];
+#pragma unroll
+    for (int a = 0; a < GEMM_RM; ++a)
+#pragma unroll
+        for (int b = 0; b < GEMM_RN; ++b) {
+            accR[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+            accI[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+        }
+
+    // ---- global -> register staging assignment
+    // K-major operand tile (LT_KT x W columns): thread handles k = tid & 7, columns (tid >> 3) + 32 r
+    // M-major A tile (LT_KT x 128 rows):        thread handles row = tid & 127, k = (tid >> 7) + 2 r
+    const int tk = tid & 7, tc = tid >> 3;
+    const cd* gA[4];
+    const cd* gB[2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (CONJA) {
+            int c = I0 + tc + 32 * r;
+            if (c > m - 1) c = m - 1;
+            gA[r] = A + (int64_t)c * lda;
+        } else {
+            int i = I0 + (tid & 127);
+            if (i > m - 1) i = m - 1;
+            gA[r] = A + i;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        int c = J0 + tc + 32 * r;
+        if (c > n - 1) c = n - 1;
+        gB[r] = B + (int64_t)c * ldb;
+    }
+    // staging registers are plain named values (arrays captured by lambdas end up in scratch)
+    struct Stage {
+        cd a0, a1, a2, a3, b0, b1;
+    };
+    auto load_tile = [&](int k0) -> Stage {
+        Stage st;
+        const int kB = min(k0 + tk, kend - 1);
+        if (CONJA) {
+            st.a0 = gA[0][kB];
+            st.a1 = gA[1][kB];
+            st.a2 = gA[2][kB];
+            st.a3 = gA[3][kB];
+        } else {
+            const int kk = k0 + (tid >> 7);
+            st.a0 = gA[0][(int64_t)min(kk, kend - 1) * lda];
+            st.a1 = gA[1][(int64_t)min(kk + 2, kend - 1) * lda];
+            st.a2 = gA[2][(int64_t)min(kk + 4, kend - 1) * lda];
+            st.a3 = gA[3][(int64_t)min(kk + 6, kend - 1) * lda];
+        }
+        st.b0 = gB[0][kB];
+        st.b1 = gB[1][kB];
+        return st;
+    };
+    // zero the entries whose k lies beyond the K range (only the last tile of a chunk needs it)
+    auto mask_tile = [&](Stage st, int k0) -> Stage {
+        const cd czero = make_double2(0.0, 0.0);
+        const bool vB = (k0 + tk) < kend;
+        if (CONJA) {
+            if (!vB) st.a0 = st.a1 = st.a2 = st.a3 = czero;
+        } else {
+            const int kk = k0 + (tid >> 7);
+            if (kk >= kend) st.a0 = czero;
+            if (kk + 2 >= kend) st.a1 = czero;
+            if (kk + 4 >= kend) st.a2 = czero;
+            if (kk + 6 >= kend) st.a3 = czero;
+        }
+        if (!vB) st.b0 = st.b1 = czero;
+        return st;
+    };
+    auto store_tile = [&](int buf, const Stage& st) {
+        if (CONJA) {
+            sA[buf][tk][(tc) ^ tk] = st.a0;
+            sA[buf][tk][(tc + 32) ^ tk] = st.a1;
+            sA[buf][tk][(tc + 64) ^ tk] = st.a2;
+            sA[buf][tk][(tc + 96) ^ tk] = st.a3;
+        } else {
+            const int kk = tid >> 7, ii = tid & 127;
+            sA[buf][kk][ii] = st.a0;
+            sA[buf][kk + 2][ii] = st.a1;
+            sA[buf][kk + 4][ii] = st.a2;
+            sA[buf][kk + 6][ii] = st.a3;
+        }
+        sB[buf][tk][(tc) ^ tk] = st.b0;
+        sB[buf][tk][(tc + 32) ^ tk] = st.b1;
+    };
+    auto compute = [&](int buf) {
+        const int k0 = 2 * lk, k1 = 2 * lk + 1;
+        cd fa[GEMM_RM][2], fb[GEMM_RN][2];
+#pragma unroll
+        for (int a = 0; a < GEMM_RM; ++a) {
+            const int c = wave * (GEMM_RM * 16) + a * 16 + li;
+            fa[a][0] = sA[buf][k0][CONJA ? (c ^ k0) : c];
+            fa[a][1] = sA[buf][k1][CONJA ? (c ^ k1) : c];
+        }
+#pragma unroll
+        for (int b = 0; b < GEMM_RN; ++b) {
+            const int c = b * 16 + li;
+            fb[b][0] = sB[buf][k0][c ^ k0];
+            fb[b][1] = sB[buf][k1][c ^ k1];
+        }
+#pragma unroll
+        for (int a = 0; a < GEMM_RM; ++a) {
+            if (a < rmv) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const double ar = fa[a][h].x;
+                    const double ai = fa[a][h].y;
+                    const double nai = -ai;
+#pragma unroll
+                    for (int b = 0; b < GEMM_RN; ++b)
+                        if (b < rnv) accR[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, fb[b][h].x, accR[a][b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < GEMM_RN; ++b)
+                        if (b < rnv) accI[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, fb[b][h].y, accI[a][b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < GEMM_RN; ++b)
+                        if (b < rnv)
+                            accR[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(CONJA ? ai : nai, fb[b][h].y, accR[a][b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < GEMM_RN; ++b)
+                        if (b < rnv)
+                            accI[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(CONJA ? nai : ai, fb[b][h].x, accI[a][b], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    const int nt = (kend - kbeg + LT_KT - 1) / LT_KT;
+    if (nt > 0) {
+        {
+            Stage st = load_tile(kbeg);
+            if (nt == 1) st = mask_tile(st, kbeg);
+            store_tile(0, st);
+        }
+        __syncthreads();
+        for (int t = 0; t < nt; ++t) {
+            const bool more = (t + 1) < nt;
+            Stage st;
+            if (more) {
+                st = load_tile(kbeg + (t + 1) * LT_KT);
+                if (t + 2 == nt) st = mask_tile(st, kbeg + (t + 1) * LT_KT);
+            }
+            if (active) compute(t & 1);
+            if (more) store_tile((t + 1) & 1, st);
+            __syncthreads();
+        }
+    }
+    if (!active) return;
+
+    // epilogue
+    const int j0 = J0;
+    const bool direct = (slab == nullptr);
+    cd* sl = direct ? nullptr : slab + (int64_t)z * m * n;
+#pragma unroll
+    for (int a = 0; a < GEMM_RM; ++a)
+#pragma unroll
+        for (int b = 0; b < GEMM_RN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = i0 + a * 16 + lk + 4 * r;
+                const int gj = j0 + b * 16 + li;
+                if (gi < m && gj < n) {
+                    const double vr = accR[a][b][r], vi = accI[a][b][r];
+                    if (direct) {
+                        cd* c = C + gi + (int64_t)gj * ldc;
+                        cd o = make_double2(alpha.x * vr - alpha.y * vi, alpha.x * vi + alpha.y * vr);
+                        if (beta.x != 0.0 || beta.y != 0.0) {
+                            const cd old = *c;
+                            o.x += beta.x * old.x - beta.y * old.y;
+                            o.y += beta.x * old.y + beta.y * old.x;
+                        }
+                        *c = o;
+                    } else {
+                        sl[gi + (int64_t)gj * m] = make_double2(vr, vi);
+                    }
+                }
+            }
+}
+
 // C = alpha * sum_z slab[z] + beta * C   (fixed summation order)
 __global__ void k_zgemm_reduce(int m, int n, int nsplit, const cd* __restrict__ slab, cd* __restrict__ C,
                                int64_t ldc, cd alpha, cd beta) {
@@ -386,12 +607,21 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
     const int64_t nblocks = ((rows_total + 7) / 8) * 8 * gn;
     if (nblocks > INT32_MAX) return DFTK_MI_EINVAL;
     dim3 grid((unsigned)nblocks);
-    if (conja)
-        hipLaunchKernelGGL(k_zgemm_mfma<true>, grid, dim3(GEMM_WAVES * 64), 0, b->stream, (int)m, (int)n, (int)k,
-                           kchunk, gm, gn, nsplit, A, lda, B, ldb, C, ldc, alpha, beta, slab);
-    else
-        hipLaunchKernelGGL(k_zgemm_mfma<false>, grid, dim3(GEMM_WAVES * 64), 0, b->stream, (int)m, (int)n, (int)k,
-                           kchunk, gm, gn, nsplit, A, lda, B, ldb, C, ldc, alpha, beta, slab);
+    if (b->use_mfma == 2) {   // direct-from-global variant (env DFTK_MI_GEMM=direct)
+        if (conja)
+            hipLaunchKernelGGL(k_zgemm_mfma<true>, grid, dim3(GEMM_WAVES * 64), 0, b->stream, (int)m, (int)n, (int)k,
+                               kchunk, gm, gn, nsplit, A, lda, B, ldb, C, ldc, alpha, beta, slab);
+        else
+            hipLaunchKernelGGL(k_zgemm_mfma<false>, grid, dim3(GEMM_WAVES * 64), 0, b->stream, (int)m, (int)n, (int)k,
+                               kchunk, gm, gn, nsplit, A, lda, B, ldb, C, ldc, alpha, beta, slab);
+    } else {
+        if (conja)
+            hipLaunchKernelGGL(k_zgemm_lds<true>, grid, dim3(GEMM_WAVES * 64), 0, b->stream, (int)m, (int)n, (int)k,
+                               kchunk, gm, gn, nsplit, A, lda, B, ldb, C, ldc, alpha, beta, slab);
+        else
+            hipLaunchKernelGGL(k_zgemm_lds<false>, grid, dim3(GEMM_WAVES * 64), 0, b->stream, (int)m, (int)n, (int)k,
+                               kchunk, gm, gn, nsplit, A, lda, B, ldb, C, ldc, alpha, beta, slab);
+    }
     if (nsplit > 1) {
         hipLaunchKernelGGL(k_zgemm_reduce, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, b->stream, (int)m,
                            (int)n, nsplit, slab, C, ldc, alpha, beta);

@@ -15,6 +15,7 @@
 // a second kernel reduces in a fixed order => bitwise reproducible results.
 #include "common.h"
 #include <cstdio>
+#include <cstdlib>
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -566,6 +567,8 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
         HIPCHK(hipGetLastError());
         return 0;
     }
+    static const bool trace = getenv("DFTK_MI_TRACE_GEMM") != nullptr;
+    if (trace) fprintf(stderr, "[zgemm] %c %lld %lld %lld\n", transA, (long long)m, (long long)n, (long long)k);
     const int slot = prof_begin(b, PROF_ZGEMM, 8.0 * (double)m * (double)n * (double)k);
     struct ProfGuard {
         dftk_mi_basis* b;
@@ -585,14 +588,19 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
     }
     const int gm = (int)((m + GEMM_BM - 1) / GEMM_BM);
     const int gn = (int)((n + GEMM_BN - 1) / GEMM_BN);
-    // split K so that the launch has ~2 workgroups per CU; only worth it for long K
+    // split K so that the launch has several rounds of workgroups (512 run concurrently: 2 per CU);
+    // ragged edge tiles finish early, so ~4 rounds keep the tail short.  Only worth it for long K.
     int nsplit = 1;
     const int64_t tiles = (int64_t)gm * gn;
-    if (k >= 2048 && tiles < 512) {
-        nsplit = (int)((512 + tiles - 1) / tiles);
-        const int64_t max_by_k = k / 512;
+    const char* senv = getenv("DFTK_MI_GEMM_BLOCKS");
+    const int64_t target = senv ? atoll(senv) : 4096;
+    if (k >= 2048 && tiles < target) {
+        nsplit = (int)((target + tiles - 1) / tiles);
+        const int64_t max_by_k = k / 256;
         if (nsplit > max_by_k) nsplit = (int)max_by_k;
-        if (nsplit > 256) nsplit = 256;
+        if (nsplit > 1024) nsplit = 1024;
+        const int64_t max_by_ws = (int64_t)(512ull << 20) / ((int64_t)m * n * (int64_t)sizeof(cd));   // slabs <= 512 MiB
+        if (nsplit > max_by_ws) nsplit = (int)max_by_ws;
         if (nsplit < 1) nsplit = 1;
     }
     int kchunk = (int)((k + nsplit - 1) / nsplit);

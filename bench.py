@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--supercell", type=int, default=4, help="n for the n x n x n Si supercell (4 = configs[1])")
     ap.add_argument("--ecut", type=float, default=30.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-bands", type=int, default=48)
+    ap.add_argument("--cpu-sample-bands", type=int, default=192)
     return ap.parse_args()
 
 

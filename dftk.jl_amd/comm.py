@@ -3,13 +3,16 @@ src/common/mpi.jl:19-53) re-designed for one process per GPU.
 
 * ``KptComm.single()``   -- one rank, no communication.
 * ``KptComm.from_torch()`` -- uses an initialised ``torch.distributed`` group for the rendezvous
-  (rank / size / shipping the RCCL unique id).  On GPUs the bulk density all-reduce goes through
-  the library's RCCL communicator (``dftk_mi_allreduce_sum_f64``); on CPU tensors (gloo tests of
-  the sharding logic) it falls through to ``torch.distributed.all_reduce``.
+  (rank / size).  The bulk density all-reduce is ``torch.distributed.all_reduce`` -- RCCL over xGMI
+  with the ``nccl`` backend on GPUs, gloo on CPU tensors (tests of the sharding logic).  With
+  ``DFTK_MI_COMM=abi`` GPU reductions go through the library's own RCCL communicator instead
+  (``dftk_mi_allreduce_sum_f64``, the entry point a Julia shim binds; the unique id is shipped
+  through the torch store).
 """
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -62,7 +65,8 @@ class KptComm:
         """mpi_sum!(arr, comm) (common/mpi.jl:19-21), in place."""
         if self.size == 1:
             return t
-        if t.is_cuda:
+        if t.is_cuda and os.environ.get("DFTK_MI_COMM", "torch") == "abi":
+            # the C-ABI communicator (what a Julia shim uses): dftk_mi_allreduce_sum_f64 -> ncclAllReduce
             if t.dtype != torch.float64 or not t.is_contiguous():
                 raise ValueError("RCCL density all-reduce expects a contiguous float64 tensor")
             from ._lib import load, check

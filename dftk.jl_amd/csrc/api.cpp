@@ -23,7 +23,7 @@ extern "C" const char* dftk_mi_version(void) {
 }
 
 // ------------------------------------------------------------------------------------ profiling
-int prof_begin(dftk_mi_basis* b, int fam, double work) {
+int prof_begin(dftk_mi_basis* b, int fam, double work, uint64_t tag) {
     Prof* p = b->prof;
     if (!p || !p->on) return -1;
     if (p->pending.size() >= 60000) prof_resolve(b);
@@ -35,6 +35,8 @@ int prof_begin(dftk_mi_basis* b, int fam, double work) {
         if (hipEventCreate(&pr.a) != hipSuccess || hipEventCreate(&pr.b) != hipSuccess) return -1;
     }
     pr.fam = fam;
+    pr.tag = tag;
+    pr.work = work;
     p->work[fam] += work;
     p->launches[fam] += 1;
     hipEventRecord(pr.a, b->stream);
@@ -51,7 +53,15 @@ int prof_resolve(dftk_mi_basis* b) {
     HIPCHK(hipStreamSynchronize(b->stream));
     for (auto& pr : p->pending) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, pr.a, pr.b) == hipSuccess) p->ms[pr.fam] += ms;
+        if (hipEventElapsedTime(&ms, pr.a, pr.b) == hipSuccess) {
+            p->ms[pr.fam] += ms;
+            if (pr.tag) {
+                auto& sh = p->shapes[pr.tag];
+                sh.ms += ms;
+                sh.work += pr.work;
+                sh.n += 1;
+            }
+        }
         p->pool.push_back(pr);
     }
     p->pending.clear();
@@ -66,6 +76,17 @@ extern "C" int dftk_mi_prof_enable(dftk_mi_basis* b, int on) {
             b->prof->work[i] = 0;
             b->prof->launches[i] = 0;
         }
+    }
+    if (!on && !b->prof->shapes.empty()) {
+        // DFTK_MI_GEMM_SHAPES: per-shape zgemm table (tag = trans | m | n | k)
+        for (auto& kv : b->prof->shapes) {
+            const uint64_t t = kv.first;
+            fprintf(stderr, "[zgemm-shape] %c m=%llu n=%llu k=%llu calls=%lld ms=%.3f TF/s=%.2f\n",
+                    (t >> 63) ? 'C' : 'N', (unsigned long long)((t >> 42) & 0xFFFFF),
+                    (unsigned long long)((t >> 22) & 0xFFFFF), (unsigned long long)(t & 0x3FFFFF),
+                    (long long)kv.second.n, kv.second.ms, kv.second.work / (kv.second.ms * 1e9));
+        }
+        b->prof->shapes.clear();
     }
     b->prof->on = on != 0;
     return 0;

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <string>
+#include <map>
 #include <vector>
 #include "../../include/dftk_mi355x.h"
 
@@ -76,14 +77,16 @@ enum ProfFamily {
 };
 struct Prof {
     bool on = false;
-    struct Pair { hipEvent_t a, b; int fam; };
+    struct Pair { hipEvent_t a, b; int fam; uint64_t tag; double work; };
+    struct Shape { double ms = 0, work = 0; int64_t n = 0; };
+    std::map<uint64_t, Shape> shapes;   // per-shape zgemm breakdown (env DFTK_MI_GEMM_SHAPES)
     std::vector<Pair> pending;
     std::vector<Pair> pool;
     double ms[PROF_NFAM] = {0};
     double work[PROF_NFAM] = {0};
     int64_t launches[PROF_NFAM] = {0};
 };
-int prof_begin(dftk_mi_basis* b, int fam, double work);   // returns slot index or -1
+int prof_begin(dftk_mi_basis* b, int fam, double work, uint64_t tag = 0);   // returns slot index or -1
 void prof_end(dftk_mi_basis* b, int slot);
 int prof_resolve(dftk_mi_basis* b);
 

@@ -16,6 +16,7 @@
 #include "common.h"
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -210,8 +211,12 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_mfma(int m, int n, in
 //   * register-staged software pipeline: the global loads of tile t+1 are in flight while the 64
 //     MFMAs of tile t issue; one barrier per tile, two LDS buffers.
 #define LT_KT 8
-template <bool CONJA>
+// FULL: launched only over tiles that lie entirely inside C -> no per-sub-tile predicates (runtime
+// predicates become a branch per MFMA and break the MFMA issue stream).  gm x gn is the tile
+// sub-grid of this launch, (rt0, ct0) its origin in tiles (see lsplit below for the border launch).
+template <bool CONJA, bool FULL>
 __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_lds(int m, int n, int K, int kchunk, int gm, int gn,
+                                                               int rt0, int ct0, int lsplit,
                                                                int nsplit, const cd* __restrict__ A, int64_t lda,
                                                                const cd* __restrict__ B, int64_t ldb,
                                                                cd* __restrict__ C, int64_t ldc, cd alpha, cd beta,
@@ -228,13 +233,17 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_lds(int m, int n, int
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const int I0 = row_t * GEMM_BM, J0 = col_t * GEMM_BN;
+    // rectangle of tiles at (rt0, ct0), or (lsplit >= 0) the L-shaped ragged border as a list:
+    // entries < lsplit are the right strip (tile column ct0), the rest the bottom strip (tile row rt0)
+    const int tr = lsplit < 0 ? row_t + rt0 : (row_t < lsplit ? row_t : rt0);
+    const int tcn = lsplit < 0 ? col_t + ct0 : (row_t < lsplit ? ct0 : row_t - lsplit);
+    const int I0 = tr * GEMM_BM, J0 = tcn * GEMM_BN;
     const int i0 = I0 + wave * (GEMM_RM * 16);
     const int kbeg = z * kchunk;
     const int kend = min(K, kbeg + kchunk);
-    const int rmv = min(GEMM_RM, max(0, (m - i0 + 15) >> 4));
-    const int rnv = min(GEMM_RN, max(0, (n - J0 + 15) >> 4));
-    const bool active = rmv > 0 && rnv > 0;
+    const int rmv = FULL ? GEMM_RM : min(GEMM_RM, max(0, (m - i0 + 15) >> 4));
+    const int rnv = FULL ? GEMM_RN : min(GEMM_RN, max(0, (n - J0 + 15) >> 4));
+    const bool active = FULL || (rmv > 0 && rnv > 0);
 
     v4d accR[GEMM_RM][GEMM_RN], accI[GEMM_RM][GEMM_RN];
 #pragma unroll
@@ -249,47 +258,76 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_lds(int m, int n, int
     // K-major operand tile (LT_KT x W columns): thread handles k = tid & 7, columns (tid >> 3) + 32 r
     // M-major A tile (LT_KT x 128 rows):        thread handles row = tid & 127, k = (tid >> 7) + 2 r
     const int tk = tid & 7, tc = tid >> 3;
-    const cd* gA[4];
-    const cd* gB[2];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        if (CONJA) {
-            int c = I0 + tc + 32 * r;
-            if (c > m - 1) c = m - 1;
-            gA[r] = A + (int64_t)c * lda;
-        } else {
-            int i = I0 + (tid & 127);
-            if (i > m - 1) i = m - 1;
-            gA[r] = A + i;
-        }
+    // running per-thread source pointers (named scalars: arrays captured by lambdas end up in scratch);
+    // every load advances them by one k-tile
+    const cd *pA0, *pA1, *pA2, *pA3, *pB0, *pB1;
+    {
+        auto a_ptr = [&](int r) -> const cd* {
+            if (CONJA) {
+                int c = I0 + tc + 32 * r;
+                if (c > m - 1) c = m - 1;
+                return A + (int64_t)c * lda + kbeg + tk;
+            } else {
+                int i = I0 + (tid & 127);
+                if (i > m - 1) i = m - 1;
+                return A + i + (int64_t)(kbeg + (tid >> 7) + 2 * r) * lda;
+            }
+        };
+        auto b_ptr = [&](int r) -> const cd* {
+            int c = J0 + tc + 32 * r;
+            if (c > n - 1) c = n - 1;
+            return B + (int64_t)c * ldb + kbeg + tk;
+        };
+        pA0 = a_ptr(0);
+        pA1 = a_ptr(1);
+        pA2 = a_ptr(2);
+        pA3 = a_ptr(3);
+        pB0 = b_ptr(0);
+        pB1 = b_ptr(1);
     }
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        int c = J0 + tc + 32 * r;
-        if (c > n - 1) c = n - 1;
-        gB[r] = B + (int64_t)c * ldb;
-    }
-    // staging registers are plain named values (arrays captured by lambdas end up in scratch)
+    const int64_t stepA = CONJA ? (int64_t)LT_KT : (int64_t)LT_KT * lda;
     struct Stage {
         cd a0, a1, a2, a3, b0, b1;
     };
+    auto advance = [&]() {
+        pA0 += stepA;
+        pA1 += stepA;
+        pA2 += stepA;
+        pA3 += stepA;
+        pB0 += LT_KT;
+        pB1 += LT_KT;
+    };
+    // tile entirely inside [kbeg, kend): plain loads
+    auto load_fast = [&]() -> Stage {
+        Stage st;
+        st.a0 = *pA0;
+        st.a1 = *pA1;
+        st.a2 = *pA2;
+        st.a3 = *pA3;
+        st.b0 = *pB0;
+        st.b1 = *pB1;
+        advance();
+        return st;
+    };
+    // any tile: k indices beyond kend-1 are clamped to kend-1 (and zeroed later by mask_tile)
     auto load_tile = [&](int k0) -> Stage {
         Stage st;
-        const int kB = min(k0 + tk, kend - 1);
+        const int oB = max(0, k0 + tk - (kend - 1));
         if (CONJA) {
-            st.a0 = gA[0][kB];
-            st.a1 = gA[1][kB];
-            st.a2 = gA[2][kB];
-            st.a3 = gA[3][kB];
+            st.a0 = *(pA0 - oB);
+            st.a1 = *(pA1 - oB);
+            st.a2 = *(pA2 - oB);
+            st.a3 = *(pA3 - oB);
         } else {
-            const int kk = k0 + (tid >> 7);
-            st.a0 = gA[0][(int64_t)min(kk, kend - 1) * lda];
-            st.a1 = gA[1][(int64_t)min(kk + 2, kend - 1) * lda];
-            st.a2 = gA[2][(int64_t)min(kk + 4, kend - 1) * lda];
-            st.a3 = gA[3][(int64_t)min(kk + 6, kend - 1) * lda];
+            const int kk = k0 + (tid >> 7) - (kend - 1);
+            st.a0 = *(pA0 - (int64_t)max(0, kk) * lda);
+            st.a1 = *(pA1 - (int64_t)max(0, kk + 2) * lda);
+            st.a2 = *(pA2 - (int64_t)max(0, kk + 4) * lda);
+            st.a3 = *(pA3 - (int64_t)max(0, kk + 6) * lda);
         }
-        st.b0 = gB[0][kB];
-        st.b1 = gB[1][kB];
+        st.b0 = *(pB0 - oB);
+        st.b1 = *(pB1 - oB);
+        advance();
         return st;
     };
     // zero the entries whose k lies beyond the K range (only the last tile of a chunk needs it)
@@ -324,66 +362,112 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_lds(int m, int n, int
         sB[buf][tk][(tc) ^ tk] = st.b0;
         sB[buf][tk][(tc + 32) ^ tk] = st.b1;
     };
-    auto compute = [&](int buf) {
-        const int k0 = 2 * lk, k1 = 2 * lk + 1;
-        cd fa[GEMM_RM][2], fb[GEMM_RN][2];
+    // MFMA fragments of one k-half of a tile: half h holds k = 2*lk + h (lk = lane >> 4)
+    struct Frag {
+        cd a[GEMM_RM], b[GEMM_RN];
+    };
+    auto read_frag = [&](int buf, int h) -> Frag {
+        Frag f;
+        const int kk = 2 * lk + h;
 #pragma unroll
         for (int a = 0; a < GEMM_RM; ++a) {
             const int c = wave * (GEMM_RM * 16) + a * 16 + li;
-            fa[a][0] = sA[buf][k0][CONJA ? (c ^ k0) : c];
-            fa[a][1] = sA[buf][k1][CONJA ? (c ^ k1) : c];
+            f.a[a] = sA[buf][kk][CONJA ? (c ^ kk) : c];
         }
 #pragma unroll
         for (int b = 0; b < GEMM_RN; ++b) {
             const int c = b * 16 + li;
-            fb[b][0] = sB[buf][k0][c ^ k0];
-            fb[b][1] = sB[buf][k1][c ^ k1];
+            f.b[b] = sB[buf][kk][c ^ kk];
         }
+        return f;
+    };
+    auto mfma_half = [&](const Frag& f) {
 #pragma unroll
         for (int a = 0; a < GEMM_RM; ++a) {
-            if (a < rmv) {
+            if (FULL || a < rmv) {
+                const double ar = f.a[a].x;
+                const double ai = f.a[a].y;
+                const double nai = -ai;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const double ar = fa[a][h].x;
-                    const double ai = fa[a][h].y;
-                    const double nai = -ai;
+                for (int b = 0; b < GEMM_RN; ++b)
+                    if (FULL || b < rnv) accR[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, f.b[b].x, accR[a][b], 0, 0, 0);
 #pragma unroll
-                    for (int b = 0; b < GEMM_RN; ++b)
-                        if (b < rnv) accR[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, fb[b][h].x, accR[a][b], 0, 0, 0);
+                for (int b = 0; b < GEMM_RN; ++b)
+                    if (FULL || b < rnv) accI[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, f.b[b].y, accI[a][b], 0, 0, 0);
 #pragma unroll
-                    for (int b = 0; b < GEMM_RN; ++b)
-                        if (b < rnv) accI[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, fb[b][h].y, accI[a][b], 0, 0, 0);
+                for (int b = 0; b < GEMM_RN; ++b)
+                    if (FULL || b < rnv)
+                        accR[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(CONJA ? ai : nai, f.b[b].y, accR[a][b], 0, 0, 0);
 #pragma unroll
-                    for (int b = 0; b < GEMM_RN; ++b)
-                        if (b < rnv)
-                            accR[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(CONJA ? ai : nai, fb[b][h].y, accR[a][b], 0, 0, 0);
-#pragma unroll
-                    for (int b = 0; b < GEMM_RN; ++b)
-                        if (b < rnv)
-                            accI[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(CONJA ? nai : ai, fb[b][h].x, accI[a][b], 0, 0, 0);
-                }
+                for (int b = 0; b < GEMM_RN; ++b)
+                    if (FULL || b < rnv)
+                        accI[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(CONJA ? nai : ai, f.b[b].x, accI[a][b], 0, 0, 0);
             }
         }
     };
 
+    // Software pipeline (two LDS buffers, ONE barrier per tile, placed in the middle of the tile's
+    // MFMA stream so that nothing waits on a fresh LDS/global access):
+    //   iteration t:  read half-1 fragments of tile t | write tile t+1 (registers) to the other buffer,
+    //                 issue the global loads of tile t+2 | 32 MFMAs on half 0 | barrier |
+    //                 read half-0 fragments of tile t+1 | 32 MFMAs on half 1
     const int nt = (kend - kbeg + LT_KT - 1) / LT_KT;
     if (nt > 0) {
-        {
-            Stage st = load_tile(kbeg);
-            if (nt == 1) st = mask_tile(st, kbeg);
-            store_tile(0, st);
-        }
+        Stage st = load_tile(kbeg);
+        if (nt == 1) st = mask_tile(st, kbeg);
+        store_tile(0, st);
+        if (nt > 1) st = load_tile(kbeg + LT_KT);
         __syncthreads();
-        for (int t = 0; t < nt; ++t) {
-            const bool more = (t + 1) < nt;
-            Stage st;
-            if (more) {
-                st = load_tile(kbeg + (t + 1) * LT_KT);
-                if (t + 2 == nt) st = mask_tile(st, kbeg + (t + 1) * LT_KT);
+        Frag f0 = read_frag(0, 0);
+        int t = 0;
+        if (FULL) {
+            // steady state (tiles t+1, t+2, t+3 exist): one branch-free block, and the
+            // scheduler is told to drop one memory instruction into the shadow of each MFMA so that this
+            // wave alone keeps the matrix pipe fed (the two workgroups of a CU run in lockstep, so
+            // "the other wave covers my memory phase" does not happen by itself).
+            for (; t + 3 < nt; ++t) {   // tile t+2 is not the last one: it lies entirely inside the chunk
+                Frag f1 = read_frag(t & 1, 1);
+                store_tile((t + 1) & 1, st);
+                st = load_fast();
+                mfma_half(f0);
+#pragma unroll
+                for (int i = 0; i < GEMM_RM + GEMM_RN; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
+                }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // pointer advance
+                }
+                __syncthreads();
+                f0 = read_frag((t + 1) & 1, 0);
+                mfma_half(f1);
+#pragma unroll
+                for (int i = 0; i < GEMM_RM + GEMM_RN; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+                }
             }
-            if (active) compute(t & 1);
-            if (more) store_tile((t + 1) & 1, st);
+        }
+        for (; t < nt; ++t) {
+            const bool more = (t + 1) < nt;
+            Frag f1 = read_frag(t & 1, 1);
+            if (more) {
+                if (t + 2 == nt) st = mask_tile(st, kbeg + (t + 1) * LT_KT);
+                store_tile((t + 1) & 1, st);
+                if (t + 2 < nt) st = load_tile(kbeg + (t + 2) * LT_KT);
+            }
+            if (active) mfma_half(f0);
             __syncthreads();
+            if (more) f0 = read_frag((t + 1) & 1, 0);
+            if (active) mfma_half(f1);
         }
     }
     if (!active) return;
@@ -569,7 +653,11 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
     }
     static const bool trace = getenv("DFTK_MI_TRACE_GEMM") != nullptr;
     if (trace) fprintf(stderr, "[zgemm] %c %lld %lld %lld\n", transA, (long long)m, (long long)n, (long long)k);
-    const int slot = prof_begin(b, PROF_ZGEMM, 8.0 * (double)m * (double)n * (double)k);
+    static const bool shapes = getenv("DFTK_MI_GEMM_SHAPES") != nullptr;
+    const uint64_t tag = !shapes ? 0
+                                 : ((uint64_t)conja << 63) | ((uint64_t)(m & 0xFFFFF) << 42) |
+                                       ((uint64_t)(n & 0xFFFFF) << 22) | (uint64_t)(k & 0x3FFFFF) | (1ull << 62);
+    const int slot = prof_begin(b, PROF_ZGEMM, 8.0 * (double)m * (double)n * (double)k, tag);
     struct ProfGuard {
         dftk_mi_basis* b;
         int s;
@@ -588,15 +676,16 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
     }
     const int gm = (int)((m + GEMM_BM - 1) / GEMM_BM);
     const int gn = (int)((n + GEMM_BN - 1) / GEMM_BN);
-    // split K so that the launch has several rounds of workgroups (512 run concurrently: 2 per CU);
-    // ragged edge tiles finish early, so ~4 rounds keep the tail short.  Only worth it for long K.
+    // split K so that the interior (full-tile) launch fills the 512 workgroup slots (2 per CU) exactly
+    // once: equal-sized chunks, no tail, and the smallest slab traffic.  Only worth it for long K.
     int nsplit = 1;
-    const int64_t tiles = (int64_t)gm * gn;
     const char* senv = getenv("DFTK_MI_GEMM_BLOCKS");
-    const int64_t target = senv ? atoll(senv) : 4096;
-    if (k >= 2048 && tiles < target) {
-        nsplit = (int)((target + tiles - 1) / tiles);
-        const int64_t max_by_k = k / 256;
+    const int64_t slots = senv ? atoll(senv) : 512;
+    int64_t tiles = (m / GEMM_BM) * (n / GEMM_BN);
+    if (tiles == 0) tiles = (int64_t)gm * gn;
+    if (k >= 128 && tiles < slots) {
+        nsplit = (int)(slots / tiles);
+        const int64_t max_by_k = k >= 2048 ? k / 256 : k / 64;   // short K: latency-bound, chunks of >= 8 tiles
         if (nsplit > max_by_k) nsplit = (int)max_by_k;
         if (nsplit > 1024) nsplit = 1024;
         const int64_t max_by_ws = (int64_t)(512ull << 20) / ((int64_t)m * n * (int64_t)sizeof(cd));   // slabs <= 512 MiB
@@ -611,11 +700,14 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
         CHK(ensure_ws(b, (size_t)nsplit * m * n * sizeof(cd)));
         slab = (cd*)b->ws;
     }
-    const int64_t rows_total = (int64_t)gm * nsplit;
-    const int64_t nblocks = ((rows_total + 7) / 8) * 8 * gn;
-    if (nblocks > INT32_MAX) return DFTK_MI_EINVAL;
-    dim3 grid((unsigned)nblocks);
+    // XCD-aware 1-D grid over a gm_s x gn_s sub-grid of tiles (x nsplit K chunks)
+    auto grid_for = [&](int gm_s, int gn_s) -> int64_t {
+        const int64_t rows_total = (int64_t)gm_s * nsplit;
+        return ((rows_total + 7) / 8) * 8 * gn_s;
+    };
+    if (grid_for(gm, gn) > INT32_MAX) return DFTK_MI_EINVAL;
     if (b->use_mfma == 2) {   // direct-from-global variant (env DFTK_MI_GEMM=direct)
+        dim3 grid((unsigned)grid_for(gm, gn));
         if (conja)
             hipLaunchKernelGGL(k_zgemm_mfma<true>, grid, dim3(GEMM_WAVES * 64), 0, b->stream, (int)m, (int)n, (int)k,
                                kchunk, gm, gn, nsplit, A, lda, B, ldb, C, ldc, alpha, beta, slab);
@@ -623,12 +715,32 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
             hipLaunchKernelGGL(k_zgemm_mfma<false>, grid, dim3(GEMM_WAVES * 64), 0, b->stream, (int)m, (int)n, (int)k,
                                kchunk, gm, gn, nsplit, A, lda, B, ldb, C, ldc, alpha, beta, slab);
     } else {
-        if (conja)
-            hipLaunchKernelGGL(k_zgemm_lds<true>, grid, dim3(GEMM_WAVES * 64), 0, b->stream, (int)m, (int)n, (int)k,
-                               kchunk, gm, gn, nsplit, A, lda, B, ldb, C, ldc, alpha, beta, slab);
-        else
-            hipLaunchKernelGGL(k_zgemm_lds<false>, grid, dim3(GEMM_WAVES * 64), 0, b->stream, (int)m, (int)n, (int)k,
-                               kchunk, gm, gn, nsplit, A, lda, B, ldb, C, ldc, alpha, beta, slab);
+        // interior tiles run the predicate-free kernel; the ragged right / bottom strips the general one
+        const int gmf = (int)(m / GEMM_BM), gnf = (int)(n / GEMM_BN);
+        static const int pad_lds = getenv("DFTK_MI_GEMM_PAD_LDS") ? atoi(getenv("DFTK_MI_GEMM_PAD_LDS")) : 0;   // occupancy experiments
+        auto launch = [&](bool full, int gm_s, int gn_s, int rt0, int ct0, int lsplit) {
+            if (gm_s <= 0 || gn_s <= 0) return;
+            dim3 grid((unsigned)grid_for(gm_s, gn_s));
+#define DFTK_LAUNCH_LDS(CJ, FL)                                                                                  \
+    hipLaunchKernelGGL((k_zgemm_lds<CJ, FL>), grid, dim3(GEMM_WAVES * 64), pad_lds, b->stream, (int)m, (int)n, (int)k, \
+                       kchunk, gm_s, gn_s, rt0, ct0, lsplit, nsplit, A, lda, B, ldb, C, ldc, alpha, beta, slab)
+            if (conja) {
+                if (full) DFTK_LAUNCH_LDS(true, true);
+                else DFTK_LAUNCH_LDS(true, false);
+            } else {
+                if (full) DFTK_LAUNCH_LDS(false, true);
+                else DFTK_LAUNCH_LDS(false, false);
+            }
+#undef DFTK_LAUNCH_LDS
+        };
+        launch(true, gmf, gnf, 0, 0, -1);           // interior
+        {
+            // ragged border in ONE launch: right strip (all tile rows of the last tile column) followed
+            // by the bottom strip (the full tile columns of the last tile row)
+            const int nright = (gn > gnf) ? gm : 0;
+            const int nbottom = (gm > gmf) ? gnf : 0;
+            launch(false, nright + nbottom, 1, gmf, gnf, nright);
+        }
     }
     if (nsplit > 1) {
         hipLaunchKernelGGL(k_zgemm_reduce, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, b->stream, (int)m,

@@ -22,6 +22,8 @@ for w in (1, 2, 4):
 nG = int(os.environ.get("NG", 135491))
 shapes = [] if os.environ.get("PEAK_ONLY") else [("C", 259, 259, nG), ("C", 640, 259, nG), ("C", 518, 259, nG), ("C", 129, 129, nG), ("C", 259, 1, nG),
           ("N", nG, 259, 259), ("N", nG, 259, 640), ("N", nG, 259, 518), ("N", nG, 129, 129), ("N", nG, 1, 259)]
+if os.environ.get("SHAPES"):   # e.g. SHAPES="N:135491:259:259,C:259:259:135491"
+    shapes = [(t.split(":")[0], *map(int, t.split(":")[1:])) for t in os.environ["SHAPES"].split(",")]
 gen = torch.Generator(device="cuda").manual_seed(0)
 
 

@@ -502,13 +502,19 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_lds(int m, int n, int
             }
 }
 
-// C = alpha * sum_z slab[z] + beta * C   (fixed summation order)
-__global__ void k_zgemm_reduce(int m, int n, int nsplit, const cd* __restrict__ slab, cd* __restrict__ C,
-                               int64_t ldc, cd alpha, cd beta) {
+// C = alpha * sum_z slab[z] + beta * C   (fixed summation order).  The interior (i < mi, j < nj) and
+// the ragged border have their own split counts / slabs; a count < 0 means that region was written
+// directly by the GEMM kernel and is skipped here.
+__global__ void k_zgemm_reduce(int m, int n, int mi, int nj, int nsI, const cd* __restrict__ slabI, int nsB,
+                               const cd* __restrict__ slabB, cd* __restrict__ C, int64_t ldc, cd alpha, cd beta) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)m * n) return;
     const int j = (int)(idx / m);
     const int i = (int)(idx - (int64_t)j * m);
+    const bool interior = i < mi && j < nj;
+    const int nsplit = interior ? nsI : nsB;
+    const cd* slab = interior ? slabI : slabB;
+    if (nsplit < 0) return;
     double sr = 0.0, si = 0.0;
     for (int z = 0; z < nsplit; ++z) {
         const cd v = slab[(int64_t)z * m * n + idx];
@@ -647,7 +653,7 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
     if (m > INT32_MAX || n > INT32_MAX || k > INT32_MAX) return DFTK_MI_EINVAL;
     if (k <= 0) {   // C = beta * C : run the reduce kernel over zero slabs
         hipLaunchKernelGGL(k_zgemm_reduce, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, b->stream, (int)m,
-                           (int)n, 0, (const cd*)nullptr, C, ldc, alpha, beta);
+                           (int)n, (int)m, (int)n, 0, (const cd*)nullptr, 0, (const cd*)nullptr, C, ldc, alpha, beta);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -676,54 +682,75 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
     }
     const int gm = (int)((m + GEMM_BM - 1) / GEMM_BM);
     const int gn = (int)((n + GEMM_BN - 1) / GEMM_BN);
-    // split K so that the interior (full-tile) launch fills the 512 workgroup slots (2 per CU) exactly
-    // once: equal-sized chunks, no tail, and the smallest slab traffic.  Only worth it for long K.
-    int nsplit = 1;
+    // Split K so that a launch fills the 512 workgroup slots (2 per CU) about once: equal-sized
+    // chunks, no tail, smallest slab traffic.  Short K is latency-bound: chunks of >= 8 tiles.
     const char* senv = getenv("DFTK_MI_GEMM_BLOCKS");
     const int64_t slots = senv ? atoll(senv) : 512;
-    int64_t tiles = (m / GEMM_BM) * (n / GEMM_BN);
-    if (tiles == 0) tiles = (int64_t)gm * gn;
-    if (k >= 128 && tiles < slots) {
-        nsplit = (int)(slots / tiles);
-        const int64_t max_by_k = k >= 2048 ? k / 256 : k / 64;   // short K: latency-bound, chunks of >= 8 tiles
-        if (nsplit > max_by_k) nsplit = (int)max_by_k;
-        if (nsplit > 1024) nsplit = 1024;
-        const int64_t max_by_ws = (int64_t)(512ull << 20) / ((int64_t)m * n * (int64_t)sizeof(cd));   // slabs <= 512 MiB
-        if (nsplit > max_by_ws) nsplit = (int)max_by_ws;
-        if (nsplit < 1) nsplit = 1;
-    }
-    int kchunk = (int)((k + nsplit - 1) / nsplit);
-    kchunk = (kchunk + 7) & ~7;
-    nsplit = (int)((k + kchunk - 1) / kchunk);
-    cd* slab = nullptr;
-    if (nsplit > 1) {
-        CHK(ensure_ws(b, (size_t)nsplit * m * n * sizeof(cd)));
-        slab = (cd*)b->ws;
-    }
+    struct Split {
+        int nsplit, kchunk;
+        cd* slab;
+    };
+    const int64_t plane = (int64_t)m * n * (int64_t)sizeof(cd);
+    auto plan_split = [&](int64_t tiles) -> Split {
+        int ns = 1;
+        if (k >= 128 && tiles > 0 && tiles < slots) {
+            ns = (int)(slots / tiles);
+            const int64_t max_by_k = k >= 2048 ? k / 256 : k / 64;
+            if (ns > max_by_k) ns = (int)max_by_k;
+            if (ns > 1024) ns = 1024;
+            const int64_t max_by_ws = (int64_t)(256ull << 20) / plane;   // each slab <= 256 MiB
+            if (ns > max_by_ws) ns = (int)max_by_ws;
+            if (ns < 1) ns = 1;
+        }
+        int kc = (int)((k + ns - 1) / ns);
+        kc = (kc + 7) & ~7;
+        ns = (int)((k + kc - 1) / kc);
+        return Split{ns, kc, nullptr};
+    };
     // XCD-aware 1-D grid over a gm_s x gn_s sub-grid of tiles (x nsplit K chunks)
-    auto grid_for = [&](int gm_s, int gn_s) -> int64_t {
-        const int64_t rows_total = (int64_t)gm_s * nsplit;
+    auto grid_for = [&](int gm_s, int gn_s, int ns) -> int64_t {
+        const int64_t rows_total = (int64_t)gm_s * ns;
         return ((rows_total + 7) / 8) * 8 * gn_s;
     };
-    if (grid_for(gm, gn) > INT32_MAX) return DFTK_MI_EINVAL;
     if (b->use_mfma == 2) {   // direct-from-global variant (env DFTK_MI_GEMM=direct)
-        dim3 grid((unsigned)grid_for(gm, gn));
+        Split sp = plan_split((int64_t)gm * gn);
+        if (sp.nsplit > 1) {
+            CHK(ensure_ws(b, (size_t)sp.nsplit * plane));
+            sp.slab = (cd*)b->ws;
+        }
+        if (grid_for(gm, gn, sp.nsplit) > INT32_MAX) return DFTK_MI_EINVAL;
+        dim3 grid((unsigned)grid_for(gm, gn, sp.nsplit));
         if (conja)
             hipLaunchKernelGGL(k_zgemm_mfma<true>, grid, dim3(GEMM_WAVES * 64), 0, b->stream, (int)m, (int)n, (int)k,
-                               kchunk, gm, gn, nsplit, A, lda, B, ldb, C, ldc, alpha, beta, slab);
+                               sp.kchunk, gm, gn, sp.nsplit, A, lda, B, ldb, C, ldc, alpha, beta, sp.slab);
         else
             hipLaunchKernelGGL(k_zgemm_mfma<false>, grid, dim3(GEMM_WAVES * 64), 0, b->stream, (int)m, (int)n, (int)k,
-                               kchunk, gm, gn, nsplit, A, lda, B, ldb, C, ldc, alpha, beta, slab);
+                               sp.kchunk, gm, gn, sp.nsplit, A, lda, B, ldb, C, ldc, alpha, beta, sp.slab);
+        if (sp.nsplit > 1)
+            hipLaunchKernelGGL(k_zgemm_reduce, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, b->stream, (int)m,
+                               (int)n, (int)m, (int)n, sp.nsplit, sp.slab, sp.nsplit, sp.slab, C, ldc, alpha, beta);
     } else {
-        // interior tiles run the predicate-free kernel; the ragged right / bottom strips the general one
+        // interior tiles run the predicate-free kernel; the ragged right / bottom strips the general one,
+        // as ONE list-shaped launch (right strip: all tile rows of the last tile column; bottom strip:
+        // the full tile columns of the last tile row) with its own K split
         const int gmf = (int)(m / GEMM_BM), gnf = (int)(n / GEMM_BN);
+        const int nright = (gn > gnf) ? gm : 0;
+        const int nbottom = (gm > gmf) ? gnf : 0;
+        Split spI = plan_split((int64_t)gmf * gnf);
+        Split spB = plan_split((int64_t)nright + nbottom);
+        const size_t bytesI = spI.nsplit > 1 ? (size_t)spI.nsplit * plane : 0;
+        const size_t bytesB = spB.nsplit > 1 ? (size_t)spB.nsplit * plane : 0;
+        if (bytesI + bytesB) CHK(ensure_ws(b, bytesI + bytesB));
+        if (bytesI) spI.slab = (cd*)b->ws;
+        if (bytesB) spB.slab = (cd*)((char*)b->ws + bytesI);
         static const int pad_lds = getenv("DFTK_MI_GEMM_PAD_LDS") ? atoi(getenv("DFTK_MI_GEMM_PAD_LDS")) : 0;   // occupancy experiments
-        auto launch = [&](bool full, int gm_s, int gn_s, int rt0, int ct0, int lsplit) {
-            if (gm_s <= 0 || gn_s <= 0) return;
-            dim3 grid((unsigned)grid_for(gm_s, gn_s));
-#define DFTK_LAUNCH_LDS(CJ, FL)                                                                                  \
+        auto launch = [&](bool full, int gm_s, int gn_s, int rt0, int ct0, int lsplit, const Split& sp) -> int {
+            if (gm_s <= 0 || gn_s <= 0) return 0;
+            if (grid_for(gm_s, gn_s, sp.nsplit) > INT32_MAX) return DFTK_MI_EINVAL;
+            dim3 grid((unsigned)grid_for(gm_s, gn_s, sp.nsplit));
+#define DFTK_LAUNCH_LDS(CJ, FL)                                                                                        \
     hipLaunchKernelGGL((k_zgemm_lds<CJ, FL>), grid, dim3(GEMM_WAVES * 64), pad_lds, b->stream, (int)m, (int)n, (int)k, \
-                       kchunk, gm_s, gn_s, rt0, ct0, lsplit, nsplit, A, lda, B, ldb, C, ldc, alpha, beta, slab)
+                       sp.kchunk, gm_s, gn_s, rt0, ct0, lsplit, sp.nsplit, A, lda, B, ldb, C, ldc, alpha, beta, sp.slab)
             if (conja) {
                 if (full) DFTK_LAUNCH_LDS(true, true);
                 else DFTK_LAUNCH_LDS(true, false);
@@ -732,19 +759,14 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
                 else DFTK_LAUNCH_LDS(false, false);
             }
 #undef DFTK_LAUNCH_LDS
+            return 0;
         };
-        launch(true, gmf, gnf, 0, 0, -1);           // interior
-        {
-            // ragged border in ONE launch: right strip (all tile rows of the last tile column) followed
-            // by the bottom strip (the full tile columns of the last tile row)
-            const int nright = (gn > gnf) ? gm : 0;
-            const int nbottom = (gm > gmf) ? gnf : 0;
-            launch(false, nright + nbottom, 1, gmf, gnf, nright);
-        }
-    }
-    if (nsplit > 1) {
-        hipLaunchKernelGGL(k_zgemm_reduce, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, b->stream, (int)m,
-                           (int)n, nsplit, slab, C, ldc, alpha, beta);
+        CHK(launch(true, gmf, gnf, 0, 0, -1, spI));
+        CHK(launch(false, nright + nbottom, 1, gmf, gnf, nright, spB));
+        if (spI.slab || spB.slab)
+            hipLaunchKernelGGL(k_zgemm_reduce, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, b->stream, (int)m,
+                               (int)n, gmf * GEMM_BM, gnf * GEMM_BN, spI.slab ? spI.nsplit : -1, spI.slab,
+                               spB.slab ? spB.nsplit : -1, spB.slab, C, ldc, alpha, beta);
     }
     HIPCHK(hipGetLastError());
     return 0;

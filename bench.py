@@ -184,6 +184,7 @@ def main():
         roof["launches"] = launches
         roof["avg_launch_ms"] = ms / max(launches, 1)
         roof["families_ms"] = {FAMILIES[f]: round(fam[f][0], 3) for f in FAMILIES}
+        roof["families_launches"] = {FAMILIES[f]: int(fam[f][2]) for f in FAMILIES}
         roof["families_rate"] = {
             FAMILIES[f]: (round(fam[f][1] / (fam[f][0] * 1e-3) / (1e12 if f == 0 else 1e9), 2)
                           if fam[f][0] > 0 and f < 7 else None) for f in FAMILIES}

@@ -132,8 +132,10 @@ int launch_kinetic_only(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi
                         int64_t ldout, bool accumulate, bool use_kin);
 
 // gemm_kernels.hip
+// upper != 0: only the 128x64 tiles that intersect the upper triangle (i <= j) are computed and
+// written; the rest of C is left untouched (Gram matrices that are hermitised afterwards)
 int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alpha, const cd* A,
-          int64_t lda, const cd* B, int64_t ldb, cd beta, cd* C, int64_t ldc);
+          int64_t lda, const cd* B, int64_t ldb, cd beta, cd* C, int64_t ldc, int upper = 0);
 int ensure_ws(dftk_mi_basis* b, size_t bytes);
 
 // dense_kernels.hip

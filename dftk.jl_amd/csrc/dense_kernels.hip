@@ -615,7 +615,7 @@ int dense_potrf_trtri(dftk_mi_basis* b, int n, cd* A, int64_t lda, cd* invR, int
             cd* R12 = A + j0 + (int64_t)(j0 + jb) * lda;
             cd* A22 = A + (j0 + jb) + (int64_t)(j0 + jb) * lda;
             const cd mone = make_double2(-1.0, 0.0), one = make_double2(1.0, 0.0);
-            CHK(zgemm(b, 'C', n2, n2, jb, mone, R12, lda, R12, lda, one, A22, lda));
+            CHK(zgemm(b, 'C', n2, n2, jb, mone, R12, lda, R12, lda, one, A22, lda, /*upper=*/1));   // only the upper triangle is ever read
         }
     }
     hipLaunchKernelGGL(k_trtri_upper, dim3(n), dim3(64), (size_t)n * sizeof(cd), b->stream, n, A, lda, invR, ldi);

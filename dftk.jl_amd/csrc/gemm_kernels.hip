@@ -216,7 +216,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_mfma(int m, int n, in
 // sub-grid of this launch, (rt0, ct0) its origin in tiles (see lsplit below for the border launch).
 template <bool CONJA, bool FULL>
 __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_lds(int m, int n, int K, int kchunk, int gm, int gn,
-                                                               int rt0, int ct0, int lsplit,
+                                                               int rt0, int ct0, int lsplit, int upper,
                                                                int nsplit, const cd* __restrict__ A, int64_t lda,
                                                                const cd* __restrict__ B, int64_t ldb,
                                                                cd* __restrict__ C, int64_t ldc, cd alpha, cd beta,
@@ -238,6 +238,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_lds(int m, int n, int
     const int tr = lsplit < 0 ? row_t + rt0 : (row_t < lsplit ? row_t : rt0);
     const int tcn = lsplit < 0 ? col_t + ct0 : (row_t < lsplit ? ct0 : row_t - lsplit);
     const int I0 = tr * GEMM_BM, J0 = tcn * GEMM_BN;
+    if (upper && I0 >= J0 + GEMM_BN) return;   // tile strictly below the diagonal (whole workgroup)
     const int i0 = I0 + wave * (GEMM_RM * 16);
     const int kbeg = z * kchunk;
     const int kend = min(K, kbeg + kchunk);
@@ -506,11 +507,13 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_lds(int m, int n, int
 // the ragged border have their own split counts / slabs; a count < 0 means that region was written
 // directly by the GEMM kernel and is skipped here.
 __global__ void k_zgemm_reduce(int m, int n, int mi, int nj, int nsI, const cd* __restrict__ slabI, int nsB,
-                               const cd* __restrict__ slabB, cd* __restrict__ C, int64_t ldc, cd alpha, cd beta) {
+                               const cd* __restrict__ slabB, cd* __restrict__ C, int64_t ldc, cd alpha, cd beta,
+                               int upper) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)m * n) return;
     const int j = (int)(idx / m);
     const int i = (int)(idx - (int64_t)j * m);
+    if (upper && (i / GEMM_BM) * GEMM_BM >= (j / GEMM_BN) * GEMM_BN + GEMM_BN) return;   // tile not computed
     const bool interior = i < mi && j < nj;
     const int nsplit = interior ? nsI : nsB;
     const cd* slab = interior ? slabI : slabB;
@@ -643,7 +646,7 @@ int ensure_ws(dftk_mi_basis* b, size_t bytes) {
 }
 
 int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alpha, const cd* A, int64_t lda,
-          const cd* B, int64_t ldb, cd beta, cd* C, int64_t ldc) {
+          const cd* B, int64_t ldb, cd beta, cd* C, int64_t ldc, int upper) {
     if (m <= 0 || n <= 0) return 0;
     const bool conja = (transA == 'C' || transA == 'c');
     if (!conja && !(transA == 'N' || transA == 'n')) {
@@ -653,7 +656,7 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
     if (m > INT32_MAX || n > INT32_MAX || k > INT32_MAX) return DFTK_MI_EINVAL;
     if (k <= 0) {   // C = beta * C : run the reduce kernel over zero slabs
         hipLaunchKernelGGL(k_zgemm_reduce, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, b->stream, (int)m,
-                           (int)n, (int)m, (int)n, 0, (const cd*)nullptr, 0, (const cd*)nullptr, C, ldc, alpha, beta);
+                           (int)n, (int)m, (int)n, 0, (const cd*)nullptr, 0, (const cd*)nullptr, C, ldc, alpha, beta, 0);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -728,7 +731,7 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
                                sp.kchunk, gm, gn, sp.nsplit, A, lda, B, ldb, C, ldc, alpha, beta, sp.slab);
         if (sp.nsplit > 1)
             hipLaunchKernelGGL(k_zgemm_reduce, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, b->stream, (int)m,
-                               (int)n, (int)m, (int)n, sp.nsplit, sp.slab, sp.nsplit, sp.slab, C, ldc, alpha, beta);
+                               (int)n, (int)m, (int)n, sp.nsplit, sp.slab, sp.nsplit, sp.slab, C, ldc, alpha, beta, 0);
     } else {
         // interior tiles run the predicate-free kernel; the ragged right / bottom strips the general one,
         // as ONE list-shaped launch (right strip: all tile rows of the last tile column; bottom strip:
@@ -736,8 +739,19 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
         const int gmf = (int)(m / GEMM_BM), gnf = (int)(n / GEMM_BN);
         const int nright = (gn > gnf) ? gm : 0;
         const int nbottom = (gm > gmf) ? gnf : 0;
-        Split spI = plan_split((int64_t)gmf * gnf);
-        Split spB = plan_split((int64_t)nright + nbottom);
+        int64_t tilesI = (int64_t)gmf * gnf, tilesB = (int64_t)nright + nbottom;
+        if (upper) {   // count only the tiles that intersect the upper triangle
+            auto live = [&](int tr, int tc) { return tr * GEMM_BM < tc * GEMM_BN + GEMM_BN; };
+            tilesI = tilesB = 0;
+            for (int tr = 0; tr < gmf; ++tr)
+                for (int tc = 0; tc < gnf; ++tc) tilesI += live(tr, tc);
+            for (int e = 0; e < nright; ++e) tilesB += live(e, gnf);
+            for (int e = 0; e < nbottom; ++e) tilesB += live(gmf, e);
+            if (tilesI == 0) tilesI = 1;
+            if (tilesB == 0) tilesB = 1;
+        }
+        Split spI = plan_split(tilesI);
+        Split spB = plan_split(tilesB);
         const size_t bytesI = spI.nsplit > 1 ? (size_t)spI.nsplit * plane : 0;
         const size_t bytesB = spB.nsplit > 1 ? (size_t)spB.nsplit * plane : 0;
         if (bytesI + bytesB) CHK(ensure_ws(b, bytesI + bytesB));
@@ -750,7 +764,7 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
             dim3 grid((unsigned)grid_for(gm_s, gn_s, sp.nsplit));
 #define DFTK_LAUNCH_LDS(CJ, FL)                                                                                        \
     hipLaunchKernelGGL((k_zgemm_lds<CJ, FL>), grid, dim3(GEMM_WAVES * 64), pad_lds, b->stream, (int)m, (int)n, (int)k, \
-                       sp.kchunk, gm_s, gn_s, rt0, ct0, lsplit, sp.nsplit, A, lda, B, ldb, C, ldc, alpha, beta, sp.slab)
+                       sp.kchunk, gm_s, gn_s, rt0, ct0, lsplit, upper, sp.nsplit, A, lda, B, ldb, C, ldc, alpha, beta, sp.slab)
             if (conja) {
                 if (full) DFTK_LAUNCH_LDS(true, true);
                 else DFTK_LAUNCH_LDS(true, false);
@@ -766,7 +780,7 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
         if (spI.slab || spB.slab)
             hipLaunchKernelGGL(k_zgemm_reduce, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, b->stream, (int)m,
                                (int)n, gmf * GEMM_BM, gnf * GEMM_BN, spI.slab ? spI.nsplit : -1, spI.slab,
-                               spB.slab ? spB.nsplit : -1, spB.slab, C, ldc, alpha, beta);
+                               spB.slab ? spB.nsplit : -1, spB.slab, C, ldc, alpha, beta, upper);
     }
     HIPCHK(hipGetLastError());
     return 0;

@@ -98,7 +98,8 @@ int ortho_X(Ctx& c, Mat X, cd* tmp, double tol, int* nchol_total_out, double* gr
             dftk_set_error("ortho!(X) did not reach the orthogonality tolerance in 30 Cholesky-QR passes");
             return DFTK_MI_NUM_CHOLESKY;
         }
-        CHK(zgemm(c.b, 'C', m, m, X.rows, ONE, X.p, X.ld, X.p, X.ld, ZERO, c.O, m));
+        CHK(zgemm(c.b, 'C', m, m, X.rows, ONE, X.p, X.ld, X.p, X.ld, ZERO, c.O, m, /*upper=*/1));
+        CHK(ew_hermitize_upper(c.b, m, c.O, m));
         CHK(ew_hermitize_upper(c.b, m, c.O, m));
         int nchol;
         double nR = 0, nI = 0;
@@ -196,8 +197,27 @@ int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol) {
     return 0;
 }
 
-// C = sum_b Yb * coef[rows of b]   (LazyHcat * Matrix, lobpcg_hyper_impl.jl:124-132)
+// true when the blocks are adjacent column ranges of one array (same leading dimension)
+bool contiguous(const std::vector<Mat>& Ys) {
+    for (size_t i = 0; i + 1 < Ys.size(); ++i)
+        if (Ys[i].ld != Ys[i + 1].ld || Ys[i].rows != Ys[i + 1].rows ||
+            Ys[i].p + (int64_t)Ys[i].cols * Ys[i].ld != Ys[i + 1].p)
+            return false;
+    return !Ys.empty();
+}
+int total_cols(const std::vector<Mat>& Ys) {
+    int n = 0;
+    for (auto& Y : Ys) n += Y.cols;
+    return n;
+}
+
+// C = sum_b Yb * coef[rows of b]   (LazyHcat * Matrix, lobpcg_hyper_impl.jl:124-132).  The active
+// blocks are kept adjacent in memory (see the workspace layout in lobpcg_run), so this is ONE GEMM
+// with k = sum of the block widths; the per-block loop only serves non-adjacent callers.
 int hcat_mul(Ctx& c, const std::vector<Mat>& Ys, const cd* coef, int64_t ldcoef, int ncols, Mat C) {
+    if (contiguous(Ys))
+        return zgemm(c.b, 'N', Ys[0].rows, ncols, total_cols(Ys), ONE, Ys[0].p, Ys[0].ld, coef, ldcoef, ZERO, C.p,
+                     C.ld);
     int64_t off = 0;
     bool first = true;
     for (auto& Y : Ys) {
@@ -225,7 +245,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
 
     // ---- workspace -------------------------------------------------------------------------
     const size_t blk = (size_t)N * M;                   // elements of one n_G x M block
-    const size_t nbig = 11;                             // AX R AR P AP newX newAX newR newP newAP tmp
+    const size_t nbig = 12;                             // Y(3: X R P) AY(3) newX newAX newR newP newAP tmp
     const size_t m3 = 3 * (size_t)M;
     const size_t small_elems = m3 * m3 * 2              // G, V
                                + m3 * M * 2             // cP, tmpS
@@ -247,9 +267,17 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
         w += n;
         return r;
     };
-    Mat AX{take(blk), N, N, M}, R{take(blk), N, N, M}, AR{take(blk), N, N, M}, P{take(blk), N, N, M},
-        AP{take(blk), N, N, M}, newX{take(blk), N, N, M}, newAX{take(blk), N, N, M}, newR{take(blk), N, N, M},
-        newP{take(blk), N, N, M}, newAP{take(blk), N, N, M};
+    // Y = [X | R | P] and AY = [AX | AR | AP] live in two n_G x 3M arrays.  X keeps columns [0, M);
+    // the ACTIVE residual block sits at columns [M, M + nact) and the active search-direction block
+    // right behind it at [M + nact, M + 2 nact), so that hcat(X_active, R, P) -- columns
+    // [lo, M + 2 nact) -- is one contiguous matrix: Rayleigh-Ritz is one Gram GEMM and the block
+    // updates one GEMM with k = 3 nact instead of per-block products.
+    Mat Ybuf{take(3 * blk), N, N, 3 * M}, AYbuf{take(3 * blk), N, N, 3 * M};
+    Mat X = Ybuf.cols_from(0, M), AX = AYbuf.cols_from(0, M);
+    auto Rblk = [&](const Mat& buf, int nact) { return buf.cols_from(M, nact); };
+    auto Pblk = [&](const Mat& buf, int nact) { return buf.cols_from(M + nact, nact); };
+    Mat newX{take(blk), N, N, M}, newAX{take(blk), N, N, M}, newR{take(blk), N, N, M}, newP{take(blk), N, N, M},
+        newAP{take(blk), N, N, M};
     cd* tmp = take(blk);
     cd* G = take(m3 * m3);
     cd* V = take(m3 * m3);
@@ -271,7 +299,8 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     c.rng.seed(seed ? seed : 0x9E3779B97F4A7C15ull);
     kb->last_AX = AX.p;
 
-    Mat X{Xp, ldX, N, M};
+    Mat Xuser{Xp, ldX, N, M};
+    CHK(ew_copy(b, N, M, Xuser.p, Xuser.ld, X.p, X.ld));
     std::vector<double> resid_history((size_t)M * (maxiter + 1), 0.0);
     auto RH = [&](int i, int it) -> double& { return resid_history[(size_t)i + (size_t)M * it]; };
     std::vector<double> full_lam(M, 0.0);
@@ -292,9 +321,8 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
             dftk_set_error("non-finite values in H*X");
             return DFTK_MI_NUM_NONFINITE;
         }
-    CHK(ew_fill_zero(b, P.p, blk));
-    CHK(ew_fill_zero(b, AP.p, blk));
-    CHK(ew_fill_zero(b, R.p, blk));
+    CHK(ew_fill_zero(b, Ybuf.p + blk, 2 * blk));
+    CHK(ew_fill_zero(b, AYbuf.p + blk, 2 * blk));
     // lambda = Re(X'AX)/(X'X) column-wise
     CHK(ew_coldots(b, N, M, X.p, X.ld, AX.p, AX.ld, c.d_a));
     CHK(ew_coldots(b, N, M, X.p, X.ld, X.p, X.ld, c.d_b));
@@ -310,8 +338,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     while (true) {
         const int nact = M - lo;
         Mat Xa = X.cols_from(lo), AXa = AX.cols_from(lo);
-        Mat Ra = R.cols_from(0, nact), ARa = AR.cols_from(0, nact), Pa = P.cols_from(0, nact),
-            APa = AP.cols_from(0, nact);
+        Mat Ra = Rblk(Ybuf, nact), ARa = Rblk(AYbuf, nact), Pa = Pblk(Ybuf, nact), APa = Pblk(AYbuf, nact);
         Mat nX = newX.cols_from(0, nact), nAX = newAX.cols_from(0, nact), nR = newR.cols_from(0, nact);
         std::vector<Mat> Ys, AYs;
         int nY = 0;
@@ -327,11 +354,15 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
                 AYs.push_back(APa);
             }
             nY = (int)Ys.size() * nact;
-            // rayleigh_ritz: G = Y' AY (upper block triangle), eigen, take the lowest nact
-            for (size_t ib = 0; ib < Ys.size(); ++ib)
-                for (size_t ia = 0; ia <= ib; ++ia)
-                    CHK(zgemm(b, 'C', nact, nact, N, ONE, Ys[ia].p, Ys[ia].ld, AYs[ib].p, AYs[ib].ld, ZERO,
-                              G + (int64_t)ia * nact + (int64_t)ib * nact * nY, nY));
+            // rayleigh_ritz: G = Y' AY (upper triangle), eigen, take the lowest nact
+            if (contiguous(Ys) && contiguous(AYs)) {
+                CHK(zgemm(b, 'C', nY, nY, N, ONE, Ys[0].p, Ys[0].ld, AYs[0].p, AYs[0].ld, ZERO, G, nY, /*upper=*/1));
+            } else {
+                for (size_t ib = 0; ib < Ys.size(); ++ib)
+                    for (size_t ia = 0; ia <= ib; ++ia)
+                        CHK(zgemm(b, 'C', nact, nact, N, ONE, Ys[ia].p, Ys[ia].ld, AYs[ib].p, AYs[ib].ld, ZERO,
+                                  G + (int64_t)ia * nact + (int64_t)ib * nact * nY, nY));
+            }
             CHK(ew_hermitize_upper(b, nY, G, nY));
             std::vector<double> wv(nY);
             {
@@ -414,14 +445,15 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
             }
         // restrict to active
         lo = nlocked;
-        CHK(ew_copy(b, N, lenXn, nR.p + (int64_t)newly_locked * nR.ld, nR.ld, R.p, R.ld));
+        Mat Rn = Rblk(Ybuf, lenXn), Pn = Pblk(Ybuf, lenXn), APn = Pblk(AYbuf, lenXn);   // next iteration's blocks
+        CHK(ew_copy(b, N, lenXn, nR.p + (int64_t)newly_locked * nR.ld, nR.ld, Rn.p, Rn.ld));
         std::vector<Mat> Zs = {X};
         if (niter > 0) {
-            CHK(ew_copy(b, N, lenXn, nP.p, nP.ld, P.p, P.ld));
-            CHK(ew_copy(b, N, lenXn, nAP.p, nAP.ld, AP.p, AP.ld));
-            Zs.push_back(P.cols_from(0, lenXn));
+            CHK(ew_copy(b, N, lenXn, nP.p, nP.ld, Pn.p, Pn.ld));
+            CHK(ew_copy(b, N, lenXn, nAP.p, nAP.ld, APn.p, APn.ld));
+            Zs.push_back(Pn);
         }
-        CHK(ortho_XY(c, R.cols_from(0, lenXn), Zs, tmp, ortho_tol));
+        CHK(ortho_XY(c, Rn, Zs, tmp, ortho_tol));
 
         if (niter >= maxiter) break;
         niter += 1;
@@ -443,6 +475,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
         CHK(ew_copy(b, N, M, tmp, N, AX.p, AX.ld));
         HIPCHK(hipStreamSynchronize(b->stream));
     }
+    CHK(ew_copy(b, N, M, X.p, X.ld, Xuser.p, Xuser.ld));   // hand the eigenvectors back to the caller's array
     double maxres = 0.0;
     for (int i = 0; i < M; ++i) {
         lambda_h[i] = full_lam[perm[i]];

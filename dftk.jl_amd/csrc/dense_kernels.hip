@@ -182,49 +182,68 @@ __global__ void k_apply_D(int n_p, int nb, int bw, const double* __restrict__ D,
 //   trailing     : A22 -= R12^H R12 through the f64-MFMA zgemm ('C', alpha = -1, beta = 1)
 // info[0] = 0 on success, else the 1-based failing column (non-positive / non-finite pivot).
 #define PB 32
-__global__ __launch_bounds__(64) void k_potrf_diag(int jb, int j0, cd* __restrict__ A, int64_t lda,
-                                                   int* __restrict__ info) {
-    __shared__ cd T[PB][PB + 1];
+__global__ __launch_bounds__(256) void k_potrf_diag(int jb, int j0, cd* __restrict__ A, int64_t lda,
+                                                    int* __restrict__ info) {
+    // 32x32 diagonal block, upper Cholesky R'R = T.  One thread per 4 elements of the tile (kept in
+    // registers); per pivot j only the scaled pivot row travels through LDS: 2 barriers per step.
+    __shared__ cd row[PB];
+    __shared__ double piv;
     __shared__ int fail;
-    const int c = threadIdx.x;
-    if (c == 0) fail = info[0];
-    for (int e = c; e < PB * PB; e += 64) {
-        const int cc = e / PB, r = e - cc * PB;
-        T[r][cc] = (r < jb && cc < jb && r <= cc) ? A[(j0 + r) + (int64_t)(j0 + cc) * lda] : make_double2(0.0, 0.0);
+    const int t = threadIdx.x;
+    const int c = t & (PB - 1);          // column of this thread's elements
+    const int r0 = t >> 5;               // rows r0, r0 + 8, r0 + 16, r0 + 24
+    if (t == 0) fail = info[0];
+    cd v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = r0 + 8 * q;
+        v[q] = (r < jb && c < jb && r <= c) ? A[(j0 + r) + (int64_t)(j0 + c) * lda] : make_double2(0.0, 0.0);
     }
     __syncthreads();
     if (fail != 0) return;   // an earlier panel already failed
     for (int j = 0; j < jb; ++j) {
-        const double d = T[j][j].x;
+        const int qj = j >> 3;           // which of the 4 registers holds row j (for threads with r0 == j % 8)
+        const bool owns_row = (r0 == (j & 7));
+        if (owns_row && c == j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q == qj) piv = v[q].x;
+        }
+        __syncthreads();
+        const double d = piv;
         if (!(d > 0.0) || !isfinite(d)) {
-            if (c == 0) info[0] = j0 + j + 1;
-            return;   // uniform: every lane read the same d
+            if (t == 0) info[0] = j0 + j + 1;
+            return;   // uniform: every thread read the same pivot
         }
         const double sd = sqrt(d), inv = 1.0 / sd;
-        __syncthreads();
-        if (c == j) T[j][j] = make_double2(sd, 0.0);
-        if (c > j && c < jb) {
-            cd v = T[j][c];
-            v.x *= inv;
-            v.y *= inv;
-            T[j][c] = v;
+        if (owns_row && c >= j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q == qj) {
+                    v[q] = (c == j) ? make_double2(sd, 0.0) : make_double2(v[q].x * inv, v[q].y * inv);
+                    row[c] = v[q];
+                }
         }
         __syncthreads();
-        if (c > j && c < jb) {
-            const cd bb = T[j][c];
-            for (int r = j + 1; r <= c; ++r) {
-                const cd a = T[j][r];
-                cd v = T[r][c];
-                v.x -= a.x * bb.x + a.y * bb.y;
-                v.y -= a.x * bb.y - a.y * bb.x;
-                T[r][c] = v;
+        // trailing update: T[r][c] -= conj(R[j][r]) * R[j][c] for j < r <= c
+        if (c > j) {
+            const cd bb = row[c];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = r0 + 8 * q;
+                if (r > j && r <= c) {
+                    const cd a = row[r];
+                    v[q].x -= a.x * bb.x + a.y * bb.y;
+                    v[q].y -= a.x * bb.y - a.y * bb.x;
+                }
             }
         }
-        __syncthreads();
+        // (the next step's first barrier orders these reads of row[] before it is rewritten)
     }
-    for (int e = c; e < PB * PB; e += 64) {
-        const int cc = e / PB, r = e - cc * PB;
-        if (r < jb && cc < jb && r <= cc) A[(j0 + r) + (int64_t)(j0 + cc) * lda] = T[r][cc];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = r0 + 8 * q;
+        if (r < jb && c < jb && r <= c) A[(j0 + r) + (int64_t)(j0 + c) * lda] = v[q];
     }
 }
 
@@ -288,9 +307,82 @@ __global__ __launch_bounds__(64) void k_trtri_upper(int n, const cd* __restrict_
     for (int i = lane; i < n; i += 64) Z[i + (int64_t)j * ldz] = z[i];
 }
 
+// Blocked inverse of an upper-triangular matrix: workgroup b owns TRI_TC columns J of Z = R^{-1}
+// (kept in LDS) and back-substitutes them in 32-row blocks, last block first:
+//   Z[bi, J] = R[bi,bi]^{-1} ( I[bi, J] - sum_{bk > bi} R[bi,bk] Z[bk, J] ).
+// The off-diagonal products read 32x32 tiles of R through LDS (coalesced); only the 32 steps of each
+// diagonal block are sequential.  Dynamic LDS: (32*nblk*TRI_TC + 32*33) complex numbers.
+#define TRI_TC 8
+__global__ __launch_bounds__(256) void k_trtri_upper_blk(int n, const cd* __restrict__ R, int64_t ldr,
+                                                         cd* __restrict__ Z, int64_t ldz) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int jc0 = blockIdx.x * TRI_TC;
+    const int jmax = min(n, jc0 + TRI_TC) - 1;
+    const int nblk = jmax / 32 + 1;
+    cd* Zs = reinterpret_cast<cd*>(sm);            // [32 * nblk][TRI_TC]
+    cd* Rt = Zs + (size_t)32 * nblk * TRI_TC;      // [32][33]
+    const int t = threadIdx.x;
+    const int cc = t & (TRI_TC - 1), rr = t / TRI_TC;   // rr in [0, 32): one (row, column) pair per thread
+    for (int bi = nblk - 1; bi >= 0; --bi) {
+        const int i0 = bi * 32;
+        cd acc = make_double2((i0 + rr == jc0 + cc) ? 1.0 : 0.0, 0.0);
+        for (int bk = nblk - 1; bk > bi; --bk) {
+            const int k0 = bk * 32;
+            __syncthreads();
+            for (int e = t; e < 1024; e += 256) {
+                const int k = e >> 5, r = e & 31;
+                const int gi = i0 + r, gk = k0 + k;
+                Rt[r * 33 + k] = (gi < n && gk < n) ? R[gi + (int64_t)gk * ldr] : make_double2(0.0, 0.0);
+            }
+            __syncthreads();
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) {
+                const cd zk = Zs[(k0 + k) * TRI_TC + cc];
+                const cd a = Rt[rr * 33 + k];
+                acc.x -= a.x * zk.x - a.y * zk.y;
+                acc.y -= a.x * zk.y + a.y * zk.x;
+            }
+        }
+        __syncthreads();
+        for (int e = t; e < 1024; e += 256) {
+            const int k = e >> 5, r = e & 31;
+            const int gi = i0 + r, gk = i0 + k;
+            Rt[r * 33 + k] = (gi < n && gk < n && r <= k) ? R[gi + (int64_t)gk * ldr] : make_double2(0.0, 0.0);
+        }
+        __syncthreads();
+        for (int k = 31; k >= 0; --k) {
+            const int gk = i0 + k;
+            if (rr == k) {
+                const double d = Rt[k * 33 + k].x;
+                Zs[gk * TRI_TC + cc] = (gk < n) ? make_double2(acc.x / d, acc.y / d) : make_double2(0.0, 0.0);
+            }
+            __syncthreads();
+            if (rr < k) {
+                const cd zk = Zs[gk * TRI_TC + cc];
+                const cd a = Rt[rr * 33 + k];
+                acc.x -= a.x * zk.x - a.y * zk.y;
+                acc.y -= a.x * zk.y + a.y * zk.x;
+            }
+        }
+    }
+    __syncthreads();
+    const int ncol = jmax - jc0 + 1;
+    for (int e = t; e < n * ncol; e += 256) {
+        const int cj = e / n, i = e - cj * n;
+        Z[i + (int64_t)(jc0 + cj) * ldz] = (i < 32 * nblk) ? Zs[i * TRI_TC + cj] : make_double2(0.0, 0.0);
+    }
+}
+
 // out[0] = max |diag|, out[1] = sum of |offdiag|^2 over the upper triangle, out[2] = non-finite flag
+// blockIdx.x selects the matrix: (M, out) or (M2, out2) -- both estimates in one launch
 __global__ __launch_bounds__(256) void k_normest_upper(int n, const cd* __restrict__ M, int64_t ldm,
-                                                       double* __restrict__ out) {
+                                                       double* __restrict__ out, const cd* __restrict__ M2,
+                                                       int64_t ldm2, double* __restrict__ out2) {
+    if (blockIdx.x == 1) {
+        M = M2;
+        ldm = ldm2;
+        out = out2;
+    }
     __shared__ double sh[4];
     __shared__ double smax[256];
     double off = 0.0, mx = 0.0, bad = 0.0;
@@ -608,7 +700,7 @@ int dense_potrf_trtri(dftk_mi_basis* b, int n, cd* A, int64_t lda, cd* invR, int
     HIPCHK(hipMemsetAsync(d_info, 0, sizeof(int), b->stream));
     for (int j0 = 0; j0 < n; j0 += PB) {
         const int jb = (n - j0) < PB ? (n - j0) : PB;
-        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(64), 0, b->stream, jb, j0, A, lda, d_info);
+        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, b->stream, jb, j0, A, lda, d_info);
         const int n2 = n - j0 - jb;
         if (n2 > 0) {
             hipLaunchKernelGGL(k_trsm_row, dim3((n2 + 63) / 64), dim3(64), 0, b->stream, n, j0, A, lda, d_info);
@@ -618,9 +710,20 @@ int dense_potrf_trtri(dftk_mi_basis* b, int n, cd* A, int64_t lda, cd* invR, int
             CHK(zgemm(b, 'C', n2, n2, jb, mone, R12, lda, R12, lda, one, A22, lda, /*upper=*/1));   // only the upper triangle is ever read
         }
     }
-    hipLaunchKernelGGL(k_trtri_upper, dim3(n), dim3(64), (size_t)n * sizeof(cd), b->stream, n, A, lda, invR, ldi);
-    hipLaunchKernelGGL(k_normest_upper, dim3(1), dim3(256), 0, b->stream, n, A, lda, b->d_scalars);
-    hipLaunchKernelGGL(k_normest_upper, dim3(1), dim3(256), 0, b->stream, n, invR, ldi, b->d_scalars + 3);
+    {
+        const size_t lds = ((size_t)32 * ((n + 31) / 32) * TRI_TC + 32 * 33) * sizeof(cd);
+        static int big_lds_ok = -1;   // > 64 KiB of dynamic LDS needs an opt-in
+        if (big_lds_ok < 0)
+            big_lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_trtri_upper_blk),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+        if (lds <= 64 * 1024 || (big_lds_ok && lds <= 150 * 1024))
+            hipLaunchKernelGGL(k_trtri_upper_blk, dim3((n + TRI_TC - 1) / TRI_TC), dim3(256), lds, b->stream, n, A, lda,
+                               invR, ldi);
+        else
+            hipLaunchKernelGGL(k_trtri_upper, dim3(n), dim3(64), (size_t)n * sizeof(cd), b->stream, n, A, lda, invR, ldi);
+    }
+    hipLaunchKernelGGL(k_normest_upper, dim3(2), dim3(256), 0, b->stream, n, A, lda, b->d_scalars, invR, ldi,
+                       b->d_scalars + 3);
     prof_end(b, ps);
     HIPCHK(hipGetLastError());
     CHK(fetch_scalars(b, 208));

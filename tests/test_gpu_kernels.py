@@ -134,7 +134,7 @@ def test_zgemm_asymmetric_layout(lib):
     np.testing.assert_allclose(Cd.cpu().numpy().T, B, rtol=0, atol=1e-12)
 
 
-@pytest.mark.parametrize("n", [1, 7, 64, 259])
+@pytest.mark.parametrize("n", [1, 7, 31, 32, 33, 64, 259, 600])
 def test_potrf_trtri(lib, n):
     rng = np.random.default_rng(n)
     bs = Basis(lib, 8, 8, 8)

@@ -356,7 +356,8 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False):
             else:
                 E[name] = math.inf
         elif name == "AtomicLocal":
-            pot = T.V_loc.clone() if pot is None else pot + T.V_loc
+            if not only_energies:
+                pot = T.V_loc.clone() if pot is None else pot + T.V_loc
             E[name] = float((rho * T.V_loc).sum().item() * basis.dvol) if rho is not None else math.inf
         elif name == "AtomicNonlocal":
             if T.P is None:
@@ -378,12 +379,14 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False):
         elif name == "Hartree":
             rho_G = basis.fft(rho)
             pot_G = T.poisson * rho_G
-            vh = basis.irfft(pot_G)
-            pot = vh if pot is None else pot + vh
+            if not only_energies:
+                vh = basis.irfft(pot_G)
+                pot = vh if pot is None else pot + vh
             E[name] = float(torch.vdot(pot_G.reshape(-1), rho_G.reshape(-1)).real.item()) / 2
         elif name == "Xc":
             exc, vxc = xc_energy_potential(basis, rho)
-            pot = vxc if pot is None else pot + vxc
+            if not only_energies:
+                pot = vxc if pot is None else pot + vxc
             E[name] = exc
         else:
             raise NotImplementedError(f"term {name} is outside the MI355X hot path")

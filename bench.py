@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--ecut", type=float, default=30.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-bands", type=int, default=192)
+    ap.add_argument("--prof-all", action="store_true",
+                    help="count kernel-family launches from the first warm-up step on (to line the counts up with a "
+                         "whole-process rocprofv3 --pmc run; see tools/pmc_traffic_bench.sh)")
     return ap.parse_args()
 
 
@@ -143,11 +146,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from dftk_jl_amd._lib import check
+    if args.prof_all:
+        check(lib.dftk_mi_prof_enable(basis.handle, 1))
     for _ in range(args.warmup):
         stepper.step()
     barrier()
-    from dftk_jl_amd._lib import check
-    check(lib.dftk_mi_prof_enable(basis.handle, 1))
+    if not args.prof_all:
+        check(lib.dftk_mi_prof_enable(basis.handle, 1))
     nmv0 = stepper.info["n_matvec"]
     iters = []
     host_timers = {}
@@ -180,11 +186,26 @@ def main():
             roof = {"bound": "hbm", "achieved": work / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["traffic"] = None
+        # HBM bytes per launch of the dominant family from the committed PMC passes (rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE over this same command, tools/pmc_traffic_bench.sh): the counters
+        # cannot be read from inside the process, so the last measured value is reported with its source
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as fh:
+                pmc = json.load(fh)
+            if FAMILIES[dom] in pmc["families"] and pmc["workload"] == f"si{n}x{n}x{n}_ecut{args.ecut:g}":
+                roof["traffic"] = pmc["families"][FAMILIES[dom]]["bytes_per_launch"]
+                roof["traffic_unit"] = "B/launch"
+                roof["traffic_source"] = "profiles/r01_pmc_traffic.json (" + pmc["collected"] + ")"
+                roof["algorithmic_bytes_per_launch"] = (prof_get(lib, basis, 10)[1] / max(launches, 1) if dom == 0
+                                                        else work / max(launches, 1))
+        except (OSError, KeyError, ValueError):
+            pass
         roof["kernel"] = FAMILIES[dom]
         roof["launches"] = launches
         roof["avg_launch_ms"] = ms / max(launches, 1)
         roof["families_ms"] = {FAMILIES[f]: round(fam[f][0], 3) for f in FAMILIES}
         roof["families_launches"] = {FAMILIES[f]: int(fam[f][2]) for f in FAMILIES}
+        roof["families_work"] = {FAMILIES[f]: fam[f][1] for f in FAMILIES}   # flops (zgemm) / algorithmic bytes (FFT)
         roof["families_rate"] = {
             FAMILIES[f]: (round(fam[f][1] / (fam[f][0] * 1e-3) / (1e12 if f == 0 else 1e9), 2)
                           if fam[f][0] > 0 and f < 7 else None) for f in FAMILIES}

@@ -73,6 +73,7 @@ enum ProfFamily {
     PROF_HEEV = 7,       // dense Hermitian eigensolver (whole call)
     PROF_CHOL = 8,       // potrf + trtri (whole call)
     PROF_APPLY_H = 9,    // whole dftk_mi_apply_H call (work = bands)
+    PROF_ZGEMM_BYTES = 10,   // no timing: work = algorithmic operand bytes of the zgemm calls (A + B + C [+ C if beta != 0])
     PROF_NFAM = 16
 };
 struct Prof {
@@ -132,8 +133,9 @@ int launch_kinetic_only(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi
                         int64_t ldout, bool accumulate, bool use_kin);
 
 // gemm_kernels.hip
-// upper != 0: only the 128x64 tiles that intersect the upper triangle (i <= j) are computed and
-// written; the rest of C is left untouched (Gram matrices that are hermitised afterwards)
+// upper & 1: only the 128x64 tiles that intersect the upper triangle (i <= j) are computed and
+//            written; the rest of C is left untouched (Gram matrices that are hermitised afterwards)
+// upper & 2: B is upper triangular (B[k][j] = 0 for k > j): the k loop of a tile column stops early
 int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alpha, const cd* A,
           int64_t lda, const cd* B, int64_t ldb, cd beta, cd* C, int64_t ldc, int upper = 0);
 int ensure_ws(dftk_mi_basis* b, size_t bytes);

@@ -291,8 +291,11 @@ __global__ __launch_bounds__(FFT_THREADS) void k_zpass(FftAxis az, int nx, int n
     cd* buf = reinterpret_cast<cd*>(dftk_smem);
     cd* tw = buf + az.n * FFT_LS;
     const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
-    const int x = blockIdx.x * FFT_L + l;
-    const int y = blockIdx.y, band = blockIdx.z;
+    // grid (bands, x tiles, y): the bands of one (x tile, y) column are consecutive workgroups, so the
+    // potential tile they all multiply with is fetched from HBM once and then served by the L2
+    const int band = blockIdx.x;
+    const int x = blockIdx.y * FFT_L + l;
+    const int y = blockIdx.z;
     const int nz = az.n;
     const int64_t plane = (int64_t)ny * nxp;
     cd* t2 = T2 + (int64_t)band * T2_stride + (int64_t)y * nxp + x;
@@ -550,11 +553,15 @@ static int run_AB(dftk_mi_kblock* kb, int nbb, const cd* psi, int64_t ldpsi) {
     const int gl = (int)((kb->n_lines + FFT_L - 1) / FFT_L);
     const int nxt = b->nxp / FFT_L;
     const double Ncube = (double)b->nx * b->ny * b->nz;
-    int ps = prof_begin(b, PROF_FFT_A, 32.0 * Ncube * nbb + 16.0 * kb->n_G * nbb);
+    // algorithmic HBM bytes of the PRUNED pipeline (what a perfect implementation must move):
+    //   T1 = n_lines x nxp, T2 = nzx x ny x nxp complex numbers per band
+    const double t1b = 16.0 * (double)kb->n_lines * b->nxp, t2b = 16.0 * (double)kb->nzx * b->ny * b->nxp;
+    (void)Ncube;
+    int ps = prof_begin(b, PROF_FFT_A, (16.0 * kb->n_G + t1b) * nbb);
     LAUNCH_FFT(k_xbwd_scatter, b->ax[0], dim3(gl, nbb), lds_bytes(b->nx), b->stream, b->ax[0],
                        b->nxp, (int)kb->n_lines, kb->d_line_start, kb->d_cpos, psi, ldpsi, b->T1, st.s1);
     prof_end(b, ps);
-    ps = prof_begin(b, PROF_FFT_B, 32.0 * Ncube * nbb);
+    ps = prof_begin(b, PROF_FFT_B, (t1b + t2b) * nbb);
     LAUNCH_FFT(k_ybwd, b->ax[1], dim3(nxt, kb->nzx, nbb), lds_bytes(b->ny), b->stream, b->ax[1],
                        b->nxp, b->ny, kb->d_zls, kb->d_line_ypos, b->T1, st.s1, b->T2, st.s2);
     prof_end(b, ps);
@@ -568,11 +575,13 @@ static int run_DE(dftk_mi_kblock* kb, int nbb, const double* kin, const cd* psi,
     const int gl = (int)((kb->n_lines + FFT_L - 1) / FFT_L);
     const int nxt = b->nxp / FFT_L;
     const double Ncube = (double)b->nx * b->ny * b->nz;
-    int ps = prof_begin(b, PROF_FFT_D, 32.0 * Ncube * nbb);
+    const double t1b = 16.0 * (double)kb->n_lines * b->nxp, t2b = 16.0 * (double)kb->nzx * b->ny * b->nxp;
+    (void)Ncube;
+    int ps = prof_begin(b, PROF_FFT_D, (t1b + t2b) * nbb);
     LAUNCH_FFT(k_yfwd, b->ax[1], dim3(nxt, kb->nzx, nbb), lds_bytes(b->ny), b->stream, b->ax[1],
                        b->nxp, b->ny, kb->d_zls, kb->d_line_ypos, b->T2, st.s2, b->T1, st.s1);
     prof_end(b, ps);
-    ps = prof_begin(b, PROF_FFT_E, 32.0 * Ncube * nbb + 40.0 * kb->n_G * nbb);
+    ps = prof_begin(b, PROF_FFT_E, (t1b + (kin ? 40.0 : 16.0) * kb->n_G) * nbb);
     LAUNCH_FFT(k_xfwd_gather, b->ax[0], dim3(gl, nbb), lds_bytes(b->nx), b->stream, b->ax[0],
                        b->nxp, (int)kb->n_lines, kb->d_line_start, kb->d_cpos, b->T1, st.s1, kin, psi, ldpsi, out,
                        ldout);
@@ -596,8 +605,10 @@ int launch_local_apply(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi,
         const int nbb = (nb - b0) < batch ? (nb - b0) : batch;
         const cd* p = psi + (int64_t)b0 * ldpsi;
         CHK(run_AB(kb, nbb, p, ldpsi));
-        const int pc = prof_begin(b, PROF_FFT_C, 72.0 * (double)b->nx * b->ny * b->nz * nbb);
-        LAUNCH_ZPASS(0, b->ax[2], dim3(nxt, b->ny, nbb), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, kb->d_zpos, kb->d_Vs, b->T2, st.s2,
+        // stage C: T2 read + written per band, the potential once per launch
+        const int pc = prof_begin(b, PROF_FFT_C, 2.0 * 16.0 * (double)kb->nzx * b->ny * b->nxp * nbb +
+                                                     8.0 * (double)b->nz * b->ny * b->nxp);
+        LAUNCH_ZPASS(0, b->ax[2], dim3(nbb, nxt, b->ny), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, kb->d_zpos, kb->d_Vs, b->T2, st.s2,
                            (cd*)nullptr);
         prof_end(b, pc);
         CHK(run_DE(kb, nbb, add_kinetic ? kb->d_kin : nullptr, p, ldpsi, out + (int64_t)b0 * ldout, ldout));
@@ -623,7 +634,7 @@ int launch_ifft_to_cube(dftk_mi_kblock* kb, const cd* c, cd* cube) {
     CHK(fft_ensure_scratch(b, kb, 1));
     const Strides st = strides(kb);
     CHK(run_AB(kb, 1, c, kb->n_G));
-    LAUNCH_ZPASS(1, b->ax[2], dim3(b->nxp / FFT_L, b->ny, 1), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, kb->d_zpos, (const double*)nullptr, b->T2, st.s2,
+    LAUNCH_ZPASS(1, b->ax[2], dim3(1, b->nxp / FFT_L, b->ny), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, kb->d_zpos, (const double*)nullptr, b->T2, st.s2,
                        cube);
     HIPCHK(hipGetLastError());
     return 0;
@@ -634,7 +645,7 @@ int launch_fft_from_cube(dftk_mi_kblock* kb, const cd* cube, cd* c) {
     CHK(check_lds(b));
     CHK(fft_ensure_scratch(b, kb, 1));
     const Strides st = strides(kb);
-    LAUNCH_ZPASS(2, b->ax[2], dim3(b->nxp / FFT_L, b->ny, 1), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, kb->d_zpos, (const double*)nullptr, b->T2, st.s2,
+    LAUNCH_ZPASS(2, b->ax[2], dim3(1, b->nxp / FFT_L, b->ny), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, kb->d_zpos, (const double*)nullptr, b->T2, st.s2,
                        const_cast<cd*>(cube));
     CHK(run_DE(kb, 1, nullptr, c, kb->n_G, c, kb->n_G));
     HIPCHK(hipGetLastError());
@@ -663,7 +674,8 @@ int launch_density(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, con
         for (int i = 0; i < nbb; ++i) b->h_scalars[i] = w_h[b0 + i];
         HIPCHK(hipMemcpyAsync(b->d_scalars, b->h_scalars, nbb * sizeof(double), hipMemcpyHostToDevice, b->stream));
         CHK(run_AB(kb, nbb, psi + (int64_t)b0 * ldpsi, ldpsi));
-        const int pz = prof_begin(b, PROF_DENS_Z, (32.0 * nbb + 16.0) * (double)b->nx * b->ny * b->nz);
+        const int pz = prof_begin(b, PROF_DENS_Z, 16.0 * (double)kb->nzx * b->ny * b->nxp * nbb +
+                                                      16.0 * (double)b->nx * b->ny * b->nz);   // T2 per band + rho read-modify-write
         LAUNCH_FFT(k_zdensity, b->ax[2], dim3(b->nxp / FFT_L, b->ny), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, kb->d_zpos, nbb, b->d_scalars, b->T2, st.s2,
                            rho);
         prof_end(b, pz);

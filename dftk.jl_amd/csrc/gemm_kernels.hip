@@ -238,10 +238,11 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_lds(int m, int n, int
     const int tr = lsplit < 0 ? row_t + rt0 : (row_t < lsplit ? row_t : rt0);
     const int tcn = lsplit < 0 ? col_t + ct0 : (row_t < lsplit ? ct0 : row_t - lsplit);
     const int I0 = tr * GEMM_BM, J0 = tcn * GEMM_BN;
-    if (upper && I0 >= J0 + GEMM_BN) return;   // tile strictly below the diagonal (whole workgroup)
+    if ((upper & 1) && I0 >= J0 + GEMM_BN) return;   // tile strictly below the diagonal (whole workgroup)
     const int i0 = I0 + wave * (GEMM_RM * 16);
     const int kbeg = z * kchunk;
-    const int kend = min(K, kbeg + kchunk);
+    // bit 1 of `upper`: B is upper triangular (B[k][j] = 0 for k > j) -> this tile column stops at k = J0 + BN
+    const int kend = min(min(K, kbeg + kchunk), (upper & 2) ? J0 + GEMM_BN : K);
     const int rmv = FULL ? GEMM_RM : min(GEMM_RM, max(0, (m - i0 + 15) >> 4));
     const int rnv = FULL ? GEMM_RN : min(GEMM_RN, max(0, (n - J0 + 15) >> 4));
     const bool active = FULL || (rmv > 0 && rnv > 0);
@@ -513,7 +514,7 @@ __global__ void k_zgemm_reduce(int m, int n, int mi, int nj, int nsI, const cd* 
     if (idx >= (int64_t)m * n) return;
     const int j = (int)(idx / m);
     const int i = (int)(idx - (int64_t)j * m);
-    if (upper && (i / GEMM_BM) * GEMM_BM >= (j / GEMM_BN) * GEMM_BN + GEMM_BN) return;   // tile not computed
+    if ((upper & 1) && (i / GEMM_BM) * GEMM_BM >= (j / GEMM_BN) * GEMM_BN + GEMM_BN) return;   // tile not computed
     const bool interior = i < mi && j < nj;
     const int nsplit = interior ? nsI : nsB;
     const cd* slab = interior ? slabI : slabB;
@@ -667,6 +668,9 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
                                  : ((uint64_t)conja << 63) | ((uint64_t)(m & 0xFFFFF) << 42) |
                                        ((uint64_t)(n & 0xFFFFF) << 22) | (uint64_t)(k & 0x3FFFFF) | (1ull << 62);
     const int slot = prof_begin(b, PROF_ZGEMM, 8.0 * (double)m * (double)n * (double)k, tag);
+    if (slot >= 0)
+        b->prof->work[PROF_ZGEMM_BYTES] += 16.0 * ((double)m * k + (double)k * n +
+                                                   (double)m * n * ((beta.x != 0.0 || beta.y != 0.0) ? 2.0 : 1.0));
     struct ProfGuard {
         dftk_mi_basis* b;
         int s;
@@ -740,7 +744,7 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
         const int nright = (gn > gnf) ? gm : 0;
         const int nbottom = (gm > gmf) ? gnf : 0;
         int64_t tilesI = (int64_t)gmf * gnf, tilesB = (int64_t)nright + nbottom;
-        if (upper) {   // count only the tiles that intersect the upper triangle
+        if (upper & 1) {   // count only the tiles that intersect the upper triangle
             auto live = [&](int tr, int tc) { return tr * GEMM_BM < tc * GEMM_BN + GEMM_BN; };
             tilesI = tilesB = 0;
             for (int tr = 0; tr < gmf; ++tr)

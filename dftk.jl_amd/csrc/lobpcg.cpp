@@ -110,7 +110,7 @@ int ortho_X(Ctx& c, Mat X, cd* tmp, double tol, int* nchol_total_out, double* gr
             return DFTK_MI_NUM_CHOLESKY;
         }
         // X <- X * invR
-        CHK(zgemm(c.b, 'N', X.rows, m, m, ONE, X.p, X.ld, c.invR, m, ZERO, tmp, X.rows));
+        CHK(zgemm(c.b, 'N', X.rows, m, m, ONE, X.p, X.ld, c.invR, m, ZERO, tmp, X.rows, /*B upper triangular=*/2));
         CHK(ew_copy(c.b, X.rows, m, tmp, X.rows, X.p, X.ld));
         growth *= nI;
         const double condR = nR * nI;

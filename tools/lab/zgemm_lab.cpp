@@ -31,6 +31,16 @@ int main(int argc, char** argv) {
             }
         return 0;
     }
+    if (argc > 1 && argv[1][0] == 'c') {   // calibration for the TCC byte counters: 1 GiB device-to-device copy
+        void *p1, *p2;
+        hipMalloc(&p1, 1ull << 30);
+        hipMalloc(&p2, 1ull << 30);
+        hipMemset(p1, 1, 1ull << 30);
+        hipMemcpy(p2, p1, 1ull << 30, hipMemcpyDeviceToDevice);
+        hipDeviceSynchronize();
+        argv += 1;
+        argc -= 1;
+    }
     for (int a = 1; a + 3 < argc; a += 4) {
         const char tr = argv[a][0];
         const long m = atol(argv[a + 1]), n = atol(argv[a + 2]), k = atol(argv[a + 3]);

@@ -17,6 +17,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include <map>
+#include <vector>
+#include <cmath>
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -225,10 +228,24 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_lds(int m, int n, int
     __shared__ cd sB[2][LT_KT][GEMM_BN];
     const int id = blockIdx.x;
     const int xcd = id & 7, slot = id >> 3;
-    const int col_t = slot % gn;
-    const int R = (slot / gn) * 8 + xcd;
-    if (R >= gm * nsplit) return;   // whole workgroup
-    const int z = R / gm, row_t = R - z * gm;
+    int z, row_t, col_t;
+    if (upper & 4) {
+        // K-split launches: all tiles of one k-chunk on the SAME XCD, so that both the A chunk and the
+        // B chunk are fetched from HBM once and shared through that XCD's L2
+        const int per = gm * gn;
+        z = (slot / per) * 8 + xcd;
+        const int rem = slot % per;
+        row_t = rem / gn;
+        col_t = rem - row_t * gn;
+        if (z >= nsplit) return;   // whole workgroup
+    } else {
+        // column tiles of one (k-chunk, row panel) on the same XCD (shares the A panel)
+        col_t = slot % gn;
+        const int R = (slot / gn) * 8 + xcd;
+        if (R >= gm * nsplit) return;   // whole workgroup
+        z = R / gm;
+        row_t = R - z * gm;
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -647,7 +664,8 @@ int ensure_ws(dftk_mi_basis* b, size_t bytes) {
 }
 
 int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alpha, const cd* A, int64_t lda,
-          const cd* B, int64_t ldb, cd beta, cd* C, int64_t ldc, int upper) {
+          const cd* B, int64_t ldb, cd beta, cd* C, int64_t ldc, int upper_in) {
+    const int upper = upper_in;
     if (m <= 0 || n <= 0) return 0;
     const bool conja = (transA == 'C' || transA == 'c');
     if (!conja && !(transA == 'N' || transA == 'n')) {
@@ -689,30 +707,75 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
     }
     const int gm = (int)((m + GEMM_BM - 1) / GEMM_BM);
     const int gn = (int)((n + GEMM_BN - 1) / GEMM_BN);
-    // Split K so that a launch fills the 512 workgroup slots (2 per CU) about once: equal-sized
-    // chunks, no tail, smallest slab traffic.  Short K is latency-bound: chunks of >= 8 tiles.
+    // K split: chosen per launch by a small cost model of the actual workgroup -> XCD placement (8 XCDs x
+    // 64 resident workgroups, 2 per CU).  Candidates: ns chunks with either mapping of the kernel
+    //   row-major: (chunk, tile row) pairs round-robin over the XCDs, their column tiles together;
+    //   z-major  : whole chunks round-robin over the XCDs (A and B chunk both shared through one L2).
+    // cost = (rounds of the fullest XCD) x (chunk length + prologue/epilogue) + slab traffic.
+    // Short K is latency-bound: chunks of >= 8 tiles.  Plans are cached per shape.
     const char* senv = getenv("DFTK_MI_GEMM_BLOCKS");
     const int64_t slots = senv ? atoll(senv) : 512;
     struct Split {
         int nsplit, kchunk;
+        bool zmajor;
         cd* slab;
     };
     const int64_t plane = (int64_t)m * n * (int64_t)sizeof(cd);
-    auto plan_split = [&](int64_t tiles) -> Split {
-        int ns = 1;
-        if (k >= 128 && tiles > 0 && tiles < slots) {
-            ns = (int)(slots / tiles);
-            const int64_t max_by_k = k >= 2048 ? k / 256 : k / 64;
-            if (ns > max_by_k) ns = (int)max_by_k;
-            if (ns > 1024) ns = 1024;
-            const int64_t max_by_ws = (int64_t)(256ull << 20) / plane;   // each slab <= 256 MiB
-            if (ns > max_by_ws) ns = (int)max_by_ws;
-            if (ns < 1) ns = 1;
+    static const bool no_zmajor = getenv("DFTK_MI_GEMM_NO_ZMAJOR") != nullptr;
+    static std::map<std::vector<int64_t>, std::pair<int, int>> plan_cache;   // key -> (nsplit, zmajor)
+    auto plan_split = [&](const std::vector<int>& live_rows, int kind) -> Split {
+        int64_t total = 0;
+        for (int v : live_rows) total += v;
+        const int gm_s = (int)live_rows.size();
+        int best_ns = 1, best_zm = 0;
+        if (k >= 128 && total > 0 && total < slots) {
+            const std::vector<int64_t> key = {m, n, k, (int64_t)(upper & 1), (int64_t)kind, slots};
+            auto it = plan_cache.find(key);
+            if (it != plan_cache.end()) {
+                best_ns = it->second.first;
+                best_zm = it->second.second;
+            } else {
+                int64_t max_ns = k >= 2048 ? k / 256 : k / 64;
+                if (max_ns > 1024) max_ns = 1024;
+                const int64_t max_by_ws = (int64_t)(256ull << 20) / plane;   // each slab <= 256 MiB
+                if (max_ns > max_by_ws) max_ns = max_by_ws;
+                if (max_ns > 2 * slots / total + 8) max_ns = 2 * slots / total + 8;
+                if (max_ns < 1) max_ns = 1;
+                const double per_xcd = (double)slots / 8.0;
+                const double slab_cost = 2.0 * (double)plane / 5e12 / 3.7e-6;   // k-tiles of time per extra chunk
+                double best = 1e300;
+                for (int ns = 1; ns <= max_ns; ++ns) {
+                    int kc = (int)((k + ns - 1) / ns);
+                    kc = (kc + 7) & ~7;
+                    if ((int)((k + kc - 1) / kc) != ns) continue;
+                    for (int zm = 0; zm < 2; ++zm) {
+                        if (zm && (ns < 8 || no_zmajor || k < 2048)) continue;
+                        int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                        if (zm) {
+                            for (int z = 0; z < ns; ++z) load[z & 7] += total;
+                        } else {
+                            const int64_t R = (int64_t)gm_s * ns;
+                            for (int64_t r = 0; r < R; ++r) load[r & 7] += live_rows[r % gm_s];
+                        }
+                        int64_t mx = 0;
+                        for (int x = 0; x < 8; ++x) mx = load[x] > mx ? load[x] : mx;
+                        const double rounds = std::ceil((double)mx / per_xcd);
+                        const double cost = rounds * (kc / 8.0 + 12.0) + (ns > 1 ? slab_cost * ns : 0.0) - (zm ? 1e-3 : 0.0);
+                        if (cost < best) {
+                            best = cost;
+                            best_ns = ns;
+                            best_zm = zm;
+                        }
+                    }
+                }
+                if (plan_cache.size() > 4096) plan_cache.clear();
+                plan_cache[key] = {best_ns, best_zm};
+            }
         }
-        int kc = (int)((k + ns - 1) / ns);
+        int kc = (int)((k + best_ns - 1) / best_ns);
         kc = (kc + 7) & ~7;
-        ns = (int)((k + kc - 1) / kc);
-        return Split{ns, kc, nullptr};
+        const int ns = (int)((k + kc - 1) / kc);
+        return Split{ns, kc, best_zm != 0 && ns >= 8, nullptr};
     };
     // XCD-aware 1-D grid over a gm_s x gn_s sub-grid of tiles (x nsplit K chunks)
     auto grid_for = [&](int gm_s, int gn_s, int ns) -> int64_t {
@@ -720,7 +783,8 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
         return ((rows_total + 7) / 8) * 8 * gn_s;
     };
     if (b->use_mfma == 2) {   // direct-from-global variant (env DFTK_MI_GEMM=direct)
-        Split sp = plan_split((int64_t)gm * gn);
+        Split sp = plan_split(std::vector<int>(gm, gn), 0);
+        sp.zmajor = false;
         if (sp.nsplit > 1) {
             CHK(ensure_ws(b, (size_t)sp.nsplit * plane));
             sp.slab = (cd*)b->ws;
@@ -743,19 +807,15 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
         const int gmf = (int)(m / GEMM_BM), gnf = (int)(n / GEMM_BN);
         const int nright = (gn > gnf) ? gm : 0;
         const int nbottom = (gm > gmf) ? gnf : 0;
-        int64_t tilesI = (int64_t)gmf * gnf, tilesB = (int64_t)nright + nbottom;
-        if (upper & 1) {   // count only the tiles that intersect the upper triangle
-            auto live = [&](int tr, int tc) { return tr * GEMM_BM < tc * GEMM_BN + GEMM_BN; };
-            tilesI = tilesB = 0;
-            for (int tr = 0; tr < gmf; ++tr)
-                for (int tc = 0; tc < gnf; ++tc) tilesI += live(tr, tc);
-            for (int e = 0; e < nright; ++e) tilesB += live(e, gnf);
-            for (int e = 0; e < nbottom; ++e) tilesB += live(gmf, e);
-            if (tilesI == 0) tilesI = 1;
-            if (tilesB == 0) tilesB = 1;
-        }
-        Split spI = plan_split(tilesI);
-        Split spB = plan_split(tilesB);
+        // live column tiles per tile row of each launch (upper: only tiles that intersect the upper triangle)
+        auto live = [&](int tr, int tc) { return !(upper & 1) || tr * GEMM_BM < tc * GEMM_BN + GEMM_BN; };
+        std::vector<int> rowsI(gmf, 0), rowsB(nright + nbottom, 0);
+        for (int tr = 0; tr < gmf; ++tr)
+            for (int tc = 0; tc < gnf; ++tc) rowsI[tr] += live(tr, tc) ? 1 : 0;
+        for (int e = 0; e < nright; ++e) rowsB[e] = live(e, gnf) ? 1 : 0;
+        for (int e = 0; e < nbottom; ++e) rowsB[nright + e] = live(gmf, e) ? 1 : 0;
+        Split spI = plan_split(rowsI, 1);
+        Split spB = plan_split(rowsB, 2);
         const size_t bytesI = spI.nsplit > 1 ? (size_t)spI.nsplit * plane : 0;
         const size_t bytesB = spB.nsplit > 1 ? (size_t)spB.nsplit * plane : 0;
         if (bytesI + bytesB) CHK(ensure_ws(b, bytesI + bytesB));
@@ -764,8 +824,11 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
         static const int pad_lds = getenv("DFTK_MI_GEMM_PAD_LDS") ? atoi(getenv("DFTK_MI_GEMM_PAD_LDS")) : 0;   // occupancy experiments
         auto launch = [&](bool full, int gm_s, int gn_s, int rt0, int ct0, int lsplit, const Split& sp) -> int {
             if (gm_s <= 0 || gn_s <= 0) return 0;
-            if (grid_for(gm_s, gn_s, sp.nsplit) > INT32_MAX) return DFTK_MI_EINVAL;
-            dim3 grid((unsigned)grid_for(gm_s, gn_s, sp.nsplit));
+            const bool zmajor = sp.zmajor;
+            const int64_t nblk = zmajor ? (int64_t)((sp.nsplit + 7) / 8) * 8 * gm_s * gn_s : grid_for(gm_s, gn_s, sp.nsplit);
+            if (nblk > INT32_MAX) return DFTK_MI_EINVAL;
+            dim3 grid((unsigned)nblk);
+            const int upper = upper_in | (zmajor ? 4 : 0);
 #define DFTK_LAUNCH_LDS(CJ, FL)                                                                                        \
     hipLaunchKernelGGL((k_zgemm_lds<CJ, FL>), grid, dim3(GEMM_WAVES * 64), pad_lds, b->stream, (int)m, (int)n, (int)k, \
                        sp.kchunk, gm_s, gn_s, rt0, ct0, lsplit, upper, sp.nsplit, A, lda, B, ldb, C, ldc, alpha, beta, sp.slab)

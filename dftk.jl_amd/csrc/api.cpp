@@ -101,14 +101,34 @@ extern "C" int dftk_mi_prof_get(dftk_mi_basis* b, int family, double* total_ms, 
 }
 
 // ------------------------------------------------------------------------------------ 1-D plans
+// Factorise n into the butterflies the kernels have in registers -- 8, 6, 5, 4, 3, 2 (then primes <= 64
+// for the generic kernel) -- with as FEW stages as possible: every stage is one LDS round trip of the
+// whole tile, which is what bounds the FFT kernels.  Largest radix first (the first DIT stage has no
+// twiddles).
 int plan_radices(int n, int* nrad, int* rad) {
-    int k = 0, m = n;
-    const int pref[4] = {5, 4, 3, 2};
-    for (int r : pref)
-        while (m % r == 0 && m > 1) {
+    int m = n, a2 = 0, a3 = 0, a5 = 0;
+    while (m % 2 == 0 && m > 1) { m /= 2; ++a2; }
+    while (m % 3 == 0 && m > 1) { m /= 3; ++a3; }
+    while (m % 5 == 0 && m > 1) { m /= 5; ++a5; }
+    static const bool small_only = getenv("DFTK_MI_FFT_SMALL_RADIX") != nullptr;   // 5,4,3,2 only (comparison runs)
+    int best8 = 0, best6 = 0, best = 1 << 30;
+    for (int n8 = 0; n8 <= (small_only ? 0 : a2 / 3); ++n8)
+        for (int n6 = 0; n6 <= (small_only ? 0 : (a2 - 3 * n8 < a3 ? a2 - 3 * n8 : a3)); ++n6) {
+            const int rem2 = a2 - 3 * n8 - n6;
+            const int stages = n8 + n6 + rem2 / 2 + rem2 % 2 + (a3 - n6) + a5;
+            if (stages < best) {
+                best = stages;
+                best8 = n8;
+                best6 = n6;
+            }
+        }
+    const int rem2 = a2 - 3 * best8 - best6;
+    const int counts[6][2] = {{8, best8}, {6, best6}, {5, a5}, {4, rem2 / 2}, {3, a3 - best6}, {2, rem2 % 2}};
+    int k = 0;
+    for (auto& c : counts)
+        for (int i = 0; i < c[1]; ++i) {
             if (k >= DFTK_MAX_RADICES) return -1;
-            rad[k++] = r;
-            m /= r;
+            rad[k++] = c[0];
         }
     for (int p = 7; m > 1; p += 2)
         while (m % p == 0) {
@@ -116,10 +136,6 @@ int plan_radices(int n, int* nrad, int* rad) {
             rad[k++] = p;
             m /= p;
         }
-    if (n == 1) {
-        rad[0] = 1;
-        k = 0;
-    }
     *nrad = k;
     return 0;
 }

@@ -68,6 +68,37 @@ __device__ __forceinline__ void dft_small(cd (&a)[R], double sgn, const cd* __re
         a[4] = csub(m1, in1);
         a[2] = cadd(m2, in2);
         a[3] = csub(m2, in2);
+    } else if constexpr (R == 6) {
+        // 6 = 2 x 3: X[k] = E[k] + w^k O[k], X[k+3] = E[k] - w^k O[k], E/O = DFT_3 of the even/odd inputs
+        const double s3 = 0.86602540378443864676;
+        cd e[3] = {a[0], a[2], a[4]}, o[3] = {a[1], a[3], a[5]};
+        dft_small<3>(e, sgn, tw, 0);
+        dft_small<3>(o, sgn, tw, 0);
+        const cd w1o = cmul(o[1], make_double2(0.5, sgn * s3));
+        const cd w2o = cmul(o[2], make_double2(-0.5, sgn * s3));
+        a[0] = cadd(e[0], o[0]);
+        a[3] = csub(e[0], o[0]);
+        a[1] = cadd(e[1], w1o);
+        a[4] = csub(e[1], w1o);
+        a[2] = cadd(e[2], w2o);
+        a[5] = csub(e[2], w2o);
+    } else if constexpr (R == 8) {
+        // 8 = 2 x 4: X[k] = E[k] + w^k O[k], X[k+4] = E[k] - w^k O[k], w = exp(sgn i pi/4)
+        const double h = 0.70710678118654752440;
+        cd e[4] = {a[0], a[2], a[4], a[6]}, o[4] = {a[1], a[3], a[5], a[7]};
+        dft_small<4>(e, sgn, tw, 0);
+        dft_small<4>(o, sgn, tw, 0);
+        const cd w1o = cmul(o[1], make_double2(h, sgn * h));
+        const cd w2o = cmuli(o[2], sgn);
+        const cd w3o = cmul(o[3], make_double2(-h, sgn * h));
+        a[0] = cadd(e[0], o[0]);
+        a[4] = csub(e[0], o[0]);
+        a[1] = cadd(e[1], w1o);
+        a[5] = csub(e[1], w1o);
+        a[2] = cadd(e[2], w2o);
+        a[6] = csub(e[2], w2o);
+        a[3] = cadd(e[3], w3o);
+        a[7] = csub(e[3], w3o);
     } else {
         cd b[R];
 #pragma unroll
@@ -176,6 +207,8 @@ __device__ __forceinline__ void fft_stage_dispatch(int R, cd* buf, const cd* tw,
         case 3: fft_stage<3, DIF>(buf, tw, n, m, sgn, l, j); break;
         case 4: fft_stage<4, DIF>(buf, tw, n, m, sgn, l, j); break;
         case 5: fft_stage<5, DIF>(buf, tw, n, m, sgn, l, j); break;
+        case 6: fft_stage<6, DIF>(buf, tw, n, m, sgn, l, j); break;
+        case 8: fft_stage<8, DIF>(buf, tw, n, m, sgn, l, j); break;
         default:
             if constexpr (GEN) {
                 if (R == 7)
@@ -513,7 +546,7 @@ static int set_lds_attr(K kernel, size_t bytes) {
 
 static bool axis_generic(const FftAxis& ax) {
     for (int s = 0; s < ax.nrad; ++s)
-        if (ax.rad[s] > 5) return true;
+        if (ax.rad[s] > 5 && ax.rad[s] != 6 && ax.rad[s] != 8) return true;
     return false;
 }
 

@@ -121,9 +121,12 @@ __device__ __forceinline__ void dft_small(cd (&a)[R], double sgn, const cd* __re
 
 // One radix-R pass over the tile.  m = product of the radices already combined (DIT) or still
 // to be split (DIF).  Thread (l, j) owns line l and butterflies j, j+TPL, ...
-template <int R, bool DIF>
+// VMUL (last stage of a backward transform only): the natural-order outputs are multiplied by the real
+// potential column vcol[z * vstride] on their way back to LDS (fused V*psi: saves one LDS round trip).
+template <int R, bool DIF, bool VMUL = false>
 __device__ __forceinline__ void fft_stage(cd* buf, const cd* __restrict__ tw, int n, int m, double sgn,
-                                          int l, int j) {
+                                          int l, int j, const double* __restrict__ vcol = nullptr,
+                                          int64_t vstride = 0) {
     const int nb = n / R;
     const int twstep = n / (R * m);
     const int nOverR = n / R;
@@ -131,6 +134,11 @@ __device__ __forceinline__ void fft_stage(cd* buf, const cd* __restrict__ tw, in
         const int g = b / m;
         const int jj = b - g * m;
         const int base = g * R * m + jj;
+        double vv[R];
+        if (VMUL) {   // issued first: the global loads fly while the butterfly is computed
+#pragma unroll
+            for (int p = 0; p < R; ++p) vv[p] = vcol[(int64_t)(base + p * m) * vstride];
+        }
         cd a[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) a[q] = buf[(base + q * m) * FFT_LS + l];
@@ -149,6 +157,13 @@ __device__ __forceinline__ void fft_stage(cd* buf, const cd* __restrict__ tw, in
                 cd w = tw[p * jj * twstep];
                 w.y *= sgn;
                 a[p] = cmul(a[p], w);
+            }
+        }
+        if (VMUL) {
+#pragma unroll
+            for (int p = 0; p < R; ++p) {
+                a[p].x *= vv[p];
+                a[p].y *= vv[p];
             }
         }
 #pragma unroll
@@ -199,6 +214,20 @@ __device__ void fft_stage_generic(cd* buf, const cd* __restrict__ tw, int n, int
 
 // GEN = false: 2-3-5-smooth lengths only (the hot path; keeps the register footprint small).
 // GEN = true : additionally radix 7 and the generic (scratch-backed) prime radix.
+// last backward stage with the fused potential multiply (2-3-5 radices only; see k_zpass)
+__device__ __forceinline__ bool fft_stage_vmul(int R, cd* buf, const cd* tw, int n, int m, double sgn, int l, int j,
+                                               const double* vcol, int64_t vstride) {
+    switch (R) {
+        case 2: fft_stage<2, false, true>(buf, tw, n, m, sgn, l, j, vcol, vstride); return true;
+        case 3: fft_stage<3, false, true>(buf, tw, n, m, sgn, l, j, vcol, vstride); return true;
+        case 4: fft_stage<4, false, true>(buf, tw, n, m, sgn, l, j, vcol, vstride); return true;
+        case 5: fft_stage<5, false, true>(buf, tw, n, m, sgn, l, j, vcol, vstride); return true;
+        case 6: fft_stage<6, false, true>(buf, tw, n, m, sgn, l, j, vcol, vstride); return true;
+        case 8: fft_stage<8, false, true>(buf, tw, n, m, sgn, l, j, vcol, vstride); return true;
+        default: return false;
+    }
+}
+
 template <bool DIF, bool GEN>
 __device__ __forceinline__ void fft_stage_dispatch(int R, cd* buf, const cd* tw, int n, int m, double sgn,
                                                    int l, int j) {
@@ -222,14 +251,20 @@ __device__ __forceinline__ void fft_stage_dispatch(int R, cd* buf, const cd* tw,
 
 // In-place transform of the whole tile; caller has synchronised after filling buf.
 // Ends with a __syncthreads().
+// vcol != nullptr (DIT only): multiply the outputs by vcol[z * vstride] in the last stage; returns false if
+// that stage's radix has no fused variant (the caller then multiplies in a separate pass).
 template <bool DIF, bool GEN>
-__device__ __forceinline__ void fft_tile(cd* buf, const cd* tw, const FftAxis& ax, double sgn, int l, int j) {
+__device__ __forceinline__ bool fft_tile(cd* buf, const cd* tw, const FftAxis& ax, double sgn, int l, int j,
+                                         const double* vcol = nullptr, int64_t vstride = 0) {
     const int n = ax.n;
+    bool fused = false;
     if (!DIF) {
         int m = 1;
         for (int s = 0; s < ax.nrad; ++s) {
             const int R = ax.rad[s];
-            fft_stage_dispatch<false, GEN>(R, buf, tw, n, m, sgn, l, j);
+            if (vcol != nullptr && s == ax.nrad - 1)
+                fused = fft_stage_vmul(R, buf, tw, n, m, sgn, l, j, vcol, vstride);
+            if (!fused) fft_stage_dispatch<false, GEN>(R, buf, tw, n, m, sgn, l, j);
             __syncthreads();
             m *= R;
         }
@@ -242,6 +277,7 @@ __device__ __forceinline__ void fft_tile(cd* buf, const cd* tw, const FftAxis& a
             __syncthreads();
         }
     }
+    return fused;
 }
 
 __device__ __forceinline__ void tile_prologue(cd* buf, cd* tw, const FftAxis& ax, bool zero) {
@@ -334,12 +370,14 @@ __global__ __launch_bounds__(FFT_THREADS) void k_zpass(FftAxis az, int nx, int n
     cd* t2 = T2 + (int64_t)band * T2_stride + (int64_t)y * nxp + x;
     tile_prologue(buf, tw, az, MODE != 2);
     __syncthreads();
+    bool fused_v = false;
     if (MODE != 2) {
         for (int zi = j; zi < nzx; zi += FFT_TPL) buf[zpos[zi] * FFT_LS + l] = t2[(int64_t)zi * plane];
         __syncthreads();
-        fft_tile<false, GEN>(buf, tw, az, +1.0, l, j);
+        fused_v = fft_tile<false, GEN>(buf, tw, az, +1.0, l, j,
+                                       (MODE == 0 && !GEN) ? Vs + (int64_t)y * nxp + x : nullptr, plane);
     }
-    if (MODE == 0) {
+    if (MODE == 0 && !fused_v) {
         const double* v = Vs + (int64_t)y * nxp + x;
         for (int z = j; z < nz; z += FFT_TPL) {
             const double s = v[(int64_t)z * plane];

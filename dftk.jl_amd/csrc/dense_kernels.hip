@@ -805,6 +805,8 @@ int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, 
         for (int i = 0; i < redblocks; ++i) o2 += hred[2 * i];
         if (!std::isfinite(o2)) return DFTK_MI_NUM_NONFINITE;
         const double off = sqrt(o2);
+        static const bool trace = getenv("DFTK_MI_HEEV_TRACE") != nullptr;   // convergence history per sweep
+        if (trace) fprintf(stderr, "[heev] n=%d sweep %d off/fro=%.3e\n", n, sweep + 1, off / fro);
         if (off <= tol * fro) done = true;
         if (!done && prev_off >= 0.0 && off > 0.5 * prev_off && off <= 1e-12 * fro) done = true;
         prev_off = off;

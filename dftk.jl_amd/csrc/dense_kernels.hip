@@ -442,13 +442,14 @@ __device__ __forceinline__ void tournament_pair(int nb, int round, int k, int& p
 //        (i, JB + (i + r) % JB), r = 0..JB-1 -- every (i, j) with i in block p and j in block q once.
 // mode 1 ("diag", one launch per sweep): block pair (2k, 2k+1); rotates the within-block pairs of both
 //        blocks (tournament of JB) -- together with the cross rounds each index pair is met once per sweep.
+// One inner round = ONE barrier: S is double-buffered (read S[cur], write S[cur ^ 1]); thread (k1, k2)
+// recomputes the rotations of pairs k1 and k2 itself from S[cur] (no parameter exchange through LDS, no
+// serial 16-thread phase), applies them two-sided to its 2x2 block and column-wise to two rows of U
+// (in place: nobody else touches those entries in this round).
 __global__ __launch_bounds__(256) void k_jacobi_pair(int n, int nb, int round, cd* __restrict__ A, int64_t lda,
                                                      cd* __restrict__ Ubuf, int mode) {
-    __shared__ cd S[J2B][J2B + 1];
+    __shared__ cd S[2][J2B][J2B + 1];
     __shared__ cd U[J2B][J2B + 1];
-    __shared__ cd rot_s[JB];
-    __shared__ double rot_c[JB];
-    __shared__ int rot_p[JB], rot_q[JB];
     int bp, bq;
     if (mode == 0) {
         tournament_pair(nb, round, blockIdx.x, bp, bq);
@@ -462,74 +463,92 @@ __global__ __launch_bounds__(256) void k_jacobi_pair(int n, int nb, int round, c
         const int c = e / J2B, r = e - c * J2B;
         const int gr = (r < JB ? bp * JB + r : bq * JB + (r - JB));
         const int gc = (c < JB ? bp * JB + c : bq * JB + (c - JB));
-        S[r][c] = A[gr + (int64_t)gc * lda];
+        S[0][r][c] = A[gr + (int64_t)gc * lda];
         U[r][c] = make_double2(r == c ? 1.0 : 0.0, 0.0);
     }
     __syncthreads();
-    {
-        const int nrounds = mode == 0 ? JB : JB - 1;
-        for (int rd = 0; rd < nrounds; ++rd) {
-            if (tid < JB) {
-                int p, q;
-                if (mode == 0) {
-                    p = tid;
-                    q = JB + ((tid + rd) & (JB - 1));
-                } else {
-                    tournament_pair(JB, rd, tid & (JB / 2 - 1), p, q);
-                    if (tid >= JB / 2) {
-                        p += JB;
-                        q += JB;
-                    }
+    const int k1 = tid >> 4, k2 = tid & 15;
+    const int nrounds = mode == 0 ? JB : JB - 1;
+    int cur = 0;
+    for (int rd = 0; rd < nrounds; ++rd) {
+        const cd(*Sc)[J2B + 1] = S[cur];
+        cd(*Sn)[J2B + 1] = S[cur ^ 1];
+        // index pair (p, q) and Jacobi rotation (c, s) of rotation slot k in this round
+        auto pair_of = [&](int k, int& p, int& q) {
+            if (mode == 0) {
+                p = k;
+                q = JB + ((k + rd) & (JB - 1));
+            } else {
+                tournament_pair(JB, rd, k & (JB / 2 - 1), p, q);
+                if (k >= JB / 2) {
+                    p += JB;
+                    q += JB;
                 }
-                const cd beta = S[p][q];
-                const double ab = sqrt(beta.x * beta.x + beta.y * beta.y);
-                const double al = S[p][p].x, ga = S[q][q].x;
-                double c = 1.0;
-                cd s = make_double2(0.0, 0.0);
-                if (ab > 1e-300 && ab > 1e-18 * sqrt(fabs(al * ga) + 1e-300)) {
-                    const double tau = (ga - al) / (2.0 * ab);
-                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                    c = 1.0 / sqrt(1.0 + t * t);
-                    const double f = t * c / ab;
-                    s = make_double2(f * beta.x, f * beta.y);
-                }
-                rot_c[tid] = c;
-                rot_s[tid] = s;
-                rot_p[tid] = p;
-                rot_q[tid] = q;
             }
-            __syncthreads();
-            // two-sided update of S in 2x2 blocks: thread (k1, k2) owns S[{p1,q1}][{p2,q2}] and applies
-            // the row rotation of pair k1 and the column rotation of pair k2 in one pass
-            {
-                const int k1 = tid >> 4, k2 = tid & 15;
-                const int p1 = rot_p[k1], q1 = rot_q[k1], p2 = rot_p[k2], q2 = rot_q[k2];
-                const double c1 = rot_c[k1], c2 = rot_c[k2];
-                const cd s1 = rot_s[k1], s2 = rot_s[k2];
-                const cd a = S[p1][p2], b2 = S[p1][q2], c3 = S[q1][p2], d = S[q1][q2];
-                // rows: (row_p, row_q) <- (c row_p - s row_q, conj(s) row_p + c row_q)
-                const cd ra = make_double2(c1 * a.x - (s1.x * c3.x - s1.y * c3.y), c1 * a.y - (s1.x * c3.y + s1.y * c3.x));
-                const cd rb = make_double2(c1 * b2.x - (s1.x * d.x - s1.y * d.y), c1 * b2.y - (s1.x * d.y + s1.y * d.x));
-                const cd rc = make_double2(s1.x * a.x + s1.y * a.y + c1 * c3.x, s1.x * a.y - s1.y * a.x + c1 * c3.y);
-                const cd rd = make_double2(s1.x * b2.x + s1.y * b2.y + c1 * d.x, s1.x * b2.y - s1.y * b2.x + c1 * d.y);
-                // cols: (x_p, x_q) <- (c x_p - conj(s) x_q, s x_p + c x_q)
-                S[p1][p2] = make_double2(c2 * ra.x - (s2.x * rb.x + s2.y * rb.y), c2 * ra.y - (s2.x * rb.y - s2.y * rb.x));
-                S[p1][q2] = make_double2(s2.x * ra.x - s2.y * ra.y + c2 * rb.x, s2.x * ra.y + s2.y * ra.x + c2 * rb.y);
-                S[q1][p2] = make_double2(c2 * rc.x - (s2.x * rd.x + s2.y * rd.y), c2 * rc.y - (s2.x * rd.y - s2.y * rd.x));
-                S[q1][q2] = make_double2(s2.x * rc.x - s2.y * rc.y + c2 * rd.x, s2.x * rc.y + s2.y * rc.x + c2 * rd.y);
+        };
+        // Jacobi rotation annihilating S[p][q]:  t = sgn(d) |b| / (|d| + sqrt(d^2 + |b|^2)), d = (g - a)/2,
+        // c = 1/sqrt(1 + t^2), s = t c b/|b| = sgn(d) c b / (|d| + sqrt(d^2 + |b|^2))  -- no |b| needed.
+        // Hardware rsq/rcp seeds + Newton steps instead of the library sqrt/div sequences: every thread
+        // evaluates two of these per round, so they must be short; c gets two steps (c^2 + |s|^2 = 1 to
+        // round-off keeps U unitary), the angle itself needs far less than full precision.
+        auto rotation = [&](int p, int q, double& c, cd& s) {
+            const cd beta = Sc[p][q];
+            const double al = Sc[p][p].x, ga = Sc[q][q].x;
+            const double b2 = beta.x * beta.x + beta.y * beta.y;
+            c = 1.0;
+            s = make_double2(0.0, 0.0);
+            if (b2 > 1e-300 && b2 > 1e-36 * (fabs(al * ga) + 1e-300)) {
+                const double d = 0.5 * (ga - al);
+                const double x = fma(d, d, b2);
+                double r = __builtin_amdgcn_rsq(x);
+                r = r * fma(-0.5 * x * r, r, 1.5);
+                const double den = fabs(d) + x * r;
+                double u = __builtin_amdgcn_rcp(den);
+                u = u * fma(-den, u, 2.0);
+                const double y = fma(b2 * u, u, 1.0);
+                double cc = __builtin_amdgcn_rsq(y);
+                cc = cc * fma(-0.5 * y * cc, cc, 1.5);
+                cc = cc * fma(-0.5 * y * cc, cc, 1.5);
+                c = cc;
+                const double f = (d >= 0.0 ? cc : -cc) * u;
+                s = make_double2(f * beta.x, f * beta.y);
             }
-            // column rotations of U
-            for (int e = tid; e < J2B * JB; e += 256) {
-                const int k = e / J2B, r = e - k * J2B;
-                const int p = rot_p[k], q = rot_q[k];
-                const double c = rot_c[k];
-                const cd s = rot_s[k];
-                const cd xp = U[r][p], xq = U[r][q];
-                U[r][p] = make_double2(c * xp.x - (s.x * xq.x + s.y * xq.y), c * xp.y - (s.x * xq.y - s.y * xq.x));
-                U[r][q] = make_double2(s.x * xp.x - s.y * xp.y + c * xq.x, s.x * xp.y + s.y * xp.x + c * xq.y);
-            }
-            __syncthreads();
+        };
+        int p1, q1, p2, q2;
+        pair_of(k1, p1, q1);
+        pair_of(k2, p2, q2);
+        double c1, c2;
+        cd s1, s2;
+        rotation(p1, q1, c1, s1);
+        if (k1 == k2) {
+            c2 = c1;
+            s2 = s1;
+        } else {
+            rotation(p2, q2, c2, s2);
         }
+        {
+            const cd a = Sc[p1][p2], b2 = Sc[p1][q2], c3 = Sc[q1][p2], d = Sc[q1][q2];
+            // rows: (row_p, row_q) <- (c row_p - s row_q, conj(s) row_p + c row_q)
+            const cd ra = make_double2(c1 * a.x - (s1.x * c3.x - s1.y * c3.y), c1 * a.y - (s1.x * c3.y + s1.y * c3.x));
+            const cd rb = make_double2(c1 * b2.x - (s1.x * d.x - s1.y * d.y), c1 * b2.y - (s1.x * d.y + s1.y * d.x));
+            const cd rc = make_double2(s1.x * a.x + s1.y * a.y + c1 * c3.x, s1.x * a.y - s1.y * a.x + c1 * c3.y);
+            const cd rdd = make_double2(s1.x * b2.x + s1.y * b2.y + c1 * d.x, s1.x * b2.y - s1.y * b2.x + c1 * d.y);
+            // cols: (x_p, x_q) <- (c x_p - conj(s) x_q, s x_p + c x_q)
+            Sn[p1][p2] = make_double2(c2 * ra.x - (s2.x * rb.x + s2.y * rb.y), c2 * ra.y - (s2.x * rb.y - s2.y * rb.x));
+            Sn[p1][q2] = make_double2(s2.x * ra.x - s2.y * ra.y + c2 * rb.x, s2.x * ra.y + s2.y * ra.x + c2 * rb.y);
+            Sn[q1][p2] = make_double2(c2 * rc.x - (s2.x * rdd.x + s2.y * rdd.y), c2 * rc.y - (s2.x * rdd.y - s2.y * rdd.x));
+            Sn[q1][q2] = make_double2(s2.x * rc.x - s2.y * rc.y + c2 * rdd.x, s2.x * rc.y + s2.y * rc.x + c2 * rdd.y);
+        }
+        // column rotations of U: rows k2 and k2 + 16, rotation k1
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = k2 + JB * h;
+            const cd xp = U[r][p1], xq = U[r][q1];
+            U[r][p1] = make_double2(c1 * xp.x - (s1.x * xq.x + s1.y * xq.y), c1 * xp.y - (s1.x * xq.y - s1.y * xq.x));
+            U[r][q1] = make_double2(s1.x * xp.x - s1.y * xp.y + c1 * xq.x, s1.x * xp.y + s1.y * xp.x + c1 * xq.y);
+        }
+        __syncthreads();
+        cur ^= 1;
     }
     cd* Uo = Ubuf + (int64_t)blockIdx.x * J2B * J2B;
     for (int e = tid; e < J2B * J2B; e += 256) {
@@ -621,6 +640,107 @@ __global__ __launch_bounds__(256) void k_jacobi_rows(int n, int nb, int round, c
             const int gr = pair_index(bp, bq, 16 * it + lk + 4 * r);
             A[gr + (int64_t)(c0 + li) * lda] = make_double2(accR[it][r], accI[it][r]);
         }
+}
+
+// Fused two-sided update of one round (replaces k_jacobi_cols + k_jacobi_rows: one launch less per round
+// and half the work on A thanks to the Hermitian symmetry):
+//   workgroups [0, ntiles):  tile (i <= j) of the pair partition, A_ij <- U_i^H A_ij U_j (32x32), the mirror
+//                            tile A_ji = A_ij^H is written along with it;  wave w owns the output quadrant
+//                            (w >> 1, w & 1): 32 MFMAs for T = A_ij U_j (through LDS), 32 for U_i^H T;
+//   workgroups [ntiles, ..): V[:, cols(pair)] <- V[:, cols(pair)] U_pair, one wave per 16-row strip.
+__global__ __launch_bounds__(256) void k_jacobi_update(int n, int nb, int round, cd* __restrict__ A, int64_t lda,
+                                                       cd* __restrict__ V, int64_t ldv,
+                                                       const cd* __restrict__ Ubuf, int ntiles, int vblocks) {
+    __shared__ cd Ts[J2B][J2B + 1];
+    const int npairs = nb / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    if ((int)blockIdx.x >= ntiles) {
+        // ---- eigenvector columns
+        const int vb = blockIdx.x - ntiles;
+        const int pj = vb / vblocks;
+        const int r0 = ((vb - pj * vblocks) * 4 + wave) * 16;
+        if (r0 >= n) return;
+        int bp, bq;
+        tournament_pair(nb, round, pj, bp, bq);
+        const cd* U = Ubuf + (int64_t)pj * J2B * J2B;
+        v4d_t accR[2], accI[2];
+        accR[0] = accR[1] = accI[0] = accI[1] = (v4d_t){0.0, 0.0, 0.0, 0.0};
+        cd fa[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) fa[t] = V[r0 + li + (int64_t)pair_index(bp, bq, 4 * t + lk) * ldv];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const double ar = fa[t].x, ai = fa[t].y, nai = -ai;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const cd u = U[(4 * t + lk) + (16 * c + li) * J2B];
+                accR[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, u.x, accR[c], 0, 0, 0);
+                accI[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, u.y, accI[c], 0, 0, 0);
+                accR[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, u.y, accR[c], 0, 0, 0);
+                accI[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, u.x, accI[c], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int64_t gc = pair_index(bp, bq, 16 * c + li);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) V[r0 + lk + 4 * r + gc * ldv] = make_double2(accR[c][r], accI[c][r]);
+        }
+        return;
+    }
+    // ---- tile (pi <= pj): linear index -> (pi, pj) of the upper triangle (row by row)
+    int pi = 0, rem = blockIdx.x;
+    while (rem >= npairs - pi) {
+        rem -= npairs - pi;
+        ++pi;
+    }
+    const int pj = pi + rem;
+    int bpi, bqi, bpj, bqj;
+    tournament_pair(nb, round, pi, bpi, bqi);
+    tournament_pair(nb, round, pj, bpj, bqj);
+    const cd* Ui = Ubuf + (int64_t)pi * J2B * J2B;
+    const cd* Uj = Ubuf + (int64_t)pj * J2B * J2B;
+    const int qi = wave >> 1, qj = wave & 1;
+    // stage 1: T[qi, qj] = A_ij[qi rows, :] * U_j[:, qj cols]
+    {
+        v4d_t tR = (v4d_t){0.0, 0.0, 0.0, 0.0}, tI = (v4d_t){0.0, 0.0, 0.0, 0.0};
+        const int gr = pair_index(bpi, bqi, 16 * qi + li);
+        cd fa[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) fa[t] = A[gr + (int64_t)pair_index(bpj, bqj, 4 * t + lk) * lda];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const double ar = fa[t].x, ai = fa[t].y, nai = -ai;
+            const cd u = Uj[(4 * t + lk) + (16 * qj + li) * J2B];
+            tR = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, u.x, tR, 0, 0, 0);
+            tI = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, u.y, tI, 0, 0, 0);
+            tR = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, u.y, tR, 0, 0, 0);
+            tI = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, u.x, tI, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ts[16 * qi + lk + 4 * r][16 * qj + li] = make_double2(tR[r], tI[r]);
+    }
+    __syncthreads();
+    // stage 2: R[qi, qj] = U_i[:, qi cols]^H * T[:, qj cols]
+    v4d_t rR = (v4d_t){0.0, 0.0, 0.0, 0.0}, rI = (v4d_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const cd u = Ui[(4 * t + lk) + (16 * qi + li) * J2B];   // A operand: conj(U_i[k][row])
+        const cd b = Ts[4 * t + lk][16 * qj + li];
+        const double nui = -u.y;
+        rR = __builtin_amdgcn_mfma_f64_16x16x4f64(u.x, b.x, rR, 0, 0, 0);
+        rI = __builtin_amdgcn_mfma_f64_16x16x4f64(u.x, b.y, rI, 0, 0, 0);
+        rR = __builtin_amdgcn_mfma_f64_16x16x4f64(u.y, b.y, rR, 0, 0, 0);
+        rI = __builtin_amdgcn_mfma_f64_16x16x4f64(nui, b.x, rI, 0, 0, 0);
+    }
+    const int64_t gc = pair_index(bpj, bqj, 16 * qj + li);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t gr = pair_index(bpi, bqi, 16 * qi + lk + 4 * r);
+        A[gr + gc * lda] = make_double2(rR[r], rI[r]);
+        if (pi != pj) A[gc + gr * lda] = make_double2(rR[r], -rI[r]);   // mirror tile A_ji = A_ij^H
+    }
 }
 
 // out[0] = sum |offdiag|^2, out[1] = sum |diag|^2   (whole matrix)
@@ -787,16 +907,23 @@ int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, 
     int sweep = 0;
     const int maxsweeps = 40;
     bool done = (off2 <= tol * tol * (dg2 + off2)) && off2 == 0.0;
+    static const bool fused_update = getenv("DFTK_MI_HEEV_UNFUSED") == nullptr;
     for (; sweep < maxsweeps && !done; ++sweep) {
         for (int round = -1; round < nb - 1; ++round) {
             // round -1: within-block rotations on the block pairs (2k, 2k+1); the update kernels see the
             // same pairing through a negative round index
             hipLaunchKernelGGL(k_jacobi_pair, dim3(npairs), dim3(256), 0, b->stream, np, nb, round, W, (int64_t)np,
                                Ubuf, round < 0 ? 1 : 0);
-            hipLaunchKernelGGL(k_jacobi_cols, dim3(npairs, (2 * np / 16 + 3) / 4), dim3(256), 0, b->stream, np, nb,
-                               round, W, (int64_t)np, Vw, (int64_t)np, Ubuf);
-            hipLaunchKernelGGL(k_jacobi_rows, dim3(npairs, (np / 16 + 3) / 4), dim3(256), 0, b->stream, np, nb, round,
-                               W, (int64_t)np, Ubuf);
+            if (fused_update) {
+                const int ntiles = npairs * (npairs + 1) / 2, vblocks = (np / 16 + 3) / 4;
+                hipLaunchKernelGGL(k_jacobi_update, dim3(ntiles + npairs * vblocks), dim3(256), 0, b->stream, np, nb,
+                                   round, W, (int64_t)np, Vw, (int64_t)np, Ubuf, ntiles, vblocks);
+            } else {
+                hipLaunchKernelGGL(k_jacobi_cols, dim3(npairs, (2 * np / 16 + 3) / 4), dim3(256), 0, b->stream, np, nb,
+                                   round, W, (int64_t)np, Vw, (int64_t)np, Ubuf);
+                hipLaunchKernelGGL(k_jacobi_rows, dim3(npairs, (np / 16 + 3) / 4), dim3(256), 0, b->stream, np, nb,
+                                   round, W, (int64_t)np, Ubuf);
+            }
         }
         hipLaunchKernelGGL(k_offdiag_norm, dim3(redblocks), dim3(256), 0, b->stream, np, W, (int64_t)np, d_red);
         HIPCHK(hipMemcpyAsync(hred.data(), d_red, hred.size() * sizeof(double), hipMemcpyDeviceToHost, b->stream));

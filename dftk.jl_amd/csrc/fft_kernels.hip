@@ -122,7 +122,8 @@ __device__ __forceinline__ void dft_small(cd (&a)[R], double sgn, const cd* __re
 // One radix-R pass over the tile.  m = product of the radices already combined (DIT) or still
 // to be split (DIF).  Thread (l, j) owns line l and butterflies j, j+TPL, ...
 // VMUL (last stage of a backward transform only): the natural-order outputs are multiplied by the real
-// potential column vcol[z * vstride] on their way back to LDS (fused V*psi: saves one LDS round trip).
+// potential column vcol[z * vstride] and pushed through the first butterfly of the forward transform
+// before they go back to LDS (fused V*psi: saves two LDS round trips; see fft_tile's `skip`).
 template <int R, bool DIF, bool VMUL = false>
 __device__ __forceinline__ void fft_stage(cd* buf, const cd* __restrict__ tw, int n, int m, double sgn,
                                           int l, int j, const double* __restrict__ vcol = nullptr,
@@ -160,10 +161,22 @@ __device__ __forceinline__ void fft_stage(cd* buf, const cd* __restrict__ tw, in
             }
         }
         if (VMUL) {
+            // middle pass of the fused local apply: these R natural-order outputs of the backward transform
+            // are exactly the inputs of the first decimation-in-frequency butterfly of the forward transform
+            // (same radix, same m): multiply by V and run that butterfly here, one LDS round trip for both
 #pragma unroll
             for (int p = 0; p < R; ++p) {
                 a[p].x *= vv[p];
                 a[p].y *= vv[p];
+            }
+            dft_small<R>(a, -sgn, tw, nOverR);
+            if (m > 1) {
+#pragma unroll
+                for (int p = 1; p < R; ++p) {
+                    cd w = tw[p * jj * twstep];
+                    w.y *= -sgn;
+                    a[p] = cmul(a[p], w);
+                }
             }
         }
 #pragma unroll
@@ -251,11 +264,13 @@ __device__ __forceinline__ void fft_stage_dispatch(int R, cd* buf, const cd* tw,
 
 // In-place transform of the whole tile; caller has synchronised after filling buf.
 // Ends with a __syncthreads().
-// vcol != nullptr (DIT only): multiply the outputs by vcol[z * vstride] in the last stage; returns false if
+// vcol != nullptr (DIT only): the last stage also multiplies by vcol[z * vstride] and runs the first
+// forward butterfly (the following forward fft_tile must then be called with skip_first); returns false if
 // that stage's radix has no fused variant (the caller then multiplies in a separate pass).
 template <bool DIF, bool GEN>
 __device__ __forceinline__ bool fft_tile(cd* buf, const cd* tw, const FftAxis& ax, double sgn, int l, int j,
-                                         const double* vcol = nullptr, int64_t vstride = 0) {
+                                         const double* vcol = nullptr, int64_t vstride = 0,
+                                         bool skip_first = false) {
     const int n = ax.n;
     bool fused = false;
     if (!DIF) {
@@ -273,6 +288,7 @@ __device__ __forceinline__ bool fft_tile(cd* buf, const cd* tw, const FftAxis& a
         for (int s = ax.nrad - 1; s >= 0; --s) {
             const int R = ax.rad[s];
             m /= R;
+            if (skip_first && s == ax.nrad - 1) continue;   // already done by the fused middle pass
             fft_stage_dispatch<true, GEN>(R, buf, tw, n, m, sgn, l, j);
             __syncthreads();
         }
@@ -398,7 +414,7 @@ __global__ __launch_bounds__(FFT_THREADS) void k_zpass(FftAxis az, int nx, int n
             buf[z * FFT_LS + l] = (x < nx) ? cube[((int64_t)z * ny + y) * nx + x] : make_double2(0.0, 0.0);
         __syncthreads();
     }
-    fft_tile<true, GEN>(buf, tw, az, -1.0, l, j);
+    fft_tile<true, GEN>(buf, tw, az, -1.0, l, j, nullptr, 0, MODE == 0 && fused_v);
     for (int zi = j; zi < nzx; zi += FFT_TPL) t2[(int64_t)zi * plane] = buf[zpos[zi] * FFT_LS + l];
 }
 

@@ -539,6 +539,16 @@ extern "C" int dftk_mi_zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n
                  be, reinterpret_cast<cd*>(C_d), ldc);
 }
 
+extern "C" int dftk_mi_zgemm_ex(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, dftk_mi_cplx alpha,
+                                const dftk_mi_cplx* A_d, int64_t lda, const dftk_mi_cplx* B_d, int64_t ldb,
+                                dftk_mi_cplx beta, dftk_mi_cplx* C_d, int64_t ldc, int flags) {
+    if (!b || m < 0 || n < 0 || k < 0 || !C_d || (flags & ~3)) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(b->device));
+    cd al = {alpha.re, alpha.im}, be = {beta.re, beta.im};
+    return zgemm(b, transA, m, n, k, al, reinterpret_cast<const cd*>(A_d), lda, reinterpret_cast<const cd*>(B_d), ldb,
+                 be, reinterpret_cast<cd*>(C_d), ldc, flags);
+}
+
 extern "C" int dftk_mi_heev(dftk_mi_basis* b, int n, dftk_mi_cplx* A_d, int64_t lda, double* W_h, dftk_mi_cplx* V_d,
                             int64_t ldv) {
     if (!b || n < 1 || !A_d || !W_h || !V_d || lda < n || ldv < n) return DFTK_MI_EINVAL;

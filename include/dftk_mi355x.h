@@ -124,6 +124,17 @@ int dftk_mi_zgemm(dftk_mi_basis* basis, char transA, int64_t m, int64_t n, int64
                   dftk_mi_cplx alpha, const dftk_mi_cplx* A_d, int64_t lda,
                   const dftk_mi_cplx* B_d, int64_t ldb, dftk_mi_cplx beta,
                   dftk_mi_cplx* C_d, int64_t ldc);
+/* Structured variants used by the LOBPCG driver (lobpcg_hyper_impl.jl:141-145 Gram matrices that are
+ * hermitised afterwards, :216-261 X*inv(R)); flags (may be combined):
+ *   DFTK_MI_GEMM_UPPER     only the 128x64 tiles of C that intersect the upper triangle (i <= j) are
+ *                          computed and written, the rest of C is left untouched;
+ *   DFTK_MI_GEMM_B_UPPER   B is upper triangular (B[k][j] = 0 for k > j): the k loop stops at the diagonal. */
+#define DFTK_MI_GEMM_UPPER 1
+#define DFTK_MI_GEMM_B_UPPER 2
+int dftk_mi_zgemm_ex(dftk_mi_basis* basis, char transA, int64_t m, int64_t n, int64_t k,
+                     dftk_mi_cplx alpha, const dftk_mi_cplx* A_d, int64_t lda,
+                     const dftk_mi_cplx* B_d, int64_t ldb, dftk_mi_cplx beta,
+                     dftk_mi_cplx* C_d, int64_t ldc, int flags);
 /* Hermitian eigen-decomposition (blocked parallel Jacobi): A (n x n, full storage, destroyed),
  * W_h[n] ascending eigenvalues (host), V_d n x n eigenvectors (columns, sorted like W). */
 int dftk_mi_heev(dftk_mi_basis* basis, int n, dftk_mi_cplx* A_d, int64_t lda, double* W_h,

@@ -121,6 +121,51 @@ def test_zgemm(lib, trans, m, n, k):
     assert relerr(Cn.cpu().numpy().T, opA @ B) < 1e-13
 
 
+@pytest.mark.parametrize("m,k", [(259, 3000), (777, 2500), (141, 4100), (64, 300), (5, 2100)])
+def test_zgemm_upper_only(lib, m, k):
+    """DFTK_MI_GEMM_UPPER: tiles that intersect the upper triangle hold A^H B, the others are untouched;
+    split-K (interior and border planned separately) must agree with the unsplit product."""
+    rng = np.random.default_rng(m + k)
+    bs = Basis(lib, 8, 8, 8)
+    A = rng.standard_normal((k, m)) + 1j * rng.standard_normal((k, m))
+    B = rng.standard_normal((k, m)) + 1j * rng.standard_normal((k, m))
+    Ad, Bd = dev(A.T.copy()), dev(B.T.copy())
+    Cd = torch.full((m, m), 7.0 + 3.0j, dtype=torch.complex128, device="cuda")
+    check(lib.dftk_mi_zgemm_ex(bs.h, b"C", m, m, k, cplx(1.0), Ad.data_ptr(), k, Bd.data_ptr(), k, cplx(0.0),
+                               Cd.data_ptr(), m, 1))
+    bs.sync()
+    C = Cd.cpu().numpy().T
+    ref = A.conj().T @ B
+    iu = np.triu_indices(m)
+    assert np.abs(C[iu] - ref[iu]).max() < 1e-12 * np.abs(ref).max()
+    # untouched entries keep the fill value, computed ones match the reference: nothing else may appear
+    computed = np.abs(C - ref) < 1e-12 * np.abs(ref).max()
+    untouched = C == 7.0 + 3.0j
+    assert np.all(computed | untouched)
+    i, j = np.indices((m, m))
+    assert np.all(untouched[(i // 128) * 128 >= (j // 64) * 64 + 64])   # tiles strictly below the diagonal
+
+
+@pytest.mark.parametrize("m,n", [(5000, 259), (700, 64), (1300, 141), (260, 17)])
+def test_zgemm_upper_triangular_B(lib, m, n):
+    """DFTK_MI_GEMM_B_UPPER (X * inv(R)): same result as the full product with triu(B), and the strictly
+    lower part of B is never read (NaN there)."""
+    rng = np.random.default_rng(m + n)
+    bs = Basis(lib, 8, 8, 8)
+    A = rng.standard_normal((m, n)) + 1j * rng.standard_normal((m, n))
+    R = np.triu(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    Rnan = R.copy()
+    Rnan[np.tril_indices(n, -64)] = np.nan     # beyond the 64-column tile granularity nothing below is read
+    Ad, Bd = dev(A.T.copy()), dev(Rnan.T.copy())
+    Cd = torch.zeros((n, m), dtype=torch.complex128, device="cuda")
+    check(lib.dftk_mi_zgemm_ex(bs.h, b"N", m, n, n, cplx(1.0), Ad.data_ptr(), m, Bd.data_ptr(), n, cplx(0.0),
+                               Cd.data_ptr(), m, 2))
+    bs.sync()
+    assert relerr(Cd.cpu().numpy().T, A @ R) < 1e-13
+    assert lib.dftk_mi_zgemm_ex(bs.h, b"N", m, n, n, cplx(1.0), Ad.data_ptr(), m, Bd.data_ptr(), n, cplx(0.0),
+                                Cd.data_ptr(), m, 8) < 0   # unknown flag
+
+
 def test_zgemm_asymmetric_layout(lib):
     """A = I with an asymmetric B catches transposed MFMA output maps."""
     bs = Basis(lib, 8, 8, 8)

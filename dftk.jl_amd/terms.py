@@ -210,20 +210,72 @@ def _lda_c_pw(rho):
 _FUNCTIONALS = {"lda_x": _lda_x, "lda_c_vwn": _lda_c_vwn, "lda_c_pw": _lda_c_pw}
 
 
+# GGA energy densities e(rho, sigma) per volume, sigma = |grad rho|^2 (closed forms of libxc's gga_x_pbe /
+# gga_c_pbe; the derivatives de/drho, de/dsigma come from torch.autograd, the oracle's from complex steps).
+def _gga_x_pbe_e(rho, sigma):
+    kappa, mu = 0.8040, 0.2195149727645171
+    cx = -0.75 * (3 / math.pi) ** (1 / 3)
+    kf = (3 * math.pi ** 2 * rho) ** (1 / 3)
+    s2 = sigma / (4 * kf * kf * rho * rho)
+    return cx * rho ** (4 / 3) * (1 + kappa - kappa * kappa / (kappa + mu * s2))
+
+
+def _gga_c_pbe_e(rho, sigma):
+    beta, gamma = 0.06672455060314922, (1 - math.log(2)) / math.pi ** 2
+    a, a1, b1, b2, b3, b4 = 0.0310907, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294    # lda_c_pw_mod
+    rs = (3 / (4 * math.pi * rho)) ** (1 / 3)
+    sq = torch.sqrt(rs)
+    eps = -2 * a * (1 + a1 * rs) * torch.log1p(1 / (2 * a * (b1 * sq + b2 * rs + b3 * rs * sq + b4 * rs * rs)))
+    kf = (3 * math.pi ** 2 * rho) ** (1 / 3)
+    t2 = sigma * math.pi / (16 * kf * rho * rho)
+    A = beta / gamma / torch.expm1(-eps / gamma)
+    f1 = t2 + A * t2 * t2
+    H = gamma * torch.log1p(beta / gamma * f1 / (1 + A * f1))
+    return rho * (eps + H)
+
+
+_GGA_FUNCTIONALS = {"gga_x_pbe": _gga_x_pbe_e, "gga_c_pbe": _gga_c_pbe_e}
+_DENSITY_THRESHOLD = 1e-12
+
+
 def xc_energy_potential(basis, rho):
-    """LDA branch of xc_potential_real (xc.jl:84-160): E = sum e dvol, V = de/drho."""
+    """xc_potential_real (xc.jl:84-160): E = sum e dvol, V = V_rho - 2 div(V_sigma grad rho); LDA terms
+    have V_sigma = 0, for GGAs grad rho and the divergence are taken in Fourier space on the cube with
+    the device FFT pipeline (LibxcDensities xc.jl:356-409, divergence_real :576-584)."""
     rc = torch.clamp(rho, min=1e-300)
     e = torch.zeros_like(rho)
     v = torch.zeros_like(rho)
+    gga = []
     for name in basis.model.functionals:
+        if name in _GGA_FUNCTIONALS:
+            gga.append(name)
+            continue
         if name not in _FUNCTIONALS:
-            raise NotImplementedError(f"XC functional {name}: only LDA (lda_x, lda_c_vwn, lda_c_pw) on this path")
+            raise NotImplementedError(f"XC functional {name}: LDA (lda_x, lda_c_vwn, lda_c_pw) and PBE "
+                                      f"(gga_x_pbe, gga_c_pbe) are on this path")
         ei, vi = _FUNCTIONALS[name](rc)
         e += ei
         v += vi
     tiny = rho <= 1e-300
     e = torch.where(tiny, torch.zeros_like(e), e)
     v = torch.where(tiny, torch.zeros_like(v), v)
+    if gga:
+        G = basis.G_vectors_cart_cube()                                      # (nz, ny, nx, 3)
+        rho_f = basis.fft(rho)
+        grad = [basis.irfft(1j * G[..., a] * rho_f) for a in range(3)]
+        sigma = grad[0] ** 2 + grad[1] ** 2 + grad[2] ** 2
+        ok = rho > _DENSITY_THRESHOLD
+        rho_s = torch.where(ok, rho, torch.ones_like(rho)).detach().requires_grad_(True)
+        sig_s = torch.where(ok, sigma, torch.zeros_like(sigma)).detach().requires_grad_(True)
+        with torch.enable_grad():
+            eg = sum(_GGA_FUNCTIONALS[name](rho_s, sig_s) for name in gga)
+            vr, vs = torch.autograd.grad(eg.sum(), (rho_s, sig_s))
+        zero = torch.zeros_like(rho)
+        e = e + torch.where(ok, eg.detach(), zero)
+        v = v + torch.where(ok, vr, zero)
+        vsig = torch.where(ok, vs, zero)
+        div = sum(1j * G[..., a] * basis.fft(vsig * grad[a]) for a in range(3))
+        v = v - 2.0 * basis.irfft(div)
     return float(e.sum().item() * basis.dvol), v
 
 

@@ -232,12 +232,60 @@ def _lda_c_pw(rho):
 _FUNCTIONALS = {"lda_x": _lda_x, "lda_c_vwn": _lda_c_vwn, "lda_c_pw": _lda_c_pw}
 
 
+# GGA functionals: energy density per volume e(rho, sigma), sigma = |grad rho|^2.  Written with analytic
+# primitives only (no abs / cbrt) so that the derivatives de/drho, de/dsigma can be taken by the
+# complex-step method to machine precision (no hand-derived formulas to get wrong).
+def _gga_x_pbe_e(rho, sigma):
+    """PBE exchange (libxc ``gga_x_pbe``; Perdew, Burke, Ernzerhof 1996): e_x^LDA F_x(s),
+    F_x = 1 + kappa - kappa^2 / (kappa + mu s^2), s = |grad rho| / (2 k_F rho)."""
+    kappa, mu = 0.8040, 0.2195149727645171
+    cx = -0.75 * (3 / math.pi) ** (1 / 3)
+    kf = (3 * math.pi ** 2 * rho) ** (1 / 3)
+    s2 = sigma / (4 * kf * kf * rho * rho)
+    return cx * rho ** (4 / 3) * (1 + kappa - kappa * kappa / (kappa + mu * s2))
+
+
+def _gga_c_pbe_e(rho, sigma):
+    """PBE correlation (libxc ``gga_c_pbe``): rho (eps_c^PW92mod(rs) + H(rs, t)), unpolarised (phi = 1),
+    H = gamma ln(1 + beta/gamma t^2 (1 + A t^2) / (1 + A t^2 + A^2 t^4)); libxc builds it on
+    ``lda_c_pw_mod`` (a = 0.0310907)."""
+    beta, gamma = 0.06672455060314922, (1 - math.log(2)) / math.pi ** 2
+    a, a1, b1, b2, b3, b4 = 0.0310907, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294
+    rs = (3 / (4 * math.pi * rho)) ** (1 / 3)
+    sq = np.sqrt(rs)
+    eps = -2 * a * (1 + a1 * rs) * np.log1p(1 / (2 * a * (b1 * sq + b2 * rs + b3 * rs * sq + b4 * rs * rs)))
+    kf = (3 * math.pi ** 2 * rho) ** (1 / 3)
+    t2 = sigma * math.pi / (16 * kf * rho * rho)
+    A = beta / gamma / np.expm1(-eps / gamma)
+    f1 = t2 + A * t2 * t2
+    H = gamma * np.log1p(beta / gamma * f1 / (1 + A * f1))
+    return rho * (eps + H)
+
+
+_GGA_FUNCTIONALS = {"gga_x_pbe": _gga_x_pbe_e, "gga_c_pbe": _gga_c_pbe_e}
+_DENSITY_THRESHOLD = 1e-12   # below it a GGA contributes nothing (libxc-style density threshold)
+
+
+def _gga_terms(fun, rho, sigma):
+    """(e, de/drho, de/dsigma) by complex-step differentiation."""
+    h = 1e-30
+    e = fun(rho, sigma)
+    vrho = np.imag(fun(rho + 1j * h, sigma.astype(complex))) / h
+    vsigma = np.imag(fun(rho.astype(complex), sigma + 1j * h)) / h
+    return e, vrho, vsigma
+
+
 def xc_energy_potential(basis, rho):
-    """E_xc = sum e dvol, V_xc = de/drho for LDA functionals (xc.jl:84-160, LDA branch)."""
+    """E_xc = sum e dvol and V_xc = V_rho - 2 div(V_sigma grad rho) (xc.jl:84-160): LDA terms have
+    V_sigma = 0; for GGAs grad rho and the divergence are taken in Fourier space on the cube
+    (LibxcDensities xc.jl:356-409, divergence_real :576-584)."""
     rho_c = np.maximum(rho, 1e-300)   # guard the cube root / log; libxc uses a density threshold
     e = np.zeros_like(rho)
     v = np.zeros_like(rho)
+    gga = [f for f in basis.model.functionals if f in _GGA_FUNCTIONALS]
     for name in basis.model.functionals:
+        if name in _GGA_FUNCTIONALS:
+            continue
         ei, vi = _FUNCTIONALS[name](rho_c)
         e += ei
         v += vi
@@ -245,6 +293,22 @@ def xc_energy_potential(basis, rho):
     if np.any(tiny):
         e[tiny] = 0.0
         v[tiny] = 0.0
+    if gga:
+        G = basis.G_vectors_cart_cube()                      # (nz, ny, nx, 3)
+        rho_f = basis.fft_cube(rho)
+        grad = [basis.irfft_cube(1j * G[..., a] * rho_f) for a in range(3)]
+        sigma = grad[0] ** 2 + grad[1] ** 2 + grad[2] ** 2
+        ok = rho > _DENSITY_THRESHOLD
+        rho_s = np.where(ok, rho, 1.0)
+        sig_s = np.where(ok, sigma, 0.0)
+        vsig = np.zeros_like(rho)
+        for name in gga:
+            ei, vr, vs = _gga_terms(_GGA_FUNCTIONALS[name], rho_s, sig_s)
+            e += np.where(ok, ei, 0.0)
+            v += np.where(ok, vr, 0.0)
+            vsig += np.where(ok, vs, 0.0)
+        div = sum(1j * G[..., a] * basis.fft_cube(vsig * grad[a]) for a in range(3))
+        v = v - 2.0 * basis.irfft_cube(div)
     return float(np.sum(e) * basis.dvol), v
 
 

@@ -306,3 +306,29 @@ def test_kpoint_sharding_gloo_world2(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o}"
         assert f"rank {r} ok" in o
+
+
+def test_pbe_pointwise_terms_match_oracle():
+    """The device mirror evaluates the PBE energy density with torch and differentiates it with autograd; the
+    oracle uses NumPy and complex-step derivatives: e, de/drho, de/dsigma agree over the physical range."""
+    from oracle.terms import _gga_terms, _GGA_FUNCTIONALS as OG
+    from dftk_jl_amd.terms import _GGA_FUNCTIONALS as DG
+    rng = np.random.default_rng(0)
+    rho = 10 ** rng.uniform(-12, 0.5, 5000)
+    s2 = 10 ** rng.uniform(-6, 4, 5000)                       # reduced gradient squared
+    kf = (3 * np.pi ** 2 * rho) ** (1 / 3)
+    sig = s2 * 4 * kf * kf * rho * rho
+    for name in ("gga_x_pbe", "gga_c_pbe"):
+        e, vr, vs = _gga_terms(OG[name], rho, sig)
+        r = torch.tensor(rho, requires_grad=True)
+        sg = torch.tensor(sig, requires_grad=True)
+        et = DG[name](r, sg)
+        gr, gs = torch.autograd.grad(et.sum(), (r, sg))
+        assert np.abs(et.detach().numpy() - e).max() < 1e-14
+        assert np.abs(gr.numpy() - vr).max() < 1e-13
+        assert np.abs((gs.numpy() - vs) * sig).max() < 1e-13   # V_sigma enters multiplied by grad rho
+    # sigma = 0 limits: LDA exchange exactly, PW92 ("mod" parameters) correlation
+    from oracle.terms import _lda_x
+    e0, v0, _ = _gga_terms(OG["gga_x_pbe"], rho, np.zeros_like(rho))
+    el, vl = _lda_x(rho)
+    assert np.abs(e0 - el).max() < 1e-15 and np.abs(v0 - vl).max() < 1e-14

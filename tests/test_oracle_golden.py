@@ -231,3 +231,42 @@ def test_silicon_lda_scf_large():
     dE = 4.46e-6 Ha, max eigenvalue deviation 6.1e-7 Ha (tests/golden/oracle_silicon_lda_large.txt)."""
     dE, dev = _run_silicon_lda(25, 33, 1e-7)
     assert abs(dE) < 1e-5 and dev < 1e-5
+
+
+REF_PBE = [   # test/silicon_pbe.jl:10-24 (ABINIT, same k-points, Ecut 25)
+    [-0.181210259413818, 0.258840553222639, 0.258840553225549, 0.258840553228459, 0.351692348652324,
+     0.351692348656259, 0.351692348660193, 0.380606400669216, 0.540705881744348, 0.540705883460555],
+    [-0.130553299114991, 0.062256443775155, 0.221871391287580, 0.221871391290802, 0.322398722411882,
+     0.386194327436667, 0.386194327439986, 0.546859898649217, 0.550571701390781, 0.550571701394327],
+    [-0.111170738096744, 0.074494899973125, 0.169461730083372, 0.169461730088140, 0.284305392082236,
+     0.330468937070505, 0.524509288492752, 0.524509288496625, 0.616964090764029, 0.619623658242765],
+    [-0.061054203629684, 0.009700769243041, 0.095769985640881, 0.180784778430457, 0.315000287382235,
+     0.471042322838057, 0.495281775946584, 0.517469860611792, 0.530124341745161, 0.539044739392045],
+]
+REF_ETOT_PBE = -7.854477356672080
+
+
+def _run_silicon_pbe(Ecut, n, tol):
+    """As _run_silicon_lda, with PBE() = gga_x_pbe + gga_c_pbe and the PBE GTH pseudopotential."""
+    model = model_DFT(LATTICE, si_atoms("pbe"), POSITIONS, functionals=("gga_x_pbe", "gga_c_pbe"))
+    basis = PlaneWaveBasis(model, Ecut, MonkhorstPack((3, 3, 3)), fft_size=(n, n, n))
+    res = self_consistent_field(basis, tol=tol, nbandsalg=AdaptiveBands(model, n_bands_converge=10))
+    devs = []
+    for kc, r in zip(KGRID.kcoords, REF_PBE):
+        ik = [i for i, k in enumerate(basis.kcoords) if np.allclose(k, kc)][0]
+        devs.append(np.abs(res["eigenvalues"][ik][:10] - np.array(r)).max())
+    return res["energies"].total - REF_ETOT_PBE, max(devs)
+
+
+def test_silicon_pbe_scf_small():
+    """test/silicon_pbe.jl (small): Ecut 7, 17^3, test_tol 0.03."""
+    dE, dev = _run_silicon_pbe(7, 17, 1e-5)
+    assert abs(dE) < 0.03 and dev < 0.03
+
+
+@pytest.mark.skipif(os.environ.get("ORACLE_SLOW") != "1", reason="~5 min; set ORACLE_SLOW=1")
+def test_silicon_pbe_scf_large():
+    """test/silicon_pbe.jl (large): Ecut 25, 33^3, test_tol 1e-5; last run recorded in
+    tests/golden/oracle_silicon_pbe_large.txt."""
+    dE, dev = _run_silicon_pbe(25, 33, 1e-7)
+    assert abs(dE) < 1e-5 and dev < 1e-5

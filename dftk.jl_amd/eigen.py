@@ -63,12 +63,38 @@ def lobpcg_hyper(A: DftHamiltonianBlock, X0: torch.Tensor, maxiter: int = 100, p
     return EigResult(lam, X, res, n_iter.value, bool(conv.value), int(nmv.value))
 
 
+def _splitmix64(x: torch.Tensor) -> torch.Tensor:
+    """splitmix64 finaliser on int64 tensors (wrapping arithmetic; logical shifts emulated with masks)."""
+    def lsr(v, k):
+        return (v >> k) & ((1 << (64 - k)) - 1)
+    x = x + (-7046029254386353131)                      # 0x9E3779B97F4A7C15 as a signed 64-bit integer
+    x = (x ^ lsr(x, 30)) * (-4658895280553007687)       # 0xBF58476D1CE4E5B9
+    x = (x ^ lsr(x, 27)) * (-7723592293110705685)       # 0x94D049BB133111EB
+    return x ^ lsr(x, 31)
+
+
+def _counter_normal(n: int, seed: int, device) -> torch.Tensor:
+    """n standard normal numbers that depend only on (seed, index): Box-Muller on two splitmix64 streams.
+    torch.randn on the GPU assigns Philox subsequences per launched thread, so its output depends on the
+    number of CUs of the device; this does not (same start vectors on every box)."""
+    idx = torch.arange(n, dtype=torch.int64, device=device)
+    base = _splitmix64(torch.tensor([seed & (2 ** 63 - 1)], dtype=torch.int64, device=device))
+    a = _splitmix64(idx * 2 + base)
+    b = _splitmix64(idx * 2 + 1 + base)
+    u1 = (((a >> 11) & ((1 << 53) - 1)).to(torch.float64) + 1.0) * 2.0 ** -53        # (0, 1]
+    u2 = ((b >> 11) & ((1 << 53) - 1)).to(torch.float64) * 2.0 ** -53                # [0, 1)
+    return torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(2.0 * np.pi * u2)
+
+
 def random_orbitals(basis, kpt, howmany: int, generator: torch.Generator | None = None) -> torch.Tensor:
     """orbitals.jl:82-86: complex normal entries; orthonormalisation is left to LOBPCG's first
     Cholesky-QR (``X = ortho!(copy(X))``, lobpcg_hyper_impl.jl:370), which spans the same space."""
-    re = torch.randn((howmany, kpt.n_G), dtype=torch.float64, device=basis.device, generator=generator)
-    im = torch.randn((howmany, kpt.n_G), dtype=torch.float64, device=basis.device, generator=generator)
-    return torch.complex(re, im) / np.sqrt(2 * kpt.n_G)
+    if generator is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    else:   # one draw advances the generator; a single-element draw does not depend on the launch geometry
+        seed = int(torch.randint(0, 2 ** 62, (1,), device=generator.device, generator=generator).item())
+    z = _counter_normal(2 * howmany * kpt.n_G, seed, basis.device).reshape(2, howmany, kpt.n_G)
+    return torch.complex(z[0], z[1]) / np.sqrt(2 * kpt.n_G)
 
 
 def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None, prec_type=PreconditionerTPA,

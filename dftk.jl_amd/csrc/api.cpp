@@ -123,8 +123,16 @@ int plan_radices(int n, int* nrad, int* rad) {
             }
         }
     const int rem2 = a2 - 3 * best8 - best6;
-    const int counts[6][2] = {{8, best8}, {6, best6}, {5, a5}, {4, rem2 / 2}, {3, a3 - best6}, {2, rem2 % 2}};
+    int counts[6][2] = {{8, best8}, {6, best6}, {5, a5}, {4, rem2 / 2}, {3, a3 - best6}, {2, rem2 % 2}};
     int k = 0;
+    // an ODD radix first when there is one: with the unpadded 8-line tiles of the y/z kernels the first
+    // stage (stride R between neighbouring butterflies) is LDS-bank-conflict-free only for odd R
+    for (int oi : {2, 4})
+        if (counts[oi][1] > 0) {
+            rad[k++] = counts[oi][0];
+            counts[oi][1] -= 1;
+            break;
+        }
     for (auto& c : counts)
         for (int i = 0; i < c[1]; ++i) {
             if (k >= DFTK_MAX_RADICES) return -1;

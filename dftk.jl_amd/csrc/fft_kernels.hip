@@ -19,7 +19,18 @@
 #include "common.h"
 
 #define FFT_L 8
-#define FFT_LS 9
+#ifndef ZPASS_MIN_BLOCKS
+#define ZPASS_MIN_BLOCKS 6   // workgroups per CU the z pass is compiled for (80 VGPRs; 5 -> 6 resident workgroups: -9 %)
+#endif
+#ifndef DENS_MIN_BLOCKS
+#define DENS_MIN_BLOCKS 1   // (6 spills: slower)
+#endif
+#ifndef YFWD_MIN_BLOCKS
+#define YFWD_MIN_BLOCKS 1   // (7 spills: slower)
+#endif
+#define FFT_LS_X 9     // x kernels: odd pitch keeps the transposed tile I/O (lanes along x) conflict-free
+#define FFT_LS_YZ 8    // y/z kernels: no padding; with an odd first radix the butterfly accesses of a
+                       // ds_read_b128 lane group (4 quads of lines x 4 consecutive butterflies) hit 16 distinct slots
 #define FFT_THREADS 256
 #define FFT_TPL (FFT_THREADS / FFT_L)
 #define DENS_MAXACC 12   // supports nz <= 12*32 = 384
@@ -124,7 +135,7 @@ __device__ __forceinline__ void dft_small(cd (&a)[R], double sgn, const cd* __re
 // VMUL (last stage of a backward transform only): the natural-order outputs are multiplied by the real
 // potential column vcol[z * vstride] and pushed through the first butterfly of the forward transform
 // before they go back to LDS (fused V*psi: saves two LDS round trips; see fft_tile's `skip`).
-template <int R, bool DIF, bool VMUL = false>
+template <int FFT_LS, int R, bool DIF, bool VMUL = false>
 __device__ __forceinline__ void fft_stage(cd* buf, const cd* __restrict__ tw, int n, int m, double sgn,
                                           int l, int j, const double* __restrict__ vcol = nullptr,
                                           int64_t vstride = 0) {
@@ -185,7 +196,7 @@ __device__ __forceinline__ void fft_stage(cd* buf, const cd* __restrict__ tw, in
 }
 
 // Arbitrary (prime) radix up to 64: slow path used only for non 2-3-5-7-11-13 sizes.
-template <bool DIF>
+template <int FFT_LS, bool DIF>
 __device__ void fft_stage_generic(cd* buf, const cd* __restrict__ tw, int n, int m, int R, double sgn,
                                   int l, int j) {
     const int nb = n / R;
@@ -228,35 +239,36 @@ __device__ void fft_stage_generic(cd* buf, const cd* __restrict__ tw, int n, int
 // GEN = false: 2-3-5-smooth lengths only (the hot path; keeps the register footprint small).
 // GEN = true : additionally radix 7 and the generic (scratch-backed) prime radix.
 // last backward stage with the fused potential multiply (2-3-5 radices only; see k_zpass)
+template <int FFT_LS>
 __device__ __forceinline__ bool fft_stage_vmul(int R, cd* buf, const cd* tw, int n, int m, double sgn, int l, int j,
                                                const double* vcol, int64_t vstride) {
     switch (R) {
-        case 2: fft_stage<2, false, true>(buf, tw, n, m, sgn, l, j, vcol, vstride); return true;
-        case 3: fft_stage<3, false, true>(buf, tw, n, m, sgn, l, j, vcol, vstride); return true;
-        case 4: fft_stage<4, false, true>(buf, tw, n, m, sgn, l, j, vcol, vstride); return true;
-        case 5: fft_stage<5, false, true>(buf, tw, n, m, sgn, l, j, vcol, vstride); return true;
-        case 6: fft_stage<6, false, true>(buf, tw, n, m, sgn, l, j, vcol, vstride); return true;
-        case 8: fft_stage<8, false, true>(buf, tw, n, m, sgn, l, j, vcol, vstride); return true;
+        case 2: fft_stage<FFT_LS, 2, false, true>(buf, tw, n, m, sgn, l, j, vcol, vstride); return true;
+        case 3: fft_stage<FFT_LS, 3, false, true>(buf, tw, n, m, sgn, l, j, vcol, vstride); return true;
+        case 4: fft_stage<FFT_LS, 4, false, true>(buf, tw, n, m, sgn, l, j, vcol, vstride); return true;
+        case 5: fft_stage<FFT_LS, 5, false, true>(buf, tw, n, m, sgn, l, j, vcol, vstride); return true;
+        case 6: fft_stage<FFT_LS, 6, false, true>(buf, tw, n, m, sgn, l, j, vcol, vstride); return true;
+        case 8: fft_stage<FFT_LS, 8, false, true>(buf, tw, n, m, sgn, l, j, vcol, vstride); return true;
         default: return false;
     }
 }
 
-template <bool DIF, bool GEN>
+template <int FFT_LS, bool DIF, bool GEN>
 __device__ __forceinline__ void fft_stage_dispatch(int R, cd* buf, const cd* tw, int n, int m, double sgn,
                                                    int l, int j) {
     switch (R) {
-        case 2: fft_stage<2, DIF>(buf, tw, n, m, sgn, l, j); break;
-        case 3: fft_stage<3, DIF>(buf, tw, n, m, sgn, l, j); break;
-        case 4: fft_stage<4, DIF>(buf, tw, n, m, sgn, l, j); break;
-        case 5: fft_stage<5, DIF>(buf, tw, n, m, sgn, l, j); break;
-        case 6: fft_stage<6, DIF>(buf, tw, n, m, sgn, l, j); break;
-        case 8: fft_stage<8, DIF>(buf, tw, n, m, sgn, l, j); break;
+        case 2: fft_stage<FFT_LS, 2, DIF>(buf, tw, n, m, sgn, l, j); break;
+        case 3: fft_stage<FFT_LS, 3, DIF>(buf, tw, n, m, sgn, l, j); break;
+        case 4: fft_stage<FFT_LS, 4, DIF>(buf, tw, n, m, sgn, l, j); break;
+        case 5: fft_stage<FFT_LS, 5, DIF>(buf, tw, n, m, sgn, l, j); break;
+        case 6: fft_stage<FFT_LS, 6, DIF>(buf, tw, n, m, sgn, l, j); break;
+        case 8: fft_stage<FFT_LS, 8, DIF>(buf, tw, n, m, sgn, l, j); break;
         default:
             if constexpr (GEN) {
                 if (R == 7)
-                    fft_stage<7, DIF>(buf, tw, n, m, sgn, l, j);
+                    fft_stage<FFT_LS, 7, DIF>(buf, tw, n, m, sgn, l, j);
                 else
-                    fft_stage_generic<DIF>(buf, tw, n, m, R, sgn, l, j);
+                    fft_stage_generic<FFT_LS, DIF>(buf, tw, n, m, R, sgn, l, j);
             }
             break;
     }
@@ -267,7 +279,7 @@ __device__ __forceinline__ void fft_stage_dispatch(int R, cd* buf, const cd* tw,
 // vcol != nullptr (DIT only): the last stage also multiplies by vcol[z * vstride] and runs the first
 // forward butterfly (the following forward fft_tile must then be called with skip_first); returns false if
 // that stage's radix has no fused variant (the caller then multiplies in a separate pass).
-template <bool DIF, bool GEN>
+template <int FFT_LS, bool DIF, bool GEN>
 __device__ __forceinline__ bool fft_tile(cd* buf, const cd* tw, const FftAxis& ax, double sgn, int l, int j,
                                          const double* vcol = nullptr, int64_t vstride = 0,
                                          bool skip_first = false) {
@@ -278,8 +290,8 @@ __device__ __forceinline__ bool fft_tile(cd* buf, const cd* tw, const FftAxis& a
         for (int s = 0; s < ax.nrad; ++s) {
             const int R = ax.rad[s];
             if (vcol != nullptr && s == ax.nrad - 1)
-                fused = fft_stage_vmul(R, buf, tw, n, m, sgn, l, j, vcol, vstride);
-            if (!fused) fft_stage_dispatch<false, GEN>(R, buf, tw, n, m, sgn, l, j);
+                fused = fft_stage_vmul<FFT_LS>(R, buf, tw, n, m, sgn, l, j, vcol, vstride);
+            if (!fused) fft_stage_dispatch<FFT_LS, false, GEN>(R, buf, tw, n, m, sgn, l, j);
             __syncthreads();
             m *= R;
         }
@@ -289,13 +301,14 @@ __device__ __forceinline__ bool fft_tile(cd* buf, const cd* tw, const FftAxis& a
             const int R = ax.rad[s];
             m /= R;
             if (skip_first && s == ax.nrad - 1) continue;   // already done by the fused middle pass
-            fft_stage_dispatch<true, GEN>(R, buf, tw, n, m, sgn, l, j);
+            fft_stage_dispatch<FFT_LS, true, GEN>(R, buf, tw, n, m, sgn, l, j);
             __syncthreads();
         }
     }
     return fused;
 }
 
+template <int FFT_LS>
 __device__ __forceinline__ void tile_prologue(cd* buf, cd* tw, const FftAxis& ax, bool zero) {
     const int n = ax.n;
     for (int t = threadIdx.x; t < n; t += FFT_THREADS) tw[t] = ax.tw[t];
@@ -314,12 +327,13 @@ __global__ __launch_bounds__(FFT_THREADS) void k_xbwd_scatter(FftAxis ax, int nx
                                                               const int* __restrict__ cpos,
                                                               const cd* __restrict__ psi, int64_t ldpsi,
                                                               cd* __restrict__ T1, int64_t T1_stride) {
+    constexpr int FFT_LS = FFT_LS_X;
     cd* buf = reinterpret_cast<cd*>(dftk_smem);
     cd* tw = buf + ax.n * FFT_LS;
     const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
     const int band = blockIdx.y;
     const int l0 = blockIdx.x * FFT_L;
-    tile_prologue(buf, tw, ax, true);
+    tile_prologue<FFT_LS>(buf, tw, ax, true);
     __syncthreads();
     const int line = l0 + l;
     if (line < n_lines) {
@@ -328,7 +342,7 @@ __global__ __launch_bounds__(FFT_THREADS) void k_xbwd_scatter(FftAxis ax, int nx
         for (int c = c0 + j; c < c1; c += FFT_TPL) buf[cpos[c] * FFT_LS + l] = p[c];
     }
     __syncthreads();
-    fft_tile<false, GEN>(buf, tw, ax, +1.0, l, j);
+    fft_tile<FFT_LS, false, GEN>(buf, tw, ax, +1.0, l, j);
     cd* out = T1 + (int64_t)band * T1_stride + (int64_t)l0 * nxp;
     const int nlv = min(FFT_L, n_lines - l0);
     const int n = ax.n;
@@ -346,19 +360,20 @@ __global__ __launch_bounds__(FFT_THREADS) void k_ybwd(FftAxis ay, int nxp, int n
                                                       const int* __restrict__ line_ypos,
                                                       const cd* __restrict__ T1, int64_t T1_stride,
                                                       cd* __restrict__ T2, int64_t T2_stride) {
+    constexpr int FFT_LS = FFT_LS_YZ;
     cd* buf = reinterpret_cast<cd*>(dftk_smem);
     cd* tw = buf + ay.n * FFT_LS;
     const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
     const int x = blockIdx.x * FFT_L + l;
     const int zi = blockIdx.y, band = blockIdx.z;
-    tile_prologue(buf, tw, ay, true);
+    tile_prologue<FFT_LS>(buf, tw, ay, true);
     __syncthreads();
     const cd* t1 = T1 + (int64_t)band * T1_stride;
     const int ln1 = zls[zi + 1];
     for (int ln = zls[zi] + j; ln < ln1; ln += FFT_TPL)
         buf[line_ypos[ln] * FFT_LS + l] = t1[(int64_t)ln * nxp + x];
     __syncthreads();
-    fft_tile<false, GEN>(buf, tw, ay, +1.0, l, j);
+    fft_tile<FFT_LS, false, GEN>(buf, tw, ay, +1.0, l, j);
     cd* t2 = T2 + (int64_t)band * T2_stride + (int64_t)zi * ny * nxp + x;
     for (int y = j; y < ny; y += FFT_TPL) t2[(int64_t)y * nxp] = buf[y * FFT_LS + l];
 }
@@ -368,11 +383,12 @@ __global__ __launch_bounds__(FFT_THREADS) void k_ybwd(FftAxis ay, int nxp, int n
 // MODE 1: backward z only, natural-order output to an (nx,ny,nz) cube
 // MODE 2: forward z only from an (nx,ny,nz) cube, sphere planes -> T2
 template <int MODE, bool GEN>
-__global__ __launch_bounds__(FFT_THREADS) void k_zpass(FftAxis az, int nx, int nxp, int ny, int nzx,
+__global__ __launch_bounds__(FFT_THREADS, ZPASS_MIN_BLOCKS) void k_zpass(FftAxis az, int nx, int nxp, int ny, int nzx,
                                                        const int* __restrict__ zpos,
                                                        const double* __restrict__ Vs,
                                                        cd* __restrict__ T2, int64_t T2_stride,
                                                        cd* __restrict__ cube) {
+    constexpr int FFT_LS = FFT_LS_YZ;
     cd* buf = reinterpret_cast<cd*>(dftk_smem);
     cd* tw = buf + az.n * FFT_LS;
     const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
@@ -384,13 +400,13 @@ __global__ __launch_bounds__(FFT_THREADS) void k_zpass(FftAxis az, int nx, int n
     const int nz = az.n;
     const int64_t plane = (int64_t)ny * nxp;
     cd* t2 = T2 + (int64_t)band * T2_stride + (int64_t)y * nxp + x;
-    tile_prologue(buf, tw, az, MODE != 2);
+    tile_prologue<FFT_LS>(buf, tw, az, MODE != 2);
     __syncthreads();
     bool fused_v = false;
     if (MODE != 2) {
         for (int zi = j; zi < nzx; zi += FFT_TPL) buf[zpos[zi] * FFT_LS + l] = t2[(int64_t)zi * plane];
         __syncthreads();
-        fused_v = fft_tile<false, GEN>(buf, tw, az, +1.0, l, j,
+        fused_v = fft_tile<FFT_LS, false, GEN>(buf, tw, az, +1.0, l, j,
                                        (MODE == 0 && !GEN) ? Vs + (int64_t)y * nxp + x : nullptr, plane);
     }
     if (MODE == 0 && !fused_v) {
@@ -414,27 +430,28 @@ __global__ __launch_bounds__(FFT_THREADS) void k_zpass(FftAxis az, int nx, int n
             buf[z * FFT_LS + l] = (x < nx) ? cube[((int64_t)z * ny + y) * nx + x] : make_double2(0.0, 0.0);
         __syncthreads();
     }
-    fft_tile<true, GEN>(buf, tw, az, -1.0, l, j, nullptr, 0, MODE == 0 && fused_v);
+    fft_tile<FFT_LS, true, GEN>(buf, tw, az, -1.0, l, j, nullptr, 0, MODE == 0 && fused_v);
     for (int zi = j; zi < nzx; zi += FFT_TPL) t2[(int64_t)zi * plane] = buf[zpos[zi] * FFT_LS + l];
 }
 
 // ---------------------------------------------------------------------------------------- stage D
 template <bool GEN>
-__global__ __launch_bounds__(FFT_THREADS) void k_yfwd(FftAxis ay, int nxp, int ny,
+__global__ __launch_bounds__(FFT_THREADS, YFWD_MIN_BLOCKS) void k_yfwd(FftAxis ay, int nxp, int ny,
                                                       const int* __restrict__ zls,
                                                       const int* __restrict__ line_ypos,
                                                       const cd* __restrict__ T2, int64_t T2_stride,
                                                       cd* __restrict__ T1, int64_t T1_stride) {
+    constexpr int FFT_LS = FFT_LS_YZ;
     cd* buf = reinterpret_cast<cd*>(dftk_smem);
     cd* tw = buf + ay.n * FFT_LS;
     const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
     const int x = blockIdx.x * FFT_L + l;
     const int zi = blockIdx.y, band = blockIdx.z;
-    tile_prologue(buf, tw, ay, false);
+    tile_prologue<FFT_LS>(buf, tw, ay, false);
     const cd* t2 = T2 + (int64_t)band * T2_stride + (int64_t)zi * ny * nxp + x;
     for (int y = j; y < ny; y += FFT_TPL) buf[y * FFT_LS + l] = t2[(int64_t)y * nxp];
     __syncthreads();
-    fft_tile<true, GEN>(buf, tw, ay, -1.0, l, j);
+    fft_tile<FFT_LS, true, GEN>(buf, tw, ay, -1.0, l, j);
     cd* t1 = T1 + (int64_t)band * T1_stride;
     const int ln1 = zls[zi + 1];
     for (int ln = zls[zi] + j; ln < ln1; ln += FFT_TPL)
@@ -444,20 +461,21 @@ __global__ __launch_bounds__(FFT_THREADS) void k_yfwd(FftAxis ay, int nxp, int n
 // ---------------------------------------------------------------------------------------- stage E
 // out[c] = FFT_x(line)[ix_c] (+ kin[c] * psi[c]) (+ out[c] if accumulate)
 template <bool GEN>
-__global__ __launch_bounds__(FFT_THREADS) void k_xfwd_gather(FftAxis ax, int nxp, int n_lines,
+__global__ __launch_bounds__(FFT_THREADS, YFWD_MIN_BLOCKS) void k_xfwd_gather(FftAxis ax, int nxp, int n_lines,
                                                              const int* __restrict__ line_start,
                                                              const int* __restrict__ cpos,
                                                              const cd* __restrict__ T1, int64_t T1_stride,
                                                              const double* __restrict__ kin,
                                                              const cd* __restrict__ psi, int64_t ldpsi,
                                                              cd* __restrict__ out, int64_t ldout) {
+    constexpr int FFT_LS = FFT_LS_X;
     cd* buf = reinterpret_cast<cd*>(dftk_smem);
     cd* tw = buf + ax.n * FFT_LS;
     const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
     const int band = blockIdx.y;
     const int l0 = blockIdx.x * FFT_L;
     const int n = ax.n;
-    tile_prologue(buf, tw, ax, false);
+    tile_prologue<FFT_LS>(buf, tw, ax, false);
     const cd* in = T1 + (int64_t)band * T1_stride + (int64_t)l0 * nxp;
     const int nlv = min(FFT_L, n_lines - l0);
     for (int idx = tid; idx < FFT_L * nxp; idx += FFT_THREADS) {
@@ -466,7 +484,7 @@ __global__ __launch_bounds__(FFT_THREADS) void k_xfwd_gather(FftAxis ax, int nxp
         if (x < n) buf[x * FFT_LS + ll] = (ll < nlv) ? in[idx] : make_double2(0.0, 0.0);
     }
     __syncthreads();
-    fft_tile<true, GEN>(buf, tw, ax, -1.0, l, j);
+    fft_tile<FFT_LS, true, GEN>(buf, tw, ax, -1.0, l, j);
     const int line = l0 + l;
     if (line < n_lines) {
         const int c0 = line_start[line], c1 = line_start[line + 1];
@@ -488,11 +506,12 @@ __global__ __launch_bounds__(FFT_THREADS) void k_xfwd_gather(FftAxis ax, int nxp
 // ---------------------------------------------------------------------------------------- density
 // rho[z,y,x] += sum_band w[band] |BFFT_z(T2[band])|^2 ; one workgroup owns an (x-tile, y) column set.
 template <bool GEN>
-__global__ __launch_bounds__(FFT_THREADS) void k_zdensity(FftAxis az, int nx, int nxp, int ny, int nzx,
+__global__ __launch_bounds__(FFT_THREADS, DENS_MIN_BLOCKS) void k_zdensity(FftAxis az, int nx, int nxp, int ny, int nzx,
                                                           const int* __restrict__ zpos, int nb,
                                                           const double* __restrict__ w,
                                                           const cd* __restrict__ T2, int64_t T2_stride,
                                                           double* __restrict__ rho) {
+    constexpr int FFT_LS = FFT_LS_YZ;
     cd* buf = reinterpret_cast<cd*>(dftk_smem);
     cd* tw = buf + az.n * FFT_LS;
     const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
@@ -513,7 +532,7 @@ __global__ __launch_bounds__(FFT_THREADS) void k_zdensity(FftAxis az, int nx, in
         const cd* t2 = T2 + (int64_t)ib * T2_stride + (int64_t)y * nxp + x;
         for (int zi = j; zi < nzx; zi += FFT_TPL) buf[zpos[zi] * FFT_LS + l] = t2[(int64_t)zi * plane];
         __syncthreads();
-        fft_tile<false, GEN>(buf, tw, az, +1.0, l, j);
+        fft_tile<FFT_LS, false, GEN>(buf, tw, az, +1.0, l, j);
 #pragma unroll
         for (int k = 0; k < DENS_MAXACC; ++k) {
             const int z = j + k * FFT_TPL;
@@ -560,7 +579,7 @@ __global__ void k_kinetic(int64_t n, int nb, const double* __restrict__ kin, con
 }
 
 // ======================================================================================== host side
-static size_t lds_bytes(int n) { return (size_t)n * (FFT_LS + 1) * sizeof(cd); }
+static size_t lds_bytes(int n, int ls = FFT_LS_YZ) { return (size_t)n * (ls + 1) * sizeof(cd); }
 
 int fft_ensure_scratch(dftk_mi_basis* b, dftk_mi_kblock* kb, int nb) {
     const size_t t1 = (size_t)nb * kb->n_lines * b->nxp * sizeof(cd);
@@ -582,8 +601,8 @@ int fft_ensure_scratch(dftk_mi_basis* b, dftk_mi_kblock* kb, int nb) {
 
 static int check_lds(dftk_mi_basis* b) {
     const int nmax = b->nx > b->ny ? (b->nx > b->nz ? b->nx : b->nz) : (b->ny > b->nz ? b->ny : b->nz);
-    if (lds_bytes(nmax) > 160 * 1024) {
-        dftk_set_error("FFT axis length %d needs %zu B of LDS (> 160 KiB)", nmax, lds_bytes(nmax));
+    if (lds_bytes(nmax, FFT_LS_X) > 160 * 1024) {
+        dftk_set_error("FFT axis length %d needs %zu B of LDS (> 160 KiB)", nmax, lds_bytes(nmax, FFT_LS_X));
         return DFTK_MI_EINVAL;
     }
     return 0;
@@ -645,7 +664,7 @@ static int run_AB(dftk_mi_kblock* kb, int nbb, const cd* psi, int64_t ldpsi) {
     const double t1b = 16.0 * (double)kb->n_lines * b->nxp, t2b = 16.0 * (double)kb->nzx * b->ny * b->nxp;
     (void)Ncube;
     int ps = prof_begin(b, PROF_FFT_A, (16.0 * kb->n_G + t1b) * nbb);
-    LAUNCH_FFT(k_xbwd_scatter, b->ax[0], dim3(gl, nbb), lds_bytes(b->nx), b->stream, b->ax[0],
+    LAUNCH_FFT(k_xbwd_scatter, b->ax[0], dim3(gl, nbb), lds_bytes(b->nx, FFT_LS_X), b->stream, b->ax[0],
                        b->nxp, (int)kb->n_lines, kb->d_line_start, kb->d_cpos, psi, ldpsi, b->T1, st.s1);
     prof_end(b, ps);
     ps = prof_begin(b, PROF_FFT_B, (t1b + t2b) * nbb);
@@ -669,7 +688,7 @@ static int run_DE(dftk_mi_kblock* kb, int nbb, const double* kin, const cd* psi,
                        b->nxp, b->ny, kb->d_zls, kb->d_line_ypos, b->T2, st.s2, b->T1, st.s1);
     prof_end(b, ps);
     ps = prof_begin(b, PROF_FFT_E, (t1b + (kin ? 40.0 : 16.0) * kb->n_G) * nbb);
-    LAUNCH_FFT(k_xfwd_gather, b->ax[0], dim3(gl, nbb), lds_bytes(b->nx), b->stream, b->ax[0],
+    LAUNCH_FFT(k_xfwd_gather, b->ax[0], dim3(gl, nbb), lds_bytes(b->nx, FFT_LS_X), b->stream, b->ax[0],
                        b->nxp, (int)kb->n_lines, kb->d_line_start, kb->d_cpos, b->T1, st.s1, kin, psi, ldpsi, out,
                        ldout);
     prof_end(b, ps);

@@ -245,7 +245,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
 
     // ---- workspace -------------------------------------------------------------------------
     const size_t blk = (size_t)N * M;                   // elements of one n_G x M block
-    const size_t nbig = 12;                             // Y(3: X R P) AY(3) newX newAX newR newP newAP tmp
+    const size_t nbig = 14;                             // 2 x Y(3: X R P), 2 x AY(3), newR, tmp
     const size_t m3 = 3 * (size_t)M;
     const size_t small_elems = m3 * m3 * 2              // G, V
                                + m3 * M * 2             // cP, tmpS
@@ -267,17 +267,20 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
         w += n;
         return r;
     };
-    // Y = [X | R | P] and AY = [AX | AR | AP] live in two n_G x 3M arrays.  X keeps columns [0, M);
+    // Y = [X | R | P] and AY = [AX | AR | AP] live in n_G x 3M arrays.  X keeps columns [0, M);
     // the ACTIVE residual block sits at columns [M, M + nact) and the active search-direction block
     // right behind it at [M + nact, M + 2 nact), so that hcat(X_active, R, P) -- columns
     // [lo, M + 2 nact) -- is one contiguous matrix: Rayleigh-Ritz is one Gram GEMM and the block
     // updates one GEMM with k = 3 nact instead of per-block products.
-    Mat Ybuf{take(3 * blk), N, N, 3 * M}, AYbuf{take(3 * blk), N, N, 3 * M};
-    Mat X = Ybuf.cols_from(0, M), AX = AYbuf.cols_from(0, M);
+    // There are TWO such pairs of arrays: an iteration reads Y/AY of the current pair and writes the new
+    // X, AX, P, AP straight into the other one (no copy-back of n_G x M blocks); locked columns are kept
+    // identical in both, then the roles swap.
+    Mat Yb[2] = {Mat{take(3 * blk), N, N, 3 * M}, Mat{take(3 * blk), N, N, 3 * M}};
+    Mat AYb[2] = {Mat{take(3 * blk), N, N, 3 * M}, Mat{take(3 * blk), N, N, 3 * M}};
+    int cur = 0;
     auto Rblk = [&](const Mat& buf, int nact) { return buf.cols_from(M, nact); };
     auto Pblk = [&](const Mat& buf, int nact) { return buf.cols_from(M + nact, nact); };
-    Mat newX{take(blk), N, N, M}, newAX{take(blk), N, N, M}, newR{take(blk), N, N, M}, newP{take(blk), N, N, M},
-        newAP{take(blk), N, N, M};
+    Mat newR{take(blk), N, N, M};
     cd* tmp = take(blk);
     cd* G = take(m3 * m3);
     cd* V = take(m3 * m3);
@@ -297,6 +300,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     double* d_norms = dd + 3 * (M + 8);
     double* d_mk = dd + 4 * (M + 8);
     c.rng.seed(seed ? seed : 0x9E3779B97F4A7C15ull);
+    Mat X = Yb[0].cols_from(0, M), AX = AYb[0].cols_from(0, M);   // views of the CURRENT pair (rebound on swap)
     kb->last_AX = AX.p;
 
     Mat Xuser{Xp, ldX, N, M};
@@ -321,8 +325,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
             dftk_set_error("non-finite values in H*X");
             return DFTK_MI_NUM_NONFINITE;
         }
-    CHK(ew_fill_zero(b, Ybuf.p + blk, 2 * blk));
-    CHK(ew_fill_zero(b, AYbuf.p + blk, 2 * blk));
+    // (R is written at the end of iteration 0 and P at the end of iteration 1, before their first use)
     // lambda = Re(X'AX)/(X'X) column-wise
     CHK(ew_coldots(b, N, M, X.p, X.ld, AX.p, AX.ld, c.d_a));
     CHK(ew_coldots(b, N, M, X.p, X.ld, X.p, X.ld, c.d_b));
@@ -337,9 +340,14 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
 
     while (true) {
         const int nact = M - lo;
+        Mat &Yc = Yb[cur], &AYc = AYb[cur], &Yn = Yb[cur ^ 1], &AYn = AYb[cur ^ 1];
+        X = Yc.cols_from(0, M);
+        AX = AYc.cols_from(0, M);
         Mat Xa = X.cols_from(lo), AXa = AX.cols_from(lo);
-        Mat Ra = Rblk(Ybuf, nact), ARa = Rblk(AYbuf, nact), Pa = Pblk(Ybuf, nact), APa = Pblk(AYbuf, nact);
-        Mat nX = newX.cols_from(0, nact), nAX = newAX.cols_from(0, nact), nR = newR.cols_from(0, nact);
+        Mat Ra = Rblk(Yc, nact), ARa = Rblk(AYc, nact), Pa = Pblk(Yc, nact), APa = Pblk(AYc, nact);
+        // iteration 0 has no update: the "new" X is X itself; afterwards it is written into the other pair
+        Mat nX = niter > 0 ? Yn.cols_from(lo, nact) : Xa, nAX = niter > 0 ? AYn.cols_from(lo, nact) : AXa;
+        Mat nR = newR.cols_from(0, nact);
         std::vector<Mat> Ys, AYs;
         int nY = 0;
         cd* cX = V;
@@ -379,9 +387,6 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
             for (int i = 0; i < nact; ++i) full_lam[lo + i] = wv[i];
             CHK(hcat_mul(c, Ys, cX, nY, nact, nX));
             CHK(hcat_mul(c, AYs, cX, nY, nact, nAX));
-        } else {
-            CHK(ew_copy(b, N, nact, Xa.p, Xa.ld, nX.p, nX.ld));
-            CHK(ew_copy(b, N, nact, AXa.p, AXa.ld, nAX.p, nAX.ld));
         }
 
         // residuals
@@ -410,9 +415,9 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
                     break;
             }
         }
+        const int tgt = niter > 0 ? (cur ^ 1) : cur;   // the pair that now holds the up-to-date X, AX
         if (nlocked >= n_conv_check) {
-            CHK(ew_copy(b, N, nact, nX.p, nX.ld, Xa.p, Xa.ld));
-            CHK(ew_copy(b, N, nact, nAX.p, nAX.ld, AXa.p, AXa.ld));
+            cur = tgt;     // locked columns [0, lo) are identical in both pairs, [lo, M) were just written
             final_iter = niter;
             finished = true;
             break;
@@ -420,7 +425,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
         const int newly_locked = nlocked - prev_nlocked;
         const int lenXn = nact - newly_locked;   // == M - nlocked
 
-        Mat nP = newP.cols_from(0, lenXn), nAP = newAP.cols_from(0, lenXn);
+        Mat nP = Pblk(Yb[tgt], lenXn), nAP = Pblk(AYb[tgt], lenXn);   // next iteration's P, AP: written in place
         if (niter > 0) {
             // cP = (cX - e)[:, newly_locked:], then orthogonalise against all of cX
             Mat cPm{cP, nY, nY, lenXn};
@@ -431,11 +436,8 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
             CHK(hcat_mul(c, Ys, cP, nY, lenXn, nP));
             CHK(hcat_mul(c, AYs, cP, nY, lenXn, nAP));
         }
-        // update all X (even newly locked), AX
-        CHK(ew_copy(b, N, nact, nX.p, nX.ld, Xa.p, Xa.ld));
-        CHK(ew_copy(b, N, nact, nAX.p, nAX.ld, AXa.p, AXa.ld));
         // sanity: |<x,x> - 1| < sqrt(eps)
-        CHK(ew_coldots(b, N, nact, Xa.p, Xa.ld, Xa.p, Xa.ld, c.d_a));
+        CHK(ew_coldots(b, N, nact, nX.p, nX.ld, nX.p, nX.ld, c.d_a));
         CHK(d2h(c, c.d_a, nact));
         for (int i = 0; i < nact; ++i)
             if (!(std::fabs(c.h[i] - 1.0) < std::sqrt(EPS))) {
@@ -443,21 +445,28 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
                                c.h[i]);
                 return DFTK_MI_NUM_NORMALIZATION;
             }
+        // newly locked columns never change again: keep them identical in both pairs
+        if (newly_locked > 0) {
+            CHK(ew_copy(b, N, newly_locked, Yb[tgt].p + (int64_t)lo * N, N, Yb[tgt ^ 1].p + (int64_t)lo * N, N));
+            CHK(ew_copy(b, N, newly_locked, AYb[tgt].p + (int64_t)lo * N, N, AYb[tgt ^ 1].p + (int64_t)lo * N, N));
+        }
         // restrict to active
         lo = nlocked;
-        Mat Rn = Rblk(Ybuf, lenXn), Pn = Pblk(Ybuf, lenXn), APn = Pblk(AYbuf, lenXn);   // next iteration's blocks
+        cur = tgt;
+        X = Yb[cur].cols_from(0, M);
+        AX = AYb[cur].cols_from(0, M);
+        Mat Rn = Rblk(Yb[cur], lenXn);   // next iteration's residual block
         CHK(ew_copy(b, N, lenXn, nR.p + (int64_t)newly_locked * nR.ld, nR.ld, Rn.p, Rn.ld));
         std::vector<Mat> Zs = {X};
-        if (niter > 0) {
-            CHK(ew_copy(b, N, lenXn, nP.p, nP.ld, Pn.p, Pn.ld));
-            CHK(ew_copy(b, N, lenXn, nAP.p, nAP.ld, APn.p, APn.ld));
-            Zs.push_back(Pn);
-        }
+        if (niter > 0) Zs.push_back(nP);
         CHK(ortho_XY(c, Rn, Zs, tmp, ortho_tol));
 
         if (niter >= maxiter) break;
         niter += 1;
     }
+    X = Yb[cur].cols_from(0, M);
+    AX = AYb[cur].cols_from(0, M);
+    kb->last_AX = AX.p;
     if (!finished) final_iter = maxiter;
     (void)status_final;
 

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <numeric>
 #include <random>
+#include <utility>
 #include <vector>
 
 namespace {
@@ -93,13 +94,15 @@ int ortho_X(Ctx& c, Mat X, cd* tmp, double tol, int* nchol_total_out, double* gr
         *nchol_total_out = 0;
         return 0;
     }
+    // the passes alternate between X and tmp (X * invR cannot be formed in place); one copy at the end
+    // if the result happens to sit in tmp
+    Mat src = X, dst{tmp, X.rows, X.rows, m};
     for (int pass = 0;; ++pass) {
         if (pass >= 30) {
             dftk_set_error("ortho!(X) did not reach the orthogonality tolerance in 30 Cholesky-QR passes");
             return DFTK_MI_NUM_CHOLESKY;
         }
-        CHK(zgemm(c.b, 'C', m, m, X.rows, ONE, X.p, X.ld, X.p, X.ld, ZERO, c.O, m, /*upper=*/1));
-        CHK(ew_hermitize_upper(c.b, m, c.O, m));
+        CHK(zgemm(c.b, 'C', m, m, src.rows, ONE, src.p, src.ld, src.p, src.ld, ZERO, c.O, m, /*upper=*/1));
         CHK(ew_hermitize_upper(c.b, m, c.O, m));
         int nchol;
         double nR = 0, nI = 0;
@@ -110,13 +113,15 @@ int ortho_X(Ctx& c, Mat X, cd* tmp, double tol, int* nchol_total_out, double* gr
             return DFTK_MI_NUM_CHOLESKY;
         }
         // X <- X * invR
-        CHK(zgemm(c.b, 'N', X.rows, m, m, ONE, X.p, X.ld, c.invR, m, ZERO, tmp, X.rows, /*B upper triangular=*/2));
-        CHK(ew_copy(c.b, X.rows, m, tmp, X.rows, X.p, X.ld));
+        CHK(zgemm(c.b, 'N', src.rows, m, m, ONE, src.p, src.ld, c.invR, m, ZERO, dst.p, dst.ld,
+                  /*B upper triangular=*/2));
+        std::swap(src, dst);
         growth *= nI;
         const double condR = nR * nI;
         const double est = EPS * condR * condR;
         if (nchol == 1 && est < tol) break;
     }
+    if (src.p != X.p) CHK(ew_copy(c.b, X.rows, m, src.p, src.ld, X.p, X.ld));
     *growth_out = growth;
     *nchol_total_out = nchol_total;
     return 0;

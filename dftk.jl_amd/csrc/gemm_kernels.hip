@@ -213,6 +213,17 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_mfma(int m, int n, in
 //     transposing ds_write_b128 of 8 consecutive-k lanes also hits 8 distinct slots;
 //   * register-staged software pipeline: the global loads of tile t+1 are in flight while the 64
 //     MFMAs of tile t issue; one barrier per tile, two LDS buffers.
+// Diagnostic (DFTK_MI_GEMM_CLOCK=1 in tools/lab): shader clock actually sustained inside the LDS kernel.
+// Workgroup 0 of every launch stores its shader-cycle and 100 MHz wall-tick counts.
+__device__ long long g_gemm_clk[4];
+int zgemm_debug_clock(double* mhz, double* us) {
+    long long h[4];
+    HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gemm_clk), sizeof(h)));
+    const double ticks = (double)(h[3] - h[2]);
+    *us = ticks / 100.0;
+    *mhz = ticks > 0 ? (double)(h[1] - h[0]) / (ticks / 100.0) : 0.0;
+    return 0;
+}
 #define LT_KT 8
 // FULL: launched only over tiles that lie entirely inside C -> no per-sub-tile predicates (runtime
 // predicates become a branch per MFMA and break the MFMA issue stream).  gm x gn is the tile
@@ -250,6 +261,12 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_lds(int m, int n, int
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
+#ifdef GEMM_EXP_CLOCK
+    if (blockIdx.x == 0 && tid == 0) {
+        g_gemm_clk[0] = clock64();
+        g_gemm_clk[2] = wall_clock64();
+    }
+#endif
     // rectangle of tiles at (rt0, ct0), or (lsplit >= 0) the L-shaped ragged border as a list:
     // entries < lsplit are the right strip (tile column ct0), the rest the bottom strip (tile row rt0)
     const int tr = lsplit < 0 ? row_t + rt0 : (row_t < lsplit ? row_t : rt0);
@@ -499,6 +516,12 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_lds(int m, int n, int
     if (!active) return;
 
     // epilogue
+#ifdef GEMM_EXP_CLOCK
+    if (blockIdx.x == 0 && tid == 0) {
+        g_gemm_clk[1] = clock64();
+        g_gemm_clk[3] = wall_clock64();
+    }
+#endif
 #ifdef GEMM_EXP_NOSTORE
     if (accR[0][0][0] != 1.2345e300) return;   // timing experiment: skip the C write (8 % of a k = 256 product)
 #endif

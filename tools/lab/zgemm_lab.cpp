@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <vector>
 #include "../../include/dftk_mi355x.h"
+int zgemm_debug_clock(double* mhz, double* us);   // gemm_kernels.hip (GEMM_EXP_CLOCK builds)
 
 __global__ void k_fill(double* p, size_t n, unsigned seed) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -74,6 +75,11 @@ int main(int argc, char** argv) {
         const double fl = 8.0 * m * n * k;
         printf("%c m=%7ld n=%5ld k=%7ld: avg %8.3f ms %6.2f TF/s | best %8.3f ms %6.2f TF/s\n", tr, m, n, k,
                sum / (reps - 1), fl / (sum / (reps - 1) * 1e9), best, fl / (best * 1e9));
+        if (getenv("DFTK_MI_GEMM_CLOCK")) {
+            double mhz = 0, us = 0;
+            zgemm_debug_clock(&mhz, &us);
+            printf("    workgroup 0 of the last launch: %.1f us at %.0f MHz shader clock\n", us, mhz);
+        }
         hipFree(A);
         hipFree(B);
         hipFree(C);

@@ -166,6 +166,40 @@ def test_zgemm_upper_triangular_B(lib, m, n):
                                 Cd.data_ptr(), m, 8) < 0   # unknown flag
 
 
+def test_zgemm_random_shapes_against_torch(lib):
+    """Seeded sweep over ragged shapes (every planner branch: no split, one-round split, z-major chunk
+    placement, interior + L-shaped border, short K): the library product against torch's complex matmul."""
+    rng = np.random.default_rng(2024)
+    bs = Basis(lib, 8, 8, 8)
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    shapes = []
+    for _ in range(28):
+        trans = "C" if rng.random() < 0.6 else "N"
+        if trans == "C":
+            m, n = int(rng.integers(1, 900)), int(rng.integers(1, 700))
+            k = int(rng.choice([rng.integers(1, 130), rng.integers(130, 2100), rng.integers(2100, 60000)]))
+        else:
+            m, n, k = int(rng.integers(1, 40000)), int(rng.integers(1, 330)), int(rng.integers(1, 900))
+        shapes.append((trans, m, n, k))
+    shapes += [("C", 128, 64, 4096), ("C", 129, 65, 4097), ("N", 128, 64, 8), ("N", 257, 129, 9), ("C", 1, 1, 1)]
+    for trans, m, n, k in shapes:
+        ra, ca = (m, k) if trans == "N" else (k, m)
+        A = torch.randn((ca, ra), dtype=torch.complex128, device="cuda", generator=gen)      # column-major (ra x ca)
+        B = torch.randn((n, k), dtype=torch.complex128, device="cuda", generator=gen)        # column-major (k x n)
+        C0 = torch.randn((n, m), dtype=torch.complex128, device="cuda", generator=gen)
+        Cd = C0.clone()
+        alpha, beta = 0.3 + 0.4j, (0.0 if (m + n + k) % 3 == 0 else -0.5 + 0.25j)
+        torch.cuda.synchronize()
+        check(lib.dftk_mi_zgemm(bs.h, trans.encode(), m, n, k, cplx(alpha), A.data_ptr(), ra, B.data_ptr(), k,
+                                cplx(beta), Cd.data_ptr(), m))
+        bs.sync()
+        # A holds the column-major (ra x ca) matrix as a (ca, ra) torch tensor, i.e. A.T is the matrix itself
+        opA = A.T if trans == "N" else A.conj()          # op(A) as an (m x k) torch matrix
+        ref = alpha * (opA @ B.T) + beta * C0.T
+        err = (Cd.T - ref).abs().max().item() / max(ref.abs().max().item(), 1e-300)
+        assert err < 2e-13, (trans, m, n, k, err)
+
+
 def test_zgemm_asymmetric_layout(lib):
     """A = I with an asymmetric B catches transposed MFMA output maps."""
     bs = Basis(lib, 8, 8, 8)

@@ -309,8 +309,12 @@ def test_sphere_fft_roundtrip_and_oracle(lib, Ecut, fft_size):
         assert relerr(back.cpu().numpy() / (nx * ny * nz), c) < RTOL
 
 
+# the z sizes end their radix plans with 3, 6 (30 = 5.6), 8 (24 = 3.8), 6 (36 = 6.6), 4 (20 = 5.4), 5 (25),
+# 2 (16 = 8.2) and a generic prime (21 = 3.7): every variant of the fused middle pass of stage C and its
+# fall-back
 @pytest.mark.parametrize("Ecut,fft_size,nbands", [(10, (21, 21, 21), 5), (15, (27, 27, 27), 11), (12, (24, 25, 27), 3),
-                                                   (15, (30, 30, 30), 19)])
+                                                   (15, (30, 30, 30), 19), (8, (20, 25, 24), 9), (9, (24, 20, 36), 4),
+                                                   (7, (25, 18, 20), 2), (7, (18, 20, 25), 17), (5, (16, 15, 16), 1)])
 def test_apply_H_vs_oracle(lib, Ecut, fft_size, nbands):
     """mul!(Hpsi, H, psi) (Hamiltonian.jl:137-192): each part and the total against the oracle."""
     obasis = make_oracle_basis(Ecut, fft_size)

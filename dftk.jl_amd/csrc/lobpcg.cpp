@@ -138,6 +138,20 @@ int randomize_column(Ctx& c, Mat X, int col) {
     return 0;
 }
 
+// true when the blocks are adjacent column ranges of one array (same leading dimension)
+bool contiguous(const std::vector<Mat>& Ys) {
+    for (size_t i = 0; i + 1 < Ys.size(); ++i)
+        if (Ys[i].ld != Ys[i + 1].ld || Ys[i].rows != Ys[i + 1].rows ||
+            Ys[i].p + (int64_t)Ys[i].cols * Ys[i].ld != Ys[i + 1].p)
+            return false;
+    return !Ys.empty();
+}
+int total_cols(const std::vector<Mat>& Ys) {
+    int n = 0;
+    for (auto& Y : Ys) n += Y.cols;
+    return n;
+}
+
 // ortho!(X, Y, BY) with Y = hcat(Ys...), B = I
 int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol) {
     if (X.cols == 0) return 0;
@@ -145,17 +159,21 @@ int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol) {
     CHK(ew_scale_cols(c.b, X.rows, X.cols, X.p, X.ld, c.d_a, true));
     int ny = 0;
     for (auto& Y : Ys) ny += Y.cols;
+    // adjacent blocks (all of X followed by the new P in lobpcg_run's layout) act as ONE matrix
+    std::vector<Mat> merged;
+    if (Ys.size() > 1 && contiguous(Ys)) merged = {Mat{Ys[0].p, Ys[0].ld, Ys[0].rows, ny}};
+    const std::vector<Mat>& Yl = merged.empty() ? Ys : merged;
     int niter = 1;
     for (;;) {
         // BYX = Y' X ; X -= Y BYX
         int off = 0;
-        for (auto& Y : Ys) {
+        for (auto& Y : Yl) {
             if (Y.cols == 0) continue;
             CHK(zgemm(c.b, 'C', Y.cols, X.cols, X.rows, ONE, Y.p, Y.ld, X.p, X.ld, ZERO, c.BYX + off, ny));
             off += Y.cols;
         }
         off = 0;
-        for (auto& Y : Ys) {
+        for (auto& Y : Yl) {
             if (Y.cols == 0) continue;
             CHK(zgemm(c.b, 'N', X.rows, X.cols, Y.cols, MONE, Y.p, Y.ld, c.BYX + off, ny, ONE, X.p, X.ld));
             off += Y.cols;
@@ -174,13 +192,13 @@ int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol) {
             int o2 = 0;
             // X[:, j] -= Y (Y' X[:, j])   (uses the tail of BYX as scratch: ny x 1 beyond the block)
             cd* scr = c.BYX + (int64_t)ny * X.cols;
-            for (auto& Y : Ys) {
+            for (auto& Y : Yl) {
                 if (Y.cols == 0) continue;
                 CHK(zgemm(c.b, 'C', Y.cols, 1, X.rows, ONE, Y.p, Y.ld, xj.p, xj.ld, ZERO, scr + o2, ny));
                 o2 += Y.cols;
             }
             o2 = 0;
-            for (auto& Y : Ys) {
+            for (auto& Y : Yl) {
                 if (Y.cols == 0) continue;
                 CHK(zgemm(c.b, 'N', X.rows, 1, Y.cols, MONE, Y.p, Y.ld, scr + o2, ny, ONE, xj.p, xj.ld));
                 o2 += Y.cols;
@@ -200,20 +218,6 @@ int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol) {
         niter += 1;
     }
     return 0;
-}
-
-// true when the blocks are adjacent column ranges of one array (same leading dimension)
-bool contiguous(const std::vector<Mat>& Ys) {
-    for (size_t i = 0; i + 1 < Ys.size(); ++i)
-        if (Ys[i].ld != Ys[i + 1].ld || Ys[i].rows != Ys[i + 1].rows ||
-            Ys[i].p + (int64_t)Ys[i].cols * Ys[i].ld != Ys[i + 1].p)
-            return false;
-    return !Ys.empty();
-}
-int total_cols(const std::vector<Mat>& Ys) {
-    int n = 0;
-    for (auto& Y : Ys) n += Y.cols;
-    return n;
 }
 
 // C = sum_b Yb * coef[rows of b]   (LazyHcat * Matrix, lobpcg_hyper_impl.jl:124-132).  The active
@@ -283,8 +287,11 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     Mat Yb[2] = {Mat{take(3 * blk), N, N, 3 * M}, Mat{take(3 * blk), N, N, 3 * M}};
     Mat AYb[2] = {Mat{take(3 * blk), N, N, 3 * M}, Mat{take(3 * blk), N, N, 3 * M}};
     int cur = 0;
-    auto Rblk = [&](const Mat& buf, int nact) { return buf.cols_from(M, nact); };
-    auto Pblk = [&](const Mat& buf, int nact) { return buf.cols_from(M + nact, nact); };
+    // memory order [X | P | R]: hcat(X_active, P, R) is contiguous for the Rayleigh-Ritz products and
+    // hcat(X, P) (all of X and the new P) for ortho!(R, [X P]); the block ORDER inside the hcat only
+    // permutes the rows of the Ritz coefficient matrix.  Until P exists (iterations 0, 1) R sits right after X.
+    auto Pblk = [&](const Mat& buf, int nact) { return buf.cols_from(M, nact); };
+    auto Rblk = [&](const Mat& buf, int nact, bool has_p) { return buf.cols_from(M + (has_p ? nact : 0), nact); };
     Mat newR{take(blk), N, N, M};
     cd* tmp = take(blk);
     cd* G = take(m3 * m3);
@@ -349,7 +356,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
         X = Yc.cols_from(0, M);
         AX = AYc.cols_from(0, M);
         Mat Xa = X.cols_from(lo), AXa = AX.cols_from(lo);
-        Mat Ra = Rblk(Yc, nact), ARa = Rblk(AYc, nact), Pa = Pblk(Yc, nact), APa = Pblk(AYc, nact);
+        Mat Ra = Rblk(Yc, nact, niter > 1), ARa = Rblk(AYc, nact, niter > 1), Pa = Pblk(Yc, nact), APa = Pblk(AYc, nact);
         // iteration 0 has no update: the "new" X is X itself; afterwards it is written into the other pair
         Mat nX = niter > 0 ? Yn.cols_from(lo, nact) : Xa, nAX = niter > 0 ? AYn.cols_from(lo, nact) : AXa;
         Mat nR = newR.cols_from(0, nact);
@@ -360,11 +367,12 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
             CHK(dftk_mi_apply_H(kb, nact, reinterpret_cast<const dftk_mi_cplx*>(Ra.p), Ra.ld,
                                 reinterpret_cast<dftk_mi_cplx*>(ARa.p), ARa.ld));
             n_matvec += nact;
-            Ys = {Xa, Ra};
-            AYs = {AXa, ARa};
             if (niter > 1) {
-                Ys.push_back(Pa);
-                AYs.push_back(APa);
+                Ys = {Xa, Pa, Ra};
+                AYs = {AXa, APa, ARa};
+            } else {
+                Ys = {Xa, Ra};
+                AYs = {AXa, ARa};
             }
             nY = (int)Ys.size() * nact;
             // rayleigh_ritz: G = Y' AY (upper triangle), eigen, take the lowest nact
@@ -460,7 +468,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
         cur = tgt;
         X = Yb[cur].cols_from(0, M);
         AX = AYb[cur].cols_from(0, M);
-        Mat Rn = Rblk(Yb[cur], lenXn);   // next iteration's residual block
+        Mat Rn = Rblk(Yb[cur], lenXn, niter > 0);   // next iteration's residual block (behind P once P exists)
         CHK(ew_copy(b, N, lenXn, nR.p + (int64_t)newly_locked * nR.ld, nR.ld, Rn.p, Rn.ld));
         std::vector<Mat> Zs = {X};
         if (niter > 0) Zs.push_back(nP);

@@ -554,6 +554,328 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_lds(int m, int n, int
             }
 }
 
+// Default interior kernel: the complex product with THREE real MFMAs per tile step instead of four
+// (Karatsuba / "3M"), on 128 x 32 workgroup tiles (wave tile 32 x 32: 12 accumulator tiles = 96 VGPRs).
+// 15-23 % faster than the 4-product kernel on every LOBPCG / projector shape; the rounding error bound
+// grows by a factor ~2 in the imaginary part (still eps * sum |a||b|).  DFTK_MI_GEMM_4M=1 selects the
+// 4-product kernel (k_zgemm_lds MODE 1).
+#define M3_RN 2
+#define M3_BN (16 * M3_RN)
+template <bool CONJA>
+__global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_3m(int m, int n, int K, int kchunk, int gm, int gn,
+                                                               int rt0, int ct0, int lsplit, int upper,
+                                                               int nsplit, const cd* __restrict__ A, int64_t lda,
+                                                               const cd* __restrict__ B, int64_t ldb,
+                                                               cd* __restrict__ C, int64_t ldc, cd alpha, cd beta,
+                                                               cd* __restrict__ slab) {
+    constexpr int MODE = 1;   // interior (full) tiles only
+    __shared__ cd sA[2][LT_KT][GEMM_BM];
+    __shared__ cd sB[2][LT_KT][M3_BN];
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    int z, row_t, col_t;
+    if (upper & 4) {
+        // K-split launches: all tiles of one k-chunk on the SAME XCD, so that both the A chunk and the
+        // B chunk are fetched from HBM once and shared through that XCD's L2
+        const int per = gm * gn;
+        z = (slot / per) * 8 + xcd;
+        const int rem = slot % per;
+        row_t = rem / gn;
+        col_t = rem - row_t * gn;
+        if (z >= nsplit) return;   // whole workgroup
+    } else {
+        // column tiles of one (k-chunk, row panel) on the same XCD (shares the A panel)
+        col_t = slot % gn;
+        const int R = (slot / gn) * 8 + xcd;
+        if (R >= gm * nsplit) return;   // whole workgroup
+        z = R / gm;
+        row_t = R - z * gm;
+    }
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+#ifdef GEMM_EXP_CLOCK
+    if (blockIdx.x == 0 && tid == 0) {
+        g_gemm_clk[0] = clock64();
+        g_gemm_clk[2] = wall_clock64();
+    }
+#endif
+    // rectangle of tiles at (rt0, ct0), or (lsplit >= 0) the L-shaped ragged border as a list:
+    // entries < lsplit are the right strip (tile column ct0), the rest the bottom strip (tile row rt0)
+    const int tr = lsplit < 0 ? row_t + rt0 : (row_t < lsplit ? row_t : rt0);
+    const int tcn = lsplit < 0 ? col_t + ct0 : (row_t < lsplit ? ct0 : row_t - lsplit);
+    const int I0 = tr * GEMM_BM, J0 = tcn * M3_BN;
+    if ((upper & 1) && I0 >= J0 + M3_BN) return;   // tile strictly below the diagonal (whole workgroup)
+    const int i0 = I0 + wave * (GEMM_RM * 16);
+    const int kbeg = z * kchunk;
+    // bit 1 of `upper`: B is upper triangular (B[k][j] = 0 for k > j) -> this tile column stops at k = J0 + BN
+    const int kend = min(min(K, kbeg + kchunk), (upper & 2) ? J0 + M3_BN : K);
+    // MODE 1: every tile of the launch is full (no predicates anywhere).  MODE 0: predicated only.
+    // MODE 2: one launch over ALL tiles; full workgroups take the predicate-free steady-state loop,
+    //         ragged ones the predicated loop -- the border shares its A/B panels with the interior
+    //         tiles through L2 instead of re-reading them from HBM in a second launch.
+    constexpr bool FULL = MODE == 1;
+    const int rmv = FULL ? GEMM_RM : min(GEMM_RM, max(0, (m - i0 + 15) >> 4));
+    const int rnv = FULL ? M3_RN : min(M3_RN, max(0, (n - J0 + 15) >> 4));
+    const bool active = FULL || (rmv > 0 && rnv > 0);
+    const bool block_full = FULL || (MODE == 2 && I0 + GEMM_BM <= m && J0 + M3_BN <= n);
+
+    // three real products per complex one (Karatsuba / "3M"):
+    //   P1 = sum Ar Br, P2 = sum Ai Bi, P3 = sum (Ar +/- Ai)(Br + Bi)   (- for conj(A))
+    //   A B      : Re = P1 - P2, Im = P3 - P1 - P2 ;   conj(A) B: Re = P1 + P2, Im = P3 - P1 + P2
+    v4d acc1[GEMM_RM][M3_RN], acc2[GEMM_RM][M3_RN], acc3[GEMM_RM][M3_RN];
+#pragma unroll
+    for (int a = 0; a < GEMM_RM; ++a)
+#pragma unroll
+        for (int b = 0; b < M3_RN; ++b) {
+            acc1[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+            acc2[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+            acc3[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+        }
+
+    // ---- global -> register staging assignment
+    // K-major operand tile (LT_KT x W columns): thread handles k = tid & 7, columns (tid >> 3) + 32 r
+    // M-major A tile (LT_KT x 128 rows):        thread handles row = tid & 127, k = (tid >> 7) + 2 r
+    const int tk = tid & 7, tc = tid >> 3;
+    // running per-thread source pointers (named scalars: arrays captured by lambdas end up in scratch);
+    // every load advances them by one k-tile
+    const cd *pA0, *pA1, *pA2, *pA3, *pB0;
+    {
+        auto a_ptr = [&](int r) -> const cd* {
+            if (CONJA) {
+                int c = I0 + tc + 32 * r;
+                if (c > m - 1) c = m - 1;
+                return A + (int64_t)c * lda + kbeg + tk;
+            } else {
+                int i = I0 + (tid & 127);
+                if (i > m - 1) i = m - 1;
+                return A + i + (int64_t)(kbeg + (tid >> 7) + 2 * r) * lda;
+            }
+        };
+        auto b_ptr = [&](int r) -> const cd* {
+            int c = J0 + tc + 32 * r;
+            if (c > n - 1) c = n - 1;
+            return B + (int64_t)c * ldb + kbeg + tk;
+        };
+        pA0 = a_ptr(0);
+        pA1 = a_ptr(1);
+        pA2 = a_ptr(2);
+        pA3 = a_ptr(3);
+        pB0 = b_ptr(0);
+    }
+    const int64_t stepA = CONJA ? (int64_t)LT_KT : (int64_t)LT_KT * lda;
+    struct Stage {
+        cd a0, a1, a2, a3, b0;
+    };
+    auto advance = [&]() {
+        pA0 += stepA;
+        pA1 += stepA;
+        pA2 += stepA;
+        pA3 += stepA;
+        pB0 += LT_KT;
+    };
+    // tile entirely inside [kbeg, kend): plain loads
+    auto load_fast = [&]() -> Stage {
+        Stage st;
+        st.a0 = *pA0;
+        st.a1 = *pA1;
+        st.a2 = *pA2;
+        st.a3 = *pA3;
+        st.b0 = *pB0;
+        advance();
+        return st;
+    };
+    // any tile: k indices beyond kend-1 are clamped to kend-1 (and zeroed later by mask_tile)
+    auto load_tile = [&](int k0) -> Stage {
+        Stage st;
+        const int oB = max(0, k0 + tk - (kend - 1));
+        if (CONJA) {
+            st.a0 = *(pA0 - oB);
+            st.a1 = *(pA1 - oB);
+            st.a2 = *(pA2 - oB);
+            st.a3 = *(pA3 - oB);
+        } else {
+            const int kk = k0 + (tid >> 7) - (kend - 1);
+            st.a0 = *(pA0 - (int64_t)max(0, kk) * lda);
+            st.a1 = *(pA1 - (int64_t)max(0, kk + 2) * lda);
+            st.a2 = *(pA2 - (int64_t)max(0, kk + 4) * lda);
+            st.a3 = *(pA3 - (int64_t)max(0, kk + 6) * lda);
+        }
+        st.b0 = *(pB0 - oB);
+        advance();
+        return st;
+    };
+    // zero the entries whose k lies beyond the K range (only the last tile of a chunk needs it)
+    auto mask_tile = [&](Stage st, int k0) -> Stage {
+        const cd czero = make_double2(0.0, 0.0);
+        const bool vB = (k0 + tk) < kend;
+        if (CONJA) {
+            if (!vB) st.a0 = st.a1 = st.a2 = st.a3 = czero;
+        } else {
+            const int kk = k0 + (tid >> 7);
+            if (kk >= kend) st.a0 = czero;
+            if (kk + 2 >= kend) st.a1 = czero;
+            if (kk + 4 >= kend) st.a2 = czero;
+            if (kk + 6 >= kend) st.a3 = czero;
+        }
+        if (!vB) st.b0 = czero;
+        return st;
+    };
+    auto store_tile = [&](int buf, const Stage& st) {
+        if (CONJA) {
+            sA[buf][tk][(tc) ^ tk] = st.a0;
+            sA[buf][tk][(tc + 32) ^ tk] = st.a1;
+            sA[buf][tk][(tc + 64) ^ tk] = st.a2;
+            sA[buf][tk][(tc + 96) ^ tk] = st.a3;
+        } else {
+            const int kk = tid >> 7, ii = tid & 127;
+            sA[buf][kk][ii] = st.a0;
+            sA[buf][kk + 2][ii] = st.a1;
+            sA[buf][kk + 4][ii] = st.a2;
+            sA[buf][kk + 6][ii] = st.a3;
+        }
+        sB[buf][tk][(tc) ^ tk] = st.b0;
+    };
+    // MFMA fragments of one k-half of a tile: half h holds k = 2*lk + h (lk = lane >> 4)
+    struct Frag {
+        cd a[GEMM_RM], b[M3_RN];
+    };
+    auto read_frag = [&](int buf, int h) -> Frag {
+        Frag f;
+        const int kk = 2 * lk + h;
+#pragma unroll
+        for (int a = 0; a < GEMM_RM; ++a) {
+            const int c = wave * (GEMM_RM * 16) + a * 16 + li;
+            f.a[a] = sA[buf][kk][CONJA ? (c ^ kk) : c];
+        }
+#pragma unroll
+        for (int b = 0; b < M3_RN; ++b) {
+            const int c = b * 16 + li;
+            f.b[b] = sB[buf][kk][c ^ kk];
+        }
+        return f;
+    };
+    auto mfma_half = [&](const Frag& f, auto) {
+        double bs[M3_RN];
+#pragma unroll
+        for (int b = 0; b < M3_RN; ++b) bs[b] = f.b[b].x + f.b[b].y;
+#pragma unroll
+        for (int a = 0; a < GEMM_RM; ++a) {
+            const double ar = f.a[a].x, ai = f.a[a].y;
+            const double as = CONJA ? ar - ai : ar + ai;
+#pragma unroll
+            for (int b = 0; b < M3_RN; ++b) acc1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, f.b[b].x, acc1[a][b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < M3_RN; ++b) acc2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, f.b[b].y, acc2[a][b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < M3_RN; ++b) acc3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, bs[b], acc3[a][b], 0, 0, 0);
+        }
+    };
+
+    // Software pipeline (two LDS buffers, ONE barrier per tile, placed in the middle of the tile's
+    // MFMA stream so that nothing waits on a fresh LDS/global access):
+    //   iteration t:  read half-1 fragments of tile t | write tile t+1 (registers) to the other buffer,
+    //                 issue the global loads of tile t+2 | 32 MFMAs on half 0 | barrier |
+    //                 read half-0 fragments of tile t+1 | 32 MFMAs on half 1
+    const int nt = (kend - kbeg + LT_KT - 1) / LT_KT;
+    if (nt > 0) {
+        Stage st = load_tile(kbeg);
+        if (nt == 1) st = mask_tile(st, kbeg);
+        store_tile(0, st);
+        if (nt > 1) st = load_tile(kbeg + LT_KT);
+        __syncthreads();
+        Frag f0 = read_frag(0, 0);
+        int t = 0;
+        if (MODE != 0 && block_full) {
+            // steady state (tiles t+1, t+2, t+3 exist): one branch-free block, and the
+            // scheduler is told to drop one memory instruction into the shadow of each MFMA so that this
+            // wave alone keeps the matrix pipe fed (the two workgroups of a CU run in lockstep, so
+            // "the other wave covers my memory phase" does not happen by itself).
+            for (; t + 3 < nt; ++t) {   // tile t+2 is not the last one: it lies entirely inside the chunk
+                Frag f1 = read_frag(t & 1, 1);
+                store_tile((t + 1) & 1, st);
+                st = load_fast();
+                mfma_half(f0, std::true_type{});
+#pragma unroll
+                for (int i = 0; i < GEMM_RM + M3_RN; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                }
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // pointer advance
+                }
+                __syncthreads();
+                f0 = read_frag((t + 1) & 1, 0);
+                mfma_half(f1, std::true_type{});
+#pragma unroll
+                for (int i = 0; i < GEMM_RM + M3_RN; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+                }
+            }
+        }
+        for (; t < nt; ++t) {
+            const bool more = (t + 1) < nt;
+            Frag f1 = read_frag(t & 1, 1);
+            if (more) {
+                if (t + 2 == nt) st = mask_tile(st, kbeg + (t + 1) * LT_KT);
+                store_tile((t + 1) & 1, st);
+                if (t + 2 < nt) st = load_tile(kbeg + (t + 2) * LT_KT);
+            }
+            if (active) mfma_half(f0, std::integral_constant<bool, FULL>{});
+            __syncthreads();
+            if (more) f0 = read_frag((t + 1) & 1, 0);
+            if (active) mfma_half(f1, std::integral_constant<bool, FULL>{});
+        }
+    }
+    if (!active) return;
+
+    // epilogue
+#ifdef GEMM_EXP_CLOCK
+    if (blockIdx.x == 0 && tid == 0) {
+        g_gemm_clk[1] = clock64();
+        g_gemm_clk[3] = wall_clock64();
+    }
+#endif
+#ifdef GEMM_EXP_NOSTORE
+    if (acc1[0][0][0] != 1.2345e300) return;   // timing experiment: skip the C write (8 % of a k = 256 product)
+#endif
+    const int j0 = J0;
+    const bool direct = (slab == nullptr);
+    cd* sl = direct ? nullptr : slab + (int64_t)z * m * n;
+#pragma unroll
+    for (int a = 0; a < GEMM_RM; ++a)
+#pragma unroll
+        for (int b = 0; b < M3_RN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = i0 + a * 16 + lk + 4 * r;
+                const int gj = j0 + b * 16 + li;
+                if (gi < m && gj < n) {
+                    const double p1 = acc1[a][b][r], p2 = acc2[a][b][r], p3 = acc3[a][b][r];
+                    const double vr = CONJA ? p1 + p2 : p1 - p2;
+                    const double vi = CONJA ? p3 - p1 + p2 : p3 - p1 - p2;
+                    if (direct) {
+                        cd* c = C + gi + (int64_t)gj * ldc;
+                        cd o = make_double2(alpha.x * vr - alpha.y * vi, alpha.x * vi + alpha.y * vr);
+                        if (beta.x != 0.0 || beta.y != 0.0) {
+                            const cd old = *c;
+                            o.x += beta.x * old.x - beta.y * old.y;
+                            o.y += beta.x * old.y + beta.y * old.x;
+                        }
+                        *c = o;
+                    } else {
+                        sl[gi + (int64_t)gj * m] = make_double2(vr, vi);
+                    }
+                }
+            }
+}
+
 // C = alpha * sum_z slab[z] + beta * C   (fixed summation order).  The interior (i < mi, j < nj) and
 // the ragged border have their own split counts / slabs; a count < 0 means that region was written
 // directly by the GEMM kernel and is skipped here.
@@ -842,13 +1164,15 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
         const int nbottom = (gm > gmf) ? gnf : 0;
         // live column tiles per tile row of each launch (upper: only tiles that intersect the upper triangle)
         auto live = [&](int tr, int tc) { return !(upper & 1) || tr * GEMM_BM < tc * GEMM_BN + GEMM_BN; };
+        static const bool use3m = getenv("DFTK_MI_GEMM_4M") == nullptr;   // DFTK_MI_GEMM_4M=1: classic 4-product interior kernel
+        const int isub = use3m ? GEMM_BN / M3_BN : 1;   // interior column tiles per 64-wide tile
         std::vector<int> rowsI(gmf, 0), rowsB(nright + nbottom, 0);
         for (int tr = 0; tr < gmf; ++tr)
-            for (int tc = 0; tc < gnf; ++tc) rowsI[tr] += live(tr, tc) ? 1 : 0;
+            for (int tc = 0; tc < gnf; ++tc) rowsI[tr] += live(tr, tc) ? isub : 0;
         for (int e = 0; e < nright; ++e) rowsB[e] = live(e, gnf) ? 1 : 0;
         for (int e = 0; e < nbottom; ++e) rowsB[nright + e] = live(gmf, e) ? 1 : 0;
         const int64_t tilesI_total = (int64_t)gmf * gnf;
-        Split spI = plan_split(rowsI, 1);
+        Split spI = plan_split(rowsI, use3m ? 3 : 1);
         Split spB = plan_split(rowsB, 2);
         const size_t bytesI = spI.nsplit > 1 ? (size_t)spI.nsplit * plane : 0;
         const size_t bytesB = spB.nsplit > 1 ? (size_t)spB.nsplit * plane : 0;
@@ -866,7 +1190,16 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
 #define DFTK_LAUNCH_LDS(CJ, FL)                                                                                        \
     hipLaunchKernelGGL((k_zgemm_lds<CJ, FL>), grid, dim3(GEMM_WAVES * 64), pad_lds, b->stream, (int)m, (int)n, (int)k, \
                        sp.kchunk, gm_s, gn_s, rt0, ct0, lsplit, upper, sp.nsplit, A, lda, B, ldb, C, ldc, alpha, beta, sp.slab)
-            if (conja) {
+            if (mode == 3) {   // 3M interior kernel (128 x 32 tiles)
+                if (conja)
+                    hipLaunchKernelGGL((k_zgemm_3m<true>), grid, dim3(GEMM_WAVES * 64), pad_lds, b->stream, (int)m, (int)n,
+                                       (int)k, sp.kchunk, gm_s, gn_s, rt0, ct0, lsplit, upper, sp.nsplit, A, lda, B, ldb, C,
+                                       ldc, alpha, beta, sp.slab);
+                else
+                    hipLaunchKernelGGL((k_zgemm_3m<false>), grid, dim3(GEMM_WAVES * 64), pad_lds, b->stream, (int)m, (int)n,
+                                       (int)k, sp.kchunk, gm_s, gn_s, rt0, ct0, lsplit, upper, sp.nsplit, A, lda, B, ldb, C,
+                                       ldc, alpha, beta, sp.slab);
+            } else if (conja) {
                 if (mode == 1) DFTK_LAUNCH_LDS(true, 1);
                 else if (mode == 2) DFTK_LAUNCH_LDS(true, 2);
                 else DFTK_LAUNCH_LDS(true, 0);
@@ -887,7 +1220,10 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
             Split one{1, spI.kchunk, false, nullptr};
             CHK(launch(2, gm, gn, 0, 0, -1, one));
         } else {
-            CHK(launch(1, gmf, gnf, 0, 0, -1, spI));
+            if (use3m)
+                CHK(launch(3, gmf, gnf * isub, 0, 0, -1, spI));
+            else
+                CHK(launch(1, gmf, gnf, 0, 0, -1, spI));
             CHK(launch(0, nright + nbottom, 1, gmf, gnf, nright, spB));
         }
         if (spI.slab || spB.slab)

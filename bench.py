@@ -185,6 +185,10 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": work / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
+        if dom == 0:
+            roof["note"] = ("achieved = algorithmic 8mnk flop / time; full tiles run the 3M (Karatsuba) complex product, "
+                            "i.e. 6mnk executed MFMA flop, so the executed-flop rate of those launches is 3/4 of it "
+                            "(an MFMA-saturated 3M kernel would read 104.8 TFLOP/s here); peak = dense f64 MFMA spec")
         roof["traffic"] = None
         # HBM bytes per launch of the dominant family from the committed PMC passes (rocprofv3 --pmc
         # FETCH_SIZE / WRITE_SIZE over this same command, tools/pmc_traffic_bench.sh): the counters

@@ -561,8 +561,11 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_lds(int m, int n, int
 // 4-product kernel (k_zgemm_lds MODE 1).
 #define M3_RN 2
 #define M3_BN (16 * M3_RN)
+// workgroups per CU the kernel is compiled for: 3 for the M-major A operand (168 VGPRs: +2.5 %), 2 for the
+// K-major one (its transposing staging spills at 168 registers: -12 %)
+#define M3_MIN_BLOCKS(CONJA) ((CONJA) ? 2 : 3)
 template <bool CONJA>
-__global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_3m(int m, int n, int K, int kchunk, int gm, int gn,
+__global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm_3m(int m, int n, int K, int kchunk, int gm, int gn,
                                                                int rt0, int ct0, int lsplit, int upper,
                                                                int nsplit, const cd* __restrict__ A, int64_t lda,
                                                                const cd* __restrict__ B, int64_t ldb,
@@ -1069,7 +1072,7 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
     // cost = (rounds of the fullest XCD) x (chunk length + prologue/epilogue) + slab traffic.
     // Short K is latency-bound: chunks of >= 8 tiles.  Plans are cached per shape.
     const char* senv = getenv("DFTK_MI_GEMM_BLOCKS");
-    const int64_t slots = senv ? atoll(senv) : 512;
+    const int64_t slots2 = senv ? atoll(senv) : 512;   // resident workgroups of the 2-per-CU kernels
     struct Split {
         int nsplit, kchunk;
         bool zmajor;
@@ -1078,7 +1081,7 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
     const int64_t plane = (int64_t)m * n * (int64_t)sizeof(cd);
     static const bool no_zmajor = getenv("DFTK_MI_GEMM_NO_ZMAJOR") != nullptr;
     static std::map<std::vector<int64_t>, std::pair<int, int>> plan_cache;   // key -> (nsplit, zmajor)
-    auto plan_split = [&](const std::vector<int>& live_rows, int kind) -> Split {
+    auto plan_split = [&](const std::vector<int>& live_rows, int kind, int64_t slots) -> Split {
         int64_t total = 0;
         for (int v : live_rows) total += v;
         const int gm_s = (int)live_rows.size();
@@ -1138,7 +1141,7 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
         return ((rows_total + 7) / 8) * 8 * gn_s;
     };
     if (b->use_mfma == 2) {   // direct-from-global variant (env DFTK_MI_GEMM=direct)
-        Split sp = plan_split(std::vector<int>(gm, gn), 0);
+        Split sp = plan_split(std::vector<int>(gm, gn), 0, slots2);
         sp.zmajor = false;
         if (sp.nsplit > 1) {
             CHK(ensure_ws(b, (size_t)sp.nsplit * plane));
@@ -1172,8 +1175,10 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
         for (int e = 0; e < nright; ++e) rowsB[e] = live(e, gnf) ? 1 : 0;
         for (int e = 0; e < nbottom; ++e) rowsB[nright + e] = live(gmf, e) ? 1 : 0;
         const int64_t tilesI_total = (int64_t)gmf * gnf;
-        Split spI = plan_split(rowsI, use3m ? 3 : 1);
-        Split spB = plan_split(rowsB, 2);
+        // the 3M kernel is compiled for M3_MIN_BLOCKS workgroups per CU
+        const int64_t slotsI = use3m ? (slots2 / 2) * M3_MIN_BLOCKS(conja) : slots2;
+        Split spI = plan_split(rowsI, use3m ? 3 : 1, slotsI);
+        Split spB = plan_split(rowsB, 2, slots2);
         const size_t bytesI = spI.nsplit > 1 ? (size_t)spI.nsplit * plane : 0;
         const size_t bytesB = spB.nsplit > 1 ? (size_t)spB.nsplit * plane : 0;
         if (bytesI + bytesB) CHK(ensure_ws(b, bytesI + bytesB));
@@ -1216,7 +1221,7 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
         // but the light border workgroups run ahead of their siblings through k, their A tiles are evicted
         // before the full tiles arrive and FETCH_SIZE rises from 2.3x to 3.5x the operand bytes -> off.
         static const bool mixed = getenv("DFTK_MI_GEMM_MIXED") != nullptr;
-        if (mixed && spI.nsplit == 1 && spB.nsplit == 1 && tilesI_total >= slots && !(upper & 1)) {
+        if (mixed && spI.nsplit == 1 && spB.nsplit == 1 && tilesI_total >= slots2 && !(upper & 1)) {
             Split one{1, spI.kchunk, false, nullptr};
             CHK(launch(2, gm, gn, 0, 0, -1, one));
         } else {

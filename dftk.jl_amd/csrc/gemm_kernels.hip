@@ -560,6 +560,11 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_lds(int m, int n, int
 // grows by a factor ~2 in the imaginary part (still eps * sum |a||b|).  DFTK_MI_GEMM_4M=1 selects the
 // 4-product kernel (k_zgemm_lds MODE 1).
 #define M3_RN 2
+#ifdef M3_NO_HINTS
+#define M3_HINT(a, b, c) ((void)0)
+#else
+#define M3_HINT(a, b, c) __builtin_amdgcn_sched_group_barrier(a, b, c)
+#endif
 #define M3_BN (16 * M3_RN)
 // workgroups per CU the kernel is compiled for: 3 for the M-major A operand (168 VGPRs: +2.5 %), 2 for the
 // K-major one (its transposing staging spills at 168 registers: -12 %)
@@ -802,23 +807,23 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm
                 mfma_half(f0, std::true_type{});
 #pragma unroll
                 for (int i = 0; i < GEMM_RM + M3_RN; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                    M3_HINT(0x008, 1, 0);   // 1 MFMA
+                    M3_HINT(0x100, 1, 0);   // 1 DS read
                 }
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // pointer advance
+                    M3_HINT(0x008, 1, 0);   // 1 MFMA
+                    M3_HINT(0x200, 1, 0);   // 1 DS write
+                    M3_HINT(0x020, 1, 0);   // 1 VMEM read
+                    M3_HINT(0x002, 2, 0);   // pointer advance
                 }
                 __syncthreads();
                 f0 = read_frag((t + 1) & 1, 0);
                 mfma_half(f1, std::true_type{});
 #pragma unroll
                 for (int i = 0; i < GEMM_RM + M3_RN; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+                    M3_HINT(0x008, 2, 1);
+                    M3_HINT(0x100, 1, 1);
                 }
             }
         }

@@ -569,14 +569,13 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_lds(int m, int n, int
 // workgroups per CU the kernel is compiled for: 3 for the M-major A operand (168 VGPRs: +2.5 %), 2 for the
 // K-major one (its transposing staging spills at 168 registers: -12 %)
 #define M3_MIN_BLOCKS(CONJA) ((CONJA) ? 2 : 3)
-template <bool CONJA>
+template <bool CONJA, int MODE>
 __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm_3m(int m, int n, int K, int kchunk, int gm, int gn,
                                                                int rt0, int ct0, int lsplit, int upper,
                                                                int nsplit, const cd* __restrict__ A, int64_t lda,
                                                                const cd* __restrict__ B, int64_t ldb,
                                                                cd* __restrict__ C, int64_t ldc, cd alpha, cd beta,
                                                                cd* __restrict__ slab) {
-    constexpr int MODE = 1;   // interior (full) tiles only
     __shared__ cd sA[2][LT_KT][GEMM_BM];
     __shared__ cd sB[2][LT_KT][M3_BN];
     const int id = blockIdx.x;
@@ -764,20 +763,26 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm
         }
         return f;
     };
-    auto mfma_half = [&](const Frag& f, auto) {
+    auto mfma_half = [&](const Frag& f, auto nopred_tag) {
+        constexpr bool NOPRED = decltype(nopred_tag)::value;
         double bs[M3_RN];
 #pragma unroll
         for (int b = 0; b < M3_RN; ++b) bs[b] = f.b[b].x + f.b[b].y;
 #pragma unroll
         for (int a = 0; a < GEMM_RM; ++a) {
-            const double ar = f.a[a].x, ai = f.a[a].y;
-            const double as = CONJA ? ar - ai : ar + ai;
+            if (NOPRED || a < rmv) {
+                const double ar = f.a[a].x, ai = f.a[a].y;
+                const double as = CONJA ? ar - ai : ar + ai;
 #pragma unroll
-            for (int b = 0; b < M3_RN; ++b) acc1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, f.b[b].x, acc1[a][b], 0, 0, 0);
+                for (int b = 0; b < M3_RN; ++b)
+                    if (NOPRED || b < rnv) acc1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, f.b[b].x, acc1[a][b], 0, 0, 0);
 #pragma unroll
-            for (int b = 0; b < M3_RN; ++b) acc2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, f.b[b].y, acc2[a][b], 0, 0, 0);
+                for (int b = 0; b < M3_RN; ++b)
+                    if (NOPRED || b < rnv) acc2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, f.b[b].y, acc2[a][b], 0, 0, 0);
 #pragma unroll
-            for (int b = 0; b < M3_RN; ++b) acc3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, bs[b], acc3[a][b], 0, 0, 0);
+                for (int b = 0; b < M3_RN; ++b)
+                    if (NOPRED || b < rnv) acc3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, bs[b], acc3[a][b], 0, 0, 0);
+            }
         }
     };
 
@@ -1167,23 +1172,24 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
         // interior tiles run the predicate-free kernel; the ragged right / bottom strips the general one,
         // as ONE list-shaped launch (right strip: all tile rows of the last tile column; bottom strip:
         // the full tile columns of the last tile row) with its own K split
-        const int gmf = (int)(m / GEMM_BM), gnf = (int)(n / GEMM_BN);
-        const int nright = (gn > gnf) ? gm : 0;
+        static const bool use3m = getenv("DFTK_MI_GEMM_4M") == nullptr;   // DFTK_MI_GEMM_4M=1: classic 4-product kernels
+        const int BNt = use3m ? M3_BN : GEMM_BN;                            // column-tile width of this kernel family
+        const int gnt = (int)((n + BNt - 1) / BNt);
+        const int gmf = (int)(m / GEMM_BM), gnf = (int)(n / BNt);
+        const int nright = (gnt > gnf) ? gm : 0;
         const int nbottom = (gm > gmf) ? gnf : 0;
         // live column tiles per tile row of each launch (upper: only tiles that intersect the upper triangle)
-        auto live = [&](int tr, int tc) { return !(upper & 1) || tr * GEMM_BM < tc * GEMM_BN + GEMM_BN; };
-        static const bool use3m = getenv("DFTK_MI_GEMM_4M") == nullptr;   // DFTK_MI_GEMM_4M=1: classic 4-product interior kernel
-        const int isub = use3m ? GEMM_BN / M3_BN : 1;   // interior column tiles per 64-wide tile
+        auto live = [&](int tr, int tc) { return !(upper & 1) || tr * GEMM_BM < tc * BNt + BNt; };
         std::vector<int> rowsI(gmf, 0), rowsB(nright + nbottom, 0);
         for (int tr = 0; tr < gmf; ++tr)
-            for (int tc = 0; tc < gnf; ++tc) rowsI[tr] += live(tr, tc) ? isub : 0;
+            for (int tc = 0; tc < gnf; ++tc) rowsI[tr] += live(tr, tc) ? 1 : 0;
         for (int e = 0; e < nright; ++e) rowsB[e] = live(e, gnf) ? 1 : 0;
         for (int e = 0; e < nbottom; ++e) rowsB[nright + e] = live(gmf, e) ? 1 : 0;
         const int64_t tilesI_total = (int64_t)gmf * gnf;
         // the 3M kernel is compiled for M3_MIN_BLOCKS workgroups per CU
         const int64_t slotsI = use3m ? (slots2 / 2) * M3_MIN_BLOCKS(conja) : slots2;
         Split spI = plan_split(rowsI, use3m ? 3 : 1, slotsI);
-        Split spB = plan_split(rowsB, 2, slots2);
+        Split spB = plan_split(rowsB, use3m ? 4 : 2, use3m ? (slots2 / 2) * M3_MIN_BLOCKS(conja) : slots2);
         const size_t bytesI = spI.nsplit > 1 ? (size_t)spI.nsplit * plane : 0;
         const size_t bytesB = spB.nsplit > 1 ? (size_t)spB.nsplit * plane : 0;
         if (bytesI + bytesB) CHK(ensure_ws(b, bytesI + bytesB));
@@ -1200,15 +1206,18 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
 #define DFTK_LAUNCH_LDS(CJ, FL)                                                                                        \
     hipLaunchKernelGGL((k_zgemm_lds<CJ, FL>), grid, dim3(GEMM_WAVES * 64), pad_lds, b->stream, (int)m, (int)n, (int)k, \
                        sp.kchunk, gm_s, gn_s, rt0, ct0, lsplit, upper, sp.nsplit, A, lda, B, ldb, C, ldc, alpha, beta, sp.slab)
-            if (mode == 3) {   // 3M interior kernel (128 x 32 tiles)
-                if (conja)
-                    hipLaunchKernelGGL((k_zgemm_3m<true>), grid, dim3(GEMM_WAVES * 64), pad_lds, b->stream, (int)m, (int)n,
-                                       (int)k, sp.kchunk, gm_s, gn_s, rt0, ct0, lsplit, upper, sp.nsplit, A, lda, B, ldb, C,
-                                       ldc, alpha, beta, sp.slab);
-                else
-                    hipLaunchKernelGGL((k_zgemm_3m<false>), grid, dim3(GEMM_WAVES * 64), pad_lds, b->stream, (int)m, (int)n,
-                                       (int)k, sp.kchunk, gm_s, gn_s, rt0, ct0, lsplit, upper, sp.nsplit, A, lda, B, ldb, C,
-                                       ldc, alpha, beta, sp.slab);
+            if (use3m) {   // 3M kernels on 128 x 32 tiles: mode 1 = full tiles, 0 = predicated border
+#define DFTK_LAUNCH_3M(CJ, MD)                                                                                         \
+    hipLaunchKernelGGL((k_zgemm_3m<CJ, MD>), grid, dim3(GEMM_WAVES * 64), pad_lds, b->stream, (int)m, (int)n, (int)k, \
+                       sp.kchunk, gm_s, gn_s, rt0, ct0, lsplit, upper, sp.nsplit, A, lda, B, ldb, C, ldc, alpha, beta, sp.slab)
+                if (conja) {
+                    if (mode == 1) DFTK_LAUNCH_3M(true, 1);
+                    else DFTK_LAUNCH_3M(true, 0);
+                } else {
+                    if (mode == 1) DFTK_LAUNCH_3M(false, 1);
+                    else DFTK_LAUNCH_3M(false, 0);
+                }
+#undef DFTK_LAUNCH_3M
             } else if (conja) {
                 if (mode == 1) DFTK_LAUNCH_LDS(true, 1);
                 else if (mode == 2) DFTK_LAUNCH_LDS(true, 2);
@@ -1226,19 +1235,16 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
         // but the light border workgroups run ahead of their siblings through k, their A tiles are evicted
         // before the full tiles arrive and FETCH_SIZE rises from 2.3x to 3.5x the operand bytes -> off.
         static const bool mixed = getenv("DFTK_MI_GEMM_MIXED") != nullptr;
-        if (mixed && spI.nsplit == 1 && spB.nsplit == 1 && tilesI_total >= slots2 && !(upper & 1)) {
+        if (mixed && !use3m && spI.nsplit == 1 && spB.nsplit == 1 && tilesI_total >= slots2 && !(upper & 1)) {
             Split one{1, spI.kchunk, false, nullptr};
             CHK(launch(2, gm, gn, 0, 0, -1, one));
         } else {
-            if (use3m)
-                CHK(launch(3, gmf, gnf * isub, 0, 0, -1, spI));
-            else
-                CHK(launch(1, gmf, gnf, 0, 0, -1, spI));
+            CHK(launch(1, gmf, gnf, 0, 0, -1, spI));
             CHK(launch(0, nright + nbottom, 1, gmf, gnf, nright, spB));
         }
         if (spI.slab || spB.slab)
             hipLaunchKernelGGL(k_zgemm_reduce, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, b->stream, (int)m,
-                               (int)n, gmf * GEMM_BM, gnf * GEMM_BN, spI.slab ? spI.nsplit : -1, spI.slab,
+                               (int)n, gmf * GEMM_BM, gnf * BNt, spI.slab ? spI.nsplit : -1, spI.slab,
                                spB.slab ? spB.nsplit : -1, spB.slab, C, ldc, alpha, beta, upper);
     }
     HIPCHK(hipGetLastError());

@@ -566,9 +566,14 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_lds(int m, int n, int
 #define M3_HINT(a, b, c) __builtin_amdgcn_sched_group_barrier(a, b, c)
 #endif
 #define M3_BN (16 * M3_RN)
-// workgroups per CU the kernel is compiled for: 3 for the M-major A operand (168 VGPRs: +2.5 %), 2 for the
-// K-major one (its transposing staging spills at 168 registers: -12 %)
-#define M3_MIN_BLOCKS(CONJA) ((CONJA) ? 2 : 3)
+// workgroups per CU the kernel is compiled for.  3 for the M-major variant (168 VGPRs) is as fast as 2,
+// but with 12 instead of 8 row panels in flight per XCD the column tiles of a panel drift apart in k and
+// re-fetch their A tiles: FETCH_SIZE 4.0x the operand bytes against 1.55x -> 2.  The K-major variant
+// spills at 168 registers (-12 %).
+#ifndef M3_N_BLOCKS
+#define M3_N_BLOCKS 2
+#endif
+#define M3_MIN_BLOCKS(CONJA) ((CONJA) ? 2 : M3_N_BLOCKS)
 template <bool CONJA, int MODE>
 __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm_3m(int m, int n, int K, int kchunk, int gm, int gn,
                                                                int rt0, int ct0, int lsplit, int upper,

@@ -547,6 +547,11 @@ extern "C" int dftk_mi_zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n
                  be, reinterpret_cast<cd*>(C_d), ldc);
 }
 
+int zgemm_plan_host(char transA, int64_t m, int64_t n, int64_t k, int flags, int* out);   // gemm_kernels.hip
+extern "C" int dftk_mi_zgemm_plan_host(char transA, int64_t m, int64_t n, int64_t k, int flags, int* out12) {
+    return zgemm_plan_host(transA, m, n, k, flags, out12);
+}
+
 extern "C" int dftk_mi_zgemm_ex(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, dftk_mi_cplx alpha,
                                 const dftk_mi_cplx* A_d, int64_t lda, const dftk_mi_cplx* B_d, int64_t ldb,
                                 dftk_mi_cplx beta, dftk_mi_cplx* C_d, int64_t ldc, int flags) {

@@ -1036,6 +1036,121 @@ int ensure_ws(dftk_mi_basis* b, size_t bytes) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------- planning
+// K split: chosen per launch by a small cost model of the actual workgroup -> XCD placement (8 XCDs x
+// 64 resident workgroups, 2 per CU).  Candidates: ns chunks with either mapping of the kernel
+//   row-major: (chunk, tile row) pairs round-robin over the XCDs, their column tiles together;
+//   z-major  : whole chunks round-robin over the XCDs (A and B chunk both shared through one L2).
+// cost = (rounds of the fullest XCD) x (chunk length + prologue/epilogue) + slab traffic.
+// Short K is latency-bound: chunks of >= 8 tiles.  Plans are cached per shape.  Host-only code
+// (dftk_mi_zgemm_plan_host exposes it to the CPU test-suite).
+struct Split {
+    int nsplit, kchunk;
+    bool zmajor;
+    cd* slab;
+};
+static int64_t gemm_slots2() {
+    const char* senv = getenv("DFTK_MI_GEMM_BLOCKS");
+    return senv ? atoll(senv) : 512;   // resident workgroups of the 2-per-CU kernels
+}
+static Split gemm_plan_split(int64_t m, int64_t n, int64_t k, int upper, const std::vector<int>& live_rows, int kind,
+                             int64_t slots) {
+    const int64_t plane = (int64_t)m * n * (int64_t)sizeof(cd);
+    static const bool no_zmajor = getenv("DFTK_MI_GEMM_NO_ZMAJOR") != nullptr;
+    static std::map<std::vector<int64_t>, std::pair<int, int>> plan_cache;   // key -> (nsplit, zmajor)
+    int64_t total = 0;
+    for (int v : live_rows) total += v;
+    const int gm_s = (int)live_rows.size();
+    int best_ns = 1, best_zm = 0;
+    if (k >= 128 && total > 0 && total < slots) {
+        const std::vector<int64_t> key = {m, n, k, (int64_t)(upper & 1), (int64_t)kind, slots};
+        auto it = plan_cache.find(key);
+        if (it != plan_cache.end()) {
+            best_ns = it->second.first;
+            best_zm = it->second.second;
+        } else {
+            int64_t max_ns = k >= 2048 ? k / 256 : k / 64;
+            if (max_ns > 1024) max_ns = 1024;
+            const int64_t max_by_ws = (int64_t)(256ull << 20) / plane;   // each slab <= 256 MiB
+            if (max_ns > max_by_ws) max_ns = max_by_ws;
+            if (max_ns > 2 * slots / total + 8) max_ns = 2 * slots / total + 8;
+            if (max_ns < 1) max_ns = 1;
+            const double per_xcd = (double)slots / 8.0;
+            const double slab_cost = 2.0 * (double)plane / 5e12 / 3.7e-6;   // k-tiles of time per extra chunk
+            double best = 1e300;
+            for (int ns = 1; ns <= max_ns; ++ns) {
+                int kc = (int)((k + ns - 1) / ns);
+                kc = (kc + 7) & ~7;
+                if ((int)((k + kc - 1) / kc) != ns) continue;
+                for (int zm = 0; zm < 2; ++zm) {
+                    if (zm && (ns < 8 || no_zmajor || k < 2048)) continue;
+                    int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (zm) {
+                        for (int z = 0; z < ns; ++z) load[z & 7] += total;
+                    } else {
+                        const int64_t R = (int64_t)gm_s * ns;
+                        for (int64_t r = 0; r < R; ++r) load[r & 7] += live_rows[r % gm_s];
+                    }
+                    int64_t mx = 0;
+                    for (int x = 0; x < 8; ++x) mx = load[x] > mx ? load[x] : mx;
+                    const double rounds = std::ceil((double)mx / per_xcd);
+                    const double cost = rounds * (kc / 8.0 + 12.0) + (ns > 1 ? slab_cost * ns : 0.0) - (zm ? 1e-3 : 0.0);
+                    if (cost < best) {
+                        best = cost;
+                        best_ns = ns;
+                        best_zm = zm;
+                    }
+                }
+            }
+            if (plan_cache.size() > 4096) plan_cache.clear();
+            plan_cache[key] = {best_ns, best_zm};
+        }
+    }
+    int kc = (int)((k + best_ns - 1) / best_ns);
+    kc = (kc + 7) & ~7;
+    const int ns = (int)((k + kc - 1) / kc);
+    return Split{ns, kc, best_zm != 0 && ns >= 8, nullptr};
+}
+
+// Tiling of one product for the default (3M) kernel family: interior rectangle of full 128 x BN tiles, ragged
+// border as a list, and the K split of each.
+struct GemmTiling {
+    int BNt, gm, gmf, gnf, gnt, nright, nbottom;
+    Split I, B;
+};
+static GemmTiling gemm_tiling(bool conja, int64_t m, int64_t n, int64_t k, int upper, bool use3m) {
+    GemmTiling t;
+    const int64_t slots2 = gemm_slots2();
+    t.BNt = use3m ? M3_BN : GEMM_BN;                            // column-tile width of this kernel family
+    t.gm = (int)((m + GEMM_BM - 1) / GEMM_BM);
+    t.gnt = (int)((n + t.BNt - 1) / t.BNt);
+    t.gmf = (int)(m / GEMM_BM);
+    t.gnf = (int)(n / t.BNt);
+    t.nright = (t.gnt > t.gnf) ? t.gm : 0;
+    t.nbottom = (t.gm > t.gmf) ? t.gnf : 0;
+    // live column tiles per tile row of each launch (upper: only tiles that intersect the upper triangle)
+    auto live = [&](int tr, int tc) { return !(upper & 1) || tr * GEMM_BM < tc * t.BNt + t.BNt; };
+    std::vector<int> rowsI(t.gmf, 0), rowsB(t.nright + t.nbottom, 0);
+    for (int tr = 0; tr < t.gmf; ++tr)
+        for (int tc = 0; tc < t.gnf; ++tc) rowsI[tr] += live(tr, tc) ? 1 : 0;
+    for (int e = 0; e < t.nright; ++e) rowsB[e] = live(e, t.gnf) ? 1 : 0;
+    for (int e = 0; e < t.nbottom; ++e) rowsB[t.nright + e] = live(t.gmf, e) ? 1 : 0;
+    // the 3M kernel is compiled for M3_MIN_BLOCKS workgroups per CU
+    const int64_t slots3 = use3m ? (slots2 / 2) * M3_MIN_BLOCKS(conja) : slots2;
+    t.I = gemm_plan_split(m, n, k, upper, rowsI, use3m ? 3 : 1, slots3);
+    t.B = gemm_plan_split(m, n, k, upper, rowsB, use3m ? 4 : 2, slots3);
+    return t;
+}
+int zgemm_plan_host(char transA, int64_t m, int64_t n, int64_t k, int flags, int* out) {
+    if (m <= 0 || n <= 0 || k <= 0 || (flags & ~3) || !out) return DFTK_MI_EINVAL;
+    const bool conja = (transA == 'C' || transA == 'c');
+    const GemmTiling t = gemm_tiling(conja, m, n, k, flags, getenv("DFTK_MI_GEMM_4M") == nullptr);
+    const int v[12] = {t.BNt, t.gmf, t.gnf, t.nright, t.nbottom, t.I.nsplit, t.I.kchunk, t.I.zmajor ? 1 : 0,
+                       t.B.nsplit, t.B.kchunk, t.B.zmajor ? 1 : 0, 0};
+    for (int i = 0; i < 12; ++i) out[i] = v[i];
+    return 0;
+}
+
 int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alpha, const cd* A, int64_t lda,
           const cd* B, int64_t ldb, cd beta, cd* C, int64_t ldc, int upper_in) {
     const int upper = upper_in;
@@ -1080,75 +1195,10 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
     }
     const int gm = (int)((m + GEMM_BM - 1) / GEMM_BM);
     const int gn = (int)((n + GEMM_BN - 1) / GEMM_BN);
-    // K split: chosen per launch by a small cost model of the actual workgroup -> XCD placement (8 XCDs x
-    // 64 resident workgroups, 2 per CU).  Candidates: ns chunks with either mapping of the kernel
-    //   row-major: (chunk, tile row) pairs round-robin over the XCDs, their column tiles together;
-    //   z-major  : whole chunks round-robin over the XCDs (A and B chunk both shared through one L2).
-    // cost = (rounds of the fullest XCD) x (chunk length + prologue/epilogue) + slab traffic.
-    // Short K is latency-bound: chunks of >= 8 tiles.  Plans are cached per shape.
-    const char* senv = getenv("DFTK_MI_GEMM_BLOCKS");
-    const int64_t slots2 = senv ? atoll(senv) : 512;   // resident workgroups of the 2-per-CU kernels
-    struct Split {
-        int nsplit, kchunk;
-        bool zmajor;
-        cd* slab;
-    };
+    const int64_t slots2 = gemm_slots2();
     const int64_t plane = (int64_t)m * n * (int64_t)sizeof(cd);
-    static const bool no_zmajor = getenv("DFTK_MI_GEMM_NO_ZMAJOR") != nullptr;
-    static std::map<std::vector<int64_t>, std::pair<int, int>> plan_cache;   // key -> (nsplit, zmajor)
     auto plan_split = [&](const std::vector<int>& live_rows, int kind, int64_t slots) -> Split {
-        int64_t total = 0;
-        for (int v : live_rows) total += v;
-        const int gm_s = (int)live_rows.size();
-        int best_ns = 1, best_zm = 0;
-        if (k >= 128 && total > 0 && total < slots) {
-            const std::vector<int64_t> key = {m, n, k, (int64_t)(upper & 1), (int64_t)kind, slots};
-            auto it = plan_cache.find(key);
-            if (it != plan_cache.end()) {
-                best_ns = it->second.first;
-                best_zm = it->second.second;
-            } else {
-                int64_t max_ns = k >= 2048 ? k / 256 : k / 64;
-                if (max_ns > 1024) max_ns = 1024;
-                const int64_t max_by_ws = (int64_t)(256ull << 20) / plane;   // each slab <= 256 MiB
-                if (max_ns > max_by_ws) max_ns = max_by_ws;
-                if (max_ns > 2 * slots / total + 8) max_ns = 2 * slots / total + 8;
-                if (max_ns < 1) max_ns = 1;
-                const double per_xcd = (double)slots / 8.0;
-                const double slab_cost = 2.0 * (double)plane / 5e12 / 3.7e-6;   // k-tiles of time per extra chunk
-                double best = 1e300;
-                for (int ns = 1; ns <= max_ns; ++ns) {
-                    int kc = (int)((k + ns - 1) / ns);
-                    kc = (kc + 7) & ~7;
-                    if ((int)((k + kc - 1) / kc) != ns) continue;
-                    for (int zm = 0; zm < 2; ++zm) {
-                        if (zm && (ns < 8 || no_zmajor || k < 2048)) continue;
-                        int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                        if (zm) {
-                            for (int z = 0; z < ns; ++z) load[z & 7] += total;
-                        } else {
-                            const int64_t R = (int64_t)gm_s * ns;
-                            for (int64_t r = 0; r < R; ++r) load[r & 7] += live_rows[r % gm_s];
-                        }
-                        int64_t mx = 0;
-                        for (int x = 0; x < 8; ++x) mx = load[x] > mx ? load[x] : mx;
-                        const double rounds = std::ceil((double)mx / per_xcd);
-                        const double cost = rounds * (kc / 8.0 + 12.0) + (ns > 1 ? slab_cost * ns : 0.0) - (zm ? 1e-3 : 0.0);
-                        if (cost < best) {
-                            best = cost;
-                            best_ns = ns;
-                            best_zm = zm;
-                        }
-                    }
-                }
-                if (plan_cache.size() > 4096) plan_cache.clear();
-                plan_cache[key] = {best_ns, best_zm};
-            }
-        }
-        int kc = (int)((k + best_ns - 1) / best_ns);
-        kc = (kc + 7) & ~7;
-        const int ns = (int)((k + kc - 1) / kc);
-        return Split{ns, kc, best_zm != 0 && ns >= 8, nullptr};
+        return gemm_plan_split(m, n, k, upper, live_rows, kind, slots);
     };
     // XCD-aware 1-D grid over a gm_s x gn_s sub-grid of tiles (x nsplit K chunks)
     auto grid_for = [&](int gm_s, int gn_s, int ns) -> int64_t {
@@ -1178,23 +1228,10 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
         // as ONE list-shaped launch (right strip: all tile rows of the last tile column; bottom strip:
         // the full tile columns of the last tile row) with its own K split
         static const bool use3m = getenv("DFTK_MI_GEMM_4M") == nullptr;   // DFTK_MI_GEMM_4M=1: classic 4-product kernels
-        const int BNt = use3m ? M3_BN : GEMM_BN;                            // column-tile width of this kernel family
-        const int gnt = (int)((n + BNt - 1) / BNt);
-        const int gmf = (int)(m / GEMM_BM), gnf = (int)(n / BNt);
-        const int nright = (gnt > gnf) ? gm : 0;
-        const int nbottom = (gm > gmf) ? gnf : 0;
-        // live column tiles per tile row of each launch (upper: only tiles that intersect the upper triangle)
-        auto live = [&](int tr, int tc) { return !(upper & 1) || tr * GEMM_BM < tc * BNt + BNt; };
-        std::vector<int> rowsI(gmf, 0), rowsB(nright + nbottom, 0);
-        for (int tr = 0; tr < gmf; ++tr)
-            for (int tc = 0; tc < gnf; ++tc) rowsI[tr] += live(tr, tc) ? 1 : 0;
-        for (int e = 0; e < nright; ++e) rowsB[e] = live(e, gnf) ? 1 : 0;
-        for (int e = 0; e < nbottom; ++e) rowsB[nright + e] = live(gmf, e) ? 1 : 0;
+        const GemmTiling til = gemm_tiling(conja, m, n, k, upper, use3m);
+        const int BNt = til.BNt, gmf = til.gmf, gnf = til.gnf, nright = til.nright, nbottom = til.nbottom;
         const int64_t tilesI_total = (int64_t)gmf * gnf;
-        // the 3M kernel is compiled for M3_MIN_BLOCKS workgroups per CU
-        const int64_t slotsI = use3m ? (slots2 / 2) * M3_MIN_BLOCKS(conja) : slots2;
-        Split spI = plan_split(rowsI, use3m ? 3 : 1, slotsI);
-        Split spB = plan_split(rowsB, use3m ? 4 : 2, use3m ? (slots2 / 2) * M3_MIN_BLOCKS(conja) : slots2);
+        Split spI = til.I, spB = til.B;
         const size_t bytesI = spI.nsplit > 1 ? (size_t)spI.nsplit * plane : 0;
         const size_t bytesB = spB.nsplit > 1 ? (size_t)spB.nsplit * plane : 0;
         if (bytesI + bytesB) CHK(ensure_ws(b, bytesI + bytesB));

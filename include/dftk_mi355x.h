@@ -165,6 +165,11 @@ int dftk_mi_prof_get(dftk_mi_basis* basis, int family, double* total_ms, double*
 int dftk_mi_diag_mfma_peak(dftk_mi_basis* basis, int waves_per_simd, int iters, double* tflops);
 
 /* ---- host-only introspection (no GPU needed; used by the CPU test-suite) ---------------------
+ * Launch plan of dftk_mi_zgemm(_ex) for one shape: out[12] = { column-tile width, full tile rows, full tile
+ * columns, right-strip tiles, bottom-strip tiles, interior {K chunks, chunk length, chunk->XCD placement},
+ * border {K chunks, chunk length, placement}, 0 }. */
+int dftk_mi_zgemm_plan_host(char transA, int64_t m, int64_t n, int64_t k, int flags, int* out12);
+/*
  * 1-D plan for length n: radices (<= 32 entries) and the in-place permutation `pos[e]` such
  * that a decimation-in-time pass wants input element e at position pos[e] and a
  * decimation-in-frequency pass leaves output frequency k at position pos[k]. */

@@ -332,3 +332,38 @@ def test_pbe_pointwise_terms_match_oracle():
     e0, v0, _ = _gga_terms(OG["gga_x_pbe"], rho, np.zeros_like(rho))
     el, vl = _lda_x(rho)
     assert np.abs(e0 - el).max() < 1e-15 and np.abs(v0 - vl).max() < 1e-14
+
+
+def _gemm_plan(lib, trans, m, n, k, flags=0):
+    out = (C.c_int * 12)()
+    check(lib.dftk_mi_zgemm_plan_host(trans.encode(), m, n, k, flags, out))
+    keys = ("bn", "gmf", "gnf", "nright", "nbottom", "nsI", "kcI", "zmI", "nsB", "kcB", "zmB")
+    return dict(zip(keys, out[:11]))
+
+
+@pytest.mark.parametrize("trans,m,n,k", [("C", 259, 259, 135491), ("C", 640, 259, 135491), ("C", 777, 777, 135491),
+                                          ("C", 5, 5, 135491), ("N", 135491, 259, 259), ("N", 135491, 54, 777),
+                                          ("C", 259, 259, 518), ("C", 259, 1, 777), ("N", 777, 1, 259), ("C", 1, 1, 1)])
+def test_zgemm_launch_plan_invariants(lib, trans, m, n, k):
+    """Host-side planning of the MFMA zgemm (tiling into full 128 x 32 tiles + ragged border, K chunks that
+    fill the resident workgroup slots, chunk -> XCD placement): structural invariants for the LOBPCG shapes."""
+    for flags in (0, 1):
+        if flags and (trans != "C" or m != n):
+            continue
+        p = _gemm_plan(lib, trans, m, n, k, flags)
+        assert p["bn"] == 32 and p["gmf"] == m // 128 and p["gnf"] == n // 32
+        assert p["nright"] == (-(-m // 128) if n % 32 else 0) and p["nbottom"] == (n // 32 if m % 128 else 0)
+        for ns, kc in ((p["nsI"], p["kcI"]), (p["nsB"], p["kcB"])):
+            assert ns >= 1 and kc % 8 == 0 and ns * kc >= k and (ns - 1) * kc < k     # chunks tile [0, k) exactly
+            assert ns == 1 or kc >= 64                                                   # no degenerate chunks
+        full = p["gmf"] * p["gnf"]
+        if 0 < full < 512 and k >= 2048 and not flags:
+            # at least half a round of the 512 resident workgroups, at most a few balanced rounds
+            assert 256 <= full * p["nsI"] <= 4 * 512
+        if p["zmI"]:
+            assert p["nsI"] >= 8 and k >= 2048
+    if trans == "N" and m > 100000:
+        assert _gemm_plan(lib, trans, m, n, k)["nsI"] == 1      # thousands of tiles: no K split
+    if trans == "C" and m == n and m >= 256:
+        # the upper-only product has fewer live tiles, so at least as many chunks fit into one round
+        assert _gemm_plan(lib, trans, m, n, k, 1)["nsI"] >= _gemm_plan(lib, trans, m, n, k, 0)["nsI"]

@@ -95,7 +95,10 @@ class KBlock:
 @pytest.mark.parametrize("trans,m,n,k", [("N", 1000, 37, 50), ("N", 128, 64, 4), ("N", 33, 17, 129),
                                          ("C", 37, 50, 1000), ("C", 64, 128, 8192), ("C", 5, 3, 40001),
                                          ("N", 5000, 259, 777), ("C", 259, 259, 30011), ("C", 1, 1, 7),
-                                         ("N", 1, 1, 1), ("C", 130, 70, 2049)])
+                                         ("N", 1, 1, 1), ("C", 130, 70, 2049),
+                                         # 1..4 remainder columns riding on the last full tile column
+                                         ("C", 300, 99, 5000), ("N", 3000, 36, 100), ("C", 131, 33, 777),
+                                         ("N", 127, 34, 13), ("C", 256, 68, 20000)])
 def test_zgemm(lib, trans, m, n, k):
     rng = np.random.default_rng(m * 7 + n * 3 + k)
     bs = Basis(lib, 8, 8, 8)

@@ -577,7 +577,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_lds(int m, int n, int
 template <bool CONJA, int MODE>
 __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm_3m(int m, int n, int K, int kchunk, int gm, int gn,
                                                                int rt0, int ct0, int lsplit, int upper,
-                                                               int nsplit, const cd* __restrict__ A, int64_t lda,
+                                                               int shift_ct, int nsplit, const cd* __restrict__ A, int64_t lda,
                                                                const cd* __restrict__ B, int64_t ldb,
                                                                cd* __restrict__ C, int64_t ldc, cd alpha, cd beta,
                                                                cd* __restrict__ slab) {
@@ -617,7 +617,12 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm
     // entries < lsplit are the right strip (tile column ct0), the rest the bottom strip (tile row rt0)
     const int tr = lsplit < 0 ? row_t + rt0 : (row_t < lsplit ? row_t : rt0);
     const int tcn = lsplit < 0 ? col_t + ct0 : (row_t < lsplit ? ct0 : row_t - lsplit);
-    const int I0 = tr * GEMM_BM, J0 = tcn * M3_BN;
+    // tile column shift_ct (the one past the last full column) is SHIFTED LEFT to end at column n: it overlaps
+    // its neighbour, recomputes up to 31 columns and stores only columns >= jmin.  A ragged n then needs no
+    // right-strip launch (which would stream all of A a second time for a handful of columns).
+    const bool shifted = tcn == shift_ct;
+    const int I0 = tr * GEMM_BM, J0 = shifted ? n - M3_BN : tcn * M3_BN;
+    const int jmin = shifted ? tcn * M3_BN : 0;
     if ((upper & 1) && I0 >= J0 + M3_BN) return;   // tile strictly below the diagonal (whole workgroup)
     const int i0 = I0 + wave * (GEMM_RM * 16);
     const int kbeg = z * kchunk;
@@ -874,7 +879,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm
             for (int r = 0; r < 4; ++r) {
                 const int gi = i0 + a * 16 + lk + 4 * r;
                 const int gj = j0 + b * 16 + li;
-                if (gi < m && gj < n) {
+                if (gi < m && gj < n && gj >= jmin) {
                     const double p1 = acc1[a][b][r], p2 = acc2[a][b][r], p3 = acc3[a][b][r];
                     const double vr = CONJA ? p1 + p2 : p1 - p2;
                     const double vi = CONJA ? p3 - p1 + p2 : p3 - p1 - p2;
@@ -1116,6 +1121,8 @@ static Split gemm_plan_split(int64_t m, int64_t n, int64_t k, int upper, const s
 // border as a list, and the K split of each.
 struct GemmTiling {
     int BNt, gm, gmf, gnf, gnt, nright, nbottom;
+    int shift;   // 1: the ragged last tile column is a full tile shifted left (3M kernel), no right strip
+    int gnI;     // tile columns of the interior launch = gnf + shift
     Split I, B;
 };
 static GemmTiling gemm_tiling(bool conja, int64_t m, int64_t n, int64_t k, int upper, bool use3m) {
@@ -1126,13 +1133,19 @@ static GemmTiling gemm_tiling(bool conja, int64_t m, int64_t n, int64_t k, int u
     t.gnt = (int)((n + t.BNt - 1) / t.BNt);
     t.gmf = (int)(m / GEMM_BM);
     t.gnf = (int)(n / t.BNt);
-    t.nright = (t.gnt > t.gnf) ? t.gm : 0;
-    t.nbottom = (t.gm > t.gmf) ? t.gnf : 0;
+    static const bool no_shift = getenv("DFTK_MI_GEMM_NO_SHIFT") != nullptr;
+    t.shift = (use3m && !no_shift && t.gnt > t.gnf && t.gnf >= 1) ? 1 : 0;
+    t.gnI = t.gnf + t.shift;
+    t.nright = (t.gnt > t.gnf && !t.shift) ? t.gm : 0;
+    t.nbottom = (t.gm > t.gmf) ? t.gnI : 0;
     // live column tiles per tile row of each launch (upper: only tiles that intersect the upper triangle)
-    auto live = [&](int tr, int tc) { return !(upper & 1) || tr * GEMM_BM < tc * t.BNt + t.BNt; };
+    auto live = [&](int tr, int tc) {
+        const int64_t jend = (t.shift && tc == t.gnf) ? n : (int64_t)tc * t.BNt + t.BNt;
+        return !(upper & 1) || (int64_t)tr * GEMM_BM < jend;
+    };
     std::vector<int> rowsI(t.gmf, 0), rowsB(t.nright + t.nbottom, 0);
     for (int tr = 0; tr < t.gmf; ++tr)
-        for (int tc = 0; tc < t.gnf; ++tc) rowsI[tr] += live(tr, tc) ? 1 : 0;
+        for (int tc = 0; tc < t.gnI; ++tc) rowsI[tr] += live(tr, tc) ? 1 : 0;
     for (int e = 0; e < t.nright; ++e) rowsB[e] = live(e, t.gnf) ? 1 : 0;
     for (int e = 0; e < t.nbottom; ++e) rowsB[t.nright + e] = live(t.gmf, e) ? 1 : 0;
     // the 3M kernel is compiled for M3_MIN_BLOCKS workgroups per CU
@@ -1146,7 +1159,7 @@ int zgemm_plan_host(char transA, int64_t m, int64_t n, int64_t k, int flags, int
     const bool conja = (transA == 'C' || transA == 'c');
     const GemmTiling t = gemm_tiling(conja, m, n, k, flags, getenv("DFTK_MI_GEMM_4M") == nullptr);
     const int v[12] = {t.BNt, t.gmf, t.gnf, t.nright, t.nbottom, t.I.nsplit, t.I.kchunk, t.I.zmajor ? 1 : 0,
-                       t.B.nsplit, t.B.kchunk, t.B.zmajor ? 1 : 0, 0};
+                       t.B.nsplit, t.B.kchunk, t.B.zmajor ? 1 : 0, t.shift};
     for (int i = 0; i < 12; ++i) out[i] = v[i];
     return 0;
 }
@@ -1251,7 +1264,8 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
             if (use3m) {   // 3M kernels on 128 x 32 tiles: mode 1 = full tiles, 0 = predicated border
 #define DFTK_LAUNCH_3M(CJ, MD)                                                                                         \
     hipLaunchKernelGGL((k_zgemm_3m<CJ, MD>), grid, dim3(GEMM_WAVES * 64), pad_lds, b->stream, (int)m, (int)n, (int)k, \
-                       sp.kchunk, gm_s, gn_s, rt0, ct0, lsplit, upper, sp.nsplit, A, lda, B, ldb, C, ldc, alpha, beta, sp.slab)
+                       sp.kchunk, gm_s, gn_s, rt0, ct0, lsplit, upper, til.shift ? gnf : -1, sp.nsplit, A, lda, B, ldb, C, ldc,  \
+                       alpha, beta, sp.slab)
                 if (conja) {
                     if (mode == 1) DFTK_LAUNCH_3M(true, 1);
                     else DFTK_LAUNCH_3M(true, 0);
@@ -1281,12 +1295,12 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
             Split one{1, spI.kchunk, false, nullptr};
             CHK(launch(2, gm, gn, 0, 0, -1, one));
         } else {
-            CHK(launch(1, gmf, gnf, 0, 0, -1, spI));
+            CHK(launch(1, gmf, til.gnI, 0, 0, -1, spI));
             CHK(launch(0, nright + nbottom, 1, gmf, gnf, nright, spB));
         }
         if (spI.slab || spB.slab)
             hipLaunchKernelGGL(k_zgemm_reduce, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, b->stream, (int)m,
-                               (int)n, gmf * GEMM_BM, gnf * BNt, spI.slab ? spI.nsplit : -1, spI.slab,
+                               (int)n, gmf * GEMM_BM, til.shift ? (int)n : gnf * BNt, spI.slab ? spI.nsplit : -1, spI.slab,
                                spB.slab ? spB.nsplit : -1, spB.slab, C, ldc, alpha, beta, upper);
     }
     HIPCHK(hipGetLastError());

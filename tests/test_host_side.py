@@ -337,8 +337,8 @@ def test_pbe_pointwise_terms_match_oracle():
 def _gemm_plan(lib, trans, m, n, k, flags=0):
     out = (C.c_int * 12)()
     check(lib.dftk_mi_zgemm_plan_host(trans.encode(), m, n, k, flags, out))
-    keys = ("bn", "gmf", "gnf", "nright", "nbottom", "nsI", "kcI", "zmI", "nsB", "kcB", "zmB")
-    return dict(zip(keys, out[:11]))
+    keys = ("bn", "gmf", "gnf", "nright", "nbottom", "nsI", "kcI", "zmI", "nsB", "kcB", "zmB", "shift")
+    return dict(zip(keys, out[:12]))
 
 
 @pytest.mark.parametrize("trans,m,n,k", [("C", 259, 259, 135491), ("C", 640, 259, 135491), ("C", 777, 777, 135491),
@@ -352,11 +352,16 @@ def test_zgemm_launch_plan_invariants(lib, trans, m, n, k):
             continue
         p = _gemm_plan(lib, trans, m, n, k, flags)
         assert p["bn"] == 32 and p["gmf"] == m // 128 and p["gnf"] == n // 32
-        assert p["nright"] == (-(-m // 128) if n % 32 else 0) and p["nbottom"] == (n // 32 if m % 128 else 0)
+        # a ragged n >= 32 is covered by a full tile shifted left to end at column n (no right strip, which
+        # would stream A a second time); only n < 32 keeps the predicated right strip
+        shift = 1 if (n % 32 and n >= 32) else 0
+        assert p["shift"] == shift
+        assert p["nright"] == (-(-m // 128) if (n % 32 and not shift) else 0)
+        assert p["nbottom"] == (n // 32 + shift if m % 128 else 0)
         for ns, kc in ((p["nsI"], p["kcI"]), (p["nsB"], p["kcB"])):
             assert ns >= 1 and kc % 8 == 0 and ns * kc >= k and (ns - 1) * kc < k     # chunks tile [0, k) exactly
             assert ns == 1 or kc >= 64                                                   # no degenerate chunks
-        full = p["gmf"] * p["gnf"]
+        full = p["gmf"] * (p["gnf"] + p["shift"])
         if 0 < full < 512 and k >= 2048 and not flags:
             # at least half a round of the 512 resident workgroups, at most a few balanced rounds
             assert 256 <= full * p["nsI"] <= 4 * 512

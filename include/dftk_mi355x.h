@@ -167,7 +167,9 @@ int dftk_mi_diag_mfma_peak(dftk_mi_basis* basis, int waves_per_simd, int iters, 
 /* ---- host-only introspection (no GPU needed; used by the CPU test-suite) ---------------------
  * Launch plan of dftk_mi_zgemm(_ex) for one shape: out[12] = { column-tile width, full tile rows, full tile
  * columns, right-strip tiles, bottom-strip tiles, interior {K chunks, chunk length, chunk->XCD placement},
- * border {K chunks, chunk length, placement}, 0 }. */
+ * border {K chunks, chunk length, placement}, shifted }.  shifted = 1: a ragged last tile column is covered by
+ * one more FULL tile in the interior launch, shifted left to end at column n (it stores only the new columns),
+ * instead of a right-strip launch. */
 int dftk_mi_zgemm_plan_host(char transA, int64_t m, int64_t n, int64_t k, int flags, int* out12);
 /*
  * 1-D plan for length n: radices (<= 32 entries) and the in-place permutation `pos[e]` such

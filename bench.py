@@ -121,9 +121,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # test hooks (tests/test_gpu_multirank.py: the N > 1 code path on a ONE-GPU box): ranks share a device and
+    # reduce over gloo.  Never set by the driver; the measured configuration is one rank per GPU over RCCL.
+    backend = os.environ.get("DFTK_MI_BENCH_BACKEND", "nccl")
+    if "DFTK_MI_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["DFTK_MI_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
         comm = dftk.KptComm.from_torch()
     else:
         comm = dftk.KptComm.single()

@@ -267,7 +267,7 @@ extern "C" int dftk_mi_basis_create(int nx, int ny, int nz, double unit_cell_vol
     b->fft_batch = 8;
     b->prof = new Prof();
     const char* g = getenv("DFTK_MI_GEMM");
-    b->use_mfma = (g && strcmp(g, "naive") == 0) ? 0 : ((g && strcmp(g, "direct") == 0) ? 2 : 1);
+    b->use_mfma = (g && strcmp(g, "naive") == 0) ? 0 : 1;
     const char* fb = getenv("DFTK_MI_FFT_BATCH");
     if (fb && atoi(fb) > 0) b->fft_batch = std::min(atoi(fb), 256);
     HIPCHK(hipStreamCreate(&b->stream));

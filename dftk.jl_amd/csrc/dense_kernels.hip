@@ -562,88 +562,7 @@ __device__ __forceinline__ int pair_index(int bp, int bq, int kk) {
     return kk < JB ? bp * JB + kk : bq * JB + (kk - JB);
 }
 
-// columns: M[:, cols(pair)] <- M[:, cols(pair)] * U  for M = A (rows [0,n)) and V (rows [0,n)).
-// f64 MFMA: one wave owns a 16-row strip of the stacked [A; V] and its 32 pair columns
-// (2 output tiles x 8 k-steps x 4 real products = 64 v_mfma_f64_16x16x4_f64).
-// grid (npairs, ceil(2n/16/4)); n is a multiple of 16.
-__global__ __launch_bounds__(256) void k_jacobi_cols(int n, int nb, int round, cd* __restrict__ A, int64_t lda,
-                                                     cd* __restrict__ V, int64_t ldv, const cd* __restrict__ Ubuf) {
-    int bp, bq;
-    tournament_pair(nb, round, blockIdx.x, bp, bq);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    const int r0 = (blockIdx.y * 4 + wave) * 16;
-    if (r0 >= 2 * n) return;
-    cd* M = r0 < n ? A : V;
-    const int64_t ld = r0 < n ? lda : ldv;
-    const int rr0 = r0 < n ? r0 : r0 - n;
-    const cd* U = Ubuf + (int64_t)blockIdx.x * J2B * J2B;
-    v4d_t accR[2], accI[2];
-    accR[0] = accR[1] = accI[0] = accI[1] = (v4d_t){0.0, 0.0, 0.0, 0.0};
-    cd fa[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) fa[t] = M[rr0 + li + (int64_t)pair_index(bp, bq, 4 * t + lk) * ld];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const double ar = fa[t].x, ai = fa[t].y, nai = -ai;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const cd u = U[(4 * t + lk) + (16 * c + li) * J2B];
-            accR[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, u.x, accR[c], 0, 0, 0);
-            accR[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, u.y, accR[c], 0, 0, 0);
-            accI[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, u.y, accI[c], 0, 0, 0);
-            accI[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, u.x, accI[c], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int64_t gc = pair_index(bp, bq, 16 * c + li);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            M[rr0 + lk + 4 * r + gc * ld] = make_double2(accR[c][r], accI[c][r]);
-    }
-}
-
-// rows: A[rows(pair), :] <- U^H * A[rows(pair), :]; one wave owns the 32 pair rows of a 16-column strip.
-// grid (npairs, ceil(n/16/4))
-__global__ __launch_bounds__(256) void k_jacobi_rows(int n, int nb, int round, cd* __restrict__ A, int64_t lda,
-                                                     const cd* __restrict__ Ubuf) {
-    int bp, bq;
-    tournament_pair(nb, round, blockIdx.x, bp, bq);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    const int c0 = (blockIdx.y * 4 + wave) * 16;
-    if (c0 >= n) return;
-    const cd* U = Ubuf + (int64_t)blockIdx.x * J2B * J2B;
-    v4d_t accR[2], accI[2];
-    accR[0] = accR[1] = accI[0] = accI[1] = (v4d_t){0.0, 0.0, 0.0, 0.0};
-    cd fb[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) fb[t] = A[pair_index(bp, bq, 4 * t + lk) + (int64_t)(c0 + li) * lda];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const double br = fb[t].x, bi = fb[t].y;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const cd u = U[(4 * t + lk) + (16 * it + li) * J2B];   // A operand: conj(U[k][i])
-            const double nui = -u.y;
-            accR[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(u.x, br, accR[it], 0, 0, 0);
-            accR[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(u.y, bi, accR[it], 0, 0, 0);
-            accI[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(u.x, bi, accI[it], 0, 0, 0);
-            accI[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(nui, br, accI[it], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < 2; ++it)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int gr = pair_index(bp, bq, 16 * it + lk + 4 * r);
-            A[gr + (int64_t)(c0 + li) * lda] = make_double2(accR[it][r], accI[it][r]);
-        }
-}
-
-// Fused two-sided update of one round (replaces k_jacobi_cols + k_jacobi_rows: one launch less per round
-// and half the work on A thanks to the Hermitian symmetry):
+// Two-sided update of one round in ONE launch (half the work on A thanks to the Hermitian symmetry; f64 MFMA):
 //   workgroups [0, ntiles):  tile (i <= j) of the pair partition, A_ij <- U_i^H A_ij U_j (32x32), the mirror
 //                            tile A_ji = A_ij^H is written along with it;  wave w owns the output quadrant
 //                            (w >> 1, w & 1): 32 MFMAs for T = A_ij U_j (through LDS), 32 for U_i^H T;
@@ -907,7 +826,6 @@ int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, 
     int sweep = 0;
     const int maxsweeps = 40;
     bool done = (off2 <= tol * tol * (dg2 + off2)) && off2 == 0.0;
-    static const bool fused_update = getenv("DFTK_MI_HEEV_UNFUSED") == nullptr;
     bool skip_next_check = off2 > 1e-4 * (dg2 + off2);   // the initial matrix is already measured
     for (; sweep < maxsweeps && !done; ++sweep) {
         for (int round = -1; round < nb - 1; ++round) {
@@ -915,16 +833,9 @@ int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, 
             // same pairing through a negative round index
             hipLaunchKernelGGL(k_jacobi_pair, dim3(npairs), dim3(256), 0, b->stream, np, nb, round, W, (int64_t)np,
                                Ubuf, round < 0 ? 1 : 0);
-            if (fused_update) {
-                const int ntiles = npairs * (npairs + 1) / 2, vblocks = (np / 16 + 3) / 4;
-                hipLaunchKernelGGL(k_jacobi_update, dim3(ntiles + npairs * vblocks), dim3(256), 0, b->stream, np, nb,
-                                   round, W, (int64_t)np, Vw, (int64_t)np, Ubuf, ntiles, vblocks);
-            } else {
-                hipLaunchKernelGGL(k_jacobi_cols, dim3(npairs, (2 * np / 16 + 3) / 4), dim3(256), 0, b->stream, np, nb,
-                                   round, W, (int64_t)np, Vw, (int64_t)np, Ubuf);
-                hipLaunchKernelGGL(k_jacobi_rows, dim3(npairs, (np / 16 + 3) / 4), dim3(256), 0, b->stream, np, nb,
-                                   round, W, (int64_t)np, Ubuf);
-            }
+            const int ntiles = npairs * (npairs + 1) / 2, vblocks = (np / 16 + 3) / 4;
+            hipLaunchKernelGGL(k_jacobi_update, dim3(ntiles + npairs * vblocks), dim3(256), 0, b->stream, np, nb, round,
+                               W, (int64_t)np, Vw, (int64_t)np, Ubuf, ntiles, vblocks);
         }
         // the sweeps converge linearly down to ~1e-3 and quadratically from there: after a check that saw more
         // than 1e-2 the next sweep cannot reach 1e-14, so its check (a host synchronisation) is skipped

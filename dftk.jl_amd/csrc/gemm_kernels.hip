@@ -6,13 +6,15 @@
 //   Y * cX, X * invR                            :124-132, 234                           (K12, K14)
 // as  C = alpha * op(A) * B + beta * C  with op(A) in {A, A^H}, B never transposed, column-major.
 //
-// A complex product is four real MFMA streams accumulated into two tiles:
-//   Cr += Ar*Br -/+ Ai*Bi ,  Ci += Ar*Bi +/- Ai*Br   (upper signs: A, lower signs: conj(A))
-// Each lane loads one interleaved complex (16 B) per operand fragment straight from global /
-// L2 -- the kernel is MFMA-bound (64 cycles per instruction per SIMD) so no LDS staging is
-// needed to feed it.  One wave owns an (RM*16) x (RN*16) output tile, a workgroup is 4 waves
-// stacked along m.  Long-K products (Gram matrices over n_G) are split along K into slabs that
-// a second kernel reduces in a fixed order => bitwise reproducible results.
+// Kernels:
+//   k_zgemm_3m   default.  Three real MFMA streams per complex product (Karatsuba), 128 x 32 workgroup
+//                tiles, operands staged through LDS, software pipeline with one mid-tile barrier.
+//   k_zgemm_lds  the classic four-product kernel on 128 x 64 tiles (same staging / pipeline), selected
+//                with DFTK_MI_GEMM_4M=1; kept as the measured baseline of the 3M kernel.
+//   k_zgemm_naive  one thread per C entry, no matrix cores (DFTK_MI_GEMM=naive): debugging reference.
+//   k_zgemm_reduce fixed-order sum of the split-K slabs => bitwise reproducible results.
+// Host side: tiling into full tiles + ragged border, a cost-model K split that fills the resident
+// workgroup slots once, XCD-aware 1-D grids (zgemm(), gemm_tiling(), gemm_plan_split()).
 #include "common.h"
 #include <cstdio>
 #include <cstdlib>
@@ -32,178 +34,11 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // lane mapping of v_mfma_f64_16x16x4_f64:
 //   A operand: lane l holds A[i = l & 15][k = l >> 4];  B operand: lane l holds B[k = l >> 4][j = l & 15]
 //   C/D: 4 values per lane, value r is C[row = (l >> 4) + 4 r][col = l & 15]
-// The four k slots of one MFMA need not be consecutive k values: each lane loads TWO consecutive k
-// (32 B, so the four lanes of a column cover a whole 128-B line of a K-major operand) and feeds
-// them to two MFMAs; a k-step is therefore 8 deep.
-//
-// Grid: 1-D, XCD-aware.  Workgroup id -> (xcd = id % 8, slot = id / 8); the column tiles of one
-// (k-slice, row-panel) pair are consecutive slots of the SAME XCD, so the A panel they share is
-// served by that XCD's L2 instead of being re-fetched through eight different L2s.
-// Tiles that lie completely outside the matrix (m, n not multiples of the tile) are skipped.
-template <bool CONJA>
-__global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_mfma(int m, int n, int K, int kchunk, int gm, int gn,
-                                                                int nsplit, const cd* __restrict__ A, int64_t lda,
-                                                                const cd* __restrict__ B, int64_t ldb,
-                                                                cd* __restrict__ C, int64_t ldc, cd alpha, cd beta,
-                                                                cd* __restrict__ slab) {
-    const int id = blockIdx.x;
-    const int xcd = id & 7, slot = id >> 3;
-    const int col_t = slot % gn;
-    const int R = (slot / gn) * 8 + xcd;
-    if (R >= gm * nsplit) return;
-    const int z = R / gm, row_t = R - z * gm;
-
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    const int i0 = row_t * GEMM_BM + wave * (GEMM_RM * 16);
-    const int j0 = col_t * GEMM_BN;
-    const int kbeg = z * kchunk;
-    const int kend = min(K, kbeg + kchunk);
-    // number of 16-wide tiles of this wave that intersect the matrix (wave-uniform)
-    const int rmv = min(GEMM_RM, max(0, (m - i0 + 15) >> 4));
-    const int rnv = min(GEMM_RN, max(0, (n - j0 + 15) >> 4));
-    if (rmv == 0 || rnv == 0) return;
-
-    v4d accR[GEMM_RM][GEMM_RN], accI[GEMM_RM][GEMM_RN];
-#pragma unroll
-    for (int a = 0; a < GEMM_RM; ++a)
-#pragma unroll
-        for (int b = 0; b < GEMM_RN; ++b) {
-            accR[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
-            accI[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
-        }
-
-    // per-fragment base pointers (clamped so that every load stays in bounds)
-    const cd* pa[GEMM_RM];
-#pragma unroll
-    for (int a = 0; a < GEMM_RM; ++a) {
-        int i = i0 + a * 16 + li;
-        if (i > m - 1) i = m - 1;
-        pa[a] = CONJA ? (A + (int64_t)i * lda) : (A + i);
-    }
-    const cd* pb[GEMM_RN];
-#pragma unroll
-    for (int b = 0; b < GEMM_RN; ++b) {
-        int j = j0 + b * 16 + li;
-        if (j > n - 1) j = n - 1;
-        pb[b] = B + (int64_t)j * ldb;
-    }
-
-    // ---- main loop: full 8-deep k-steps, register double-buffered (loads of step s+1 are in
-    //      flight while the 64 MFMAs of step s issue); every load is unconditional (clamped
-    //      addresses) so that the compiler emits them back to back with a single counted wait.
-    struct Frags {
-        cd a[GEMM_RM][2];
-        cd b[GEMM_RN][2];
-    };
-    auto load_frags = [&](Frags& f, int k0) {
-        const int ka = k0 + 2 * lk;
-#pragma unroll
-        for (int a = 0; a < GEMM_RM; ++a) {
-            f.a[a][0] = CONJA ? pa[a][ka] : pa[a][(int64_t)ka * lda];
-            f.a[a][1] = CONJA ? pa[a][ka + 1] : pa[a][(int64_t)(ka + 1) * lda];
-        }
-#pragma unroll
-        for (int b = 0; b < GEMM_RN; ++b) {
-            f.b[b][0] = pb[b][ka];
-            f.b[b][1] = pb[b][ka + 1];
-        }
-    };
-    auto mfma_step = [&](const Frags& f) {
-#pragma unroll
-        for (int a = 0; a < GEMM_RM; ++a) {
-            if (a < rmv) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const double ar = f.a[a][h].x;
-                    const double ai = f.a[a][h].y;
-                    const double nai = -ai;
-#pragma unroll
-                    for (int b = 0; b < GEMM_RN; ++b)
-                        if (b < rnv) accR[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, f.b[b][h].x, accR[a][b], 0, 0, 0);
-#pragma unroll
-                    for (int b = 0; b < GEMM_RN; ++b)
-                        if (b < rnv) accI[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, f.b[b][h].y, accI[a][b], 0, 0, 0);
-#pragma unroll
-                    for (int b = 0; b < GEMM_RN; ++b)
-                        if (b < rnv)
-                            accR[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(CONJA ? ai : nai, f.b[b][h].y, accR[a][b], 0, 0, 0);
-#pragma unroll
-                    for (int b = 0; b < GEMM_RN; ++b)
-                        if (b < rnv)
-                            accI[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(CONJA ? nai : ai, f.b[b][h].x, accI[a][b], 0, 0, 0);
-                }
-            }
-        }
-    };
-    const int kfull = kbeg + ((kend - kbeg) & ~7);
-    if (kfull > kbeg) {
-        Frags cur, nxt;
-        load_frags(cur, kbeg);
-        for (int k0 = kbeg; k0 < kfull; k0 += 8) {
-            const bool more = (k0 + 8) < kfull;
-            if (more) load_frags(nxt, k0 + 8);
-            mfma_step(cur);
-            if (more) cur = nxt;
-        }
-    }
-    // ---- tail: fewer than 8 k left, masked
-    if (kfull < kend) {
-        const cd czero = make_double2(0.0, 0.0);
-        const int ka = kfull + 2 * lk, kb2 = ka + 1;
-        const bool va = ka < kend, vb = kb2 < kend;
-        const int kca = va ? ka : (kend - 1), kcb = vb ? kb2 : (kend - 1);
-        Frags f;
-#pragma unroll
-        for (int a = 0; a < GEMM_RM; ++a) {
-            const cd v0 = CONJA ? pa[a][kca] : pa[a][(int64_t)kca * lda];
-            const cd v1 = CONJA ? pa[a][kcb] : pa[a][(int64_t)kcb * lda];
-            f.a[a][0] = va ? v0 : czero;
-            f.a[a][1] = vb ? v1 : czero;
-        }
-#pragma unroll
-        for (int b = 0; b < GEMM_RN; ++b) {
-            const cd v0 = pb[b][kca];
-            const cd v1 = pb[b][kcb];
-            f.b[b][0] = va ? v0 : czero;
-            f.b[b][1] = vb ? v1 : czero;
-        }
-        mfma_step(f);
-    }
-
-    // epilogue
-    const bool direct = (slab == nullptr);
-    cd* sl = direct ? nullptr : slab + (int64_t)z * m * n;
-#pragma unroll
-    for (int a = 0; a < GEMM_RM; ++a)
-#pragma unroll
-        for (int b = 0; b < GEMM_RN; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gi = i0 + a * 16 + lk + 4 * r;
-                const int gj = j0 + b * 16 + li;
-                if (gi < m && gj < n) {
-                    const double vr = accR[a][b][r], vi = accI[a][b][r];
-                    if (direct) {
-                        cd* c = C + gi + (int64_t)gj * ldc;
-                        cd o = make_double2(alpha.x * vr - alpha.y * vi, alpha.x * vi + alpha.y * vr);
-                        if (beta.x != 0.0 || beta.y != 0.0) {
-                            const cd old = *c;
-                            o.x += beta.x * old.x - beta.y * old.y;
-                            o.y += beta.x * old.y + beta.y * old.x;
-                        }
-                        *c = o;
-                    } else {
-                        sl[gi + (int64_t)gj * m] = make_double2(vr, vi);
-                    }
-                }
-            }
-}
 
 // ------------------------------------------------------------------------------------------------
-// LDS-staged variant (default).  Same tiling / grid / epilogue as k_zgemm_mfma, but the K-tile
-// (8 deep) of both operands is staged through LDS:
+// LDS-staged four-product kernel.  A wave owns a 32 x 64 output tile (two accumulator sets of 8 MFMA
+// tiles = 128 VGPRs), a workgroup is 4 waves stacked along m.  The K-tile (8 deep) of both operands is
+// staged through LDS:
 //   * global reads are fully coalesced (8 lanes x 16 B = one 128-B line per column of a K-major
 //     operand; 128 consecutive rows of an M-major one) and each element is fetched ONCE per
 //     workgroup instead of once per wave that needs it;
@@ -278,14 +113,10 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_lds(int m, int n, int
     // bit 1 of `upper`: B is upper triangular (B[k][j] = 0 for k > j) -> this tile column stops at k = J0 + BN
     const int kend = min(min(K, kbeg + kchunk), (upper & 2) ? J0 + GEMM_BN : K);
     // MODE 1: every tile of the launch is full (no predicates anywhere).  MODE 0: predicated only.
-    // MODE 2: one launch over ALL tiles; full workgroups take the predicate-free steady-state loop,
-    //         ragged ones the predicated loop -- the border shares its A/B panels with the interior
-    //         tiles through L2 instead of re-reading them from HBM in a second launch.
     constexpr bool FULL = MODE == 1;
     const int rmv = FULL ? GEMM_RM : min(GEMM_RM, max(0, (m - i0 + 15) >> 4));
     const int rnv = FULL ? GEMM_RN : min(GEMM_RN, max(0, (n - J0 + 15) >> 4));
     const bool active = FULL || (rmv > 0 && rnv > 0);
-    const bool block_full = FULL || (MODE == 2 && I0 + GEMM_BM <= m && J0 + GEMM_BN <= n);
 
     v4d accR[GEMM_RM][GEMM_RN], accI[GEMM_RM][GEMM_RN];
 #pragma unroll
@@ -463,7 +294,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_lds(int m, int n, int
         __syncthreads();
         Frag f0 = read_frag(0, 0);
         int t = 0;
-        if (MODE != 0 && block_full) {
+        if (FULL) {
             // steady state (tiles t+1, t+2, t+3 exist): one branch-free block, and the
             // scheduler is told to drop one memory instruction into the shadow of each MFMA so that this
             // wave alone keeps the matrix pipe fed (the two workgroups of a CU run in lockstep, so
@@ -629,14 +460,10 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm
     // bit 1 of `upper`: B is upper triangular (B[k][j] = 0 for k > j) -> this tile column stops at k = J0 + BN
     const int kend = min(min(K, kbeg + kchunk), (upper & 2) ? J0 + M3_BN : K);
     // MODE 1: every tile of the launch is full (no predicates anywhere).  MODE 0: predicated only.
-    // MODE 2: one launch over ALL tiles; full workgroups take the predicate-free steady-state loop,
-    //         ragged ones the predicated loop -- the border shares its A/B panels with the interior
-    //         tiles through L2 instead of re-reading them from HBM in a second launch.
     constexpr bool FULL = MODE == 1;
     const int rmv = FULL ? GEMM_RM : min(GEMM_RM, max(0, (m - i0 + 15) >> 4));
     const int rnv = FULL ? M3_RN : min(M3_RN, max(0, (n - J0 + 15) >> 4));
     const bool active = FULL || (rmv > 0 && rnv > 0);
-    const bool block_full = FULL || (MODE == 2 && I0 + GEMM_BM <= m && J0 + M3_BN <= n);
 
     // three real products per complex one (Karatsuba / "3M"):
     //   P1 = sum Ar Br, P2 = sum Ai Bi, P3 = sum (Ar +/- Ai)(Br + Bi)   (- for conj(A))
@@ -810,7 +637,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm
         __syncthreads();
         Frag f0 = read_frag(0, 0);
         int t = 0;
-        if (MODE != 0 && block_full) {
+        if (FULL) {
             // steady state (tiles t+1, t+2, t+3 exist): one branch-free block, and the
             // scheduler is told to drop one memory instruction into the shadow of each MFMA so that this
             // wave alone keeps the matrix pipe fed (the two workgroups of a CU run in lockstep, so
@@ -1206,103 +1033,68 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
         HIPCHK(hipGetLastError());
         return 0;
     }
-    const int gm = (int)((m + GEMM_BM - 1) / GEMM_BM);
-    const int gn = (int)((n + GEMM_BN - 1) / GEMM_BN);
-    const int64_t slots2 = gemm_slots2();
     const int64_t plane = (int64_t)m * n * (int64_t)sizeof(cd);
-    auto plan_split = [&](const std::vector<int>& live_rows, int kind, int64_t slots) -> Split {
-        return gemm_plan_split(m, n, k, upper, live_rows, kind, slots);
-    };
     // XCD-aware 1-D grid over a gm_s x gn_s sub-grid of tiles (x nsplit K chunks)
     auto grid_for = [&](int gm_s, int gn_s, int ns) -> int64_t {
         const int64_t rows_total = (int64_t)gm_s * ns;
         return ((rows_total + 7) / 8) * 8 * gn_s;
     };
-    if (b->use_mfma == 2) {   // direct-from-global variant (env DFTK_MI_GEMM=direct)
-        Split sp = plan_split(std::vector<int>(gm, gn), 0, slots2);
-        sp.zmajor = false;
-        if (sp.nsplit > 1) {
-            CHK(ensure_ws(b, (size_t)sp.nsplit * plane));
-            sp.slab = (cd*)b->ws;
-        }
-        if (grid_for(gm, gn, sp.nsplit) > INT32_MAX) return DFTK_MI_EINVAL;
-        dim3 grid((unsigned)grid_for(gm, gn, sp.nsplit));
-        if (conja)
-            hipLaunchKernelGGL(k_zgemm_mfma<true>, grid, dim3(GEMM_WAVES * 64), 0, b->stream, (int)m, (int)n, (int)k,
-                               sp.kchunk, gm, gn, sp.nsplit, A, lda, B, ldb, C, ldc, alpha, beta, sp.slab);
-        else
-            hipLaunchKernelGGL(k_zgemm_mfma<false>, grid, dim3(GEMM_WAVES * 64), 0, b->stream, (int)m, (int)n, (int)k,
-                               sp.kchunk, gm, gn, sp.nsplit, A, lda, B, ldb, C, ldc, alpha, beta, sp.slab);
-        if (sp.nsplit > 1)
-            hipLaunchKernelGGL(k_zgemm_reduce, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, b->stream, (int)m,
-                               (int)n, (int)m, (int)n, sp.nsplit, sp.slab, sp.nsplit, sp.slab, C, ldc, alpha, beta, 0);
-    } else {
-        // interior tiles run the predicate-free kernel; the ragged right / bottom strips the general one,
-        // as ONE list-shaped launch (right strip: all tile rows of the last tile column; bottom strip:
-        // the full tile columns of the last tile row) with its own K split
-        static const bool use3m = getenv("DFTK_MI_GEMM_4M") == nullptr;   // DFTK_MI_GEMM_4M=1: classic 4-product kernels
-        const GemmTiling til = gemm_tiling(conja, m, n, k, upper, use3m);
-        const int BNt = til.BNt, gmf = til.gmf, gnf = til.gnf, nright = til.nright, nbottom = til.nbottom;
-        const int64_t tilesI_total = (int64_t)gmf * gnf;
-        Split spI = til.I, spB = til.B;
-        const size_t bytesI = spI.nsplit > 1 ? (size_t)spI.nsplit * plane : 0;
-        const size_t bytesB = spB.nsplit > 1 ? (size_t)spB.nsplit * plane : 0;
-        if (bytesI + bytesB) CHK(ensure_ws(b, bytesI + bytesB));
-        if (bytesI) spI.slab = (cd*)b->ws;
-        if (bytesB) spB.slab = (cd*)((char*)b->ws + bytesI);
-        static const int pad_lds = getenv("DFTK_MI_GEMM_PAD_LDS") ? atoi(getenv("DFTK_MI_GEMM_PAD_LDS")) : 0;   // occupancy experiments
-        auto launch = [&](int mode, int gm_s, int gn_s, int rt0, int ct0, int lsplit, const Split& sp) -> int {
-            if (gm_s <= 0 || gn_s <= 0) return 0;
-            const bool zmajor = sp.zmajor;
-            const int64_t nblk = zmajor ? (int64_t)((sp.nsplit + 7) / 8) * 8 * gm_s * gn_s : grid_for(gm_s, gn_s, sp.nsplit);
-            if (nblk > INT32_MAX) return DFTK_MI_EINVAL;
-            dim3 grid((unsigned)nblk);
-            const int upper = upper_in | (zmajor ? 4 : 0);
+    // Full tiles run the predicate-free instantiation (a ragged last tile column as one more full tile,
+    // shifted left); the remaining ragged strips the predicated one, as ONE list-shaped launch (right strip:
+    // all tile rows of the last tile column; bottom strip: the tile columns of the last tile row) with its own
+    // K split.  (One mixed launch over all tiles was measured 2-7 % faster on the block updates, but the light
+    // border workgroups run ahead of their siblings through k and FETCH_SIZE rose from 2.3x to 3.5x the
+    // operand bytes -- dropped.)
+    static const bool use3m = getenv("DFTK_MI_GEMM_4M") == nullptr;   // DFTK_MI_GEMM_4M=1: classic 4-product kernels
+    const GemmTiling til = gemm_tiling(conja, m, n, k, upper, use3m);
+    const int BNt = til.BNt, gmf = til.gmf, gnf = til.gnf, nright = til.nright, nbottom = til.nbottom;
+    Split spI = til.I, spB = til.B;
+    const size_t bytesI = spI.nsplit > 1 ? (size_t)spI.nsplit * plane : 0;
+    const size_t bytesB = spB.nsplit > 1 ? (size_t)spB.nsplit * plane : 0;
+    if (bytesI + bytesB) CHK(ensure_ws(b, bytesI + bytesB));
+    if (bytesI) spI.slab = (cd*)b->ws;
+    if (bytesB) spB.slab = (cd*)((char*)b->ws + bytesI);
+    static const int pad_lds = getenv("DFTK_MI_GEMM_PAD_LDS") ? atoi(getenv("DFTK_MI_GEMM_PAD_LDS")) : 0;   // occupancy experiments
+    auto launch = [&](int mode, int gm_s, int gn_s, int rt0, int ct0, int lsplit, const Split& sp) -> int {
+        if (gm_s <= 0 || gn_s <= 0) return 0;
+        const bool zmajor = sp.zmajor;
+        const int64_t nblk = zmajor ? (int64_t)((sp.nsplit + 7) / 8) * 8 * gm_s * gn_s : grid_for(gm_s, gn_s, sp.nsplit);
+        if (nblk > INT32_MAX) return DFTK_MI_EINVAL;
+        dim3 grid((unsigned)nblk);
+        const int upper = upper_in | (zmajor ? 4 : 0);
 #define DFTK_LAUNCH_LDS(CJ, FL)                                                                                        \
     hipLaunchKernelGGL((k_zgemm_lds<CJ, FL>), grid, dim3(GEMM_WAVES * 64), pad_lds, b->stream, (int)m, (int)n, (int)k, \
                        sp.kchunk, gm_s, gn_s, rt0, ct0, lsplit, upper, sp.nsplit, A, lda, B, ldb, C, ldc, alpha, beta, sp.slab)
-            if (use3m) {   // 3M kernels on 128 x 32 tiles: mode 1 = full tiles, 0 = predicated border
 #define DFTK_LAUNCH_3M(CJ, MD)                                                                                         \
-    hipLaunchKernelGGL((k_zgemm_3m<CJ, MD>), grid, dim3(GEMM_WAVES * 64), pad_lds, b->stream, (int)m, (int)n, (int)k, \
-                       sp.kchunk, gm_s, gn_s, rt0, ct0, lsplit, upper, til.shift ? gnf : -1, sp.nsplit, A, lda, B, ldb, C, ldc,  \
-                       alpha, beta, sp.slab)
-                if (conja) {
-                    if (mode == 1) DFTK_LAUNCH_3M(true, 1);
-                    else DFTK_LAUNCH_3M(true, 0);
-                } else {
-                    if (mode == 1) DFTK_LAUNCH_3M(false, 1);
-                    else DFTK_LAUNCH_3M(false, 0);
-                }
-#undef DFTK_LAUNCH_3M
-            } else if (conja) {
-                if (mode == 1) DFTK_LAUNCH_LDS(true, 1);
-                else if (mode == 2) DFTK_LAUNCH_LDS(true, 2);
-                else DFTK_LAUNCH_LDS(true, 0);
+    hipLaunchKernelGGL((k_zgemm_3m<CJ, MD>), grid, dim3(GEMM_WAVES * 64), pad_lds, b->stream, (int)m, (int)n, (int)k,  \
+                       sp.kchunk, gm_s, gn_s, rt0, ct0, lsplit, upper, til.shift ? gnf : -1, sp.nsplit, A, lda, B, ldb, C, \
+                       ldc, alpha, beta, sp.slab)
+        // mode 1 = full tiles, 0 = predicated border
+        if (use3m) {
+            if (conja) {
+                if (mode == 1) DFTK_LAUNCH_3M(true, 1);
+                else DFTK_LAUNCH_3M(true, 0);
             } else {
-                if (mode == 1) DFTK_LAUNCH_LDS(false, 1);
-                else if (mode == 2) DFTK_LAUNCH_LDS(false, 2);
-                else DFTK_LAUNCH_LDS(false, 0);
+                if (mode == 1) DFTK_LAUNCH_3M(false, 1);
+                else DFTK_LAUNCH_3M(false, 0);
             }
-#undef DFTK_LAUNCH_LDS
-            return 0;
-        };
-        // Experiment (DFTK_MI_GEMM_MIXED=1): ONE launch over all tiles, full workgroups predicate-free and
-        // ragged ones predicated.  Measured on the n_G x M block updates: 2-7 % faster than two launches,
-        // but the light border workgroups run ahead of their siblings through k, their A tiles are evicted
-        // before the full tiles arrive and FETCH_SIZE rises from 2.3x to 3.5x the operand bytes -> off.
-        static const bool mixed = getenv("DFTK_MI_GEMM_MIXED") != nullptr;
-        if (mixed && !use3m && spI.nsplit == 1 && spB.nsplit == 1 && tilesI_total >= slots2 && !(upper & 1)) {
-            Split one{1, spI.kchunk, false, nullptr};
-            CHK(launch(2, gm, gn, 0, 0, -1, one));
+        } else if (conja) {
+            if (mode == 1) DFTK_LAUNCH_LDS(true, 1);
+            else DFTK_LAUNCH_LDS(true, 0);
         } else {
-            CHK(launch(1, gmf, til.gnI, 0, 0, -1, spI));
-            CHK(launch(0, nright + nbottom, 1, gmf, gnf, nright, spB));
+            if (mode == 1) DFTK_LAUNCH_LDS(false, 1);
+            else DFTK_LAUNCH_LDS(false, 0);
         }
-        if (spI.slab || spB.slab)
-            hipLaunchKernelGGL(k_zgemm_reduce, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, b->stream, (int)m,
-                               (int)n, gmf * GEMM_BM, til.shift ? (int)n : gnf * BNt, spI.slab ? spI.nsplit : -1, spI.slab,
-                               spB.slab ? spB.nsplit : -1, spB.slab, C, ldc, alpha, beta, upper);
-    }
+#undef DFTK_LAUNCH_3M
+#undef DFTK_LAUNCH_LDS
+        return 0;
+    };
+    CHK(launch(1, gmf, til.gnI, 0, 0, -1, spI));
+    CHK(launch(0, nright + nbottom, 1, gmf, gnf, nright, spB));
+    if (spI.slab || spB.slab)
+        hipLaunchKernelGGL(k_zgemm_reduce, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, b->stream, (int)m,
+                           (int)n, gmf * GEMM_BM, til.shift ? (int)n : gnf * BNt, spI.slab ? spI.nsplit : -1, spI.slab,
+                           spB.slab ? spB.nsplit : -1, spB.slab, C, ldc, alpha, beta, upper);
     HIPCHK(hipGetLastError());
     return 0;
 }

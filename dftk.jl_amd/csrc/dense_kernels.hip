@@ -413,9 +413,16 @@ __global__ __launch_bounds__(256) void k_normest_upper(int n, const cd* __restri
 
 // ---------------------------------------------------------------------------- Hermitian eigensolver
 // Blocked two-sided Jacobi with round-robin (tournament) ordering.  Block size JB; per round the
-// n/(2 JB) disjoint block pairs are (1) diagonalised approximately in LDS by one cyclic Jacobi
-// sweep (k_jacobi_pair), (2) the rotations are applied to the columns of A and V and (3) to the
-// rows of A.
+// n/(2 JB) disjoint block pairs are diagonalised approximately in LDS by one cyclic Jacobi sweep (the
+// "pair" part), and the accumulated 32 x 32 rotations U are applied two-sided to A and to the columns of V
+// (the "update" part, f64 MFMA).
+// Both parts of consecutive rounds run in ONE launch (k_jacobi_round): the pair workgroups of round r do
+// not wait for the update of round r-1 -- they apply U(r-1) themselves to the three 32 x 32 tiles their
+// 2 x 2 block problem lives in (reading the matrix as it was BEFORE round r-1, hence the update writes out of
+// place into a second copy) while the update workgroups of round r-1 fill the rest of the chip.  The
+// latency-bound pair solve is the whole critical path: one launch of ~22 us per round instead of two
+// (18 + 13 us).
+typedef double v4d_t __attribute__((ext_vector_type(4)));
 #define JB 16
 #define J2B (2 * JB)
 
@@ -438,6 +445,25 @@ __device__ __forceinline__ void tournament_pair(int nb, int round, int k, int& p
     q = a < b2 ? b2 : a;
 }
 
+// inverse of tournament_pair: block `blk` is member h (0: the smaller index) of pair k in `round`
+__device__ __forceinline__ void tournament_find(int nb, int round, int blk, int& k, int& h) {
+    if (round < 0) {
+        k = blk >> 1;
+        h = blk & 1;
+        return;
+    }
+    const int m = nb - 1;
+    if (blk == m || blk == round) {
+        k = 0;
+    } else {
+        const int d = (blk - round + m) % m;
+        k = (d <= nb / 2 - 1) ? d : m - d;
+    }
+    int p, q;
+    tournament_pair(nb, round, k, p, q);
+    h = (blk == p) ? 0 : 1;
+}
+
 // mode 0 ("cross", round in [0, nb-1)): tournament block pair (bp, bq); rotates the JB*JB cross pairs
 //        (i, JB + (i + r) % JB), r = 0..JB-1 -- every (i, j) with i in block p and j in block q once.
 // mode 1 ("diag", one launch per sweep): block pair (2k, 2k+1); rotates the within-block pairs of both
@@ -446,24 +472,86 @@ __device__ __forceinline__ void tournament_pair(int nb, int round, int k, int& p
 // recomputes the rotations of pairs k1 and k2 itself from S[cur] (no parameter exchange through LDS, no
 // serial 16-thread phase), applies them two-sided to its 2x2 block and column-wise to two rows of U
 // (in place: nobody else touches those entries in this round).
-__global__ __launch_bounds__(256) void k_jacobi_pair(int n, int nb, int round, cd* __restrict__ A, int64_t lda,
-                                                     cd* __restrict__ Ubuf, int mode) {
-    __shared__ cd S[2][J2B][J2B + 1];
-    __shared__ cd U[J2B][J2B + 1];
+// Look-ahead (have_prev): A is the matrix BEFORE round prev_round and Uprev that round's rotations; the
+// 2 x 2 block problem of this round is  S[r][c] = u_r^H A[rows(P(r)), cols(P(c))] u_c  with P(.) the
+// prev_round pair a block belonged to and u the matching 16 columns of that pair's U.
+__device__ __forceinline__ void jacobi_pair_part(int pair_id, int nb, int round, int prev_round, bool have_prev,
+                                                 const cd* __restrict__ A, int64_t lda,
+                                                 const cd* __restrict__ Uprev, cd* __restrict__ Ubuf,
+                                                 cd (*S)[J2B][J2B + 1], cd (*U)[J2B + 1]) {
+    const int mode = round < 0 ? 1 : 0;
     int bp, bq;
-    if (mode == 0) {
-        tournament_pair(nb, round, blockIdx.x, bp, bq);
-    } else {
-        bp = 2 * blockIdx.x;
-        bq = bp + 1;
-    }
+    tournament_pair(nb, round, pair_id, bp, bq);
     const int tid = threadIdx.x;
-    // load the 2x2 block sub-matrix (global index of local i)
+    if (!have_prev) {
+        // load the 2x2 block sub-matrix (global index of local i)
+        for (int e = tid; e < J2B * J2B; e += 256) {
+            const int c = e / J2B, r = e - c * J2B;
+            const int gr = (r < JB ? bp * JB + r : bq * JB + (r - JB));
+            const int gc = (c < JB ? bp * JB + c : bq * JB + (c - JB));
+            S[0][r][c] = A[gr + (int64_t)gc * lda];
+        }
+    } else {
+        int ka, ha, kb, hb, pa, qa, pb, qb;
+        tournament_find(nb, prev_round, bp, ka, ha);
+        tournament_find(nb, prev_round, bq, kb, hb);
+        tournament_pair(nb, prev_round, ka, pa, qa);
+        tournament_pair(nb, prev_round, kb, pb, qb);
+        // waves 0..2 take the three tiles (row side, column side) = (a,a), (a,b), (b,b); only the 16 x 16
+        // quadrant (h_row, h_col) of  U_row^H T U_col  is needed.  f64 MFMA straight from global operands: the
+        // accumulator layout of  Y = T U_col[:, h_col]  (value r = row lk + 4r) is exactly the B-operand layout
+        // of the second product, so Y never leaves the registers (96 MFMAs per wave).
+        const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+        if (wave < 3) {
+            const bool rb = wave == 2, cb = wave >= 1;
+            const int rp = rb ? pb : pa, rq = rb ? qb : qa, cp = cb ? pb : pa, cq = cb ? qb : qa;
+            const cd* UR = Uprev + (int64_t)(rb ? kb : ka) * J2B * J2B + (int64_t)(JB * (rb ? hb : ha)) * J2B;
+            const cd* UC = Uprev + (int64_t)(cb ? kb : ka) * J2B * J2B + (int64_t)(JB * (cb ? hb : ha)) * J2B;
+            cd fa[2][8], uc[8], ur[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int k = 4 * t + lk;
+                const int64_t gc = (k < JB ? cp * JB + k : cq * JB + (k - JB));
+                fa[0][t] = A[(rp * JB + li) + gc * lda];
+                fa[1][t] = A[(rq * JB + li) + gc * lda];
+                uc[t] = UC[k + li * J2B];
+                ur[t] = UR[k + li * J2B];   // A operand of the second product: conj(U_row[k][row li])
+            }
+            v4d_t yR[2], yI[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                yR[h] = yI[h] = (v4d_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const double ar = fa[h][t].x, ai = fa[h][t].y, nai = -ai;
+                    yR[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, uc[t].x, yR[h], 0, 0, 0);
+                    yI[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, uc[t].y, yI[h], 0, 0, 0);
+                    yR[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, uc[t].y, yR[h], 0, 0, 0);
+                    yI[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, uc[t].x, yI[h], 0, 0, 0);
+                }
+            }
+            v4d_t zR = (v4d_t){0.0, 0.0, 0.0, 0.0}, zI = (v4d_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {   // k-step (h, r): k = 16 h + 4 r + lk
+                    const cd u = ur[4 * h + r];
+                    const double br = yR[h][r], bi = yI[h][r], nui = -u.y;
+                    zR = __builtin_amdgcn_mfma_f64_16x16x4f64(u.x, br, zR, 0, 0, 0);
+                    zI = __builtin_amdgcn_mfma_f64_16x16x4f64(u.x, bi, zI, 0, 0, 0);
+                    zR = __builtin_amdgcn_mfma_f64_16x16x4f64(u.y, bi, zR, 0, 0, 0);
+                    zI = __builtin_amdgcn_mfma_f64_16x16x4f64(nui, br, zI, 0, 0, 0);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = lk + 4 * r;
+                S[0][JB * (rb ? 1 : 0) + i][JB * (cb ? 1 : 0) + li] = make_double2(zR[r], zI[r]);
+                if (wave == 1) S[0][JB + li][i] = make_double2(zR[r], -zI[r]);
+            }
+        }
+    }
     for (int e = tid; e < J2B * J2B; e += 256) {
         const int c = e / J2B, r = e - c * J2B;
-        const int gr = (r < JB ? bp * JB + r : bq * JB + (r - JB));
-        const int gc = (c < JB ? bp * JB + c : bq * JB + (c - JB));
-        S[0][r][c] = A[gr + (int64_t)gc * lda];
         U[r][c] = make_double2(r == c ? 1.0 : 0.0, 0.0);
     }
     __syncthreads();
@@ -550,33 +638,33 @@ __global__ __launch_bounds__(256) void k_jacobi_pair(int n, int nb, int round, c
         __syncthreads();
         cur ^= 1;
     }
-    cd* Uo = Ubuf + (int64_t)blockIdx.x * J2B * J2B;
+    cd* Uo = Ubuf + (int64_t)pair_id * J2B * J2B;
     for (int e = tid; e < J2B * J2B; e += 256) {
         const int c = e / J2B, r = e - c * J2B;
         Uo[e] = U[r][c];   // column-major 2b x 2b
     }
 }
 
-typedef double v4d_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int pair_index(int bp, int bq, int kk) {
     return kk < JB ? bp * JB + kk : bq * JB + (kk - JB);
 }
 
-// Two-sided update of one round in ONE launch (half the work on A thanks to the Hermitian symmetry; f64 MFMA):
-//   workgroups [0, ntiles):  tile (i <= j) of the pair partition, A_ij <- U_i^H A_ij U_j (32x32), the mirror
-//                            tile A_ji = A_ij^H is written along with it;  wave w owns the output quadrant
-//                            (w >> 1, w & 1): 32 MFMAs for T = A_ij U_j (through LDS), 32 for U_i^H T;
-//   workgroups [ntiles, ..): V[:, cols(pair)] <- V[:, cols(pair)] U_pair, one wave per 16-row strip.
-__global__ __launch_bounds__(256) void k_jacobi_update(int n, int nb, int round, cd* __restrict__ A, int64_t lda,
-                                                       cd* __restrict__ V, int64_t ldv,
-                                                       const cd* __restrict__ Ubuf, int ntiles, int vblocks) {
-    __shared__ cd Ts[J2B][J2B + 1];
+// Two-sided update of one round (half the work on A thanks to the Hermitian symmetry; f64 MFMA), out of place
+// A -> Aout (every tile is rewritten: each block is in exactly one pair):
+//   ids [0, ntiles):  tile (i <= j) of the pair partition, Aout_ij = U_i^H A_ij U_j (32x32), the mirror
+//                     tile Aout_ji = Aout_ij^H is written along with it;  wave w owns the output quadrant
+//                     (w >> 1, w & 1): 32 MFMAs for T = A_ij U_j (through LDS), 32 for U_i^H T;
+//   ids [ntiles, ..): V[:, cols(pair)] <- V[:, cols(pair)] U_pair (in place), one wave per 16-row strip.
+__device__ __forceinline__ void jacobi_update_part(int id, int n, int nb, int round, const cd* __restrict__ A,
+                                                   cd* __restrict__ Aout, int64_t lda, cd* __restrict__ V,
+                                                   int64_t ldv, const cd* __restrict__ Ubuf, int ntiles, int vblocks,
+                                                   cd (*Ts)[J2B + 1]) {
     const int npairs = nb / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    if ((int)blockIdx.x >= ntiles) {
+    if (id >= ntiles) {
         // ---- eigenvector columns
-        const int vb = blockIdx.x - ntiles;
+        const int vb = id - ntiles;
         const int pj = vb / vblocks;
         const int r0 = ((vb - pj * vblocks) * 4 + wave) * 16;
         if (r0 >= n) return;
@@ -609,7 +697,7 @@ __global__ __launch_bounds__(256) void k_jacobi_update(int n, int nb, int round,
         return;
     }
     // ---- tile (pi <= pj): linear index -> (pi, pj) of the upper triangle (row by row)
-    int pi = 0, rem = blockIdx.x;
+    int pi = 0, rem = id;
     while (rem >= npairs - pi) {
         rem -= npairs - pi;
         ++pi;
@@ -657,9 +745,25 @@ __global__ __launch_bounds__(256) void k_jacobi_update(int n, int nb, int round,
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t gr = pair_index(bpi, bqi, 16 * qi + lk + 4 * r);
-        A[gr + gc * lda] = make_double2(rR[r], rI[r]);
-        if (pi != pj) A[gc + gr * lda] = make_double2(rR[r], -rI[r]);   // mirror tile A_ji = A_ij^H
+        Aout[gr + gc * lda] = make_double2(rR[r], rI[r]);
+        if (pi != pj) Aout[gc + gr * lda] = make_double2(rR[r], -rI[r]);   // mirror tile A_ji = A_ij^H
     }
+}
+
+// One launch per round: pair workgroups of `round` first (they are the critical path), then the update
+// workgroups of `prev_round`.  flags bit 0: pair part present, bit 1: a previous round is pending.
+__global__ __launch_bounds__(256) void k_jacobi_round(int n, int nb, int round, int prev_round, int flags,
+                                                      const cd* __restrict__ Win, cd* __restrict__ Wout, int64_t lda,
+                                                      cd* __restrict__ V, int64_t ldv, const cd* __restrict__ Uprev,
+                                                      cd* __restrict__ Uout, int ntiles, int vblocks) {
+    __shared__ cd S[2][J2B][J2B + 1];
+    __shared__ cd U[J2B][J2B + 1];
+    const int npair_wg = (flags & 1) ? nb / 2 : 0;
+    if ((int)blockIdx.x < npair_wg)
+        jacobi_pair_part(blockIdx.x, nb, round, prev_round, (flags & 2) != 0, Win, lda, Uprev, Uout, S, U);
+    else
+        jacobi_update_part(blockIdx.x - npair_wg, n, nb, prev_round, Win, Wout, lda, V, ldv, Uprev, ntiles, vblocks,
+                           S[0]);
 }
 
 // out[0] = sum |offdiag|^2, out[1] = sum |diag|^2   (whole matrix)
@@ -788,16 +892,17 @@ int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, 
     if (nb < 2) nb = 2;
     const int np = nb * JB;
     const int npairs = nb / 2;
-    // workspace: W (np x np), Vw (np x np), Ubuf (npairs x 2b x 2b), diag (np doubles), perm (np ints)
+    // workspace: W, W2 (np x np, ping-pong), Vw (np x np), 2 x Ubuf (npairs x 2b x 2b), diag (np doubles), perm (np ints)
     const size_t szW = (size_t)np * np * sizeof(cd);
     const size_t szU = (size_t)npairs * J2B * J2B * sizeof(cd);
-    const size_t total = 2 * szW + szU + (size_t)np * (sizeof(double) + sizeof(int)) + 4096 * sizeof(double);
+    const size_t total = 3 * szW + 2 * szU + (size_t)np * (sizeof(double) + sizeof(int)) + 4096 * sizeof(double);
     CHK(dws_ensure(b, &g_dense_ws, &g_dense_ws_bytes, total));
     char* base = reinterpret_cast<char*>(g_dense_ws);
     cd* W = reinterpret_cast<cd*>(base);
     cd* Vw = reinterpret_cast<cd*>(base + szW);
-    cd* Ubuf = reinterpret_cast<cd*>(base + 2 * szW);
-    double* d_diag = reinterpret_cast<double*>(base + 2 * szW + szU);
+    cd* Wb[2] = {W, reinterpret_cast<cd*>(base + 2 * szW)};
+    cd* Ub[2] = {reinterpret_cast<cd*>(base + 3 * szW), reinterpret_cast<cd*>(base + 3 * szW + szU)};
+    double* d_diag = reinterpret_cast<double*>(base + 3 * szW + 2 * szU);
     int* d_perm = reinterpret_cast<int*>(d_diag + np);
     double* d_red = reinterpret_cast<double*>(d_perm + np + (np & 1));
 
@@ -827,23 +932,34 @@ int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, 
     const int maxsweeps = 40;
     bool done = (off2 <= tol * tol * (dg2 + off2)) && off2 == 0.0;
     bool skip_next_check = off2 > 1e-4 * (dg2 + off2);   // the initial matrix is already measured
-    for (; sweep < maxsweeps && !done; ++sweep) {
-        for (int round = -1; round < nb - 1; ++round) {
-            // round -1: within-block rotations on the block pairs (2k, 2k+1); the update kernels see the
-            // same pairing through a negative round index
-            hipLaunchKernelGGL(k_jacobi_pair, dim3(npairs), dim3(256), 0, b->stream, np, nb, round, W, (int64_t)np,
-                               Ubuf, round < 0 ? 1 : 0);
-            const int ntiles = npairs * (npairs + 1) / 2, vblocks = (np / 16 + 3) / 4;
-            hipLaunchKernelGGL(k_jacobi_update, dim3(ntiles + npairs * vblocks), dim3(256), 0, b->stream, np, nb, round,
-                               W, (int64_t)np, Vw, (int64_t)np, Ubuf, ntiles, vblocks);
+    // software pipeline over rounds: launch i = pair part of round i + update part of round i-1
+    const int ntiles = npairs * (npairs + 1) / 2, vblocks = (np / 16 + 3) / 4;
+    int cur = 0, uw = 0, pending_round = 0;
+    bool pending = false;
+    auto launch_round = [&](bool do_pair, int round) {
+        const int flags = (do_pair ? 1 : 0) | (pending ? 2 : 0);
+        const int grid = (do_pair ? npairs : 0) + (pending ? ntiles + npairs * vblocks : 0);
+        if (grid == 0) return;
+        hipLaunchKernelGGL(k_jacobi_round, dim3(grid), dim3(256), 0, b->stream, np, nb, round, pending_round, flags,
+                           Wb[cur], Wb[cur ^ 1], (int64_t)np, Vw, (int64_t)np, Ub[uw ^ 1], Ub[uw], ntiles, vblocks);
+        if (pending) cur ^= 1;      // the update of the pending round has been written to the other copy
+        pending = do_pair;
+        if (do_pair) {
+            pending_round = round;
+            uw ^= 1;
         }
+    };
+    for (; sweep < maxsweeps && !done; ++sweep) {
+        // round -1: within-block rotations on the block pairs (2k, 2k+1); rounds 0 .. nb-2: the tournament
+        for (int round = -1; round < nb - 1; ++round) launch_round(true, round);
         // the sweeps converge linearly down to ~1e-3 and quadratically from there: after a check that saw more
         // than 1e-2 the next sweep cannot reach 1e-14, so its check (a host synchronisation) is skipped
         if (skip_next_check && sweep + 1 < maxsweeps) {
             skip_next_check = false;
             continue;
         }
-        hipLaunchKernelGGL(k_offdiag_norm, dim3(redblocks), dim3(256), 0, b->stream, np, W, (int64_t)np, d_red);
+        launch_round(false, 0);   // drain the pipeline: the check needs the matrix after the last round
+        hipLaunchKernelGGL(k_offdiag_norm, dim3(redblocks), dim3(256), 0, b->stream, np, Wb[cur], (int64_t)np, d_red);
         HIPCHK(hipMemcpyAsync(hred.data(), d_red, hred.size() * sizeof(double), hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
         double o2 = 0.0;
@@ -863,7 +979,7 @@ int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, 
         return DFTK_MI_NUM_EIGEN;
     }
     // eigenvalues = diag(W); sort ascending on the host, gather eigenvector columns
-    hipLaunchKernelGGL(k_extract_diag, dim3((np + 255) / 256), dim3(256), 0, b->stream, np, W, (int64_t)np, d_diag);
+    hipLaunchKernelGGL(k_extract_diag, dim3((np + 255) / 256), dim3(256), 0, b->stream, np, Wb[cur], (int64_t)np, d_diag);
     std::vector<double> diag(np);
     HIPCHK(hipMemcpyAsync(diag.data(), d_diag, np * sizeof(double), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));

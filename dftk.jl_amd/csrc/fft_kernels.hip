@@ -366,12 +366,26 @@ __global__ __launch_bounds__(FFT_THREADS) void k_ybwd(FftAxis ay, int nxp, int n
     const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
     const int x = blockIdx.x * FFT_L + l;
     const int zi = blockIdx.y, band = blockIdx.z;
+    const cd* t1 = T1 + (int64_t)band * T1_stride;
+    const int ln0 = zls[zi] + j, ln1 = zls[zi + 1];
+    // lines of this plane to registers before the prologue (HBM latency overlaps twiddles + zero fill);
+    // up to 3 per thread (96 lines per plane), otherwise the plain loop
+    const bool early = ln1 - zls[zi] <= 3 * FFT_TPL;
+    cd e0, e1, e2;
+    if (early) {
+        if (ln0 < ln1) e0 = t1[(int64_t)ln0 * nxp + x];
+        if (ln0 + FFT_TPL < ln1) e1 = t1[(int64_t)(ln0 + FFT_TPL) * nxp + x];
+        if (ln0 + 2 * FFT_TPL < ln1) e2 = t1[(int64_t)(ln0 + 2 * FFT_TPL) * nxp + x];
+    }
     tile_prologue<FFT_LS>(buf, tw, ay, true);
     __syncthreads();
-    const cd* t1 = T1 + (int64_t)band * T1_stride;
-    const int ln1 = zls[zi + 1];
-    for (int ln = zls[zi] + j; ln < ln1; ln += FFT_TPL)
-        buf[line_ypos[ln] * FFT_LS + l] = t1[(int64_t)ln * nxp + x];
+    if (early) {
+        if (ln0 < ln1) buf[line_ypos[ln0] * FFT_LS + l] = e0;
+        if (ln0 + FFT_TPL < ln1) buf[line_ypos[ln0 + FFT_TPL] * FFT_LS + l] = e1;
+        if (ln0 + 2 * FFT_TPL < ln1) buf[line_ypos[ln0 + 2 * FFT_TPL] * FFT_LS + l] = e2;
+    } else {
+        for (int ln = ln0; ln < ln1; ln += FFT_TPL) buf[line_ypos[ln] * FFT_LS + l] = t1[(int64_t)ln * nxp + x];
+    }
     __syncthreads();
     fft_tile<FFT_LS, false, GEN>(buf, tw, ay, +1.0, l, j);
     cd* t2 = T2 + (int64_t)band * T2_stride + (int64_t)zi * ny * nxp + x;
@@ -400,11 +414,26 @@ __global__ __launch_bounds__(FFT_THREADS, ZPASS_MIN_BLOCKS) void k_zpass(FftAxis
     const int nz = az.n;
     const int64_t plane = (int64_t)ny * nxp;
     cd* t2 = T2 + (int64_t)band * T2_stride + (int64_t)y * nxp + x;
+    // the sphere planes of this column go to registers BEFORE the prologue (twiddles + zero fill), so that the
+    // HBM latency of the tile overlaps it (up to 3 planes per thread: nzx <= 96; more -> plain loop below)
+    const bool early = MODE != 2 && nzx <= 3 * FFT_TPL;
+    cd e0, e1, e2;
+    if (early) {
+        if (j < nzx) e0 = t2[(int64_t)j * plane];
+        if (j + FFT_TPL < nzx) e1 = t2[(int64_t)(j + FFT_TPL) * plane];
+        if (j + 2 * FFT_TPL < nzx) e2 = t2[(int64_t)(j + 2 * FFT_TPL) * plane];
+    }
     tile_prologue<FFT_LS>(buf, tw, az, MODE != 2);
     __syncthreads();
     bool fused_v = false;
     if (MODE != 2) {
-        for (int zi = j; zi < nzx; zi += FFT_TPL) buf[zpos[zi] * FFT_LS + l] = t2[(int64_t)zi * plane];
+        if (early) {
+            if (j < nzx) buf[zpos[j] * FFT_LS + l] = e0;
+            if (j + FFT_TPL < nzx) buf[zpos[j + FFT_TPL] * FFT_LS + l] = e1;
+            if (j + 2 * FFT_TPL < nzx) buf[zpos[j + 2 * FFT_TPL] * FFT_LS + l] = e2;
+        } else {
+            for (int zi = j; zi < nzx; zi += FFT_TPL) buf[zpos[zi] * FFT_LS + l] = t2[(int64_t)zi * plane];
+        }
         __syncthreads();
         fused_v = fft_tile<FFT_LS, false, GEN>(buf, tw, az, +1.0, l, j,
                                        (MODE == 0 && !GEN) ? Vs + (int64_t)y * nxp + x : nullptr, plane);

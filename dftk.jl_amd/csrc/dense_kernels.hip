@@ -373,12 +373,15 @@ __global__ __launch_bounds__(256) void k_trtri_upper_blk(int n, const cd* __rest
     }
 }
 
-// out[0] = max |diag|, out[1] = sum of |offdiag|^2 over the upper triangle, out[2] = non-finite flag
-// blockIdx.x selects the matrix: (M, out) or (M2, out2) -- both estimates in one launch
+// Partial results of column chunk blockIdx.x of matrix blockIdx.y -- (M, out) or (M2, out2), both estimates in
+// one launch: out[3 chunk + 0] = max |diag|, [+1] = sum of |offdiag|^2 over the upper triangle, [+2] = non-finite
+// flag.  The host combines the NORMEST_CHUNKS partials in fixed order.  A wave owns a column (rows contiguous:
+// coalesced, no index division); columns are dealt round-robin so that the triangle is balanced.
+#define NORMEST_CHUNKS 8
 __global__ __launch_bounds__(256) void k_normest_upper(int n, const cd* __restrict__ M, int64_t ldm,
                                                        double* __restrict__ out, const cd* __restrict__ M2,
                                                        int64_t ldm2, double* __restrict__ out2) {
-    if (blockIdx.x == 1) {
+    if (blockIdx.y == 1) {
         M = M2;
         ldm = ldm2;
         out = out2;
@@ -386,17 +389,18 @@ __global__ __launch_bounds__(256) void k_normest_upper(int n, const cd* __restri
     __shared__ double sh[4];
     __shared__ double smax[256];
     double off = 0.0, mx = 0.0, bad = 0.0;
-    const int64_t total = (int64_t)n * n;
-    for (int64_t e = threadIdx.x; e < total; e += 256) {
-        const int c = (int)(e / n), r = (int)(e - (int64_t)c * n);
-        if (r > c) continue;
-        const cd v = M[r + (int64_t)c * ldm];
-        if (!(isfinite(v.x) && isfinite(v.y))) bad = 1.0;
-        const double a2 = v.x * v.x + v.y * v.y;
-        if (r == c)
-            mx = fmax(mx, sqrt(a2));
-        else
-            off += a2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = blockIdx.x * 4 + wave; c < n; c += 4 * NORMEST_CHUNKS) {
+        const cd* col = M + (int64_t)c * ldm;
+        for (int r = lane; r <= c; r += 64) {
+            const cd v = col[r];
+            if (!(isfinite(v.x) && isfinite(v.y))) bad = 1.0;
+            const double a2 = v.x * v.x + v.y * v.y;
+            if (r == c)
+                mx = fmax(mx, sqrt(a2));
+            else
+                off += a2;
+        }
     }
     smax[threadIdx.x] = mx;
     __syncthreads();
@@ -405,9 +409,9 @@ __global__ __launch_bounds__(256) void k_normest_upper(int n, const cd* __restri
     if (threadIdx.x == 0) {
         double m2 = 0.0;
         for (int i = 0; i < 256; ++i) m2 = fmax(m2, smax[i]);
-        out[0] = m2;
-        out[1] = o;
-        out[2] = bsum;
+        out[3 * blockIdx.x + 0] = m2;
+        out[3 * blockIdx.x + 1] = o;
+        out[3 * blockIdx.x + 2] = bsum;
     }
 }
 
@@ -865,17 +869,24 @@ int dense_potrf_trtri(dftk_mi_basis* b, int n, cd* A, int64_t lda, cd* invR, int
         else
             hipLaunchKernelGGL(k_trtri_upper, dim3(n), dim3(64), (size_t)n * sizeof(cd), b->stream, n, A, lda, invR, ldi);
     }
-    hipLaunchKernelGGL(k_normest_upper, dim3(2), dim3(256), 0, b->stream, n, A, lda, b->d_scalars, invR, ldi,
-                       b->d_scalars + 3);
+    hipLaunchKernelGGL(k_normest_upper, dim3(NORMEST_CHUNKS, 2), dim3(256), 0, b->stream, n, A, lda, b->d_scalars, invR,
+                       ldi, b->d_scalars + 3 * NORMEST_CHUNKS);
     prof_end(b, ps);
     HIPCHK(hipGetLastError());
     CHK(fetch_scalars(b, 208));
     int info;
     std::memcpy(&info, (const void*)(b->h_scalars + 200), sizeof(int));
-    const double* h = b->h_scalars;
-    if (info != 0 || h[2] != 0.0 || h[5] != 0.0) return DFTK_MI_NUM_CHOLESKY;
-    if (normest_R) *normest_R = h[0] + sqrt(h[1]);
-    if (normest_invR) *normest_invR = h[3] + sqrt(h[4]);
+    double est[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};   // max |diag|, sum |offdiag|^2, non-finite flag
+    for (int mtx = 0; mtx < 2; ++mtx)
+        for (int ch = 0; ch < NORMEST_CHUNKS; ++ch) {
+            const double* h = b->h_scalars + 3 * (NORMEST_CHUNKS * mtx + ch);
+            est[mtx][0] = std::max(est[mtx][0], h[0]);
+            est[mtx][1] += h[1];
+            est[mtx][2] += h[2];
+        }
+    if (info != 0 || est[0][2] != 0.0 || est[1][2] != 0.0) return DFTK_MI_NUM_CHOLESKY;
+    if (normest_R) *normest_R = est[0][0] + sqrt(est[0][1]);
+    if (normest_invR) *normest_invR = est[1][0] + sqrt(est[1][1]);
     return 0;
 }
 

@@ -149,12 +149,14 @@ int apply_D(dftk_mi_kblock* kb, int n_bands, const cd* X /*n_p x nb*/, cd* Y);
 int ew_colnorms(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, double* out_d);
 int ew_coldots(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, const cd* Y, int64_t ldy,
                double* out_re_d);
-int ew_weighted_colnorm2(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx,
-                         const double* w, double* out_d);
+// R = AX - X diag(lam), norms = column norms of R; optionally (kin / xx non-null) mean_kin = sum kin |X|^2 and
+// xx = sum |X|^2 per column in the same pass
 int ew_residual(dftk_mi_basis* b, int64_t n, int m, const cd* AX, int64_t lda, const cd* X, int64_t ldx,
-                const double* lam_d, cd* R, int64_t ldr, double* norms_d);
-int ew_tpa(dftk_mi_basis* b, int64_t n, int m, cd* R, int64_t ldr, const double* kin,
-           const double* mean_kin_d);
+                const double* lam_d, cd* R, int64_t ldr, double* norms_d, const double* kin, double* mean_kin_d,
+                double* xx_d);
+// dst = TPA-preconditioned src (kin == null: copy), norms = column norms of dst
+int ew_tpa(dftk_mi_basis* b, int64_t n, int m, const cd* src, int64_t lds, cd* dst, int64_t ldd, const double* kin,
+           const double* mean_kin_d, double* norms_d);
 int ew_scale_cols(dftk_mi_basis* b, int64_t n, int m, cd* X, int64_t ldx, const double* s_d, bool invert);
 int ew_copy(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, cd* Y, int64_t ldy);
 int ew_fill_zero(dftk_mi_basis* b, cd* X, size_t count);

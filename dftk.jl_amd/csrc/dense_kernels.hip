@@ -60,40 +60,59 @@ __global__ __launch_bounds__(256) void k_col_reduce(int mode, int64_t n, const c
     if (threadIdx.x == 0) out[c] = (mode == 0) ? sqrt(r) : r;
 }
 
-// R = AX - X * lam ; norms[c] = ||R[:,c]||
+// R = AX - X * lam ; norms[c] = ||R[:,c]|| ; in the same pass over X (optional, kin != null / xx != null):
+// mk[c] = sum kin |X|^2 (precondprep! of the TPA preconditioner) and xx[c] = sum |X|^2 (normalisation check)
 __global__ __launch_bounds__(256) void k_residual(int64_t n, const cd* __restrict__ AX, int64_t lda,
                                                   const cd* __restrict__ X, int64_t ldx,
                                                   const double* __restrict__ lam, cd* __restrict__ R, int64_t ldr,
-                                                  double* __restrict__ norms) {
+                                                  double* __restrict__ norms, const double* __restrict__ kin,
+                                                  double* __restrict__ mk, double* __restrict__ xx) {
     __shared__ double sh[4];
     const int c = blockIdx.x;
     const double l = lam[c];
-    double acc = 0.0;
+    double acc = 0.0, acck = 0.0, accx = 0.0;
     for (int64_t i = threadIdx.x; i < n; i += 256) {
         const cd a = AX[(int64_t)c * lda + i];
         const cd x = X[(int64_t)c * ldx + i];
         const cd r = make_double2(a.x - l * x.x, a.y - l * x.y);
         R[(int64_t)c * ldr + i] = r;
         acc += r.x * r.x + r.y * r.y;
+        const double x2 = x.x * x.x + x.y * x.y;
+        accx += x2;
+        if (kin) acck += kin[i] * x2;
+    }
+    const double s = block_sum256(acc, sh);
+    const double sk = block_sum256(acck, sh);
+    const double sx = block_sum256(accx, sh);
+    if (threadIdx.x == 0) {
+        norms[c] = sqrt(s);
+        if (kin) mk[c] = sk;
+        if (xx) xx[c] = sx;
+    }
+}
+
+// ldiv!(precon, R) of the TPA preconditioner, out of place and with the column norms of the result:
+//   dst[:,c] = src[:,c] * mean_kin[c] / (mean_kin[c] + kin) ; norms[c] = ||dst[:,c]||     (kin == null: plain copy)
+// One workgroup per column (same reduction tree as k_col_reduce).
+__global__ __launch_bounds__(256) void k_tpa(int64_t n, const cd* __restrict__ src, int64_t lds, cd* __restrict__ dst,
+                                             int64_t ldd, const double* __restrict__ kin,
+                                             const double* __restrict__ mean_kin, double* __restrict__ norms) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x;
+    const double mk = kin ? mean_kin[c] : 0.0;
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        cd r = src[(int64_t)c * lds + i];
+        if (kin) {
+            const double f = mk / (mk + kin[i]);
+            r.x *= f;
+            r.y *= f;
+        }
+        dst[(int64_t)c * ldd + i] = r;
+        acc += r.x * r.x + r.y * r.y;
     }
     const double s = block_sum256(acc, sh);
     if (threadIdx.x == 0) norms[c] = sqrt(s);
-}
-
-// R[:,c] *= mean_kin[c] / (mean_kin[c] + kin)
-__global__ void k_tpa(int64_t n, int m, cd* __restrict__ R, int64_t ldr, const double* __restrict__ kin,
-                      const double* __restrict__ mean_kin) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double k = kin[i];
-    for (int c = 0; c < m; ++c) {
-        const double mk = mean_kin[c];
-        const double f = mk / (mk + k);
-        cd r = R[(int64_t)c * ldr + i];
-        r.x *= f;
-        r.y *= f;
-        R[(int64_t)c * ldr + i] = r;
-    }
 }
 
 __global__ void k_scale_cols(int64_t n, int m, cd* __restrict__ X, int64_t ldx, const double* __restrict__ s,
@@ -1031,14 +1050,6 @@ int ew_coldots(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, con
     HIPCHK(hipGetLastError());
     return 0;
 }
-int ew_weighted_colnorm2(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, const double* w,
-                         double* out_d) {
-    if (m <= 0) return 0;
-    hipLaunchKernelGGL(k_col_reduce, dim3(m), dim3(256), 0, b->stream, 2, n, X, ldx, (const cd*)nullptr, (int64_t)0,
-                       w, out_d);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
 int ew_frob2(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, double* out_d) {
     if (m <= 0) return 0;
     hipLaunchKernelGGL(k_col_reduce, dim3(m), dim3(256), 0, b->stream, 3, n, X, ldx, (const cd*)nullptr, (int64_t)0,
@@ -1047,16 +1058,18 @@ int ew_frob2(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, doubl
     return 0;
 }
 int ew_residual(dftk_mi_basis* b, int64_t n, int m, const cd* AX, int64_t lda, const cd* X, int64_t ldx,
-                const double* lam_d, cd* R, int64_t ldr, double* norms_d) {
+                const double* lam_d, cd* R, int64_t ldr, double* norms_d, const double* kin, double* mean_kin_d,
+                double* xx_d) {
     if (m <= 0) return 0;
-    hipLaunchKernelGGL(k_residual, dim3(m), dim3(256), 0, b->stream, n, AX, lda, X, ldx, lam_d, R, ldr, norms_d);
+    hipLaunchKernelGGL(k_residual, dim3(m), dim3(256), 0, b->stream, n, AX, lda, X, ldx, lam_d, R, ldr, norms_d, kin,
+                       mean_kin_d, xx_d);
     HIPCHK(hipGetLastError());
     return 0;
 }
-int ew_tpa(dftk_mi_basis* b, int64_t n, int m, cd* R, int64_t ldr, const double* kin, const double* mean_kin_d) {
+int ew_tpa(dftk_mi_basis* b, int64_t n, int m, const cd* src, int64_t lds, cd* dst, int64_t ldd, const double* kin,
+           const double* mean_kin_d, double* norms_d) {
     if (m <= 0) return 0;
-    hipLaunchKernelGGL(k_tpa, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, n, m, R, ldr, kin,
-                       mean_kin_d);
+    hipLaunchKernelGGL(k_tpa, dim3(m), dim3(256), 0, b->stream, n, src, lds, dst, ldd, kin, mean_kin_d, norms_d);
     HIPCHK(hipGetLastError());
     return 0;
 }

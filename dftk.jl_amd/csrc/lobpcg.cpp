@@ -153,10 +153,14 @@ int total_cols(const std::vector<Mat>& Ys) {
 }
 
 // ortho!(X, Y, BY) with Y = hcat(Ys...), B = I
-int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol) {
+// norms_d (optional): device array of the column norms of X, when the producer of X already has them
+int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol, const double* norms_d = nullptr) {
     if (X.cols == 0) return 0;
-    CHK(ew_colnorms(c.b, X.rows, X.cols, X.p, X.ld, c.d_a));
-    CHK(ew_scale_cols(c.b, X.rows, X.cols, X.p, X.ld, c.d_a, true));
+    if (!norms_d) {
+        CHK(ew_colnorms(c.b, X.rows, X.cols, X.p, X.ld, c.d_a));
+        norms_d = c.d_a;
+    }
+    CHK(ew_scale_cols(c.b, X.rows, X.cols, X.p, X.ld, norms_d, true));
     int ny = 0;
     for (auto& Y : Ys) ny += Y.cols;
     // adjacent blocks (all of X followed by the new P in lobpcg_run's layout) act as ONE matrix
@@ -311,6 +315,8 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     double* d_lam = dd + 2 * (M + 8);
     double* d_norms = dd + 3 * (M + 8);
     double* d_mk = dd + 4 * (M + 8);
+    double* d_xx = dd + 6 * (M + 8);    // (slot 5 holds the final permutation)
+    double* d_rn = dd + 7 * (M + 8);
     c.rng.seed(seed ? seed : 0x9E3779B97F4A7C15ull);
     Mat X = Yb[0].cols_from(0, M), AX = AYb[0].cols_from(0, M);   // views of the CURRENT pair (rebound on swap)
     kb->last_AX = AX.p;
@@ -404,7 +410,9 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
 
         // residuals
         HIPCHK(hipMemcpyAsync(d_lam, full_lam.data() + lo, nact * sizeof(double), hipMemcpyHostToDevice, b->stream));
-        CHK(ew_residual(b, N, nact, nAX.p, nAX.ld, nX.p, nX.ld, d_lam, nR.p, nR.ld, d_norms));
+        // residuals; the same pass over the new X yields precondprep!'s mean kinetic energies and <x,x>
+        CHK(ew_residual(b, N, nact, nAX.p, nAX.ld, nX.p, nX.ld, d_lam, nR.p, nR.ld, d_norms,
+                        use_tpa ? kb->d_kin : nullptr, d_mk, d_xx));
         CHK(d2h(c, d_norms, nact));
         for (int i = 0; i < nact; ++i) {
             if (!std::isfinite(c.h[i])) {
@@ -413,11 +421,8 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
             }
             RH(nlocked + i, niter) = c.h[i];
         }
-        // preconditioning: precondprep!(new_X); ldiv!(precon, new_R)
-        if (use_tpa) {
-            CHK(ew_weighted_colnorm2(b, N, nact, nX.p, nX.ld, kb->d_kin, d_mk));
-            CHK(ew_tpa(b, N, nact, nR.p, nR.ld, kb->d_kin, d_mk));
-        }
+        // (preconditioning -- precondprep!(new_X); ldiv!(precon, new_R) -- is applied further down, to the columns
+        //  that stay active only and straight into their place in the next iteration's Y)
         // locking
         const int prev_nlocked = nlocked;
         if (niter >= miniter) {
@@ -450,8 +455,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
             CHK(hcat_mul(c, AYs, cP, nY, lenXn, nAP));
         }
         // sanity: |<x,x> - 1| < sqrt(eps)
-        CHK(ew_coldots(b, N, nact, nX.p, nX.ld, nX.p, nX.ld, c.d_a));
-        CHK(d2h(c, c.d_a, nact));
+        CHK(d2h(c, d_xx, nact));
         for (int i = 0; i < nact; ++i)
             if (!(std::fabs(c.h[i] - 1.0) < std::sqrt(EPS))) {
                 dftk_set_error("LOBPCG is badly failing to keep the vectors normalized (column %d: %g)", lo + i,
@@ -469,10 +473,11 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
         X = Yb[cur].cols_from(0, M);
         AX = AYb[cur].cols_from(0, M);
         Mat Rn = Rblk(Yb[cur], lenXn, niter > 0);   // next iteration's residual block (behind P once P exists)
-        CHK(ew_copy(b, N, lenXn, nR.p + (int64_t)newly_locked * nR.ld, nR.ld, Rn.p, Rn.ld));
+        CHK(ew_tpa(b, N, lenXn, nR.p + (int64_t)newly_locked * nR.ld, nR.ld, Rn.p, Rn.ld,
+                   use_tpa ? kb->d_kin : nullptr, d_mk + newly_locked, d_rn));
         std::vector<Mat> Zs = {X};
         if (niter > 0) Zs.push_back(nP);
-        CHK(ortho_XY(c, Rn, Zs, tmp, ortho_tol));
+        CHK(ortho_XY(c, Rn, Zs, tmp, ortho_tol, d_rn));
 
         if (niter >= maxiter) break;
         niter += 1;

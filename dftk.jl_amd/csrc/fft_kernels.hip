@@ -23,7 +23,7 @@
 #define ZPASS_MIN_BLOCKS 6   // workgroups per CU the z pass is compiled for (80 VGPRs; 5 -> 6 resident workgroups: -9 %)
 #endif
 #ifndef DENS_MIN_BLOCKS
-#define DENS_MIN_BLOCKS 1   // (6 spills: slower)
+#define DENS_MIN_BLOCKS 1   // (6 spills: slower; prefetching the next band's planes into registers: 130 VGPRs, 165 vs 150 us)
 #endif
 #ifndef YFWD_MIN_BLOCKS
 #define YFWD_MIN_BLOCKS 1   // (7 spills: slower)
@@ -797,21 +797,20 @@ int launch_density(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, con
     const int batch = b->fft_batch;
     CHK(fft_ensure_scratch(b, kb, nb < batch ? nb : batch));
     const Strides st = strides(kb);
-    // weights: stage through the pinned scalar buffer in chunks of <= 256
+    // all weights go to the device once (general workspace; the copy from the caller's pageable array is
+    // staged by the runtime before the call returns) -- no host synchronisation between the band batches
+    CHK(ensure_ws(b, (size_t)nb * sizeof(double)));
+    double* w_d = reinterpret_cast<double*>(b->ws);
+    HIPCHK(hipMemcpyAsync(w_d, w_h, (size_t)nb * sizeof(double), hipMemcpyHostToDevice, b->stream));
     for (int b0 = 0; b0 < nb; b0 += batch) {
         const int nbb = (nb - b0) < batch ? (nb - b0) : batch;
         bool any = false;
         for (int i = 0; i < nbb; ++i) any = any || (w_h[b0 + i] != 0.0);
         if (!any) continue;
-        if (nbb > 256) return DFTK_MI_EINVAL;
-        // the pinned buffer may still be read by an earlier async copy: synchronise before reuse
-        HIPCHK(hipStreamSynchronize(b->stream));
-        for (int i = 0; i < nbb; ++i) b->h_scalars[i] = w_h[b0 + i];
-        HIPCHK(hipMemcpyAsync(b->d_scalars, b->h_scalars, nbb * sizeof(double), hipMemcpyHostToDevice, b->stream));
         CHK(run_AB(kb, nbb, psi + (int64_t)b0 * ldpsi, ldpsi));
         const int pz = prof_begin(b, PROF_DENS_Z, 16.0 * (double)kb->nzx * b->ny * b->nxp * nbb +
                                                       16.0 * (double)b->nx * b->ny * b->nz);   // T2 per band + rho read-modify-write
-        LAUNCH_FFT(k_zdensity, b->ax[2], dim3(b->nxp / FFT_L, b->ny), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, kb->d_zpos, nbb, b->d_scalars, b->T2, st.s2,
+        LAUNCH_FFT(k_zdensity, b->ax[2], dim3(b->nxp / FFT_L, b->ny), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, kb->d_zpos, nbb, w_d + b0, b->T2, st.s2,
                            rho);
         prof_end(b, pz);
     }

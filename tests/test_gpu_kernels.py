@@ -467,6 +467,10 @@ def test_lobpcg_core_hamiltonian_vs_oracle_and_dense(lib):
         R = H.mul(X) - X * lam[None, :]
         assert np.linalg.norm(R, axis=0).max() < 1e-8
         assert nmv >= 5 * (nit + 1) - 5 * nit   # at least one block apply
+        if ik == 0:   # no preconditioner (prec = I, lobpcg_hyper_impl.jl:354): same eigenvalues, more iterations
+            lam0, _, nit0, conv0, _, _ = run_lobpcg(lib, kb, X0, 1e-8, use_tpa=0, maxiter=400)
+            assert conv0 == 1 and nit0 >= nit
+            np.testing.assert_allclose(lam0, dense, atol=1e-8)
 
 
 def test_lobpcg_n_conv_check_and_locking(lib):

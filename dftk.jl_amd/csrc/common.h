@@ -166,7 +166,6 @@ int ew_gather_cols(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx,
 int ew_add_diag(dftk_mi_basis* b, int n, cd* A, int64_t lda, double shift);
 int ew_frob2(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, double* out_d);
 int ew_hermitize_upper(dftk_mi_basis* b, int n, cd* A, int64_t lda);
-int ew_has_nonfinite(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, double* out_d);
 
 // lobpcg.cpp
 int lobpcg_run(dftk_mi_kblock* kb, int M, cd* X, int64_t ldX, double tol, int miniter, int maxiter,

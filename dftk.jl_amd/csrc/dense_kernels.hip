@@ -164,19 +164,6 @@ __global__ void k_hermitize_upper(int n, cd* __restrict__ A, int64_t lda) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_has_nonfinite(int64_t n, const cd* __restrict__ X, int64_t ldx,
-                                                       double* __restrict__ out) {
-    __shared__ double sh[4];
-    const int c = blockIdx.x;
-    double bad = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 256) {
-        const cd a = X[(int64_t)c * ldx + i];
-        if (!(isfinite(a.x) && isfinite(a.y))) bad = 1.0;
-    }
-    const double r = block_sum256(bad, sh);
-    if (threadIdx.x == 0) out[c] = r;
-}
-
 // Y = D * X for the banded real D (n_p x n_p, half bandwidth bw), X is n_p x nb complex
 __global__ void k_apply_D(int n_p, int nb, int bw, const double* __restrict__ D, const cd* __restrict__ X,
                           cd* __restrict__ Y) {
@@ -1113,12 +1100,6 @@ int ew_add_diag(dftk_mi_basis* b, int n, cd* A, int64_t lda, double shift) {
 int ew_hermitize_upper(dftk_mi_basis* b, int n, cd* A, int64_t lda) {
     hipLaunchKernelGGL(k_hermitize_upper, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, b->stream, n,
                        A, lda);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-int ew_has_nonfinite(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, double* out_d) {
-    if (m <= 0) return 0;
-    hipLaunchKernelGGL(k_has_nonfinite, dim3(m), dim3(256), 0, b->stream, n, X, ldx, out_d);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -336,19 +336,19 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     int64_t n_matvec = M;
     CHK(dftk_mi_apply_H(kb, M, reinterpret_cast<const dftk_mi_cplx*>(X.p), X.ld,
                         reinterpret_cast<dftk_mi_cplx*>(AX.p), AX.ld));
-    CHK(ew_has_nonfinite(b, N, M, AX.p, AX.ld, c.d_a));
-    CHK(d2h(c, c.d_a, M));
-    for (int i = 0; i < M; ++i)
-        if (c.h[i] != 0.0) {
-            dftk_set_error("non-finite values in H*X");
-            return DFTK_MI_NUM_NONFINITE;
-        }
     // (R is written at the end of iteration 0 and P at the end of iteration 1, before their first use)
-    // lambda = Re(X'AX)/(X'X) column-wise
+    // lambda = Re(X'AX)/(X'X) column-wise.  The reference's "any(!isfinite, AX)" check (:380) rides on the same
+    // pass: a non-finite entry of AX makes its column's dot non-finite (0 * inf and x * nan are nan).
     CHK(ew_coldots(b, N, M, X.p, X.ld, AX.p, AX.ld, c.d_a));
     CHK(ew_coldots(b, N, M, X.p, X.ld, X.p, X.ld, c.d_b));
     CHK(d2h(c, c.d_a, 2 * (M + 8)));
-    for (int i = 0; i < M; ++i) full_lam[i] = c.h[i] / c.h[(M + 8) + i];
+    for (int i = 0; i < M; ++i) {
+        if (!std::isfinite(c.h[i])) {
+            dftk_set_error("non-finite values in H*X");
+            return DFTK_MI_NUM_NONFINITE;
+        }
+        full_lam[i] = c.h[i] / c.h[(M + 8) + i];
+    }
 
     int nlocked = 0, niter = 0, lo = 0;
     int status_final = 0;

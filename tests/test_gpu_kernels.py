@@ -498,3 +498,11 @@ def test_lobpcg_n_conv_check_and_locking(lib):
     st = lib.dftk_mi_lobpcg(kb.h, 400, Xbig.data_ptr(), H.n_G, 1e-6, 1, 10, 0, 1, 1, lam2.ctypes.data,
                             lam2.ctypes.data, C.byref(C.c_int()), C.byref(C.c_int()), C.byref(C.c_int64()))
     assert st == 5
+    # a non-finite potential is reported as the reference's "NaN in AX" assertion (lobpcg_hyper_impl.jl:380)
+    Vbad = H.potential.copy()
+    Vbad[3, 4, 5] = np.nan
+    kb.set_potential(Vbad)
+    Xd = dev(np.linalg.qr(X0)[0].T.copy())
+    st = lib.dftk_mi_lobpcg(kb.h, M, Xd.data_ptr(), H.n_G, 1e-6, 1, 10, 0, 1, 1, lam2.ctypes.data, lam2.ctypes.data,
+                            C.byref(C.c_int()), C.byref(C.c_int()), C.byref(C.c_int64()))
+    assert st == 1 and b"non-finite" in lib.dftk_mi_last_error()

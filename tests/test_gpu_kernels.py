@@ -238,7 +238,7 @@ def test_potrf_trtri(lib, n):
     assert st == 2
 
 
-@pytest.mark.parametrize("n", [1, 5, 32, 33, 100, 300, 777])
+@pytest.mark.parametrize("n", [1, 5, 16, 17, 32, 33, 48, 64, 100, 300, 500, 777])
 def test_heev(lib, n):
     rng = np.random.default_rng(n)
     bs = Basis(lib, 8, 8, 8)
@@ -246,6 +246,12 @@ def test_heev(lib, n):
     A = (X + X.conj().T) / 2
     if n == 300:   # LOBPCG-like: nearly diagonal with clusters
         A = np.diag(np.sort(rng.standard_normal(n))) + 1e-3 * A
+    if n == 48:    # already diagonal (unsorted): no rotation at all
+        A = np.diag(rng.standard_normal(n)).astype(complex)
+    if n in (64, 500):   # exactly degenerate spectrum: three eigenvalues with large multiplicities
+        Q = np.linalg.qr(X)[0]
+        A = (Q * rng.choice([-1.0, 0.0, 2.0], n)[None, :]) @ Q.conj().T
+        A = (A + A.conj().T) / 2
     Ad = dev(A.T.copy())
     Vd = torch.full_like(Ad, float("nan"))
     W = np.zeros(n)

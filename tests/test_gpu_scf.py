@@ -33,9 +33,10 @@ def oracle_model(functionals=("lda_x", "lda_c_vwn")):
     return oracle.model_DFT(LATTICE, [Si, Si], POSITIONS, functionals=functionals)
 
 
-@pytest.fixture(scope="module", autouse=True)
+@pytest.fixture(autouse=True)
 def _gpu():
     assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    torch.manual_seed(20240917)   # random_orbitals draws its counter-RNG seeds from torch's global generator
 
 
 def test_energies_guess_density_reference_pins():
@@ -47,7 +48,8 @@ def test_energies_guess_density_reference_pins():
     E, ham = dftk.energy_hamiltonian(basis, None, None, rho=rho0)
     assert E["Hartree"] == pytest.approx(0.3527293727197568, abs=5e-8)
     assert E["Xc"] == pytest.approx(-2.3033165870558165, abs=5e-8)
-    res = dftk.diagonalize_all_kblocks(dftk.lobpcg_hyper, ham, 8, tol=1e-9)
+    # all 8 bands (no buffer bands) to 1e-9: the highest one needs 40-95 iterations depending on the start vectors
+    res = dftk.diagonalize_all_kblocks(dftk.lobpcg_hyper, ham, 8, tol=1e-9, maxiter=300)
     assert res["converged"]
     occ = [np.array([2.0, 2.0, 2.0, 2.0, 0.0, 0.0, 0.0, 0.0]) for _ in basis.kpoints]
     rho = dftk.compute_density(basis, res["X"], occ)

@@ -62,6 +62,8 @@ _SIGNATURES = {
     "dftk_mi_prof_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                    C.POINTER(_i64)]),
     "dftk_mi_diag_mfma_peak": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "dftk_mi_jacobi_schedule_host": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                               C.POINTER(C.c_int)]),
     "dftk_mi_fft_plan_host": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dftk_mi_sphere_tables_host": (C.c_int, [C.c_int, C.c_int, C.c_int, _i64, C.c_void_p, C.POINTER(_i64),
                                              C.POINTER(C.c_int), C.c_void_p, C.c_void_p]),

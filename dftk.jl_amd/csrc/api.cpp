@@ -166,6 +166,10 @@ void plan_positions(int n, int nrad, const int* rad, int* pos) {
     }
 }
 
+extern "C" int dftk_mi_jacobi_schedule_host(int n, int round, int* n_blocks, int* pairs, int* where) {
+    return jacobi_schedule_host(n, round, n_blocks, pairs, where);
+}
+
 extern "C" int dftk_mi_fft_plan_host(int n, int* n_radices, int* radices, int* pos) {
     if (n < 1 || !n_radices || !radices || !pos) return DFTK_MI_EINVAL;
     if (plan_radices(n, n_radices, radices) != 0) {

@@ -436,7 +436,7 @@ typedef double v4d_t __attribute__((ext_vector_type(4)));
 #define JB 16
 #define J2B (2 * JB)
 
-__device__ __forceinline__ void tournament_pair(int nb, int round, int k, int& p, int& q) {
+__host__ __device__ __forceinline__ void tournament_pair(int nb, int round, int k, int& p, int& q) {
     // nb even, round in [0, nb-1), k in [0, nb/2): pair k of the round; round < 0: the fixed pairing (2k, 2k+1)
     if (round < 0) {
         p = 2 * k;
@@ -456,7 +456,7 @@ __device__ __forceinline__ void tournament_pair(int nb, int round, int k, int& p
 }
 
 // inverse of tournament_pair: block `blk` is member h (0: the smaller index) of pair k in `round`
-__device__ __forceinline__ void tournament_find(int nb, int round, int blk, int& k, int& h) {
+__host__ __device__ __forceinline__ void tournament_find(int nb, int round, int blk, int& k, int& h) {
     if (round < 0) {
         k = blk >> 1;
         h = blk & 1;
@@ -893,6 +893,24 @@ int dense_potrf_trtri(dftk_mi_basis* b, int n, cd* A, int64_t lda, cd* invR, int
     if (info != 0 || est[0][2] != 0.0 || est[1][2] != 0.0) return DFTK_MI_NUM_CHOLESKY;
     if (normest_R) *normest_R = est[0][0] + sqrt(est[0][1]);
     if (normest_invR) *normest_invR = est[1][0] + sqrt(est[1][1]);
+    return 0;
+}
+
+// Host-only view of the Jacobi schedule (CPU test-suite): number of 16-wide blocks for an n x n matrix and, for
+// `round` in [-1, nb - 2], the block pairs (p_k, q_k) of that round plus, for every block, its (pair, member)
+// as the look-ahead pair solve finds them.
+int jacobi_schedule_host(int n, int round, int* nb_out, int* pairs, int* where) {
+    if (n <= 0 || !nb_out) return DFTK_MI_EINVAL;
+    int nb = (n + JB - 1) / JB;
+    if (nb % 2) nb += 1;
+    if (nb < 2) nb = 2;
+    *nb_out = nb;
+    if (!pairs && !where) return 0;
+    if (round < -1 || round > nb - 2) return DFTK_MI_EINVAL;
+    if (pairs)
+        for (int k = 0; k < nb / 2; ++k) tournament_pair(nb, round, k, pairs[2 * k], pairs[2 * k + 1]);
+    if (where)
+        for (int blk = 0; blk < nb; ++blk) tournament_find(nb, round, blk, where[2 * blk], where[2 * blk + 1]);
     return 0;
 }
 

@@ -171,6 +171,13 @@ int dftk_mi_diag_mfma_peak(dftk_mi_basis* basis, int waves_per_simd, int iters, 
  * one more FULL tile in the interior launch, shifted left to end at column n (it stores only the new columns),
  * instead of a right-strip launch. */
 int dftk_mi_zgemm_plan_host(char transA, int64_t m, int64_t n, int64_t k, int flags, int* out12);
+/* Schedule of the blocked Jacobi eigensolver for an n x n matrix: *n_blocks = number of 16-wide blocks (even,
+ * padded); for round in [-1, *n_blocks - 2] (pass pairs = where = NULL to query n_blocks only):
+ * pairs[2k], pairs[2k+1] = the k-th disjoint block pair of the round (round -1: (2k, 2k+1), then a round-robin
+ * tournament); where[2b], where[2b+1] = (pair index, member 0/1) of block b -- the inverse map the look-ahead
+ * pair solve uses to find last round's rotations of its two blocks. */
+int dftk_mi_jacobi_schedule_host(int n, int round, int* n_blocks, int* pairs /* [n_blocks] */,
+                                 int* where /* [2 n_blocks] */);
 /*
  * 1-D plan for length n: radices (<= 32 entries) and the in-place permutation `pos[e]` such
  * that a decimation-in-time pass wants input element e at position pos[e] and a

@@ -372,3 +372,33 @@ def test_zgemm_launch_plan_invariants(lib, trans, m, n, k):
     if trans == "C" and m == n and m >= 256:
         # the upper-only product has fewer live tiles, so at least as many chunks fit into one round
         assert _gemm_plan(lib, trans, m, n, k, 1)["nsI"] >= _gemm_plan(lib, trans, m, n, k, 0)["nsI"]
+
+
+@pytest.mark.parametrize("n", [1, 16, 33, 100, 259, 518, 777, 1509])
+def test_jacobi_round_schedule(lib, n):
+    """Host view of the blocked-Jacobi schedule (dense_kernels.hip): every round pairs each 16-wide block exactly
+    once, a sweep (round -1 = neighbours, rounds 0 .. nb-2 = round-robin tournament) meets every block pair
+    exactly once across its cross rounds, and the inverse map used by the look-ahead pair solve is consistent."""
+    nb = C.c_int()
+    check(lib.dftk_mi_jacobi_schedule_host(n, 0, C.byref(nb), None, None))
+    nb = nb.value
+    assert nb % 2 == 0 and nb >= 2 and nb * 16 >= n and (nb - 2) * 16 < max(n, 17)
+    met = set()
+    for rnd in range(-1, nb - 1):
+        pairs = (C.c_int * nb)()
+        where = (C.c_int * (2 * nb))()
+        check(lib.dftk_mi_jacobi_schedule_host(n, rnd, C.byref(C.c_int()), pairs, where))
+        pr = [(pairs[2 * k], pairs[2 * k + 1]) for k in range(nb // 2)]
+        assert all(0 <= p < q < nb for p, q in pr)
+        assert sorted(b for pq in pr for b in pq) == list(range(nb))          # a perfect matching of the blocks
+        for blk in range(nb):                                                 # inverse map
+            k, h = where[2 * blk], where[2 * blk + 1]
+            assert pr[k][h] == blk
+        if rnd < 0:
+            assert pr == [(2 * k, 2 * k + 1) for k in range(nb // 2)]
+        else:
+            for pq in pr:
+                assert pq not in met
+                met.add(pq)
+    assert len(met) == nb * (nb - 1) // 2                                      # all block pairs, once per sweep
+    assert lib.dftk_mi_jacobi_schedule_host(n, nb - 1, C.byref(C.c_int()), (C.c_int * nb)(), None) < 0

@@ -402,3 +402,46 @@ def test_jacobi_round_schedule(lib, n):
                 met.add(pq)
     assert len(met) == nb * (nb - 1) // 2                                      # all block pairs, once per sweep
     assert lib.dftk_mi_jacobi_schedule_host(n, nb - 1, C.byref(C.c_int()), (C.c_int * nb)(), None) < 0
+
+
+def test_jacobi_lookahead_identity(lib):
+    """NumPy twin of the look-ahead of k_jacobi_round (dense_kernels.hip), driven by the library's own schedule:
+    the 2 x 2 block problem of round r, assembled from the matrix BEFORE round r-1 with last round's rotations of
+    the two pairs the blocks belonged to (three 32 x 32 tiles, one 16 x 16 quadrant of each), equals the block
+    problem read from the fully updated matrix."""
+    n, JB = 100, 16
+    nbc = C.c_int()
+    check(lib.dftk_mi_jacobi_schedule_host(n, 0, C.byref(nbc), None, None))
+    nb = nbc.value
+    N = nb * JB
+    rng = np.random.default_rng(7)
+    A = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    A = (A + A.conj().T) / 2
+
+    def schedule(rnd):
+        pairs, where = (C.c_int * nb)(), (C.c_int * (2 * nb))()
+        check(lib.dftk_mi_jacobi_schedule_host(n, rnd, C.byref(C.c_int()), pairs, where))
+        return ([(pairs[2 * k], pairs[2 * k + 1]) for k in range(nb // 2)],
+                [(where[2 * b], where[2 * b + 1]) for b in range(nb)])
+
+    def idx(p, q):      # global indices of the local 0..31 of a pair: block p first, then block q
+        return np.r_[p * JB:(p + 1) * JB, q * JB:(q + 1) * JB]
+
+    for prev, rnd in ((-1, 0), (0, 1), (3, 4), (nb - 2, -1)):
+        pr_prev, where_prev = schedule(prev)
+        U = [np.linalg.qr(rng.standard_normal((2 * JB, 2 * JB)) + 1j * rng.standard_normal((2 * JB, 2 * JB)))[0]
+             for _ in pr_prev]
+        J = np.zeros((N, N), complex)
+        for (p, q), u in zip(pr_prev, U):
+            J[np.ix_(idx(p, q), idx(p, q))] = u
+        A_upd = J.conj().T @ A @ J                                  # what the update workgroups write
+        for bp, bq in schedule(rnd)[0]:
+            (ka, ha), (kb, hb) = where_prev[bp], where_prev[bq]
+            Ia, Ib = idx(*pr_prev[ka]), idx(*pr_prev[kb])
+            ua, ub = U[ka][:, JB * ha:JB * (ha + 1)], U[kb][:, JB * hb:JB * (hb + 1)]
+            S = np.zeros((2 * JB, 2 * JB), complex)
+            S[:JB, :JB] = ua.conj().T @ A[np.ix_(Ia, Ia)] @ ua
+            S[:JB, JB:] = ua.conj().T @ A[np.ix_(Ia, Ib)] @ ub
+            S[JB:, JB:] = ub.conj().T @ A[np.ix_(Ib, Ib)] @ ub
+            S[JB:, :JB] = S[:JB, JB:].conj().T
+            np.testing.assert_allclose(S, A_upd[np.ix_(idx(bp, bq), idx(bp, bq))], atol=1e-12)

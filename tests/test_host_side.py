@@ -445,3 +445,46 @@ def test_jacobi_lookahead_identity(lib):
             S[JB:, JB:] = ub.conj().T @ A[np.ix_(Ib, Ib)] @ ub
             S[JB:, :JB] = S[:JB, JB:].conj().T
             np.testing.assert_allclose(S, A_upd[np.ix_(idx(bp, bq), idx(bp, bq))], atol=1e-12)
+
+
+@pytest.mark.parametrize("trans,m,n,k", [("C", 259, 259, 135491), ("C", 640, 259, 135491), ("C", 777, 777, 4000),
+                                          ("N", 1500, 259, 259), ("N", 1000, 54, 777), ("C", 130, 33, 512),
+                                          ("N", 127, 31, 64), ("C", 128, 64, 64), ("C", 5, 5, 100), ("N", 300, 1, 259)])
+def test_zgemm_tiling_covers_every_entry_once(lib, trans, m, n, k):
+    """The launches the planner describes -- full 128 x 32 tiles (a ragged last column as a tile shifted left
+    that stores only its new columns), right strip, bottom strip -- write every entry of C exactly once; with
+    the upper-only flag every entry on or above the diagonal exactly once (tiles strictly below are skipped)."""
+    BM = 128
+    for flags in (0, 1):
+        if flags and (trans != "C" or m != n):
+            continue
+        p = _gemm_plan(lib, trans, m, n, k, flags)
+        bn, gmf, gnf, shift = p["bn"], p["gmf"], p["gnf"], p["shift"]
+        gm = -(-m // BM)
+        cover = np.zeros((m, n), dtype=int)
+
+        def tile(tr, j_lo, j_hi, j_end_for_liveness):
+            if flags and tr * BM >= j_end_for_liveness:
+                return                                              # strictly below the diagonal: not computed
+            cover[tr * BM:min(m, tr * BM + BM), j_lo:j_hi] += 1
+
+        def column_tile(tr, tc):
+            if shift and tc == gnf:                                 # shifted tile: spans [n - bn, n), stores [gnf bn, n)
+                tile(tr, gnf * bn, n, n)
+            else:
+                tile(tr, tc * bn, min(n, tc * bn + bn), tc * bn + bn)
+
+        for tr in range(gmf):                                       # interior launch
+            for tc in range(gnf + shift):
+                column_tile(tr, tc)
+        assert p["nright"] in (0, gm) and p["nbottom"] in (0, gnf + shift)
+        for e in range(p["nright"]):                                # border list: right strip, then bottom strip
+            column_tile(e, gnf)
+        for e in range(p["nbottom"]):
+            column_tile(gmf, e)
+        if flags:
+            iu = np.triu_indices(m)
+            assert np.all(cover[iu] == 1)
+            assert cover.max() == 1
+        else:
+            assert np.all(cover == 1)

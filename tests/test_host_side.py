@@ -488,3 +488,16 @@ def test_zgemm_tiling_covers_every_entry_once(lib, trans, m, n, k):
             assert cover.max() == 1
         else:
             assert np.all(cover == 1)
+
+
+def test_bench_and_smoke_refuse_to_run_without_gpu():
+    """No silent CPU path in the measured / smoke entry points: without a GPU they stop with a clear message."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]          # no measurement line
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], capture_output=True,
+                       text=True, cwd=ROOT, timeout=300)
+    assert r.returncode != 0 and "needs a GPU" in r.stderr

@@ -501,3 +501,21 @@ def test_bench_and_smoke_refuse_to_run_without_gpu():
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], capture_output=True,
                        text=True, cwd=ROOT, timeout=300)
     assert r.returncode != 0 and "needs a GPU" in r.stderr
+
+
+@pytest.mark.parametrize("Ecut,fft_size", [(4.0, (15, 15, 15)), (3.0, (15, 13, 13)), (4.0, (11, 13, 11))])
+def test_host_mirror_planewave_basis_invariants(Ecut, fft_size):
+    """The reference's PlaneWaveBasis tests (test/PlaneWaveBasis.jl:1-58) on the host mirror's descriptors: reciprocal
+    lattice, G-vector bounds, `g_all[kpt.mapping] == G_vectors(kpt)`, cutoff respected -- and the sphere complete."""
+    from test_oracle_golden import _check_basis_invariants, LATTICE as LAT
+    model = dftk.Model(LAT, [], [], ("Kinetic",), n_electrons=2)
+    basis = dftk.PlaneWaveBasis(model, Ecut, dftk.MonkhorstPack((2, 5, 5), (0.5, 0, 0)), fft_size=fft_size,
+                                device="cpu", build_terms=False)
+    assert basis.fft_size == tuple(fft_size) and len(basis.kpoints) == 50
+    assert abs(sum(basis.kweights) - 1.0) < 1e-14
+    _check_basis_invariants(basis, basis.kpoints, LAT, Ecut, to_numpy=lambda t: t.cpu().numpy())
+    # identical descriptors to the oracle's (same k-point order, same spheres)
+    ob = oracle.PlaneWaveBasis(oracle.Model(LAT, [], [], terms=("Kinetic",), n_electrons=2), Ecut,
+                               oracle.MonkhorstPack((2, 5, 5), (0.5, 0, 0)), fft_size=fft_size)
+    for k, ok in zip(basis.kpoints, ob.kpoints):
+        assert np.allclose(k.coordinate, ok.coordinate) and np.array_equal(k.mapping, ok.mapping)

@@ -270,3 +270,44 @@ def test_silicon_pbe_scf_large():
     tests/golden/oracle_silicon_pbe_large.txt."""
     dE, dev = _run_silicon_pbe(25, 33, 1e-7)
     assert abs(dE) < 1e-5 and dev < 1e-5
+
+
+def _g_axis(n):
+    """FFT-order frequencies [0 .. floor((n-1)/2), -ceil((n-1)/2) .. -1] (fft.jl:27-30)."""
+    return np.concatenate([np.arange(0, (n - 1) // 2 + 1), np.arange(-((n - 1) - (n - 1) // 2), 0)])
+
+
+def _check_basis_invariants(basis, kpoints, lattice, Ecut, to_numpy=np.asarray):
+    """test/PlaneWaveBasis.jl:1-58 ("Check struct construction", "Energy cutoff is respected")."""
+    nx, ny, nz = basis.fft_size
+    B = np.asarray(basis.model.recip_lattice)
+    assert np.allclose(B, 2 * np.pi * np.linalg.inv(lattice).T)                # structure.jl:24-26
+    assert np.isclose(basis.model.unit_cell_volume, abs(np.linalg.det(lattice)))
+    gx, gy, gz = _g_axis(nx), _g_axis(ny), _g_axis(nz)
+    lo = -np.ceil((np.array(basis.fft_size) - 1) / 2)
+    hi = np.floor((np.array(basis.fft_size) - 1) / 2)
+    # all cube vectors in x-fastest (Julia column-major) order, what mapping indexes into
+    g_all = np.stack([np.tile(gx, ny * nz), np.tile(np.repeat(gy, nx), nz), np.repeat(gz, nx * ny)], axis=1)
+    kin_all = None
+    for kpt in kpoints:
+        G = to_numpy(kpt.G_vectors)
+        mapping = np.asarray(kpt.mapping)
+        assert np.all(G >= lo) and np.all(G <= hi)                              # :24-26
+        assert np.array_equal(g_all[mapping], G)                                # :27  g_all[kpt.mapping] == G_vectors
+        assert np.all(np.diff(mapping) > 0)                                     # ascending cube order (Kpoint.jl:30-35)
+        k = np.asarray(kpt.coordinate, dtype=float)
+        kin = ((B @ (g_all + k).T) ** 2).sum(axis=0) / 2
+        assert np.all(kin[mapping] <= Ecut + 1e-12)                             # :44-52 cutoff respected
+        inside = np.nonzero(kin <= Ecut)[0]
+        assert np.array_equal(inside, mapping)                                  # ... and the sphere is complete
+        kin_all = kin
+    assert kin_all is not None
+
+
+@pytest.mark.parametrize("Ecut,fft_size", [(4.0, (15, 15, 15)), (3.0, (15, 13, 13)), (4.0, (11, 13, 11))])
+def test_planewave_basis_invariants(Ecut, fft_size):
+    model = Model(LATTICE, [], [], terms=("Kinetic",), n_electrons=2)
+    basis = PlaneWaveBasis(model, Ecut, MonkhorstPack((2, 5, 5), (0.5, 0, 0)), fft_size=fft_size)
+    assert basis.fft_size == tuple(fft_size) and len(basis.kpoints) == 50
+    assert np.isclose(sum(basis.kweights), 1.0)
+    _check_basis_invariants(basis, basis.kpoints, LATTICE, Ecut)

@@ -191,6 +191,14 @@ def test_energies_guess_density():
                Xc=-2.4489960475309056, Ewald=-8.397893578467201, PspCorrection=-0.294622067031369)
     for k, v in ref.items():
         assert E[k] == pytest.approx(v, abs=5e-8), k
+    # :38-57 -- the same orbitals and density in a PBE model: the reference pins E["Xc"] of libxc's
+    # gga_x_pbe + gga_c_pbe at atol 5e-8 (gradient / divergence in Fourier space, xc.jl:356-409)
+    pbe_model = model_DFT(LATTICE, si_atoms(), POSITIONS, functionals=("gga_x_pbe", "gga_c_pbe"))
+    pbe_basis = PlaneWaveBasis(pbe_model, 15, MonkhorstPack((1, 2, 3), (0, 0.5, 0)), fft_size=(27, 27, 27))
+    E_pbe, _ = energy_hamiltonian(pbe_basis, res["X"], occ, rho=rho)
+    assert E_pbe["Xc"] == pytest.approx(-2.469375219486637, abs=5e-8)
+    for k in ("Kinetic", "AtomicLocal", "AtomicNonlocal", "Hartree", "Ewald", "PspCorrection"):
+        assert E_pbe[k] == pytest.approx(ref[k], abs=5e-8), k
 
 
 REF_LDA = [   # test/silicon_lda.jl:10-20 (ABINIT, same k-points, Ecut 25)

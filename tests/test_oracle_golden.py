@@ -319,3 +319,52 @@ def test_planewave_basis_invariants(Ecut, fft_size):
     assert basis.fft_size == tuple(fft_size) and len(basis.kpoints) == 50
     assert np.isclose(sum(basis.kweights), 1.0)
     _check_basis_invariants(basis, basis.kpoints, LATTICE, Ecut)
+
+
+@pytest.mark.parametrize("terms,functionals", [
+    (("Kinetic",), ()),
+    (("Kinetic", "AtomicLocal"), ()),
+    (("Kinetic", "AtomicNonlocal"), ()),
+    (("Kinetic", "Hartree"), ()),
+    (("Kinetic", "Xc"), ("lda_x", "lda_c_vwn")),
+    (("Kinetic", "Xc"), ("lda_x", "lda_c_pw")),
+    (("Kinetic", "Xc"), ("gga_x_pbe", "gga_c_pbe")),
+    (("Kinetic", "AtomicLocal", "AtomicNonlocal", "Hartree", "Xc"), ("gga_x_pbe", "gga_c_pbe")),
+])
+def test_hamiltonian_is_derivative_of_energy(terms, functionals):
+    """The reference's operator-consistency recipe (test/hamiltonian_consistency.jl:10-109) on the oracle: for
+    random orbitals, occupations and directions  d/d eps E[psi + eps dpsi] = 2 sum_k w_k sum_n f_n Re<dpsi_n|H psi_n>
+    (central differences, eps = 1e-6), and H psi equals the dense matrix of H applied to psi.  Ties every potential
+    (in particular V_xc of LDA and PBE with its Fourier-space divergence) to its energy expression."""
+    kw = dict(functionals=functionals) if functionals else {}
+    model = Model(LATTICE, si_atoms("pbe" if "gga_x_pbe" in functionals else "lda"), POSITIONS, terms=terms, **kw)
+    basis = PlaneWaveBasis(model, 10, MonkhorstPack((1, 2, 3), (0, 0.5, 0)))
+    rng = np.random.default_rng(42)
+    n_bands, n_empty = 4, 3
+    psi, dpsi, occ = [], [], []
+    for kpt in basis.kpoints:
+        n = len(kpt.mapping)
+        z = rng.standard_normal((n, n_bands + n_empty)) + 1j * rng.standard_normal((n, n_bands + n_empty))
+        psi.append(np.linalg.qr(z)[0])
+        dpsi.append(rng.standard_normal((n, n_bands + n_empty)) + 1j * rng.standard_normal((n, n_bands + n_empty)))
+        occ.append(np.concatenate([2.0 * rng.random(n_bands), np.zeros(n_empty)]))
+    scale = len(basis.kpoints) * 8 / sum(o.sum() for o in occ)
+    occ = [o * scale for o in occ]
+    rho = compute_density(basis, psi, occ)
+    E0, ham = energy_hamiltonian(basis, psi, occ, rho=rho)
+
+    def energy(eps):
+        trial = [p + eps * d for p, d in zip(psi, dpsi)]
+        return energy_hamiltonian(basis, trial, occ, rho=compute_density(basis, trial, occ))[0].total
+
+    eps = 1e-6
+    diff = (energy(eps) - energy(-eps)) / (2 * eps)
+    predicted = 0.0
+    for ik, H in enumerate(ham):
+        Hpsi = H.mul(psi[ik])
+        predicted += 2 * basis.kweights[ik] * sum(occ[ik][n] * np.vdot(dpsi[ik][:, n], Hpsi[:, n]).real
+                                                  for n in range(n_bands))
+        if ik == 0:   # operator == its matrix form (:47-52)
+            assert np.linalg.norm(H.to_dense() @ psi[ik] - Hpsi) < 1e-10
+    assert abs(diff) > 1e-8                                      # not 0 == 0
+    assert abs(diff - predicted) < 1e-6 * max(1.0, abs(diff)), (diff, predicted)

@@ -519,3 +519,16 @@ def test_host_mirror_planewave_basis_invariants(Ecut, fft_size):
                                oracle.MonkhorstPack((2, 5, 5), (0.5, 0, 0)), fft_size=fft_size)
     for k, ok in zip(basis.kpoints, ob.kpoints):
         assert np.allclose(k.coordinate, ok.coordinate) and np.array_equal(k.mapping, ok.mapping)
+
+
+def test_host_mirror_fermi_level_reference_pins():
+    """test/occupation.jl:100-139 on the host mirror's compute_occupation (Fermi-Dirac, emulated metal)."""
+    from test_oracle_golden import MG_EIGENVALUES, MG_FERMI_DIRAC_PINS, LATTICE as LAT
+    kc = [[i / 13.0, 0, 0] for i in range(12)]                      # 12 k-points of equal weight (values irrelevant)
+    for T, ref in MG_FERMI_DIRAC_PINS:
+        model = dftk.Model(LAT, [], [], ("Kinetic",), n_electrons=4, temperature=T, smearing="fermi_dirac")
+        basis = dftk.PlaneWaveBasis(model, 3, dftk.ExplicitKpoints(kc, [1 / 12] * 12), fft_size=(9, 9, 9),
+                                    device="cpu", build_terms=False)
+        occ, eF = dftk.compute_occupation(basis, [np.array(e) for e in MG_EIGENVALUES], tol_n_elec=1e-10)
+        assert abs(eF - ref) < 1e-12
+        assert abs(sum(w * o.sum() for w, o in zip(basis.kweights, occ)) - 4.0) < 1e-9

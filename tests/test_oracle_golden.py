@@ -368,3 +368,56 @@ def test_hamiltonian_is_derivative_of_energy(terms, functionals):
             assert np.linalg.norm(H.to_dense() @ psi[ik] - Hpsi) < 1e-10
     assert abs(diff) > 1e-8                                      # not 0 == 0
     assert abs(diff - predicted) < 1e-6 * max(1.0, abs(diff)), (diff, predicted)
+
+
+MG_EIGENVALUES = [   # test/occupation.jl:106-118 ("Smearing for a simple metal", 12 k-points of equal weight)
+    [-0.08063210585291, 0.11227915155236, 0.13057816014162, 0.57672256037074],
+    [0.09509047528102, 0.09538152469111, 0.27197836572013, 0.28750689088845],
+    [-0.00144586520885, 0.18640677556553, 0.19603060374450, 0.24422060327989],
+    [0.05693643182609, 0.16919740718547, 0.24190245274401, 0.25674283154835],
+    [-0.06756541677784, 0.03381889875058, 0.23162853469956, 0.50981867707851],
+    [0.10685980948954, 0.10728887405642, 0.20784971952147, 0.20786603845828],
+    [0.01122399002894, 0.11011069317735, 0.24016826005369, 0.30770620467001],
+    [0.06925846412968, 0.16087157153058, 0.19146746736359, 0.27463770659603],
+    [-0.02937886574534, -0.02937886574483, 0.36206906745747, 0.36206906745749],
+    [0.13314087354890, 0.13314087354890, 0.15834732772541, 0.15834732772541],
+    [0.04869672986772, 0.04869672986772, 0.27749728805752, 0.27749728805768],
+    [0.10585630776222, 0.10585630776223, 0.22191839818805, 0.22191839818822],
+]
+MG_FERMI_DIRAC_PINS = [(0.01, 0.16163115311626172), (0.02, 0.1624111568340279), (0.03, 0.1630075080960013)]  # :122-126
+
+
+def test_fermi_level_reference_pins():
+    """test/occupation.jl:100-139: Fermi level of the emulated metal with Fermi-Dirac smearing (n_electrons = 4,
+    tol_n_elec 1e-10) and the electron count; smearing limits and the insulator rules of :19-66."""
+    import types
+    from oracle.scf import compute_occupation, smearing_occupation
+    ev = [np.array(e) for e in MG_EIGENVALUES]
+    for T, ref in MG_FERMI_DIRAC_PINS:
+        model = types.SimpleNamespace(temperature=T, smearing="fermi_dirac", n_electrons=4, filled_occupation=2)
+        basis = types.SimpleNamespace(model=model, kweights=[1 / 12] * 12)
+        occ, eF = compute_occupation(basis, ev, tol_n_elec=1e-10)
+        assert eF == pytest.approx(ref, abs=1e-12)
+        assert sum(w * o.sum() for w, o in zip(basis.kweights, occ)) == pytest.approx(4.0, abs=1e-9)
+    for kind in ("fermi_dirac", "gaussian"):
+        assert smearing_occupation(kind, np.array([-np.inf]))[0] == 1 and smearing_occupation(kind, np.array([np.inf]))[0] == 0
+        x, e = 0.04, 1e-6
+        d = (smearing_occupation(kind, np.array([x + e]))[0] - smearing_occupation(kind, np.array([x - e]))[0]) / (2 * e)
+        exact = -1 / (4 * np.cosh(x / 2) ** 2) if kind == "fermi_dirac" else -np.exp(-x * x) / np.sqrt(np.pi)
+        assert d == pytest.approx(exact, abs=1e-8)                            # Smearing.jl occupation_derivative
+    # insulator: HOMO < eF < LUMO, eF = mid-gap at T = 0, electron count kept when a temperature is added
+    rng = np.random.default_rng(3)
+    evs = []
+    for _ in range(4):
+        e = np.sort(rng.random(10))
+        e[4:] += 2
+        evs.append(e)
+    homo, lumo = max(e[3] for e in evs), min(e[4] for e in evs)
+    for T, kind in [(0.0, "none"), (1e-6, "fermi_dirac"), (0.1, "gaussian"), (1.0, "fermi_dirac")]:
+        model = types.SimpleNamespace(temperature=T, smearing=kind, n_electrons=8, filled_occupation=2)
+        basis = types.SimpleNamespace(model=model, kweights=[0.25] * 4)
+        occ, eF = compute_occupation(basis, evs, tol_n_elec=1e-12)
+        assert homo < eF < lumo
+        assert sum(0.25 * o.sum() for o in occ) == pytest.approx(8.0, abs=1e-9)
+        if T == 0:
+            assert eF == pytest.approx((homo + lumo) / 2)

@@ -532,3 +532,20 @@ def test_host_mirror_fermi_level_reference_pins():
         occ, eF = dftk.compute_occupation(basis, [np.array(e) for e in MG_EIGENVALUES], tol_n_elec=1e-10)
         assert abs(eF - ref) < 1e-12
         assert abs(sum(w * o.sum() for w, o in zip(basis.kweights, occ)) - 4.0) < 1e-9
+
+
+def test_split_evenly_and_nuclear_energies():
+    """test/split_evenly.jl (concatenation of the parts is the range) and the ABINIT pins of test/energy_nuclear.jl
+    on the host mirror's set-up code."""
+    for n, parts in [(12, 4), (31, 7), (168, 16), (14, 16)]:
+        chunks = dftk.split_evenly(n, parts)
+        assert len(chunks) == parts and [i for c in chunks for i in c] == list(range(n))
+        sizes = [len(c) for c in chunks]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    from dftk_jl_amd.terms import energy_ewald, energy_psp_correction
+    lat, atoms, pos = dftk.silicon_cell()
+    a = 5.131570667152971
+    lat = np.array([[0, a, a], [a, 0, a], [a, a, 0.0]])
+    assert abs(energy_ewald(lat, [4, 4], pos) - (-8.39789357839024)) < 1e-10
+    model = dftk.Model(lat, atoms, pos, ("PspCorrection",))
+    assert abs(energy_psp_correction(model) - (-0.294622067023269)) < 1e-10

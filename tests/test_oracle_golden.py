@@ -421,3 +421,27 @@ def test_fermi_level_reference_pins():
         assert sum(0.25 * o.sum() for o in occ) == pytest.approx(8.0, abs=1e-9)
         if T == 0:
             assert eF == pytest.approx((homo + lumo) / 2)
+
+
+def test_nuclear_energies_abinit_pins():
+    """test/energy_nuclear.jl:20-56: Ewald and pseudopotential-correction energies of silicon against ABINIT, atol 1e-10."""
+    from oracle.terms import energy_psp_correction
+    assert energy_ewald(LATTICE, [4, 4], POSITIONS) == pytest.approx(-8.39789357839024, abs=1e-10)
+    model = Model(LATTICE, si_atoms(), POSITIONS, terms=("PspCorrection",))
+    assert energy_psp_correction(model) == pytest.approx(-0.294622067023269, abs=1e-10)
+
+
+@pytest.mark.parametrize("size,shift", [((2, 3, 2), (0, 0, 0)), ((3, 3, 3), (0, 0, 0)), ((3, 3, 3), (0.5, 0, 0)),
+                                        ((2, 3, 4), (0, 0, 0)), ((9, 11, 13), (0, 0, 0))])
+def test_monkhorst_pack_reducible_mesh(size, shift):
+    """test/bzmesh.jl:1-27 (the reference compares with Spglib's unreduced mesh): prod(size) distinct points
+    (i + shift) / size modulo 1, normalised into [-1/2, 1/2), uniform weights."""
+    kg = MonkhorstPack(size, shift).reducible()
+    kc = np.array(kg.kcoords)
+    n = int(np.prod(size))
+    assert kc.shape == (n, 3) and np.allclose(kg.kweights, 1 / n)
+    assert np.all(kc >= -0.5) and np.all(kc < 0.5)
+    idx = kc * np.array(size) - np.array(shift)
+    assert np.allclose(idx, np.round(idx))                                      # on the shifted grid
+    keys = {tuple(int(v) for v in np.mod(np.round(idx).astype(int), size)) for idx in [idx[i] for i in range(n)]}
+    assert len(keys) == n                                                        # all grid points, once

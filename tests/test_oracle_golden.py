@@ -445,3 +445,29 @@ def test_monkhorst_pack_reducible_mesh(size, shift):
     assert np.allclose(idx, np.round(idx))                                      # on the shifted grid
     keys = {tuple(int(v) for v in np.mod(np.round(idx).astype(int), size)) for idx in [idx[i] for i in range(n)]}
     assert len(keys) == n                                                        # all grid points, once
+
+
+def test_guess_density_integrates_to_electron_count():
+    """test/guess_density.jl:1-11,31-34 (ValenceDensityGaussian, spin-unpolarised)."""
+    model = model_DFT(LATTICE, si_atoms(), POSITIONS, functionals=("lda_x", "lda_c_pw"), temperature=0.01,
+                      smearing="fermi_dirac")
+    basis = PlaneWaveBasis(model, 7, MonkhorstPack((3, 3, 3), (0.5, 0.5, 0.5)))
+    rho = guess_density(basis)
+    assert rho.sum() * model.unit_cell_volume / np.prod(basis.fft_size) == pytest.approx(model.n_electrons, abs=1e-10)
+
+
+def test_supercell_scf_equals_unit_cell_scf():
+    """test/supercell.jl:22-45 ("Compare scf results in unit cell and supercell"): a 2x2x2 silicon supercell at
+    Gamma with the doubled FFT cube reproduces 8 x the unit-cell energy of the 2x2x2 k-mesh (oracle, Ecut 4)."""
+    from oracle.basis import create_supercell
+    model = model_DFT(LATTICE, si_atoms(), POSITIONS, functionals=("lda_x", "lda_c_pw"))
+    basis = PlaneWaveBasis(model, 4, MonkhorstPack((2, 2, 2)), fft_size=(15, 15, 15))
+    res = self_consistent_field(basis, tol=1e-9)
+    lat, atoms, pos = create_supercell(LATTICE, si_atoms(), POSITIONS, (2, 2, 2))
+    smodel = model_DFT(lat, atoms, pos, functionals=("lda_x", "lda_c_pw"))
+    sbasis = PlaneWaveBasis(smodel, 4, MonkhorstPack((1, 1, 1)), fft_size=(30, 30, 30))
+    sres = self_consistent_field(sbasis, tol=1e-9)
+    assert res["converged"] and sres["converged"]
+    assert abs(8 * res["energies"].total - sres["energies"].total) < 1e-8 * 16          # 1e-8 Ha / atom
+    occ_prim = np.sort(np.concatenate([lam[:4] for lam in res["eigenvalues"]]))
+    np.testing.assert_allclose(np.sort(sres["eigenvalues"][0])[:32], occ_prim, atol=1e-6)

@@ -471,3 +471,16 @@ def test_supercell_scf_equals_unit_cell_scf():
     assert abs(8 * res["energies"].total - sres["energies"].total) < 1e-8 * 16          # 1e-8 Ha / atom
     occ_prim = np.sort(np.concatenate([lam[:4] for lam in res["eigenvalues"]]))
     np.testing.assert_allclose(np.sort(sres["eigenvalues"][0])[:32], occ_prim, atol=1e-6)
+
+
+def test_scf_fixed_point_independent_of_acceleration():
+    """test/anderson.jl:1-30 in spirit: the converged density does not depend on the acceleration history depth
+    (Anderson m = 10, m = 2 and plain damped iteration m = 0), ||rho_a - rho_b|| sqrt(dvol) < 5e-9."""
+    model = model_DFT(LATTICE, si_atoms(), POSITIONS, functionals=("lda_x", "lda_c_pw"))
+    basis = PlaneWaveBasis(model, 5, MonkhorstPack((2, 2, 2)), fft_size=(18, 18, 18))
+    runs = [self_consistent_field(basis, tol=1e-10, anderson_m=m, maxiter=200) for m in (10, 2, 0)]
+    assert all(r["converged"] for r in runs)
+    assert runs[0]["n_iter"] <= runs[2]["n_iter"]                     # acceleration does not hurt
+    for r in runs[1:]:
+        assert np.linalg.norm(r["rho"] - runs[0]["rho"]) * np.sqrt(basis.dvol) < 5e-9
+        assert abs(r["energies"].total - runs[0]["energies"].total) < 1e-9

@@ -294,3 +294,21 @@ def test_graphene_pbe_potential_and_hpsi_match_oracle():
         got = (H @ torch.from_numpy(psi.T.copy()).cuda()).cpu().numpy().T
         ref = oH.mul(psi)
         assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-12
+
+
+def test_seeded_scf_is_bitwise_reproducible():
+    """test/reproducibility.jl:1-20: two SCF runs with the same seed agree EXACTLY (energy and density-change
+    histories, orbitals, density) -- no atomics anywhere on the path, split-K slabs are reduced in a fixed order."""
+    basis = dftk.PlaneWaveBasis(device_model(("lda_x", "lda_c_pw")), 15, dftk.MonkhorstPack((2, 2, 2)),
+                                fft_size=(27, 27, 27))
+    r1 = dftk.self_consistent_field(basis, tol=1e-7, seed=3)
+    r2 = dftk.self_consistent_field(basis, tol=1e-7, seed=3)
+    assert r1["converged"] and r1["n_iter"] == r2["n_iter"]
+    assert r1["history_Etot"] == r2["history_Etot"]
+    assert r1["history_drho"] == r2["history_drho"]
+    assert torch.equal(r1["rho"], r2["rho"])
+    for a, b in zip(r1["psi"], r2["psi"]):
+        assert torch.equal(a, b)
+    r3 = dftk.self_consistent_field(basis, tol=1e-7, seed=4)                  # another seed: another trajectory ...
+    assert r3["history_Etot"] != r1["history_Etot"]
+    assert abs(r3["energies"].total - r1["energies"].total) < 1e-8           # ... same fixed point

@@ -82,6 +82,8 @@ class Model:
 def model_atomic(lattice, atoms, positions, extra_terms=(), **kw):
     """standard_models.jl:45-61."""
     terms = ("Kinetic", "AtomicLocal", "AtomicNonlocal", "Ewald", "PspCorrection") + tuple(extra_terms)
+    if kw.get("temperature", 0) != 0:          # :56-58: the total becomes the free energy E - TS
+        terms = terms + ("Entropy",)
     return Model(lattice, atoms, positions, terms, **kw)
 
 

@@ -277,7 +277,8 @@ class ScfStepper:
                            occupation=info["occupation"], tol=diagtol, generator=self.gen, seed=self.seed,
                            timers=timers)
         t = time.time()
-        energies, _ = energy_hamiltonian(basis, nxt["psi"], nxt["occupation"], rho=nxt["rho"], only_energies=True)
+        energies, _ = energy_hamiltonian(basis, nxt["psi"], nxt["occupation"], rho=nxt["rho"], only_energies=True,
+                                         eigenvalues=nxt["eigenvalues"], eF=nxt["eF"])
         t = lap("energies", t)
         drho = nxt["rho"] - self.rho_in
         n_matvec_total = info["n_matvec"] + nxt["n_matvec"]
@@ -299,7 +300,8 @@ class ScfStepper:
 
     def finalize(self):
         info = self.info
-        energies, ham = energy_hamiltonian(self.basis, info["psi"], info["occupation"], rho=info["rho"])
+        energies, ham = energy_hamiltonian(self.basis, info["psi"], info["occupation"], rho=info["rho"],
+                                       eigenvalues=info["eigenvalues"], eF=info["eF"])
         info.update(energies=energies, ham=ham)
         return info
 

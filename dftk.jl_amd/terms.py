@@ -388,9 +388,27 @@ class Energies(dict):
         return float(sum(self.values()))
 
 
-def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False):
-    """``energy_hamiltonian(basis, psi, occupation; rho)`` (Hamiltonian.jl:200-227); with
-    ``only_energies`` it is ``energy(...)`` (:232-236).  Returns (Energies, [DftHamiltonianBlock])."""
+def smearing_entropy(kind, x):
+    """Smearing.entropy (Smearing.jl:47,84-93,114) on host arrays: s(x) with s' = x f'."""
+    x = np.asarray(x, dtype=float)
+    if kind == "none":
+        return np.zeros_like(x)
+    if kind == "fermi_dirac":
+        y = np.exp(-np.abs(x))
+        f = np.where(x > 0, y / (1 + y), 1 / (1 + y))
+        eps = np.finfo(float).eps
+        safe = (np.abs(f) >= eps) & (np.abs(1 - f) >= eps)
+        fs = np.where(safe, f, 0.5)
+        return np.where(safe, -(fs * np.log(fs) + (1 - fs) * np.log(1 - fs)), 0.0)
+    if kind == "gaussian":
+        return np.exp(-x * x) / (2 * math.sqrt(math.pi))
+    raise NotImplementedError(f"smearing {kind}")
+
+
+def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, eigenvalues=None, eF=None):
+    """``energy_hamiltonian(basis, psi, occupation; rho, eigenvalues, eF)`` (Hamiltonian.jl:200-227); with
+    ``only_energies`` it is ``energy(...)`` (:232-236).  Returns (Energies, [DftHamiltonianBlock]).  The entropy
+    term -TS (terms/entropy.jl:11-42) needs this rank's eigenvalues and the Fermi level, else it is Inf."""
     basis._require_gpu()
     T = basis.terms
     E = Energies()
@@ -440,6 +458,19 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False):
             if not only_energies:
                 pot = vxc if pot is None else pot + vxc
             E[name] = exc
+        elif name == "Entropy":
+            model = basis.model
+            if model.temperature == 0:
+                E[name] = 0.0
+            elif not have_psi or eigenvalues is None or eF is None:
+                E[name] = math.inf
+            else:
+                e = 0.0
+                for ik, psik in enumerate(psi):
+                    x = (np.asarray(eigenvalues[ik], dtype=float)[:psik.shape[0]] - eF) / model.temperature
+                    e -= (model.temperature * basis.kweights[ik] * model.filled_occupation
+                          * float(np.sum(smearing_entropy(model.smearing, x))))
+                E[name] = basis.comm_kpts.sum_scalar(e)
         else:
             raise NotImplementedError(f"term {name} is outside the MI355X hot path")
     if only_energies:

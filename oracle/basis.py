@@ -127,6 +127,8 @@ class Model:
 def model_atomic(lattice, atoms, positions, extra_terms=(), **kw):
     """``model_atomic`` (standard_models.jl:45-61): Kinetic + AtomicLocal + AtomicNonlocal + ..."""
     terms = ("Kinetic", "AtomicLocal", "AtomicNonlocal", "Ewald", "PspCorrection") + tuple(extra_terms)
+    if kw.get("temperature", 0) != 0:          # standard_models.jl:56-58: the total becomes the free energy E - TS
+        terms = terms + ("Entropy",)
     return Model(lattice, atoms, positions, terms=terms, **kw)
 
 

@@ -242,7 +242,8 @@ def self_consistent_field(basis, rho=None, psi=None, tol=1e-6, maxiter=100, damp
         diagtol = determine_diagtol(info_for_tol["n_iter"], info_for_tol["history_drho"])
         nxt = next_density(basis, ham, nbandsalg, psi=info["psi"], eigenvalues=info["eigenvalues"],
                            occupation=info["occupation"], tol=diagtol, rng=rng)
-        energies, _ = energy_hamiltonian(basis, nxt["psi"], nxt["occupation"], rho=nxt["rho"])
+        energies, _ = energy_hamiltonian(basis, nxt["psi"], nxt["occupation"], rho=nxt["rho"],
+                                         eigenvalues=nxt["eigenvalues"], eF=nxt["eF"])
         drho = nxt["rho"] - rho_in
         info = dict(info, **nxt)
         info["n_iter"] = n_iter
@@ -258,7 +259,8 @@ def self_consistent_field(basis, rho=None, psi=None, tol=1e-6, maxiter=100, damp
             break
         # fixpoint map returns rho_in + mix(drho) = rho_out; the solver then damps + accelerates
         rho_in = accel(rho_in, damping, nxt["rho"] - rho_in)
-    energies, ham = energy_hamiltonian(basis, info["psi"], info["occupation"], rho=info["rho"])
+    energies, ham = energy_hamiltonian(basis, info["psi"], info["occupation"], rho=info["rho"],
+                                       eigenvalues=info["eigenvalues"], eF=info["eF"])
     info["energies"] = energies
     info["ham"] = ham
     return info

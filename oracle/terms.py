@@ -438,9 +438,26 @@ class Energies(dict):
         return float(sum(self.values()))
 
 
-def energy_hamiltonian(basis, psi, occupation, rho=None):
-    """``energy_hamiltonian(basis, psi, occ; rho)`` (Hamiltonian.jl:200-227): per-term energies and
-    one HamiltonianBlock per k-point; ``energy`` (:232-236) gives the same energies."""
+def smearing_entropy(kind, x):
+    """Smearing.entropy (Smearing.jl:47,84-93,114): s(x) with s' = x f'."""
+    x = np.asarray(x, dtype=float)
+    if kind == "none":
+        return np.zeros_like(x)
+    if kind == "fermi_dirac":
+        f = np.where(x > 0, np.exp(-np.abs(x)) / (1 + np.exp(-np.abs(x))), 1 / (1 + np.exp(-np.abs(x))))
+        eps = np.finfo(float).eps
+        safe = (np.abs(f) >= eps) & (np.abs(1 - f) >= eps)
+        fs = np.where(safe, f, 0.5)
+        return np.where(safe, -(fs * np.log(fs) + (1 - fs) * np.log(1 - fs)), 0.0)
+    if kind == "gaussian":
+        return np.exp(-x * x) / (2 * math.sqrt(math.pi))
+    raise NotImplementedError(kind)
+
+
+def energy_hamiltonian(basis, psi, occupation, rho=None, eigenvalues=None, eF=None):
+    """``energy_hamiltonian(basis, psi, occ; rho, eigenvalues, eF)`` (Hamiltonian.jl:200-227): per-term energies and
+    one HamiltonianBlock per k-point; ``energy`` (:232-236) gives the same energies.  The entropy term -TS
+    (terms/entropy.jl:11-42) needs the eigenvalues and the Fermi level, otherwise it is Inf as in the reference."""
     T = basis.terms
     model = basis.model
     E = Energies()
@@ -489,6 +506,18 @@ def energy_hamiltonian(basis, psi, occupation, rho=None):
             exc, vxc = xc_energy_potential(basis, rho)
             add_pot(vxc)
             E[name] = exc
+        elif name == "Entropy":
+            if model.temperature == 0:
+                E[name] = 0.0
+            elif not have_psi or eigenvalues is None or eF is None:
+                E[name] = math.inf
+            else:
+                e = 0.0
+                for ik, psik in enumerate(psi):
+                    x = (np.asarray(eigenvalues[ik], dtype=float)[:psik.shape[1]] - eF) / model.temperature
+                    e -= (model.temperature * basis.kweights[ik] * model.filled_occupation
+                          * float(np.sum(smearing_entropy(model.smearing, x))))
+                E[name] = e
         else:
             raise NotImplementedError(name)
     ham = [HamiltonianBlock(basis, kpt,

@@ -549,3 +549,18 @@ def test_split_evenly_and_nuclear_energies():
     assert abs(energy_ewald(lat, [4, 4], pos) - (-8.39789357839024)) < 1e-10
     model = dftk.Model(lat, atoms, pos, ("PspCorrection",))
     assert abs(energy_psp_correction(model) - (-0.294622067023269)) < 1e-10
+
+
+def test_host_mirror_entropy_term():
+    """Entropy term -TS (terms/entropy.jl, standard_models.jl:56-58): present exactly when temperature != 0, and the
+    mirror's smearing entropy equals the oracle's (s' = x f' is checked on the oracle)."""
+    from dftk_jl_amd.terms import smearing_entropy
+    from oracle.terms import smearing_entropy as oracle_entropy
+    lat, atoms, pos = dftk.silicon_cell()
+    assert "Entropy" not in dftk.model_DFT(lat, atoms, pos).term_types
+    m = dftk.model_DFT(lat, atoms, pos, temperature=1e-3, smearing="gaussian")
+    assert m.term_types[-1] == "Entropy"
+    x = np.linspace(-40, 40, 2001)
+    for kind in ("none", "fermi_dirac", "gaussian"):
+        np.testing.assert_allclose(smearing_entropy(kind, x), oracle_entropy(kind, x), rtol=0, atol=1e-16)
+    assert np.all(smearing_entropy("fermi_dirac", x) >= 0) and smearing_entropy("fermi_dirac", np.array([0.0]))[0] == pytest.approx(np.log(2))

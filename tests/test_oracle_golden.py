@@ -405,6 +405,10 @@ def test_fermi_level_reference_pins():
         d = (smearing_occupation(kind, np.array([x + e]))[0] - smearing_occupation(kind, np.array([x - e]))[0]) / (2 * e)
         exact = -1 / (4 * np.cosh(x / 2) ** 2) if kind == "fermi_dirac" else -np.exp(-x * x) / np.sqrt(np.pi)
         assert d == pytest.approx(exact, abs=1e-8)                            # Smearing.jl occupation_derivative
+        from oracle.terms import smearing_entropy                            # entropy functions satisfy s' = x f' (:27-30)
+        sp = (smearing_entropy(kind, np.array([x + e]))[0] - smearing_entropy(kind, np.array([x - e]))[0]) / (2 * e)
+        assert sp == pytest.approx(x * exact, abs=1e-8)
+        assert smearing_entropy(kind, np.array([-50.0, 50.0])) == pytest.approx([0.0, 0.0], abs=1e-20)
     # insulator: HOMO < eF < LUMO, eF = mid-gap at T = 0, electron count kept when a temperature is added
     rng = np.random.default_rng(3)
     evs = []
@@ -484,3 +488,23 @@ def test_scf_fixed_point_independent_of_acceleration():
     for r in runs[1:]:
         assert np.linalg.norm(r["rho"] - runs[0]["rho"]) * np.sqrt(basis.dvol) < 5e-9
         assert abs(r["energies"].total - runs[0]["energies"].total) < 1e-9
+
+
+def test_total_energy_from_orbital_eigenvalues():
+    """test/energy_orbital_eigenvalues.jl: E_tot = sum_k w_k sum_n f_n eps_n + E_Ewald + E_psp-corr (+ entropy term)
+    - E_Hartree + E_xc - int rho v_xc  at self-consistency (PBE, the reference's 1e-5 at SCF tol 1e-6)."""
+    from oracle.terms import xc_energy_potential
+    model = model_DFT(LATTICE, si_atoms("pbe"), POSITIONS, functionals=("gga_x_pbe", "gga_c_pbe"), temperature=1e-2,
+                      smearing="fermi_dirac")
+    assert model.terms[-1] == "Entropy"                       # standard_models.jl:56-58
+    basis = PlaneWaveBasis(model, 8, MonkhorstPack((1, 2, 3), (0, 0.5, 0)))
+    res = self_consistent_field(basis, tol=1e-7)
+    assert res["converged"]
+    E = res["energies"]
+    assert E["Entropy"] < 0 and np.isfinite(E["Entropy"])     # -TS
+    bands = sum(w * float(np.dot(occ, lam[:len(occ)]))
+                for w, occ, lam in zip(basis.kweights, res["occupation"], res["eigenvalues"]))
+    _, vxc = xc_energy_potential(basis, res["rho"])
+    e_xcpot = float((vxc * res["rho"]).sum() * basis.dvol)
+    total = bands + E["Ewald"] + E["PspCorrection"] + E["Entropy"] - E["Hartree"] + E["Xc"] - e_xcpot
+    assert abs(total - E.total) < 1e-5

@@ -207,7 +207,8 @@ def main():
             if FAMILIES[dom] in pmc["families"] and pmc["workload"] == f"si{n}x{n}x{n}_ecut{args.ecut:g}":
                 roof["traffic"] = pmc["families"][FAMILIES[dom]]["bytes_per_launch"]
                 roof["traffic_unit"] = "B/launch"
-                roof["traffic_source"] = "profiles/r01_pmc_traffic.json (" + pmc["collected"] + ")"
+                roof["traffic_source"] = ("profiles/r01_pmc_traffic.json (" + pmc["collected"] + ")"
+                                          + ("; " + pmc["note"] if pmc.get("note") else ""))
                 roof["algorithmic_bytes_per_launch"] = (prof_get(lib, basis, 10)[1] / max(launches, 1) if dom == 0
                                                         else work / max(launches, 1))
         except (OSError, KeyError, ValueError):

@@ -251,6 +251,11 @@ class ScfStepper:
         self.rho_in = guess_density(basis) if rho is None else rho
         self.nbandsalg = nbandsalg if nbandsalg is not None else AdaptiveBands(basis.model)
         self.is_converged = is_converged or (lambda info: info["history_drho"][-1] < tol)   # ScfConvergenceDensity
+        if determine_tol is determine_diagtol:
+            # default_diagtolalg (scf_callbacks.jl:223-233): AdaptiveDiagtol(; diagtol_first = tol / 5) for models
+            # without nonlinear / exact-exchange terms -- the first two SCF steps diagonalise to tol / 5
+            def determine_tol(n_iter, history_drho, _first=tol / 5):
+                return determine_diagtol(n_iter, history_drho, diagtol_first=_first)
         self.eigensolver, self.damping, self.determine_tol = eigensolver, damping, determine_tol
         self.accel = AndersonAcceleration(m=anderson_m)
         self.sqrt_dvol = math.sqrt(basis.dvol)

@@ -239,7 +239,8 @@ def self_consistent_field(basis, rho=None, psi=None, tol=1e-6, maxiter=100, damp
         n_iter = info["n_iter"] + 1
         _, ham = energy_hamiltonian(basis, info["psi"], info["occupation"], rho=rho_in)
         info_for_tol = dict(n_iter=info["n_iter"], history_drho=info["history_drho"])
-        diagtol = determine_diagtol(info_for_tol["n_iter"], info_for_tol["history_drho"])
+        # default_diagtolalg (scf_callbacks.jl:223-233): AdaptiveDiagtol(; diagtol_first = tol / 5)
+        diagtol = determine_diagtol(info_for_tol["n_iter"], info_for_tol["history_drho"], diagtol_first=tol / 5)
         nxt = next_density(basis, ham, nbandsalg, psi=info["psi"], eigenvalues=info["eigenvalues"],
                            occupation=info["occupation"], tol=diagtol, rng=rng)
         energies, _ = energy_hamiltonian(basis, nxt["psi"], nxt["occupation"], rho=nxt["rho"],

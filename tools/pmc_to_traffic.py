@@ -51,6 +51,9 @@ def main():
                    "bytes_per_launch": b / n}
         if f in work and f != "zgemm_f64_mfma":
             fams[f]["algorithmic_bytes_per_launch"] = work[f] / n
+        elif f == "zgemm_f64_mfma" and line["roofline"].get("kernel") == f:
+            # operand bytes per launch of THIS pass (bench.py --prof-all counts from the first warm-up step on)
+            fams[f]["algorithmic_bytes_per_launch"] = line["roofline"].get("algorithmic_bytes_per_launch")
     json.dump({"workload": sys.argv[5] if len(sys.argv) > 5 else "si4x4x4_ecut30",
                "collected": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, python bench.py --prof-all",
                "correction": "FETCH_SIZE x2 (gfx950), WRITE_SIZE x1, KiB -> B", "families": fams},

@@ -508,3 +508,48 @@ def test_total_energy_from_orbital_eigenvalues():
     e_xcpot = float((vxc * res["rho"]).sum() * basis.dvol)
     total = bands + E["Ewald"] + E["PspCorrection"] + E["Entropy"] - E["Hartree"] + E["Xc"] - e_xcpot
     assert abs(total - E.total) < 1e-5
+
+
+@pytest.mark.parametrize("symbol,functional", [("Si", "lda"), ("Si", "pbe"), ("Al", "pbe"), ("C", "lda"), ("C", "pbe")])
+def test_hgh_fourier_forms_against_real_space_quadrature(symbol, functional):
+    """test/PspHgh.jl:88-176 for every pseudopotential of the embedded table: the closed Fourier-space forms equal the
+    (modified) spherical Hankel transforms of the real-space HGH projectors (PspHgh.jl:154-160), the local potential's
+    Fourier form matches the regularised radial integral, the q -> 0 energy correction is its non-Coulomb limit; and
+    the table reproduces the reference's "C-lda-q4" file values (:1-18)."""
+    from math import gamma
+    from scipy.integrate import quad
+    from scipy.special import spherical_jn, erf
+    from oracle.psp import eval_psp_energy_correction
+    psp = load_psp_hgh(symbol, functional)
+    if (symbol, functional) == ("C", "lda"):
+        assert psp.Zion == 4 and psp.rloc == 0.34883045 and psp.lmax == 1
+        assert list(psp.cloc[:2]) == [-8.51377110, 1.22843203] and all(c == 0 for c in psp.cloc[2:])
+        assert list(psp.rp) == [0.30455321, 0.2326773]
+        assert np.array_equal(psp.h[0], 9.52284179 * np.ones((1, 1))) and psp.h[1].size == 0
+
+    def proj_real(i, l, r):                                     # PspHgh.jl:154-160
+        rp = psp.rp[l]
+        ired = (4 * i - 1) / 2
+        return np.sqrt(2) * r ** (l + 2 * (i - 1)) * np.exp(-r * r / (2 * rp * rp)) / (rp ** (l + ired) * np.sqrt(gamma(l + ired)))
+
+    for l in range(psp.lmax + 1):
+        for i in range(1, psp.h[l].shape[0] + 1):
+            for p in (0.01, 0.1, 0.5, 1.0, 2.0, 5.0, 10.0):
+                ref = quad(lambda r: 4 * np.pi * r * r * proj_real(i, l, r) * spherical_jn(l, p * r), 0, 12 * psp.rp[l] + 6,
+                           epsabs=1e-13, epsrel=1e-12, limit=400)[0] / p ** l
+                got = eval_psp_projector_fourier(psp, i, l, np.array([p]))[0]
+                assert got == pytest.approx(ref, rel=1e-8, abs=5e-13), (l, i, p)
+
+    def vloc_real(r):                                           # PspHgh.jl:126-135
+        x = r / psp.rloc
+        c = list(psp.cloc) + [0.0] * (4 - len(psp.cloc))
+        return (-psp.Zion / r * erf(x / np.sqrt(2))
+                + np.exp(-x * x / 2) * (c[0] + c[1] * x ** 2 + c[2] * x ** 4 + c[3] * x ** 6))
+
+    reg = 1e-3
+    for p in (0.2, 1.0, 1.3):
+        ref = quad(lambda r: 4 * np.pi * vloc_real(r) * np.exp(-reg * r) / p * r, 0, np.inf, weight="sin", wvar=p)[0]
+        assert eval_psp_local_fourier(psp, np.array([p]))[0] == pytest.approx(ref, rel=0.1, abs=0.1)
+    p_small = 1e-3
+    lim = eval_psp_local_fourier(psp, np.array([p_small]))[0] + 4 * np.pi * psp.Zion / p_small ** 2
+    assert eval_psp_energy_correction(psp) == pytest.approx(lim, abs=1e-3)

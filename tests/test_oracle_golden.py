@@ -540,15 +540,15 @@ def test_hgh_fourier_forms_against_real_space_quadrature(symbol, functional):
                 got = eval_psp_projector_fourier(psp, i, l, np.array([p]))[0]
                 assert got == pytest.approx(ref, rel=1e-8, abs=5e-13), (l, i, p)
 
-    def vloc_real(r):                                           # PspHgh.jl:126-135
+    def r_vloc_real(r):                                         # r * V_loc(r), PspHgh.jl:126-135 (finite at r = 0)
         x = r / psp.rloc
         c = list(psp.cloc) + [0.0] * (4 - len(psp.cloc))
-        return (-psp.Zion / r * erf(x / np.sqrt(2))
-                + np.exp(-x * x / 2) * (c[0] + c[1] * x ** 2 + c[2] * x ** 4 + c[3] * x ** 6))
+        return (-psp.Zion * erf(x / np.sqrt(2))
+                + r * np.exp(-x * x / 2) * (c[0] + c[1] * x ** 2 + c[2] * x ** 4 + c[3] * x ** 6))
 
     reg = 1e-3
     for p in (0.2, 1.0, 1.3):
-        ref = quad(lambda r: 4 * np.pi * vloc_real(r) * np.exp(-reg * r) / p * r, 0, np.inf, weight="sin", wvar=p)[0]
+        ref = quad(lambda r: 4 * np.pi * r_vloc_real(r) * np.exp(-reg * r) / p, 0, np.inf, weight="sin", wvar=p)[0]
         assert eval_psp_local_fourier(psp, np.array([p]))[0] == pytest.approx(ref, rel=0.1, abs=0.1)
     p_small = 1e-3
     lim = eval_psp_local_fourier(psp, np.array([p_small]))[0] + 4 * np.pi * psp.Zion / p_small ** 2

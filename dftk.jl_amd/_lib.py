@@ -47,6 +47,17 @@ _SIGNATURES = {
                                  C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(C.c_int),
                                  C.POINTER(C.c_int), C.POINTER(_i64)]),
     "dftk_mi_lobpcg_last_AX": (C.c_void_p, [C.c_void_p]),
+    "dftk_mi_lobpcg_history": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t,
+                                         C.POINTER(C.c_int)]),
+    "dftk_mi_columnwise_norms": (C.c_int, [C.c_void_p, _i64, C.c_int, C.c_void_p, _i64, C.c_void_p]),
+    "dftk_mi_columnwise_dots": (C.c_int, [C.c_void_p, _i64, C.c_int, C.c_void_p, _i64, C.c_void_p, _i64, C.c_void_p]),
+    "dftk_mi_ortho_qr": (C.c_int, [C.c_void_p, _i64, C.c_int, C.c_void_p, _i64, C.c_int, C.POINTER(C.c_int),
+                                   C.POINTER(C.c_int)]),
+    "dftk_mi_tpa_precondprep": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p]),
+    "dftk_mi_tpa_ldiv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, C.c_double, C.c_void_p, _i64]),
+    "dftk_mi_block_residual": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, _i64, C.c_void_p,
+                                         C.c_void_p, _i64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dftk_mi_kblock_set_shard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dftk_mi_zgemm": (C.c_int, [C.c_void_p, C.c_char, _i64, _i64, _i64, dftk_mi_cplx, C.c_void_p, _i64,
                                 C.c_void_p, _i64, dftk_mi_cplx, C.c_void_p, _i64]),
     "dftk_mi_zgemm_ex": (C.c_int, [C.c_void_p, C.c_char, _i64, _i64, _i64, dftk_mi_cplx, C.c_void_p, _i64,
@@ -56,7 +67,11 @@ _SIGNATURES = {
     "dftk_mi_potrf_trtri": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, _i64]),
     "dftk_mi_comm_get_unique_id": (C.c_int, [C.c_char_p]),
     "dftk_mi_comm_init_rank": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "dftk_mi_comm_create_host": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.POINTER(C.c_void_p)]),
     "dftk_mi_comm_destroy": (C.c_int, [C.c_void_p]),
+    "dftk_mi_comm_rank": (C.c_int, [C.c_void_p]),
+    "dftk_mi_comm_size": (C.c_int, [C.c_void_p]),
     "dftk_mi_allreduce_sum_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dftk_mi_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "dftk_mi_prof_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -68,6 +83,10 @@ _SIGNATURES = {
     "dftk_mi_sphere_tables_host": (C.c_int, [C.c_int, C.c_int, C.c_int, _i64, C.c_void_p, C.POINTER(_i64),
                                              C.POINTER(C.c_int), C.c_void_p, C.c_void_p]),
 }
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)
+ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                           C.POINTER(C.c_double), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t))
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 _lib = None

@@ -26,7 +26,9 @@ extern "C" const char* dftk_mi_version(void) {
 int prof_begin(dftk_mi_basis* b, int fam, double work, uint64_t tag) {
     Prof* p = b->prof;
     if (!p || !p->on) return -1;
-    if (p->pending.size() >= 60000) prof_resolve(b);
+    // slots index `pending`, and scopes nest (apply_H / heev hold one across inner zgemm / FFT scopes): never
+    // flush while a scope is open
+    if (p->pending.size() >= 60000 && p->open == 0) prof_resolve(b);
     Prof::Pair pr;
     if (!p->pool.empty()) {
         pr = p->pool.back();
@@ -41,11 +43,14 @@ int prof_begin(dftk_mi_basis* b, int fam, double work, uint64_t tag) {
     p->launches[fam] += 1;
     hipEventRecord(pr.a, b->stream);
     p->pending.push_back(pr);
+    p->open += 1;
     return (int)p->pending.size() - 1;
 }
 void prof_end(dftk_mi_basis* b, int slot) {
     if (slot < 0) return;
-    hipEventRecord(b->prof->pending[slot].b, b->stream);
+    Prof* p = b->prof;
+    if (p->open > 0) p->open -= 1;
+    if ((size_t)slot < p->pending.size()) hipEventRecord(p->pending[slot].b, b->stream);
 }
 int prof_resolve(dftk_mi_basis* b) {
     Prof* p = b->prof;
@@ -65,6 +70,7 @@ int prof_resolve(dftk_mi_basis* b) {
         p->pool.push_back(pr);
     }
     p->pending.clear();
+    p->open = 0;
     return 0;
 }
 extern "C" int dftk_mi_prof_enable(dftk_mi_basis* b, int on) {
@@ -317,6 +323,7 @@ extern "C" int dftk_mi_basis_destroy(dftk_mi_basis* b) {
     if (b->T1) hipFree(b->T1);
     if (b->T2) hipFree(b->T2);
     if (b->ws) hipFree(b->ws);
+    if (b->dense_ws) hipFree(b->dense_ws);
     if (b->d_scalars) hipFree(b->d_scalars);
     if (b->h_scalars) hipHostFree(b->h_scalars);
     if (b->prof) {
@@ -408,9 +415,118 @@ extern "C" int dftk_mi_kblock_destroy(dftk_mi_kblock* kb) {
                     kb->d_zpos, kb->d_zval, kb->d_kin, kb->d_Vs, kb->d_D, kb->lob_buf};
     for (void* p : ptrs)
         if (p) hipFree(p);
+    if (kb->sh_buf) hipFree(kb->sh_buf);
+    delete kb->sh_rows;
+    delete kb->lob_hist;
     delete kb;
     return 0;
 }
+
+// ------------------------------------------------------------------------------------ plane-wave sharding
+static int64_t local_rows(const dftk_mi_kblock* kb) {
+    if (!kb->sh_comm) return kb->n_G;
+    const int r = comm_rank(kb->sh_comm);
+    return (*kb->sh_rows)[r + 1] - (*kb->sh_rows)[r];
+}
+
+extern "C" int dftk_mi_kblock_set_shard(dftk_mi_kblock* kb, dftk_mi_comm* comm, const int64_t* row_starts_h) {
+    if (!kb) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(kb->basis->device));
+    HIPCHK(hipStreamSynchronize(kb->basis->stream));
+    if (!comm) {
+        kb->sh_comm = nullptr;
+        return 0;
+    }
+    const int p = comm_size(comm);
+    if (!row_starts_h || row_starts_h[0] != 0 || row_starts_h[p] != kb->n_G) {
+        dftk_set_error("set_shard: row_starts must run from 0 to n_G over n_ranks + 1 entries");
+        return DFTK_MI_EINVAL;
+    }
+    for (int r = 0; r < p; ++r)
+        if (row_starts_h[r + 1] <= row_starts_h[r]) {
+            dftk_set_error("set_shard: every rank needs a non-empty row slab");
+            return DFTK_MI_EINVAL;
+        }
+    if (kb->n_p != 0) {
+        dftk_set_error("set_shard: call before dftk_mi_kblock_set_projectors (P becomes the row slab of this rank)");
+        return DFTK_MI_EINVAL;
+    }
+    if (!kb->sh_rows) kb->sh_rows = new std::vector<int64_t>();
+    kb->sh_rows->assign(row_starts_h, row_starts_h + p + 1);
+    kb->sh_comm = comm;
+    return 0;
+}
+
+// columns [c0[s], c0[s+1]) of an nb-column block are transformed by rank s (split_evenly)
+static void band_split(int nb, int p, std::vector<int>& c0) {
+    c0.assign(p + 1, 0);
+    const int base = nb / p, rem = nb % p;
+    for (int s = 0; s < p; ++s) c0[s + 1] = c0[s] + base + (s < rem ? 1 : 0);
+}
+
+static int shard_buffers(dftk_mi_kblock* kb, int nb, cd** R1, cd** F, cd** G) {
+    const int p = comm_size(kb->sh_comm);
+    const size_t maxc = (size_t)(nb + p - 1) / p;
+    const size_t each = (size_t)kb->n_G * (maxc ? maxc : 1);
+    const size_t need = 3 * each * sizeof(cd);
+    if (need > kb->sh_bytes) {
+        HIPCHK(hipStreamSynchronize(kb->basis->stream));
+        if (kb->sh_buf) HIPCHK(hipFree(kb->sh_buf));
+        kb->sh_buf = nullptr;
+        kb->sh_bytes = 0;
+        HIPCHK(hipMalloc((void**)&kb->sh_buf, need));
+        kb->sh_bytes = need;
+    }
+    *R1 = kb->sh_buf;
+    *F = kb->sh_buf + each;
+    *G = kb->sh_buf + 2 * each;
+    return 0;
+}
+
+// slab layout (n_loc x nb, this rank's rows of every band) -> band layout (n_G x mine, all rows of this rank's
+// bands) and back: one all-to-all each way, pieces are contiguous column groups on the slab side
+struct Transposer {
+    dftk_mi_kblock* kb;
+    int p, me, nb, mine;
+    int64_t nloc;
+    std::vector<int> c0;
+    std::vector<size_t> slab_off, slab_cnt, band_off, band_cnt;
+    Transposer(dftk_mi_kblock* k, int nbands) : kb(k), nb(nbands) {
+        p = comm_size(kb->sh_comm);
+        me = comm_rank(kb->sh_comm);
+        nloc = local_rows(kb);
+        band_split(nb, p, c0);
+        mine = c0[me + 1] - c0[me];
+        slab_off.resize(p), slab_cnt.resize(p), band_off.resize(p), band_cnt.resize(p);
+        for (int s = 0; s < p; ++s) {
+            slab_off[s] = (size_t)c0[s] * nloc;
+            slab_cnt[s] = (size_t)(c0[s + 1] - c0[s]) * nloc;
+            const int64_t rows = (*kb->sh_rows)[s + 1] - (*kb->sh_rows)[s];
+            band_off[s] = (size_t)(*kb->sh_rows)[s] * mine;
+            band_cnt[s] = (size_t)rows * mine;
+        }
+    }
+    // psi_loc (ld == nloc required by the caller) -> F (n_G x mine, ld n_G); R1 is scratch
+    int to_bands(const cd* slab, cd* R1, cd* F) {
+        dftk_mi_basis* b = kb->basis;
+        CHK(comm_alltoallv(kb->sh_comm, b, slab, slab_off.data(), slab_cnt.data(), R1, band_off.data(),
+                           band_cnt.data()));
+        for (int r = 0; r < p; ++r) {
+            const int64_t rows = (*kb->sh_rows)[r + 1] - (*kb->sh_rows)[r];
+            CHK(ew_copy(b, rows, mine, R1 + band_off[r], rows, F + (*kb->sh_rows)[r], kb->n_G));
+        }
+        return 0;
+    }
+    int to_slabs(const cd* Gfull, cd* R1, cd* slab) {
+        dftk_mi_basis* b = kb->basis;
+        for (int r = 0; r < p; ++r) {
+            const int64_t rows = (*kb->sh_rows)[r + 1] - (*kb->sh_rows)[r];
+            CHK(ew_copy(b, rows, mine, Gfull + (*kb->sh_rows)[r], kb->n_G, R1 + band_off[r], rows));
+        }
+        return comm_alltoallv(kb->sh_comm, b, R1, band_off.data(), band_cnt.data(), slab, slab_off.data(),
+                              slab_cnt.data());
+    }
+};
 
 extern "C" int dftk_mi_kblock_set_projectors(dftk_mi_kblock* kb, int n_p, const dftk_mi_cplx* P_d, int64_t ldP,
                                              const double* D_h) {
@@ -424,7 +540,7 @@ extern "C" int dftk_mi_kblock_set_projectors(dftk_mi_kblock* kb, int n_p, const 
     kb->n_p = 0;
     kb->P = nullptr;
     if (n_p == 0) return 0;
-    if (!P_d || !D_h || ldP < kb->n_G) return DFTK_MI_EINVAL;
+    if (!P_d || !D_h || ldP < local_rows(kb)) return DFTK_MI_EINVAL;
     int bw = 0;
     for (int j = 0; j < n_p; ++j)
         for (int i = 0; i < n_p; ++i)
@@ -460,7 +576,8 @@ static int apply_nonlocal(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldp
     const cd one = {1.0, 0.0}, zero = {0.0, 0.0};
     if (kb->n_p == 0) {
         if (!accumulate)
-            for (int c = 0; c < nb; ++c) HIPCHK(hipMemsetAsync(Hpsi + (int64_t)c * ldH, 0, kb->n_G * sizeof(cd), b->stream));
+            for (int c = 0; c < nb; ++c)
+                HIPCHK(hipMemsetAsync(Hpsi + (int64_t)c * ldH, 0, local_rows(kb) * sizeof(cd), b->stream));
         return 0;
     }
     // scratch for the two n_p x nb panels lives in T1 (free outside the FFT pipeline)
@@ -475,16 +592,20 @@ static int apply_nonlocal(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldp
     }
     cd* Ppsi = b->T1;
     cd* DPpsi = b->T1 + (size_t)kb->n_p * nb;
-    CHK(zgemm(b, 'C', kb->n_p, nb, kb->n_G, one, kb->P, kb->ldP, psi, ldpsi, zero, Ppsi, kb->n_p));
+    // (sharded block: P, psi, Hpsi are row slabs; the projections are partial sums -> one small all-reduce)
+    const int64_t rows = local_rows(kb);
+    CHK(zgemm(b, 'C', kb->n_p, nb, rows, one, kb->P, kb->ldP, psi, ldpsi, zero, Ppsi, kb->n_p));
+    if (kb->sh_comm) CHK(comm_allreduce(kb->sh_comm, b, reinterpret_cast<double*>(Ppsi), 2 * (size_t)kb->n_p * nb));
     CHK(apply_D(kb, nb, Ppsi, DPpsi));
-    CHK(zgemm(b, 'N', kb->n_G, nb, kb->n_p, one, kb->P, kb->ldP, DPpsi, kb->n_p, accumulate ? one : zero, Hpsi, ldH));
+    CHK(zgemm(b, 'N', rows, nb, kb->n_p, one, kb->P, kb->ldP, DPpsi, kb->n_p, accumulate ? one : zero, Hpsi, ldH));
     return 0;
 }
 
 extern "C" int dftk_mi_apply_H_parts(dftk_mi_kblock* kb, int which, int n_bands, const dftk_mi_cplx* psi_d,
                                      int64_t ld_psi, dftk_mi_cplx* Hpsi_d, int64_t ld_Hpsi) {
-    if (!kb || !psi_d || !Hpsi_d || n_bands < 0 || ld_psi < kb->n_G || ld_Hpsi < kb->n_G || (which & ~7))
-        return DFTK_MI_EINVAL;
+    if (!kb || !psi_d || !Hpsi_d || n_bands < 0 || (which & ~7)) return DFTK_MI_EINVAL;
+    const int64_t rows = local_rows(kb);
+    if (ld_psi < rows || ld_Hpsi < rows) return DFTK_MI_EINVAL;
     if (n_bands == 0) return 0;   // "Nothing to do if psi empty" (Hamiltonian.jl:141)
     HIPCHK(hipSetDevice(kb->basis->device));
     const cd* psi = reinterpret_cast<const cd*>(psi_d);
@@ -493,10 +614,29 @@ extern "C" int dftk_mi_apply_H_parts(dftk_mi_kblock* kb, int which, int n_bands,
     const bool kinetic = which & 2;
     const bool nonlocal = which & 4;
     const int slot = prof_begin(kb->basis, PROF_APPLY_H, (double)n_bands);
-    // local (+ kinetic fused into the gather epilogue), or kinetic only / zero
-    CHK(launch_local_apply(kb, n_bands, psi, ld_psi, H, ld_Hpsi, kinetic, local));
+    struct G {
+        dftk_mi_basis* b;
+        int s;
+        ~G() { prof_end(b, s); }
+    } guard{kb->basis, slot};
+    if (!kb->sh_comm) {
+        // local (+ kinetic fused into the gather epilogue), or kinetic only / zero
+        CHK(launch_local_apply(kb, n_bands, psi, ld_psi, H, ld_Hpsi, kinetic, local));
+    } else {
+        // row-slab sharded block: the FFT pipeline needs whole bands -> slab -> band all-to-all, every rank
+        // transforms its share of the bands, band -> slab all-to-all back
+        if (ld_psi != rows || ld_Hpsi != rows) {
+            dftk_set_error("sharded apply_H: blocks must be packed (leading dimension == local rows %lld)", (long long)rows);
+            return DFTK_MI_EINVAL;
+        }
+        cd *R1, *F, *Gf;
+        CHK(shard_buffers(kb, n_bands, &R1, &F, &Gf));
+        Transposer t(kb, n_bands);
+        CHK(t.to_bands(psi, R1, F));
+        if (t.mine > 0) CHK(launch_local_apply(kb, t.mine, F, kb->n_G, Gf, kb->n_G, kinetic, local));
+        CHK(t.to_slabs(Gf, R1, H));
+    }
     if (nonlocal) CHK(apply_nonlocal(kb, n_bands, psi, ld_psi, H, ld_Hpsi, true));
-    prof_end(kb->basis, slot);
     return 0;
 }
 
@@ -519,16 +659,28 @@ extern "C" int dftk_mi_fft_sphere(dftk_mi_kblock* kb, const dftk_mi_cplx* cube_d
 
 extern "C" int dftk_mi_density_accumulate(dftk_mi_kblock* kb, int n_bands, const dftk_mi_cplx* psi_d, int64_t ld_psi,
                                           const double* weight_h, double* rho_d) {
-    if (!kb || !psi_d || !weight_h || !rho_d || n_bands < 0 || ld_psi < kb->n_G) return DFTK_MI_EINVAL;
+    if (!kb || !psi_d || !weight_h || !rho_d || n_bands < 0 || ld_psi < local_rows(kb)) return DFTK_MI_EINVAL;
     if (n_bands == 0) return 0;
     HIPCHK(hipSetDevice(kb->basis->device));
-    return launch_density(kb, n_bands, reinterpret_cast<const cd*>(psi_d), ld_psi, weight_h, rho_d);
+    if (!kb->sh_comm) return launch_density(kb, n_bands, reinterpret_cast<const cd*>(psi_d), ld_psi, weight_h, rho_d);
+    // sharded block: every rank accumulates |psi|^2 of its share of the bands into ITS rho (partial sum);
+    // the caller's density all-reduce (mpi_sum!(rho, comm), densities.jl:46) completes it
+    if (ld_psi != local_rows(kb)) {
+        dftk_set_error("sharded density: blocks must be packed (leading dimension == local rows)");
+        return DFTK_MI_EINVAL;
+    }
+    cd *R1, *F, *Gf;
+    CHK(shard_buffers(kb, n_bands, &R1, &F, &Gf));
+    Transposer t(kb, n_bands);
+    CHK(t.to_bands(reinterpret_cast<const cd*>(psi_d), R1, F));
+    if (t.mine == 0) return 0;
+    return launch_density(kb, t.mine, F, kb->n_G, weight_h + t.c0[t.me], rho_d);
 }
 
 extern "C" int dftk_mi_lobpcg(dftk_mi_kblock* kb, int M, dftk_mi_cplx* X_d, int64_t ldX, double tol, int miniter,
                               int maxiter, int n_conv_check, int use_tpa, uint64_t seed, double* lambda_h,
                               double* resid_h, int* n_iter, int* converged, int64_t* n_matvec) {
-    if (!kb || !X_d || M < 1 || ldX < kb->n_G || !lambda_h || !resid_h || !n_iter || !converged || !n_matvec ||
+    if (!kb || !X_d || M < 1 || ldX < local_rows(kb) || !lambda_h || !resid_h || !n_iter || !converged || !n_matvec ||
         maxiter < 0)
         return DFTK_MI_EINVAL;
     HIPCHK(hipSetDevice(kb->basis->device));
@@ -579,4 +731,112 @@ extern "C" int dftk_mi_potrf_trtri(dftk_mi_basis* b, int n, dftk_mi_cplx* A_d, i
     HIPCHK(hipSetDevice(b->device));
     double a, c;
     return dense_potrf_trtri(b, n, reinterpret_cast<cd*>(A_d), lda, reinterpret_cast<cd*>(invR_d), ldi, &a, &c);
+}
+
+// ------------------------------------------------------------------------------------ LOBPCG building blocks
+extern "C" int dftk_mi_lobpcg_history(dftk_mi_kblock* kb, int* M_out, int* n_iter_out, double* hist_h, size_t cap,
+                                      int* n_svd_out) {
+    if (!kb || !kb->lob_hist) return DFTK_MI_EINVAL;
+    if (M_out) *M_out = kb->lob_hist_M;
+    if (n_iter_out) *n_iter_out = kb->lob_hist_iters;
+    if (n_svd_out) *n_svd_out = kb->lob_n_svd;
+    if (hist_h) {
+        if (cap < kb->lob_hist->size()) return DFTK_MI_EINVAL;
+        std::copy(kb->lob_hist->begin(), kb->lob_hist->end(), hist_h);
+    }
+    return 0;
+}
+
+static int fetch(dftk_mi_basis* b, const double* d, double* h, size_t n) {
+    HIPCHK(hipMemcpyAsync(h, d, n * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+extern "C" int dftk_mi_columnwise_norms(dftk_mi_basis* b, int64_t n, int m, const dftk_mi_cplx* X_d, int64_t ldx,
+                                        double* norms_h) {
+    if (!b || !X_d || !norms_h || n < 0 || m < 0 || ldx < n || m > 100000) return DFTK_MI_EINVAL;
+    if (m == 0) return 0;
+    HIPCHK(hipSetDevice(b->device));
+    CHK(ensure_ws(b, (size_t)m * sizeof(double)));
+    double* d = reinterpret_cast<double*>(b->ws);
+    CHK(ew_colnorms(b, n, m, reinterpret_cast<const cd*>(X_d), ldx, d));
+    return fetch(b, d, norms_h, m);
+}
+
+extern "C" int dftk_mi_columnwise_dots(dftk_mi_basis* b, int64_t n, int m, const dftk_mi_cplx* A_d, int64_t lda,
+                                       const dftk_mi_cplx* B_d, int64_t ldb, dftk_mi_cplx* dots_h) {
+    if (!b || !A_d || !B_d || !dots_h || n < 0 || m < 0 || lda < n || ldb < n) return DFTK_MI_EINVAL;
+    if (m == 0) return 0;
+    HIPCHK(hipSetDevice(b->device));
+    CHK(ensure_ws(b, 2 * (size_t)m * sizeof(double)));
+    double* d = reinterpret_cast<double*>(b->ws);
+    CHK(ew_coldots(b, n, m, reinterpret_cast<const cd*>(A_d), lda, reinterpret_cast<const cd*>(B_d), ldb, d));
+    CHK(ew_coldots_im(b, n, m, reinterpret_cast<const cd*>(A_d), lda, reinterpret_cast<const cd*>(B_d), ldb, d + m));
+    std::vector<double> h(2 * (size_t)m);
+    CHK(fetch(b, d, h.data(), h.size()));
+    for (int i = 0; i < m; ++i) {
+        dots_h[i].re = h[i];
+        dots_h[i].im = h[m + i];
+    }
+    return 0;
+}
+
+extern "C" int dftk_mi_ortho_qr(dftk_mi_basis* b, int64_t n, int m, dftk_mi_cplx* X_d, int64_t ldx, int force_svd,
+                                int* n_chol, int* used_svd) {
+    if (!b || !X_d || n < 1 || m < 0 || ldx < n || m > n) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(b->device));
+    return lobpcg_ortho(b, n, m, reinterpret_cast<cd*>(X_d), ldx, force_svd, n_chol, used_svd);
+}
+
+extern "C" int dftk_mi_tpa_precondprep(dftk_mi_kblock* kb, int m, const dftk_mi_cplx* X_d, int64_t ldx,
+                                       double* mean_kin_h) {
+    if (!kb || !X_d || !mean_kin_h || m < 0 || ldx < kb->n_G || kb->sh_comm) return DFTK_MI_EINVAL;
+    if (m == 0) return 0;
+    dftk_mi_basis* b = kb->basis;
+    HIPCHK(hipSetDevice(b->device));
+    CHK(ensure_ws(b, (size_t)m * sizeof(double)));
+    double* d = reinterpret_cast<double*>(b->ws);
+    CHK(ew_weighted_colsums(b, kb->n_G, m, reinterpret_cast<const cd*>(X_d), ldx, kb->d_kin, d));
+    return fetch(b, d, mean_kin_h, m);
+}
+
+extern "C" int dftk_mi_tpa_ldiv(dftk_mi_kblock* kb, int m, const dftk_mi_cplx* R_d, int64_t ldr,
+                                const double* mean_kin_h, double default_shift, dftk_mi_cplx* Y_d, int64_t ldy) {
+    if (!kb || !R_d || !Y_d || m < 0 || ldr < kb->n_G || ldy < kb->n_G || kb->sh_comm) return DFTK_MI_EINVAL;
+    if (m == 0) return 0;
+    dftk_mi_basis* b = kb->basis;
+    HIPCHK(hipSetDevice(b->device));
+    CHK(ensure_ws(b, 2 * (size_t)m * sizeof(double)));
+    double* d = reinterpret_cast<double*>(b->ws);
+    if (mean_kin_h) {
+        HIPCHK(hipMemcpyAsync(d, mean_kin_h, m * sizeof(double), hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+    }
+    return ew_tpa(b, kb->n_G, m, reinterpret_cast<const cd*>(R_d), ldr, reinterpret_cast<cd*>(Y_d), ldy, kb->d_kin,
+                  mean_kin_h ? d : nullptr, d + m, default_shift);
+}
+
+extern "C" int dftk_mi_block_residual(dftk_mi_kblock* kb, int m, const dftk_mi_cplx* AX_d, int64_t lda,
+                                      const dftk_mi_cplx* X_d, int64_t ldx, const double* lambda_h, dftk_mi_cplx* R_d,
+                                      int64_t ldr, double* norms_h, double* mean_kin_h, double* xx_h) {
+    if (!kb || !AX_d || !X_d || !lambda_h || !R_d || !norms_h || m < 0 || lda < kb->n_G || ldx < kb->n_G ||
+        ldr < kb->n_G || kb->sh_comm)
+        return DFTK_MI_EINVAL;
+    if (m == 0) return 0;
+    dftk_mi_basis* b = kb->basis;
+    HIPCHK(hipSetDevice(b->device));
+    CHK(ensure_ws(b, 4 * (size_t)m * sizeof(double)));
+    double* d = reinterpret_cast<double*>(b->ws);
+    HIPCHK(hipMemcpyAsync(d, lambda_h, m * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    CHK(ew_residual(b, kb->n_G, m, reinterpret_cast<const cd*>(AX_d), lda, reinterpret_cast<const cd*>(X_d), ldx, d,
+                    reinterpret_cast<cd*>(R_d), ldr, d + m, kb->d_kin, d + 2 * m, d + 3 * m));
+    std::vector<double> h(3 * (size_t)m);
+    CHK(fetch(b, d + m, h.data(), h.size()));
+    for (int i = 0; i < m; ++i) {
+        norms_h[i] = h[i];
+        if (mean_kin_h) mean_kin_h[i] = h[m + i];
+        if (xx_h) xx_h[i] = h[2 * m + i];
+    }
+    return 0;
 }

@@ -58,12 +58,16 @@ struct dftk_mi_basis {
     double* h_scalars;            // pinned host mirror
     int use_mfma;                 // 0 => naive GEMM kernels (env DFTK_MI_GEMM=naive)
     struct Prof* prof;            // per-family HIP-event timing (dftk_mi_prof_*)
+    // workspace of the dense factorizations (heev ping-pong copies, rotation buffers); owned by the basis so
+    // that several bases / devices in one process never share it (freed in dftk_mi_basis_destroy)
+    void* dense_ws; size_t dense_ws_bytes;
+    struct dftk_mi_comm* comm;    // plane-wave (row-slab) communicator of a sharded k-block, or null (borrowed)
 };
 
 // ------------------------------------------------------------------------------------ profiling
 // Kernel families timed with HIP events on the basis' stream (bench.py roofline numbers).
 enum ProfFamily {
-    PROF_ZGEMM = 0,      // work = 8 m n k flops
+    PROF_ZGEMM = 0,      // UNSTRUCTURED zgemm calls: work = 8 m n k flops
     PROF_FFT_A = 1,      // x-lines backward + scatter      (work = algorithmic bytes, dense 3-pass convention)
     PROF_FFT_B = 2,      // y backward
     PROF_FFT_C = 3,      // fused z backward * V * z forward
@@ -74,6 +78,11 @@ enum ProfFamily {
     PROF_CHOL = 8,       // potrf + trtri (whole call)
     PROF_APPLY_H = 9,    // whole dftk_mi_apply_H call (work = bands)
     PROF_ZGEMM_BYTES = 10,   // no timing: work = algorithmic operand bytes of the zgemm calls (A + B + C [+ C if beta != 0])
+    PROF_ZGEMM_STRUCT = 11,  // structured calls (UPPER / B_UPPER), timed apart: work = flops of the part of the product
+                             // that is mathematically needed (upper triangle of C; k <= j for triangular B)
+    PROF_ZGEMM_EXEC = 12,    // no timing: real flops the launched tiles execute on the matrix pipe, all zgemm calls
+                             // (3M kernel: 6 per complex multiply-add, 4M: 8; full tiles incl. shifted/border recompute)
+    PROF_COMM = 13,          // collectives of a sharded k-block (work = bytes handed to the communicator)
     PROF_NFAM = 16
 };
 struct Prof {
@@ -83,6 +92,7 @@ struct Prof {
     std::map<uint64_t, Shape> shapes;   // per-shape zgemm breakdown (env DFTK_MI_GEMM_SHAPES)
     std::vector<Pair> pending;
     std::vector<Pair> pool;
+    int open = 0;                       // scopes begun and not yet ended: no flush while > 0 (slots index `pending`)
     double ms[PROF_NFAM] = {0};
     double work[PROF_NFAM] = {0};
     int64_t launches[PROF_NFAM] = {0};
@@ -117,6 +127,14 @@ struct dftk_mi_kblock {
     // LOBPCG workspace (owned, grown on demand)
     cd* lob_buf; size_t lob_bytes;
     cd* last_AX;
+    // plane-wave (row-slab) sharding of this block over a communicator (dftk_mi_kblock_set_shard): orbital blocks
+    // handed to apply_H / lobpcg / density_accumulate and the projector matrix are the rows
+    // [sh_rows[rank], sh_rows[rank + 1]) of the sphere; the sphere tables / potential above stay complete
+    dftk_mi_comm* sh_comm;           // borrowed; null = not sharded
+    std::vector<int64_t>* sh_rows;   // [n_ranks + 1] row offsets (owned)
+    cd* sh_buf; size_t sh_bytes;     // transpose buffers (owned, grown on demand)
+    // residual history of the last dftk_mi_lobpcg call: hist[i + M * it], it = 0 .. n_iter (host, owned)
+    std::vector<double>* lob_hist; int lob_hist_M, lob_hist_iters, lob_n_svd;
 };
 
 // ------------------------------------------------------------------------------------ internal API
@@ -156,8 +174,9 @@ int ew_residual(dftk_mi_basis* b, int64_t n, int m, const cd* AX, int64_t lda, c
                 const double* lam_d, cd* R, int64_t ldr, double* norms_d, const double* kin, double* mean_kin_d,
                 double* xx_d);
 // dst = TPA-preconditioned src (kin == null: copy), norms = column norms of dst
+// (mean_kin_d == null with kin != null: the default-shift form 1 / (kin + shift), preconditioners.jl:52-53)
 int ew_tpa(dftk_mi_basis* b, int64_t n, int m, const cd* src, int64_t lds, cd* dst, int64_t ldd, const double* kin,
-           const double* mean_kin_d, double* norms_d);
+           const double* mean_kin_d, double* norms_d, double default_shift = 1.0);
 int ew_scale_cols(dftk_mi_basis* b, int64_t n, int m, cd* X, int64_t ldx, const double* s_d, bool invert);
 int ew_copy(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, cd* Y, int64_t ldy);
 int ew_fill_zero(dftk_mi_basis* b, cd* X, size_t count);
@@ -167,8 +186,28 @@ int ew_gather_cols(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx,
 int ew_add_diag(dftk_mi_basis* b, int n, cd* A, int64_t lda, double shift);
 int ew_frob2(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, double* out_d);
 int ew_hermitize_upper(dftk_mi_basis* b, int n, cd* A, int64_t lda);
+int ew_conj_transpose(dftk_mi_basis* b, int n, const cd* A, int64_t lda, cd* B, int64_t ldb);   // B = A^H (n x n)
+int ew_square(dftk_mi_basis* b, double* d, size_t n);
+int ew_sqrt(dftk_mi_basis* b, double* d, size_t n);
+// imaginary parts of the column-wise dots  Im <x_c, y_c>  (ew_coldots gives the real parts)
+int ew_coldots_im(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, const cd* Y, int64_t ldy,
+                  double* out_im_d);
+// mean_kin_c = sum_G kin_G |X_Gc|^2  (precondprep!, preconditioners.jl:75-77)
+int ew_weighted_colsums(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, const double* w_d,
+                        double* out_d);
+
+// comm.cpp (internal side; all on the basis' stream; null communicator / one rank = no-op)
+int comm_size(const dftk_mi_comm* c);
+int comm_rank(const dftk_mi_comm* c);
+int comm_allreduce(dftk_mi_comm* c, dftk_mi_basis* b, double* d, size_t n);
+int comm_allreduce_norms(dftk_mi_comm* c, dftk_mi_basis* b, double* d, size_t n);   // d holds sqrt(local sums)
+int comm_alltoallv(dftk_mi_comm* c, dftk_mi_basis* b, const cd* send, const size_t* soff, const size_t* scnt,
+                   cd* recv, const size_t* roff, const size_t* rcnt);
 
 // lobpcg.cpp
+// ortho!(X) (Cholesky-QR with the reference's shift-and-retry and SVD fallback) on a stand-alone block;
+// force_svd = 1 takes the SVD branch directly (tests)
+int lobpcg_ortho(dftk_mi_basis* b, int64_t n, int m, cd* X, int64_t ldx, int force_svd, int* n_chol, int* used_svd);
 int lobpcg_run(dftk_mi_kblock* kb, int M, cd* X, int64_t ldX, double tol, int miniter, int maxiter,
                int n_conv_check, int use_tpa, uint64_t seed, double* lambda_h, double* resid_h,
                int* n_iter, int* converged, int64_t* n_matvec);

@@ -50,6 +50,9 @@ __global__ __launch_bounds__(256) void k_col_reduce(int mode, int64_t n, const c
         if (mode == 1) {
             const cd bb = y[i];
             acc += a.x * bb.x + a.y * bb.y;
+        } else if (mode == 4) {      // Im conj(a) b
+            const cd bb = y[i];
+            acc += a.x * bb.y - a.y * bb.x;
         } else if (mode == 2) {
             acc += w[i] * (a.x * a.x + a.y * a.y);
         } else {
@@ -96,15 +99,17 @@ __global__ __launch_bounds__(256) void k_residual(int64_t n, const cd* __restric
 // One workgroup per column (same reduction tree as k_col_reduce).
 __global__ __launch_bounds__(256) void k_tpa(int64_t n, const cd* __restrict__ src, int64_t lds, cd* __restrict__ dst,
                                              int64_t ldd, const double* __restrict__ kin,
-                                             const double* __restrict__ mean_kin, double* __restrict__ norms) {
+                                             const double* __restrict__ mean_kin, double* __restrict__ norms,
+                                             double default_shift) {
     __shared__ double sh[4];
     const int c = blockIdx.x;
-    const double mk = kin ? mean_kin[c] : 0.0;
+    const double mk = (kin && mean_kin) ? mean_kin[c] : 0.0;
     double acc = 0.0;
     for (int64_t i = threadIdx.x; i < n; i += 256) {
         cd r = src[(int64_t)c * lds + i];
         if (kin) {
-            const double f = mk / (mk + kin[i]);
+            // mean_kin == null: precondprep! has not run yet -> ldiv!(Y, Diagonal(kin .+ default_shift), R)
+            const double f = mean_kin ? mk / (mk + kin[i]) : 1.0 / (kin[i] + default_shift);
             r.x *= f;
             r.y *= f;
         }
@@ -113,6 +118,18 @@ __global__ __launch_bounds__(256) void k_tpa(int64_t n, const cd* __restrict__ s
     }
     const double s = block_sum256(acc, sh);
     if (threadIdx.x == 0) norms[c] = sqrt(s);
+}
+
+__global__ void k_conj_transpose(int n, const cd* __restrict__ A, int64_t lda, cd* __restrict__ B, int64_t ldb) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)n * n) return;
+    const int j = (int)(idx / n), i = (int)(idx - (int64_t)j * n);
+    const cd v = A[j + (int64_t)i * lda];
+    B[i + (int64_t)j * ldb] = make_double2(v.x, -v.y);
+}
+__global__ void k_unary(int mode, double* __restrict__ d, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = mode == 0 ? d[i] * d[i] : sqrt(d[i]);
 }
 
 __global__ void k_scale_cols(int64_t n, int m, cd* __restrict__ X, int64_t ldx, const double* __restrict__ s,
@@ -836,10 +853,6 @@ static int dws_ensure(dftk_mi_basis* b, void** buf, size_t* cur, size_t bytes) {
     return 0;
 }
 
-// scratch owned by this translation unit (one set per process; calls are serialised per basis stream)
-static void* g_dense_ws = nullptr;
-static size_t g_dense_ws_bytes = 0;
-
 static int fetch_scalars(dftk_mi_basis* b, int count) {
     HIPCHK(hipMemcpyAsync(b->h_scalars, b->d_scalars, count * sizeof(double), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -931,8 +944,8 @@ int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, 
     const size_t szW = (size_t)np * np * sizeof(cd);
     const size_t szU = (size_t)npairs * J2B * J2B * sizeof(cd);
     const size_t total = 3 * szW + 2 * szU + (size_t)np * (sizeof(double) + sizeof(int)) + 4096 * sizeof(double);
-    CHK(dws_ensure(b, &g_dense_ws, &g_dense_ws_bytes, total));
-    char* base = reinterpret_cast<char*>(g_dense_ws);
+    CHK(dws_ensure(b, &b->dense_ws, &b->dense_ws_bytes, total));   // per basis: one stream, one device
+    char* base = reinterpret_cast<char*>(b->dense_ws);
     cd* W = reinterpret_cast<cd*>(base);
     cd* Vw = reinterpret_cast<cd*>(base + szW);
     cd* Wb[2] = {W, reinterpret_cast<cd*>(base + 2 * szW)};
@@ -1055,6 +1068,41 @@ int ew_coldots(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, con
     HIPCHK(hipGetLastError());
     return 0;
 }
+int ew_coldots_im(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, const cd* Y, int64_t ldy,
+                  double* out_im_d) {
+    if (m <= 0) return 0;
+    hipLaunchKernelGGL(k_col_reduce, dim3(m), dim3(256), 0, b->stream, 4, n, X, ldx, Y, ldy, (const double*)nullptr,
+                       out_im_d);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int ew_weighted_colsums(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, const double* w_d,
+                        double* out_d) {
+    if (m <= 0) return 0;
+    hipLaunchKernelGGL(k_col_reduce, dim3(m), dim3(256), 0, b->stream, 2, n, X, ldx, (const cd*)nullptr, (int64_t)0,
+                       w_d, out_d);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int ew_conj_transpose(dftk_mi_basis* b, int n, const cd* A, int64_t lda, cd* B, int64_t ldb) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_conj_transpose, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, b->stream, n, A,
+                       lda, B, ldb);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int ew_square(dftk_mi_basis* b, double* d, size_t n) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_unary, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, 0, d, n);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int ew_sqrt(dftk_mi_basis* b, double* d, size_t n) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_unary, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, 1, d, n);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 int ew_frob2(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, double* out_d) {
     if (m <= 0) return 0;
     hipLaunchKernelGGL(k_col_reduce, dim3(m), dim3(256), 0, b->stream, 3, n, X, ldx, (const cd*)nullptr, (int64_t)0,
@@ -1072,9 +1120,10 @@ int ew_residual(dftk_mi_basis* b, int64_t n, int m, const cd* AX, int64_t lda, c
     return 0;
 }
 int ew_tpa(dftk_mi_basis* b, int64_t n, int m, const cd* src, int64_t lds, cd* dst, int64_t ldd, const double* kin,
-           const double* mean_kin_d, double* norms_d) {
+           const double* mean_kin_d, double* norms_d, double default_shift) {
     if (m <= 0) return 0;
-    hipLaunchKernelGGL(k_tpa, dim3(m), dim3(256), 0, b->stream, n, src, lds, dst, ldd, kin, mean_kin_d, norms_d);
+    hipLaunchKernelGGL(k_tpa, dim3(m), dim3(256), 0, b->stream, n, src, lds, dst, ldd, kin, mean_kin_d, norms_d,
+                       default_shift);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -22,6 +22,8 @@
 #include <map>
 #include <vector>
 #include <cmath>
+#include <algorithm>
+#include <mutex>
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -890,6 +892,8 @@ static Split gemm_plan_split(int64_t m, int64_t n, int64_t k, int upper, const s
     const int64_t plane = (int64_t)m * n * (int64_t)sizeof(cd);
     static const bool no_zmajor = getenv("DFTK_MI_GEMM_NO_ZMAJOR") != nullptr;
     static std::map<std::vector<int64_t>, std::pair<int, int>> plan_cache;   // key -> (nsplit, zmajor)
+    static std::mutex plan_mutex;   // host-only cache shared by every basis / thread of the process
+    std::lock_guard<std::mutex> plan_lock(plan_mutex);
     int64_t total = 0;
     for (int v : live_rows) total += v;
     const int gm_s = (int)live_rows.size();
@@ -1013,10 +1017,52 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
     const uint64_t tag = !shapes ? 0
                                  : ((uint64_t)conja << 63) | ((uint64_t)(m & 0xFFFFF) << 42) |
                                        ((uint64_t)(n & 0xFFFFF) << 22) | (uint64_t)(k & 0x3FFFFF) | (1ull << 62);
-    const int slot = prof_begin(b, PROF_ZGEMM, 8.0 * (double)m * (double)n * (double)k, tag);
-    if (slot >= 0)
+    static const bool use3m = getenv("DFTK_MI_GEMM_4M") == nullptr;   // DFTK_MI_GEMM_4M=1: classic 4-product kernels
+    const GemmTiling til = gemm_tiling(conja, m, n, k, upper, use3m);
+    // Flop booking (bench.py roofline).  `useful` = the part of the product that is mathematically needed:
+    // 8mnk for an unstructured call, only the (i <= j) entries of C for UPPER, only k <= j for a triangular B.
+    // `executed` = what the launched tiles really run on the matrix pipe (whole tiles, shifted-tile and border
+    // recompute included; 6 real flops per complex multiply-add in the 3M kernels, 8 in the 4M ones).
+    double useful = 0.0, executed = 0.0;
+    if (b->prof && b->prof->on) {
+        if (!(upper & 3)) {
+            useful = 8.0 * (double)m * (double)n * (double)k;
+        } else {
+            for (int64_t j = 0; j < n; ++j) {
+                const double rows = (upper & 1) ? (double)std::min<int64_t>(m, j + 1) : (double)m;
+                const double kk = (upper & 2) ? (double)std::min<int64_t>(k, j + 1) : (double)k;
+                useful += 8.0 * rows * kk;
+            }
+        }
+        const double per_mac = (b->use_mfma && use3m) ? 6.0 : 8.0;
+        const int BNt = til.BNt;
+        auto kext = [&](int tc) {   // k range a tile column runs (triangular B stops at the diagonal)
+            const int64_t j0 = (til.shift && tc == til.gnf) ? n - BNt : (int64_t)tc * BNt;
+            return (double)((upper & 2) ? std::min<int64_t>(k, j0 + BNt) : k);
+        };
+        auto live = [&](int64_t i0, int tc) {
+            const int64_t jend = (til.shift && tc == til.gnf) ? n : std::min<int64_t>(n, (int64_t)tc * BNt + BNt);
+            return !(upper & 1) || i0 < jend;
+        };
+        for (int tr = 0; tr < til.gmf; ++tr)
+            for (int tc = 0; tc < til.gnI; ++tc)
+                if (live((int64_t)tr * GEMM_BM, tc)) executed += per_mac * GEMM_BM * BNt * kext(tc);
+        const int64_t mrem = m - (int64_t)til.gmf * GEMM_BM;
+        const double rows_b = (double)(((mrem + 31) / 32) * 32);   // border: 32-row wave tiles that hold rows run
+        for (int tc = 0; tc < til.nbottom; ++tc)
+            if (live((int64_t)til.gmf * GEMM_BM, tc)) executed += per_mac * rows_b * BNt * kext(tc);
+        for (int tr = 0; tr < til.nright; ++tr) {
+            const double rr = tr < til.gmf ? (double)GEMM_BM : rows_b;
+            if (live((int64_t)tr * GEMM_BM, til.gnf)) executed += per_mac * rr * BNt * kext(til.gnf);
+        }
+        if (!b->use_mfma) executed = useful;
+    }
+    const int slot = prof_begin(b, (upper & 3) ? PROF_ZGEMM_STRUCT : PROF_ZGEMM, useful, tag);
+    if (slot >= 0) {
         b->prof->work[PROF_ZGEMM_BYTES] += 16.0 * ((double)m * k + (double)k * n +
                                                    (double)m * n * ((beta.x != 0.0 || beta.y != 0.0) ? 2.0 : 1.0));
+        b->prof->work[PROF_ZGEMM_EXEC] += executed;
+    }
     struct ProfGuard {
         dftk_mi_basis* b;
         int s;
@@ -1045,8 +1091,6 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
     // K split.  (One mixed launch over all tiles was measured 2-7 % faster on the block updates, but the light
     // border workgroups run ahead of their siblings through k and FETCH_SIZE rose from 2.3x to 3.5x the
     // operand bytes -- dropped.)
-    static const bool use3m = getenv("DFTK_MI_GEMM_4M") == nullptr;   // DFTK_MI_GEMM_4M=1: classic 4-product kernels
-    const GemmTiling til = gemm_tiling(conja, m, n, k, upper, use3m);
     const int BNt = til.BNt, gmf = til.gmf, gnf = til.gnf, nright = til.nright, nbottom = til.nbottom;
     Split spI = til.I, spB = til.B;
     const size_t bytesI = spI.nsplit > 1 ? (size_t)spI.nsplit * plane : 0;

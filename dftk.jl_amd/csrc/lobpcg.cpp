@@ -41,6 +41,15 @@ struct Ctx {
     double *d_a, *d_b;        // M-sized double scratch
     std::vector<double> h;    // host scratch
     std::mt19937_64 rng;
+    int n_svd = 0;            // SVD fallbacks taken
+    // Row-slab (plane-wave) sharding: every product with the long dimension n_G as its inner dimension and
+    // every column reduction is a LOCAL partial sum followed by an all-reduce over the block's communicator
+    // (no-ops for an unsharded block).  reduce_norms: the buffer holds sqrt(local sums).
+    dftk_mi_comm* comm = nullptr;
+    int reduce_c(cd* d, size_t n) { return comm ? comm_allreduce(comm, c_b(), reinterpret_cast<double*>(d), 2 * n) : 0; }
+    int reduce_d(double* d, size_t n) { return comm ? comm_allreduce(comm, c_b(), d, n) : 0; }
+    int reduce_norms(double* d, size_t n) { return comm ? comm_allreduce_norms(comm, c_b(), d, n) : 0; }
+    dftk_mi_basis* c_b() { return b; }
 };
 
 int d2h(Ctx& c, const double* d, int n) {
@@ -84,9 +93,19 @@ int safe_cholesky(Ctx& c, int m, int* nchol_out, double* nR, double* nI) {
     return 0;
 }
 
+int randomize_column(Ctx& c, Mat X, int col);
+
+// SVD fallback of ortho! (lobpcg_hyper_impl.jl:226-231, :307-314): X <- U V' with X = U S V' (the unitary polar
+// factor).  Built from the m x m Gram matrix: X'X = V S^2 V' (blocked Jacobi heev), W = X V has orthogonal
+// columns of norm s_i; columns with s_i <= 1e-7 s_max carry no direction (LAPACK completes U arbitrarily there)
+// and are re-randomised; the scaled W is polished by Cholesky-QR passes (it is close to orthonormal, so these
+// are benign), then X = W V'.  `X` holds the data, `scratch` (n x m, leading dimension scratch_ld) is destroyed.
+int svd_polar(Ctx& c, Mat X, cd* scratch, int64_t scratch_ld);
+
 // ortho!(X): Cholesky-QR until the a-posteriori estimate eps*cond(R)^2 < tol.
-// tmp must hold rows x cols elements.
-int ortho_X(Ctx& c, Mat X, cd* tmp, double tol, int* nchol_total_out, double* growth_out) {
+// tmp must hold rows x cols elements (leading dimension tmp_ld, default rows).
+int ortho_X(Ctx& c, Mat X, cd* tmp, double tol, int* nchol_total_out, double* growth_out, bool allow_svd = true,
+            int64_t tmp_ld = 0, bool force_svd = false) {
     double growth = 1.0;
     int nchol_total = 0;
     const int m = X.cols;
@@ -95,23 +114,34 @@ int ortho_X(Ctx& c, Mat X, cd* tmp, double tol, int* nchol_total_out, double* gr
         *nchol_total_out = 0;
         return 0;
     }
+    if (tmp_ld <= 0) tmp_ld = X.rows;
     // the passes alternate between X and tmp (X * invR cannot be formed in place); one copy at the end
     // if the result happens to sit in tmp
-    Mat src = X, dst{tmp, X.rows, X.rows, m};
+    Mat src = X, dst{tmp, tmp_ld, X.rows, m};
     for (int pass = 0;; ++pass) {
         if (pass >= 30) {
             dftk_set_error("ortho!(X) did not reach the orthogonality tolerance in 30 Cholesky-QR passes");
             return DFTK_MI_NUM_CHOLESKY;
         }
         CHK(zgemm(c.b, 'C', m, m, src.rows, ONE, src.p, src.ld, src.p, src.ld, ZERO, c.O, m, /*upper=*/1));
+        CHK(c.reduce_c(c.O, (size_t)m * m));
         CHK(ew_hermitize_upper(c.b, m, c.O, m));
-        int nchol;
+        int nchol = 10000;
         double nR = 0, nI = 0;
-        CHK(safe_cholesky(c, m, &nchol, &nR, &nI));
+        if (!force_svd) CHK(safe_cholesky(c, m, &nchol, &nR, &nI));
         nchol_total += nchol;
         if (nchol > 10) {
-            dftk_set_error("ortho!(X) is failing badly (the reference falls back to an SVD here)");
-            return DFTK_MI_NUM_CHOLESKY;
+            if (!allow_svd) {
+                dftk_set_error("ortho!(X): Cholesky keeps failing inside the SVD fallback");
+                return DFTK_MI_NUM_CHOLESKY;
+            }
+            // "Ortho(X) is failing badly, falling back to SVD": X = U V', nchol = 100, growth_factor = 1
+            CHK(svd_polar(c, src, dst.p, dst.ld));
+            if (src.p != X.p) CHK(ew_copy(c.b, X.rows, m, src.p, src.ld, X.p, X.ld));
+            *growth_out = 1.0;
+            *nchol_total_out = 100;
+            c.n_svd += 1;
+            return 0;
         }
         // X <- X * invR
         CHK(zgemm(c.b, 'N', src.rows, m, m, ONE, src.p, src.ld, c.invR, m, ZERO, dst.p, dst.ld,
@@ -125,6 +155,45 @@ int ortho_X(Ctx& c, Mat X, cd* tmp, double tol, int* nchol_total_out, double* gr
     if (src.p != X.p) CHK(ew_copy(c.b, X.rows, m, src.p, src.ld, X.p, X.ld));
     *growth_out = growth;
     *nchol_total_out = nchol_total;
+    return 0;
+}
+
+int svd_polar(Ctx& c, Mat X, cd* scratch, int64_t scratch_ld) {
+    const int m = X.cols;
+    // c.O holds the hermitised Gram matrix X'X (ortho_X computed it; the shifts of safe_cholesky may have
+    // touched it, so recompute)
+    CHK(zgemm(c.b, 'C', m, m, X.rows, ONE, X.p, X.ld, X.p, X.ld, ZERO, c.O, m, /*upper=*/1));
+    CHK(c.reduce_c(c.O, (size_t)m * m));
+    CHK(ew_hermitize_upper(c.b, m, c.O, m));
+    std::vector<double> w(m);
+    CHK(dense_heev(c.b, m, c.O, m, w.data(), c.Rw, m));          // V in Rw (O is destroyed)
+    Mat W{scratch, scratch_ld, X.rows, m};
+    CHK(zgemm(c.b, 'N', X.rows, m, m, ONE, X.p, X.ld, c.Rw, m, ZERO, W.p, W.ld));
+    CHK(ew_colnorms(c.b, W.rows, m, W.p, W.ld, c.d_a));
+    CHK(c.reduce_norms(c.d_a, m));
+    CHK(d2h(c, c.d_a, m));
+    double smax = 0.0;
+    for (int i = 0; i < m; ++i) {
+        if (!std::isfinite(c.h[i])) return DFTK_MI_NUM_NONFINITE;
+        smax = std::max(smax, c.h[i]);
+    }
+    std::vector<double> sig(c.h.begin(), c.h.begin() + m);
+    bool any_null = false;
+    for (int i = 0; i < m; ++i)
+        if (!(sig[i] > 1e-7 * smax) || smax == 0.0) {
+            CHK(randomize_column(c, W, i));
+            any_null = true;
+        }
+    if (any_null) {
+        CHK(ew_colnorms(c.b, W.rows, m, W.p, W.ld, c.d_a));
+        CHK(c.reduce_norms(c.d_a, m));
+    }
+    CHK(ew_scale_cols(c.b, W.rows, m, W.p, W.ld, c.d_a, true));
+    int nch;
+    double gr;
+    CHK(ortho_X(c, W, X.p, 2 * EPS, &nch, &gr, /*allow_svd=*/false, X.ld));   // X's storage is free now
+    CHK(ew_conj_transpose(c.b, m, c.Rw, m, c.invR, m));                       // V'
+    CHK(zgemm(c.b, 'N', X.rows, m, m, ONE, W.p, W.ld, c.invR, m, ZERO, X.p, X.ld));
     return 0;
 }
 
@@ -159,6 +228,7 @@ int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol, con
     if (X.cols == 0) return 0;
     if (!norms_d) {
         CHK(ew_colnorms(c.b, X.rows, X.cols, X.p, X.ld, c.d_a));
+        CHK(c.reduce_norms(c.d_a, X.cols));
         norms_d = c.d_a;
     }
     CHK(ew_scale_cols(c.b, X.rows, X.cols, X.p, X.ld, norms_d, true));
@@ -177,6 +247,7 @@ int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol, con
             CHK(zgemm(c.b, 'C', Y.cols, X.cols, X.rows, ONE, Y.p, Y.ld, X.p, X.ld, ZERO, c.BYX + off, ny));
             off += Y.cols;
         }
+        CHK(c.reduce_c(c.BYX, (size_t)ny * X.cols));
         off = 0;
         for (auto& Y : Yl) {
             if (Y.cols == 0) continue;
@@ -185,6 +256,7 @@ int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol, con
         }
         // drop_small!
         CHK(ew_colnorms(c.b, X.rows, X.cols, X.p, X.ld, c.d_a));
+        CHK(c.reduce_norms(c.d_a, X.cols));
         CHK(d2h(c, c.d_a, X.cols));
         std::vector<int> dropped;
         for (int j = 0; j < X.cols; ++j) {
@@ -202,6 +274,7 @@ int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol, con
                 CHK(zgemm(c.b, 'C', Y.cols, 1, X.rows, ONE, Y.p, Y.ld, xj.p, xj.ld, ZERO, scr + o2, ny));
                 o2 += Y.cols;
             }
+            CHK(c.reduce_c(scr, (size_t)ny));
             o2 = 0;
             for (auto& Y : Yl) {
                 if (Y.cols == 0) continue;
@@ -217,8 +290,10 @@ int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol, con
         CHK(ortho_X(c, X, tmp, tol, &ninner, &growth));
         if (growth * EPS < tol) break;
         if (niter > 10) {
-            dftk_set_error("ortho!(X, Y) is failing badly (the reference falls back to an SVD here)");
-            return DFTK_MI_NUM_CHOLESKY;
+            // "Ortho(X, Y) is failing badly, falling back to SVD" (:307-314): X = U V' and return
+            CHK(svd_polar(c, X, tmp, X.rows));
+            c.n_svd += 1;
+            return 0;
         }
         niter += 1;
     }
@@ -243,16 +318,59 @@ int hcat_mul(Ctx& c, const std::vector<Mat>& Ys, const cd* coef, int64_t ldcoef,
     return 0;
 }
 
+// small replicated matrices (Ritz coefficients) are orthogonalised with the same routines: no reductions there
+struct NoComm {
+    Ctx& c;
+    dftk_mi_comm* saved;
+    explicit NoComm(Ctx& ctx) : c(ctx), saved(ctx.comm) { c.comm = nullptr; }
+    ~NoComm() { c.comm = saved; }
+};
+
 }  // namespace
+
+int lobpcg_ortho(dftk_mi_basis* b, int64_t n, int m, cd* X, int64_t ldx, int force_svd, int* n_chol, int* used_svd) {
+    if (m <= 0) return 0;
+    const size_t elems = (size_t)n * m + 3 * (size_t)m * m;
+    void* buf = nullptr;
+    HIPCHK(hipMalloc(&buf, elems * sizeof(cd) + 2 * (size_t)(m + 8) * sizeof(double)));
+    Ctx c;
+    c.kb = nullptr;
+    c.b = b;
+    cd* w = reinterpret_cast<cd*>(buf);
+    cd* tmp = w;
+    c.O = w + (size_t)n * m;
+    c.Rw = c.O + (size_t)m * m;
+    c.invR = c.Rw + (size_t)m * m;
+    c.BYX = c.tmpS = nullptr;
+    c.d_a = reinterpret_cast<double*>(c.invR + (size_t)m * m);
+    c.d_b = c.d_a + (m + 8);
+    c.rng.seed(0x9E3779B97F4A7C15ull);
+    int nch = 0;
+    double gr = 1.0;
+    int st = ortho_X(c, Mat{X, ldx, n, m}, tmp, 2 * EPS, &nch, &gr, true, n, force_svd != 0);
+    if (st == 0 && hipStreamSynchronize(b->stream) != hipSuccess) st = DFTK_MI_EHIP;
+    hipFree(buf);
+    if (n_chol) *n_chol = nch;
+    if (used_svd) *used_svd = c.n_svd;
+    return st;
+}
 
 int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int miniter, int maxiter,
                int n_conv_check, int use_tpa, uint64_t seed, double* lambda_h, double* resid_h, int* n_iter_out,
                int* converged_out, int64_t* n_matvec_out) {
     dftk_mi_basis* b = kb->basis;
-    const int64_t N = kb->n_G;
-    if (!(N > 3 * (int64_t)M)) {
-        dftk_set_error("The eigenproblem is too small (n_G=%lld, M=%d): N > 3M required", (long long)N, M);
+    if (!(kb->n_G > 3 * (int64_t)M)) {
+        dftk_set_error("The eigenproblem is too small (n_G=%lld, M=%d): N > 3M required", (long long)kb->n_G, M);
         return DFTK_MI_NUM_TOO_SMALL;
+    }
+    // a sharded block works on this rank's row slab of every n_G-sized array (see Ctx::reduce_*)
+    dftk_mi_comm* comm = (kb->sh_comm && comm_size(kb->sh_comm) > 1) ? kb->sh_comm : nullptr;
+    const int64_t row0 = comm ? (*kb->sh_rows)[comm_rank(comm)] : 0;
+    const int64_t N = comm ? (*kb->sh_rows)[comm_rank(comm) + 1] - row0 : kb->n_G;
+    const double* kin = use_tpa ? kb->d_kin + row0 : nullptr;
+    if (N < 1) {
+        dftk_set_error("sharded k-block: empty row slab on rank %d", comm_rank(comm));
+        return DFTK_MI_EINVAL;
     }
     if (n_conv_check <= 0 || n_conv_check > M) n_conv_check = M;
     const double ortho_tol = 2 * EPS;
@@ -265,7 +383,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
                                + m3 * M * 2             // cP, tmpS
                                + (size_t)M * M * 3      // O, Rw, invR
                                + (2 * (size_t)M + m3) * (M + 1);   // BYX (+1 scratch column)
-    const size_t dbl = 8 * (size_t)(M + 8);
+    const size_t dbl = 9 * (size_t)(M + 8);
     const size_t need = (nbig * blk + small_elems) * sizeof(cd) + dbl * sizeof(double) + m3 * sizeof(int) + 1024;
     if (need > kb->lob_bytes) {
         HIPCHK(hipStreamSynchronize(b->stream));
@@ -305,6 +423,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     Ctx c;
     c.kb = kb;
     c.b = b;
+    c.comm = comm;
     c.tmpS = take(m3 * M);
     c.O = take((size_t)M * M);
     c.Rw = take((size_t)M * M);
@@ -316,9 +435,10 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     double* d_lam = dd + 2 * (M + 8);
     double* d_norms = dd + 3 * (M + 8);
     double* d_mk = dd + 4 * (M + 8);
-    double* d_xx = dd + 6 * (M + 8);    // (slot 5 holds the final permutation)
-    double* d_rn = dd + 7 * (M + 8);
-    c.rng.seed(seed ? seed : 0x9E3779B97F4A7C15ull);
+    double* d_xx = dd + 5 * (M + 8);
+    double* d_rn = dd + 6 * (M + 8);    // (slot 7 holds the final permutation)
+    // every rank of a sharded block draws its own slab of a re-randomised column
+    c.rng.seed((seed ? seed : 0x9E3779B97F4A7C15ull) + 0x632BE59BD9B4E019ull * (uint64_t)comm_rank(comm));
     Mat X = Yb[0].cols_from(0, M), AX = AYb[0].cols_from(0, M);   // views of the CURRENT pair (rebound on swap)
     kb->last_AX = AX.p;
 
@@ -342,6 +462,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     // pass: a non-finite entry of AX makes its column's dot non-finite (0 * inf and x * nan are nan).
     CHK(ew_coldots(b, N, M, X.p, X.ld, AX.p, AX.ld, c.d_a));
     CHK(ew_coldots(b, N, M, X.p, X.ld, X.p, X.ld, c.d_b));
+    CHK(c.reduce_d(c.d_a, 2 * (size_t)(M + 8)));
     CHK(d2h(c, c.d_a, 2 * (M + 8)));
     for (int i = 0; i < M; ++i) {
         if (!std::isfinite(c.h[i])) {
@@ -385,11 +506,13 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
             // rayleigh_ritz: G = Y' AY (upper triangle), eigen, take the lowest nact
             if (contiguous(Ys) && contiguous(AYs)) {
                 CHK(zgemm(b, 'C', nY, nY, N, ONE, Ys[0].p, Ys[0].ld, AYs[0].p, AYs[0].ld, ZERO, G, nY, /*upper=*/1));
+                CHK(c.reduce_c(G, (size_t)nY * nY));
             } else {
                 for (size_t ib = 0; ib < Ys.size(); ++ib)
                     for (size_t ia = 0; ia <= ib; ++ia)
                         CHK(zgemm(b, 'C', nact, nact, N, ONE, Ys[ia].p, Ys[ia].ld, AYs[ib].p, AYs[ib].ld, ZERO,
                                   G + (int64_t)ia * nact + (int64_t)ib * nact * nY, nY));
+                CHK(c.reduce_c(G, (size_t)nY * nY));
             }
             CHK(ew_hermitize_upper(b, nY, G, nY));
             std::vector<double> wv(nY);
@@ -407,6 +530,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
             if (rr_reortho) {
                 int nch;
                 double gr;
+                NoComm replicated(c);
                 CHK(ortho_X(c, Mat{cX, nY, nY, ncx}, c.tmpS, ortho_tol, &nch, &gr));
             }
             for (int i = 0; i < nact; ++i) full_lam[lo + i] = wv[i];
@@ -417,8 +541,11 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
         // residuals
         HIPCHK(hipMemcpyAsync(d_lam, full_lam.data() + lo, nact * sizeof(double), hipMemcpyHostToDevice, b->stream));
         // residuals; the same pass over the new X yields precondprep!'s mean kinetic energies and <x,x>
-        CHK(ew_residual(b, N, nact, nAX.p, nAX.ld, nX.p, nX.ld, d_lam, nR.p, nR.ld, d_norms,
-                        use_tpa ? kb->d_kin : nullptr, d_mk, d_xx));
+        CHK(ew_residual(b, N, nact, nAX.p, nAX.ld, nX.p, nX.ld, d_lam, nR.p, nR.ld, d_norms, kin, d_mk, d_xx));
+        if (comm) {   // norms hold sqrt(local sums); mean_kin and <x,x> are plain sums (adjacent slots)
+            CHK(c.reduce_norms(d_norms, nact));
+            CHK(c.reduce_d(d_mk, (size_t)(M + 8) + nact));
+        }
         CHK(d2h(c, d_norms, nact));
         for (int i = 0; i < nact; ++i) {
             if (!std::isfinite(c.h[i])) {
@@ -456,7 +583,10 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
             CHK(ew_copy(b, nY, lenXn, cX + (int64_t)newly_locked * nY, nY, cP, nY));
             CHK(ew_sub_identity_shifted(b, nY, lenXn - newly_locked, cP, nY, 2 * newly_locked));
             std::vector<Mat> cXs = {Mat{cX, nY, nY, ncx}};
-            CHK(ortho_XY(c, cPm, cXs, c.tmpS, ortho_tol));
+            {
+                NoComm replicated(c);
+                CHK(ortho_XY(c, cPm, cXs, c.tmpS, ortho_tol));
+            }
             CHK(hcat_mul(c, Ys, cP, nY, lenXn, nP));
             CHK(hcat_mul(c, AYs, cP, nY, lenXn, nAP));
         }
@@ -479,8 +609,9 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
         X = Yb[cur].cols_from(0, M);
         AX = AYb[cur].cols_from(0, M);
         Mat Rn = Rblk(Yb[cur], lenXn, niter > 0);   // next iteration's residual block (behind P once P exists)
-        CHK(ew_tpa(b, N, lenXn, nR.p + (int64_t)newly_locked * nR.ld, nR.ld, Rn.p, Rn.ld,
-                   use_tpa ? kb->d_kin : nullptr, d_mk + newly_locked, d_rn));
+        CHK(ew_tpa(b, N, lenXn, nR.p + (int64_t)newly_locked * nR.ld, nR.ld, Rn.p, Rn.ld, kin, d_mk + newly_locked,
+                   d_rn));
+        CHK(c.reduce_norms(d_rn, lenXn));
         std::vector<Mat> Zs = {X};
         if (niter > 0) Zs.push_back(nP);
         CHK(ortho_XY(c, Rn, Zs, tmp, ortho_tol, d_rn));
@@ -500,7 +631,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     bool sorted = std::is_sorted(full_lam.begin(), full_lam.end());
     if (!sorted) {
         std::stable_sort(perm.begin(), perm.end(), [&](int a, int d) { return full_lam[a] < full_lam[d]; });
-        int* d_perm = reinterpret_cast<int*>(dd + 5 * (M + 8));
+        int* d_perm = reinterpret_cast<int*>(dd + 7 * (M + 8));
         HIPCHK(hipMemcpyAsync(d_perm, perm.data(), M * sizeof(int), hipMemcpyHostToDevice, b->stream));
         CHK(ew_gather_cols(b, N, M, X.p, X.ld, d_perm, tmp, N));
         CHK(ew_copy(b, N, M, tmp, N, X.p, X.ld));
@@ -515,6 +646,14 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
         resid_h[i] = RH(perm[i], final_iter);
     }
     for (int i = 0; i < n_conv_check; ++i) maxres = std::max(maxres, resid_h[i]);
+    // residual history of this call, rows permuted like the returned eigenpairs (final_retval :325-338)
+    if (!kb->lob_hist) kb->lob_hist = new std::vector<double>();
+    kb->lob_hist->assign((size_t)M * (final_iter + 1), 0.0);
+    for (int it = 0; it <= final_iter; ++it)
+        for (int i = 0; i < M; ++i) (*kb->lob_hist)[(size_t)i + (size_t)M * it] = RH(perm[i], it);
+    kb->lob_hist_M = M;
+    kb->lob_hist_iters = final_iter;
+    kb->lob_n_svd = c.n_svd;
     *converged_out = (maxres < tol) ? 1 : 0;
     *n_iter_out = final_iter;
     *n_matvec_out = n_matvec;

@@ -114,9 +114,40 @@ int dftk_mi_lobpcg(dftk_mi_kblock* kb, int M, dftk_mi_cplx* X_d, int64_t ldX, do
                    int miniter, int maxiter, int n_conv_check, int use_tpa, uint64_t seed,
                    double* lambda_h, double* resid_h, int* n_iter, int* converged,
                    int64_t* n_matvec);
+/* Residual-norm history of the last dftk_mi_lobpcg call on this block (`resid_history` of
+ * lobpcg_hyper_impl.jl:368,443-446, rows ordered like the returned eigenpairs): hist_h[i + M * it] for
+ * it = 0 .. n_iter; cap = capacity of hist_h in doubles (hist_h may be NULL to query the sizes).
+ * *n_svd = how many times ortho! took its SVD fallback (:226-231, :307-314) during the call. */
+int dftk_mi_lobpcg_history(dftk_mi_kblock* kb, int* M, int* n_iter, double* hist_h, size_t cap, int* n_svd);
 /* Optional: device pointer to H*X of the last dftk_mi_lobpcg call on this block (n_G x M,
  * leading dimension n_G; valid until the next lobpcg call on the block). */
 const dftk_mi_cplx* dftk_mi_lobpcg_last_AX(dftk_mi_kblock* kb);
+
+/* ---- column helpers of LOBPCG as stand-alone calls (results on the host) ------------------------
+ * columnwise_norms / columnwise_dots (src/common/linalg.jl:2-15, GPU forms src/gpu/linalg.jl:17-27):
+ * X, A, B are n x m column-major device blocks. */
+int dftk_mi_columnwise_norms(dftk_mi_basis* basis, int64_t n, int m, const dftk_mi_cplx* X_d, int64_t ldx,
+                             double* norms_h /* [m] */);
+int dftk_mi_columnwise_dots(dftk_mi_basis* basis, int64_t n, int m, const dftk_mi_cplx* A_d, int64_t lda,
+                            const dftk_mi_cplx* B_d, int64_t ldb, dftk_mi_cplx* dots_h /* [m]: dot(A[:,i], B[:,i]) */);
+/* ortho_qr (src/common/ortho.jl:1-9) / ortho!(X) (lobpcg_hyper_impl.jl:216-261): orthonormalise the columns of X
+ * in place by Cholesky-QR with the reference's shift-and-retry and SVD fallback (same column space as Householder
+ * QR; Q differs from LAPACK's by a unitary diagonal).  force_svd = 1 takes the SVD branch (X = U V').
+ * *n_chol = Cholesky factorizations used (100 after an SVD fallback, as the reference reports). */
+int dftk_mi_ortho_qr(dftk_mi_basis* basis, int64_t n, int m, dftk_mi_cplx* X_d, int64_t ldx, int force_svd,
+                     int* n_chol, int* used_svd);
+/* PreconditionerTPA (src/eigen/preconditioners.jl:27-78; GPU forms src/gpu/linalg.jl:25-43) on the block's kinetic
+ * vector: precondprep! -> mean_kin_h[m]; ldiv!(Y, P, R) with mean_kin_h (NULL = not prepared yet: the
+ * 1 / (kin + default_shift) form). */
+int dftk_mi_tpa_precondprep(dftk_mi_kblock* kb, int m, const dftk_mi_cplx* X_d, int64_t ldx, double* mean_kin_h);
+int dftk_mi_tpa_ldiv(dftk_mi_kblock* kb, int m, const dftk_mi_cplx* R_d, int64_t ldr, const double* mean_kin_h,
+                     double default_shift, dftk_mi_cplx* Y_d, int64_t ldy);
+/* The fused residual pass of one LOBPCG iteration (lobpcg_hyper_impl.jl:441-449): R = AX - X diag(lambda),
+ * norms_h = column norms of R, and from the same read of X: mean_kin_h (precondprep!) and xx_h = <x, x>
+ * (normalisation check :533); mean_kin_h / xx_h may be NULL. */
+int dftk_mi_block_residual(dftk_mi_kblock* kb, int m, const dftk_mi_cplx* AX_d, int64_t lda,
+                           const dftk_mi_cplx* X_d, int64_t ldx, const double* lambda_h, dftk_mi_cplx* R_d,
+                           int64_t ldr, double* norms_h, double* mean_kin_h, double* xx_h);
 
 /* ---- dense helpers exposed for tests (the LOBPCG building blocks) ----------------------------
  * zgemm: C = alpha*op(A)*B + beta*C, op(A) = A ('N') or A^H ('C'); f64 MFMA, deterministic split-K. */
@@ -150,14 +181,40 @@ int dftk_mi_potrf_trtri(dftk_mi_basis* basis, int n, dftk_mi_cplx* A_d, int64_t 
 int dftk_mi_comm_get_unique_id(char id_out[128]);
 int dftk_mi_comm_init_rank(const char id[128], int n_ranks, int rank, int device,
                            dftk_mi_comm** comm_out);
+/* Host-staged communicator: the library copies device data to pinned host buffers and calls back -- the hook
+ * for MPI (MPI.Allreduce! / MPI.Alltoallv! in a Julia shim) and for running several ranks on one GPU in tests.
+ * allreduce: in-place sum of n doubles.  alltoallv: piece i of send_h (offset / count in DOUBLES) goes to rank i,
+ * piece i of recv_h comes from rank i (alltoallv may be NULL if no k-block is sharded).  Return 0 on success. */
+typedef int (*dftk_mi_allreduce_fn)(void* user, double* buf_h, size_t n);
+typedef int (*dftk_mi_alltoallv_fn)(void* user, const double* send_h, const size_t* send_counts,
+                                    const size_t* send_offsets, double* recv_h, const size_t* recv_counts,
+                                    const size_t* recv_offsets);
+int dftk_mi_comm_create_host(int n_ranks, int rank, int device, dftk_mi_allreduce_fn allreduce,
+                             dftk_mi_alltoallv_fn alltoallv, void* user, dftk_mi_comm** comm_out);
 int dftk_mi_comm_destroy(dftk_mi_comm* comm);
+int dftk_mi_comm_rank(const dftk_mi_comm* comm);
+int dftk_mi_comm_size(const dftk_mi_comm* comm);
 /* In-place sum all-reduce of n doubles on `stream` (hipStream_t as void*, NULL = default). */
 int dftk_mi_allreduce_sum_f64(dftk_mi_comm* comm, double* buf_d, size_t n, void* stream);
 
+/* ---- plane-wave sharding of ONE k-block over a communicator (Gamma-only cells) ----------
+ * The reference can only duplicate a k-point on surplus ranks (src/PlaneWaveBasis.jl:190-203).  Here rank r owns
+ * the rows [row_starts_h[r], row_starts_h[r+1]) of the sphere (row_starts_h has n_ranks + 1 entries, 0 .. n_G):
+ * after this call every orbital block handed to dftk_mi_apply_H(_parts) / dftk_mi_lobpcg /
+ * dftk_mi_density_accumulate is that row slab (packed: leading dimension == local rows for apply_H / density),
+ * and dftk_mi_kblock_set_projectors takes the row slab of P.  Inside: products over n_G become local partial
+ * sums + one small all-reduce, the small dense factorizations run replicated, and the FFT pipeline is fed by
+ * a slab <-> band all-to-all (every rank transforms n_bands / n_ranks whole bands).  dftk_mi_density_accumulate
+ * then adds only this rank's bands into rho_d: complete it with dftk_mi_allreduce_sum_f64 over the same
+ * communicator.  Call before set_projectors; comm = NULL un-shards.  The communicator is borrowed. */
+int dftk_mi_kblock_set_shard(dftk_mi_kblock* kb, dftk_mi_comm* comm, const int64_t* row_starts_h);
+
 /* ---- per-family kernel timing with HIP events on the basis' stream (used by bench.py) ----------
- * family: 0 zgemm (work = flops), 1..5 FFT stages A..E (work = algorithmic bytes, dense 3-pass
- * convention of SURVEY.md section 8d), 6 density z-pass, 7 heev, 8 potrf+trtri, 9 whole apply_H
- * (work = bands).  enable(1) resets the counters. */
+ * family: 0 UNSTRUCTURED zgemm calls (work = 8mnk flops), 1..5 FFT stages A..E (work = algorithmic bytes of
+ * the pruned pipeline), 6 density z-pass, 7 heev, 8 potrf+trtri, 9 whole apply_H
+ * (work = bands), 10 zgemm operand bytes (no time), 11 STRUCTURED zgemm calls (UPPER / B_UPPER; work = flops of
+ * the mathematically needed part only), 12 real flops the launched zgemm tiles execute (no time; 6 per complex
+ * multiply-add in the 3M kernels), 13 collectives of a sharded block (work = bytes).  enable(1) resets. */
 int dftk_mi_prof_enable(dftk_mi_basis* basis, int on);
 int dftk_mi_prof_get(dftk_mi_basis* basis, int family, double* total_ms, double* work, int64_t* launches);
 

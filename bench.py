@@ -1,19 +1,31 @@
 #!/usr/bin/env python
 """bench.py -- SCF-iteration throughput of the MI355X plane-wave hot path (BASELINE.json metric).
 
-Workload (``config.workload``): fcc silicon n x n x n supercell (default 4x4x4 = 128 atoms, BASELINE
-configs[1]), LDA (lda_x + lda_c_pw), HGH pseudopotential, Ecut = 30 Ha, FFT cube from
-``compute_fft_size`` (150^3), fp64.  One "step" = one SCF iteration of DFTK's
-``self_consistent_field``: build V = V_loc + V_H + V_xc, LOBPCG (AdaptiveDiagtol / AdaptiveBands)
-with H psi on the device, ``compute_density`` (+ RCCL all-reduce), energies, Anderson mixing.
-N = 1: Gamma only (exactly configs[1]).  N > 1: one k-point per GPU (the first N points of the
-unshifted 2x2x2 Monkhorst-Pack mesh, weight 1/N each) so that per-GPU work is fixed (weak
-scaling) and the only data-path collective is the density all-reduce; ``value`` then counts
-k-block SCF iterations per second summed over ranks.
+Workload (``config.workload``), default = the north-star cell: fcc silicon 5 x 5 x 5 supercell (250 atoms,
+1000 electrons), LDA (lda_x + lda_c_pw), HGH pseudopotential, Ecut = 30 Ha, Gamma only, FFT cube from
+``compute_fft_size`` (192^3), fp64 -- BASELINE configs[4]'s "~1000 electrons" cell, which fits one GPU
+(``--supercell 4`` = configs[1]).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with ``roofline`` (dominant
-kernel family, HIP-event timed inside the library on its own stream) and ``cpu_baseline`` (the
-CPU oracle timed on a bounded sample of the same workload on this host's cores).
+What is timed: ONE WHOLE ``self_consistent_field`` in the sense of the reference's own ``scf_full`` benchmark
+(benchmark/cases/common.jl:70-71): from ``guess_density`` (Gaussian superposition) to ``tol = 1e-6`` in the
+density change, ScfAndersonDensitySolver, damping 0.8, AdaptiveDiagtol / AdaptiveBands defaults, random start
+orbitals.  One "step" = one SCF iteration (build V = V_loc + V_H + V_xc, LOBPCG with H psi on the device,
+``compute_density`` + all-reduce, energies, Anderson mixing).  ``--warmup W`` runs W SCF steps on a THROW-AWAY
+stepper first (allocator, plan caches, lazy initialisation); the timed run then starts again from the guess
+density.  ``--steps K`` caps the timed run: it stops at convergence or after K steps, and ``steps`` in the
+JSON line is the number of steps actually run.  ``value`` = steps run / wall time, ``hpsi_applies_per_s`` =
+n_matvec / wall time.
+
+N > 1 (``--gpus N``, one process per GPU, launched by torch.distributed.run):
+  --mode gamma   (default) the SAME Gamma-only workload, plane waves of the single k-block sharded over the
+                 N GPUs as row slabs (``comm_pw``) -> strong scaling, N = 1 comparable.
+  --mode kpoints BASELINE configs[2]-class k-point workload, fixed for every N: fcc Al, PBE, Ecut 40,
+                 unreduced 6x6x6 Monkhorst-Pack mesh (216 k-points), Gaussian smearing T = 1e-3, split by
+                 ``distribute_kpoints`` with ONE density all-reduce per step -> strong scaling.
+  --mode weak    one k-point of the Si supercell per GPU (weak scaling; the round-1 behaviour).
+
+Prints ONE JSON line on rank 0 with ``roofline`` (dominant kernel family, HIP-event timed inside the library
+on its own stream) and ``cpu_baseline`` (the CPU oracle timed on this host's cores).
 """
 from __future__ import annotations
 
@@ -33,21 +45,23 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 F64_MFMA_PEAK_TF = 78.6      # MI355X fp64 matrix peak (64-cycle v_mfma_f64_16x16x4_f64)
 
 FAMILIES = {0: "zgemm_f64_mfma", 1: "fft_A_xbwd_scatter", 2: "fft_B_ybwd", 3: "fft_C_z_fused_V", 4: "fft_D_yfwd",
-            5: "fft_E_xfwd_gather", 6: "density_z", 7: "heev_jacobi", 8: "potrf_trtri", 9: "apply_H_total"}
+            5: "fft_E_xfwd_gather", 6: "density_z", 7: "heev_jacobi", 8: "potrf_trtri", 9: "apply_H_total",
+            11: "zgemm_f64_mfma_structured", 13: "collectives"}
+KERNEL_FAMS = (0, 1, 2, 3, 4, 5, 6)      # candidates for "the dominant kernel" (0 stands for 0 + 11)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--supercell", type=int, default=4, help="n for the n x n x n Si supercell (4 = configs[1])")
-    ap.add_argument("--ecut", type=float, default=30.0)
+    ap.add_argument("--steps", type=int, default=100, help="cap on the timed SCF steps (stops earlier at convergence)")
+    ap.add_argument("--warmup", type=int, default=1, help="SCF steps on a throw-away stepper before the timed run")
+    ap.add_argument("--mode", choices=("gamma", "kpoints", "weak"), default="gamma")
+    ap.add_argument("--supercell", type=int, default=5, help="n for the n x n x n Si supercell (5 = 1000 e-, 4 = configs[1])")
+    ap.add_argument("--ecut", type=float, default=None)
+    ap.add_argument("--kgrid", type=int, default=6, help="--mode kpoints: n for the unreduced n x n x n mesh")
+    ap.add_argument("--tol", type=float, default=1e-6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-bands", type=int, default=192)
-    ap.add_argument("--prof-all", action="store_true",
-                    help="count kernel-family launches from the first warm-up step on (to line the counts up with a "
-                         "whole-process rocprofv3 --pmc run; see tools/pmc_traffic_bench.sh)")
+    ap.add_argument("--cpu-sample-bands", type=int, default=64)
     return ap.parse_args()
 
 
@@ -58,14 +72,27 @@ def prof_get(lib, basis, fam):
     return ms.value, work.value, n.value
 
 
-def cpu_baseline(basis, info, n_sample, n_lobpcg_iters_per_step, n_matvec_per_step):
-    """Time the NumPy/SciPy oracle (kind = "port") on a bounded sample of the same workload and
-    scale to SCF iterations/s with the per-step operation counts measured on the device run."""
+def library_source_hash():
+    """Hash of the library's sources (also compiled into dftk_mi_version()): ties a PMC traffic file to the build."""
+    from dftk_jl_amd import _build
+    return _build.source_hash()
+
+
+# ------------------------------------------------------------------------------------------ CPU leg
+def cpu_baseline_gamma(basis, info, n_sample, per_step):
+    """kind = "port": the NumPy/SciPy oracle's arithmetic timed on this host, BATCHED over bands so that every
+    core is busy (the reference threads H psi over bands, src/terms/Hamiltonian.jl:155, src/common/threading.jl),
+    on a bounded sample of the same workload; scaled to SCF iterations/s with the operation counts of the device
+    run.  Not DFTK itself (no Julia in the image)."""
+    import scipy.fft as sfft
     import oracle
     from oracle.terms import HamiltonianBlock
     t_all = time.time()
+    cores = os.cpu_count()
     kpt = basis.kpoints[0]
     T = basis.terms
+    nx, ny, nz = basis.fft_size
+    N = basis.N
 
     class OB:   # the minimal basis interface oracle.HamiltonianBlock needs
         pass
@@ -77,39 +104,92 @@ def cpu_baseline(basis, info, n_sample, n_lobpcg_iters_per_step, n_matvec_per_st
     okpt = oracle.Kpoint(1, kpt.coordinate, kpt.G_vectors.cpu().numpy(), kpt.mapping)
     P = T.P[0].cpu().numpy().T if T.P is not None else None       # (n_G, n_p)
     V = info["ham"][0].potential.cpu().numpy()
-    H = HamiltonianBlock(ob, okpt, kpt.kinetic.cpu().numpy(), V, P, T.D)
+    kin = kpt.kinetic.cpu().numpy()
+    H = HamiltonianBlock(ob, okpt, kin, V, P, T.D)
     rng = np.random.default_rng(0)
     n_G, M = kpt.n_G, info["psi"][0].shape[0]
     psi = rng.standard_normal((n_G, n_sample)) + 1j * rng.standard_normal((n_G, n_sample))
-    H.mul(psi[:, :1])                                              # warm FFT plans / BLAS threads
+    pot = V.reshape(-1) * (basis.fft_normalization * basis.ifft_normalization)
+
+    def hpsi_batched(block):          # the oracle's H psi (oracle/terms.py:HamiltonianBlock.mul), all bands at once
+        nb = block.shape[1]
+        cube = np.zeros((nb, N), dtype=complex)
+        cube[:, kpt.mapping] = block.T
+        cube = sfft.ifftn(cube.reshape(nb, nz, ny, nx), axes=(1, 2, 3), workers=cores, norm="forward", overwrite_x=True)
+        cube = cube.reshape(nb, N)
+        cube *= pot[None, :]
+        cube = sfft.fftn(cube.reshape(nb, nz, ny, nx), axes=(1, 2, 3), workers=cores, norm="backward", overwrite_x=True)
+        out = cube.reshape(nb, N)[:, kpt.mapping].T + kin[:, None] * block
+        if P is not None:
+            out = out + P @ (T.D @ (P.conj().T @ block))
+        return out
+
+    chk = hpsi_batched(psi[:, :2])
+    ref = H.mul(psi[:, :2])
+    err = float(np.linalg.norm(chk - ref) / np.linalg.norm(ref))
+    assert err < 1e-12, f"batched CPU H psi deviates from the oracle: {err}"
+    bsz = 16
     t0 = time.time()
-    H.mul(psi)
+    for c0 in range(0, n_sample, bsz):
+        hpsi_batched(psi[:, c0:c0 + bsz])
     t_hpsi = (time.time() - t0) / n_sample
     t0 = time.time()
-    for n in range(n_sample):
-        np.abs(ob.ifft(okpt, psi[:, n], normalize=False)) ** 2
+    for c0 in range(0, n_sample, bsz):
+        nb = min(bsz, n_sample - c0)
+        cube = np.zeros((nb, N), dtype=complex)
+        cube[:, kpt.mapping] = psi[:, c0:c0 + nb].T
+        cube = sfft.ifftn(cube.reshape(nb, nz, ny, nx), axes=(1, 2, 3), workers=cores, norm="forward", overwrite_x=True)
+        (cube.real ** 2 + cube.imag ** 2).sum(axis=0)
     t_dens = (time.time() - t0) / n_sample
-    # dense algebra rate: Gram matrix and rotation of a 64-column panel
-    mcols = 64
+    # dense algebra rate: Gram matrix and rotation of a panel (threaded OpenBLAS zgemm)
+    mcols = min(128, M)
     Xs = rng.standard_normal((n_G, mcols)) + 1j * rng.standard_normal((n_G, mcols))
+    G = Xs.conj().T @ Xs
     t0 = time.time()
     G = Xs.conj().T @ Xs
     Xs @ G
     t_blas = time.time() - t0
     rate = 2 * 8.0 * n_G * mcols * mcols / t_blas                  # flop/s of zgemm on this host
-    flops_dense = 224.0 * n_G * M * M                              # SURVEY section 8(d), Unit C
     n_occ = basis.model.n_electrons // 2
-    t_step = n_matvec_per_step * t_hpsi + n_lobpcg_iters_per_step * flops_dense / rate + n_occ * t_dens
-    return {"value": 1.0 / t_step, "unit": "SCF iterations/s", "cores": os.cpu_count(), "kind": "port",
+    t_step = (per_step["n_matvec"] * t_hpsi + per_step["zgemm_flops"] / rate + n_occ * t_dens)
+    return {"value": 1.0 / t_step, "unit": "SCF iterations/s", "cores": cores, "kind": "port",
             "hpsi_applies_per_s": 1.0 / t_hpsi,
-            "sample": (f"oracle (NumPy/SciPy restatement, scipy.fft workers=all, OpenBLAS threads=all) timed on "
-                       f"{n_sample} bands of H psi ({t_hpsi * 1e3:.1f} ms/band), {n_sample} density bands "
-                       f"({t_dens * 1e3:.1f} ms/band) and a {mcols}-column zgemm panel ({rate / 1e9:.1f} GF/s); "
-                       f"scaled with the device run's per-step counts (n_matvec={n_matvec_per_step:.0f}, "
-                       f"LOBPCG iterations={n_lobpcg_iters_per_step:.1f}, dense flops/iter=224 n_G M^2); "
-                       f"sample wall {time.time() - t_all:.1f} s")}
+            "sample": (f"NumPy/SciPy oracle arithmetic (not DFTK: no Julia here), bands batched {bsz} at a time with "
+                       f"scipy.fft workers={cores} and threaded OpenBLAS: {n_sample} bands of H psi "
+                       f"({t_hpsi * 1e3:.2f} ms/band; checked against oracle.HamiltonianBlock.mul to {err:.1e}), "
+                       f"{n_sample} density bands ({t_dens * 1e3:.2f} ms/band), a {mcols}-column zgemm panel "
+                       f"({rate / 1e9:.0f} GF/s); one SCF step modelled as the device run's per-step averages: "
+                       f"n_matvec={per_step['n_matvec']:.0f} H psi + {per_step['zgemm_flops'] / 1e12:.2f} TF of zgemm + "
+                       f"{n_occ} density bands; sample wall {time.time() - t_all:.1f} s")}
 
 
+def cfg1_scf_3steps(device):
+    """A REAL SCF on both sides (no model): BASELINE configs[0] (Si primitive, LDA, Ecut 15, unreduced 4x4x4 mesh)
+    run as the reference's ``scf_3steps`` benchmark (benchmark/cases/common.jl:70: maxiter = 3) by the CPU oracle
+    and by the device path; wall times in seconds."""
+    import dftk_jl_amd as dftk
+    import oracle
+    lat, atoms, pos = oracle.basis.silicon_primitive(a=10.26, functional="lda")
+    om = oracle.model_DFT(lat, atoms, pos, functionals=("lda_x", "lda_c_pw"))
+    t0 = time.time()
+    ob = oracle.PlaneWaveBasis(om, 15, oracle.MonkhorstPack((4, 4, 4)))
+    ores = oracle.self_consistent_field(ob, tol=1e-6, maxiter=3)
+    t_cpu = time.time() - t0
+    lat, atoms, pos = dftk.silicon_cell()
+    dm = dftk.model_DFT(lat, atoms, pos, functionals=("lda_x", "lda_c_pw"))
+    db = dftk.PlaneWaveBasis(dm, 15, dftk.MonkhorstPack((4, 4, 4)), device=device)
+    dftk.self_consistent_field(db, tol=1e-6, maxiter=1)      # warm
+    t0 = time.time()
+    dres = dftk.self_consistent_field(db, tol=1e-6, maxiter=3)
+    t_dev = time.time() - t0
+    return {"workload": "configs[0]: Si primitive LDA Ecut 15, unreduced 4x4x4 k-mesh, fft 27^3, scf_3steps (maxiter = 3)",
+            "cpu_oracle_s": round(t_cpu, 2), "device_s": round(t_dev, 3),
+            "cpu_it_per_s": round(3 / t_cpu, 4), "device_it_per_s": round(3 / t_dev, 3),
+            "E_total_cpu": ores["energies"].total, "E_total_device": dres["energies"].total,
+            "note": "64 tiny k-blocks (n_G ~ 725, 7 bands): launch-latency bound on the device"}
+
+
+# ------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
     import torch
@@ -136,17 +216,41 @@ def main():
     else:
         comm = dftk.KptComm.single()
     n_gpus = world
+    device = f"cuda:{local_rank}"
 
     lib = dftk.load_library()
-    n = args.supercell
-    lat, atoms, pos = dftk.silicon_cell((n, n, n))
-    model = dftk.model_DFT(lat, atoms, pos, functionals=("lda_x", "lda_c_pw"))
-    allk = dftk.MonkhorstPack((2, 2, 2)).reducible().kcoords
-    kgrid = dftk.ExplicitKpoints(allk[:n_gpus], [1.0 / n_gpus] * n_gpus)
     t0 = time.time()
-    basis = dftk.PlaneWaveBasis(model, args.ecut, kgrid, device=f"cuda:{local_rank}", comm_kpts=comm)
+    if args.mode == "kpoints":
+        a = 7.6324708938577865                                       # test/testcases.jl:74
+        lat = a / 2 * np.array([[0, 1, 1.0], [1, 0, 1.0], [1, 1, 0.0]])
+        Al = dftk.ElementPsp("Al", dftk.load_psp("Al", "pbe"))
+        model = dftk.model_DFT(lat, [Al], [np.zeros(3)], functionals=("gga_x_pbe", "gga_c_pbe"), temperature=1e-3,
+                               smearing="gaussian")
+        ecut = args.ecut or 40.0
+        kg = dftk.MonkhorstPack((args.kgrid,) * 3)
+        basis = dftk.PlaneWaveBasis(model, ecut, kg, device=device, comm_kpts=comm)
+        n_kblocks_total = args.kgrid ** 3
+        workload = (f"Al fcc (1 atom, 3 e-) PBE HGH, Ecut={ecut:g} Ha, fft={'x'.join(map(str, basis.fft_size))}, "
+                    f"unreduced {args.kgrid}x{args.kgrid}x{args.kgrid} k-mesh ({n_kblocks_total} k-points, "
+                    f"{len(basis.kpoints)} on rank 0), Gaussian smearing T=1e-3")
+        parallelism, scaling = f"kpt{n_gpus}", "strong"
+    else:
+        n = args.supercell
+        ecut = args.ecut or 30.0
+        lat, atoms, pos = dftk.silicon_cell((n, n, n))
+        model = dftk.model_DFT(lat, atoms, pos, functionals=("lda_x", "lda_c_pw"))
+        if args.mode == "weak" and n_gpus > 1:
+            allk = dftk.MonkhorstPack((2, 2, 2)).reducible().kcoords
+            kgrid = dftk.ExplicitKpoints(allk[:n_gpus], [1.0 / n_gpus] * n_gpus)
+            basis = dftk.PlaneWaveBasis(model, ecut, kgrid, device=device, comm_kpts=comm)
+            parallelism, scaling, ktxt = f"kpt{n_gpus}", "weak", f"{n_gpus} k-points (1 per GPU)"
+        else:
+            basis = dftk.PlaneWaveBasis(model, ecut, dftk.MonkhorstPack((1, 1, 1)), device=device, comm_pw=comm)
+            parallelism = "single" if n_gpus == 1 else f"pw{n_gpus} (plane-wave row slabs of the one k-block)"
+            scaling, ktxt = "strong", "Gamma-only"
+        workload = (f"Si {n}x{n}x{n} supercell ({len(atoms)} atoms, {model.n_electrons} e-) LDA HGH, "
+                    f"Ecut={ecut:g} Ha, fft={'x'.join(map(str, basis.fft_size))}, {ktxt}")
     t_setup = time.time() - t0
-    stepper = dftk.ScfStepper(basis, tol=1e-6)
 
     def barrier():
         torch.cuda.synchronize()
@@ -155,22 +259,32 @@ def main():
         torch.cuda.synchronize()
 
     from dftk_jl_amd._lib import check
-    if args.prof_all:
-        check(lib.dftk_mi_prof_enable(basis.handle, 1))
-    for _ in range(args.warmup):
-        stepper.step()
+    # ---- warm-up on a throw-away stepper (same seed: the timed run repeats these steps from the same guess)
+    if args.warmup > 0:
+        warm = dftk.ScfStepper(basis, tol=args.tol)
+        for _ in range(args.warmup):
+            if warm.step()["converged"]:
+                break
+        del warm
     barrier()
-    if not args.prof_all:
-        check(lib.dftk_mi_prof_enable(basis.handle, 1))
-    nmv0 = stepper.info["n_matvec"]
-    iters = []
+    check(lib.dftk_mi_prof_enable(basis.handle, 1))
+    iters, diagtols, step_s, nmv_steps = [], [], [], []
     host_timers = {}
     t0 = time.time()
-    for _ in range(args.steps):
+    stepper = dftk.ScfStepper(basis, tol=args.tol)          # guess_density is part of self_consistent_field
+    info = None
+    for _ in range(max(args.steps, 1)):
+        ts = time.time()
         info = stepper.step()
+        step_s.append(time.time() - ts)
         iters.append(float(np.mean(info["diagonalization"]["n_iter"])))
+        diagtols.append(info["diagtol"])
+        nmv_steps.append(int(info["n_matvec_step"]))
         for k_, v_ in info["timers"].items():
             host_timers[k_] = host_timers.get(k_, 0.0) + v_
+        if info["converged"]:
+            break
+    info = stepper.finalize()                                # energies + Hamiltonian of the final state, as the reference
     barrier()
     elapsed = time.time() - t0
     check(lib.dftk_mi_prof_enable(basis.handle, 0))
@@ -178,71 +292,91 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    n_matvec = info["n_matvec"] - nmv0          # already summed over ranks
-    kblocks = n_gpus                             # one k-block per rank
-    value = kblocks * args.steps / elapsed
+    steps_run = info["n_iter"]
+    n_matvec = info["n_matvec"]                  # already summed over the k-point ranks
+    kblocks = n_gpus if (args.mode == "weak" and n_gpus > 1) else 1
+    value = kblocks * steps_run / elapsed
 
     if rank == 0:
-        fam = {f: prof_get(lib, basis, f) for f in FAMILIES}
-        kernel_fams = [f for f in range(0, 7) if fam[f][2] > 0]
-        dom = max(kernel_fams, key=lambda f: fam[f][0])
-        ms, work, launches = fam[dom]
+        fam = {f: prof_get(lib, basis, f) for f in list(FAMILIES) + [10, 12]}
+        zg_ms = fam[0][0] + fam[11][0]
+        zg_useful = fam[0][1] + fam[11][1]
+        zg_launch = fam[0][2] + fam[11][2]
+        fam_ms = {f: (zg_ms if f == 0 else fam[f][0]) for f in KERNEL_FAMS}
+        dom = max((f for f in KERNEL_FAMS if fam_ms[f] > 0), key=lambda f: fam_ms[f])
         if dom == 0:
-            roof = {"bound": "mfma", "achieved": work / (ms * 1e-3) / 1e12, "peak": F64_MFMA_PEAK_TF,
-                    "unit": "TFLOP/s"}
+            ms, work, launches = zg_ms, zg_useful, zg_launch
+            roof = {"bound": "mfma", "achieved": work / (ms * 1e-3) / 1e12, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s"}
+            roof["frac"] = roof["achieved"] / roof["peak"]
+            roof["achieved_unstructured_8mnk"] = (fam[0][1] / (fam[0][0] * 1e-3) / 1e12) if fam[0][0] > 0 else None
+            roof["mfma_executed_tflops"] = fam[12][1] / (ms * 1e-3) / 1e12
+            roof["mfma_busy_frac"] = roof["mfma_executed_tflops"] / F64_MFMA_PEAK_TF
+            roof["note"] = ("achieved = USEFUL flops / time over all zgemm launches: 8mnk for unstructured calls; "
+                            "for UPPER (Gram, only i <= j needed) and B_UPPER (X inv(R), k <= j) only the "
+                            "mathematically needed part.  achieved_unstructured_8mnk = 8mnk / time of the unstructured "
+                            "calls alone.  mfma_executed_tflops = real flops the launched tiles run on the matrix pipe "
+                            "(3M complex product: 6 per complex multiply-add; whole tiles incl. shifted / border "
+                            "recompute) / time; mfma_busy_frac = that / dense f64 MFMA peak")
         else:
+            ms, work, launches = fam[dom]
             roof = {"bound": "hbm", "achieved": work / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
-        roof["frac"] = roof["achieved"] / roof["peak"]
-        if dom == 0:
-            roof["note"] = ("achieved = algorithmic 8mnk flop / time; full tiles run the 3M (Karatsuba) complex product, "
-                            "i.e. 6mnk executed MFMA flop, so the executed-flop rate of those launches is 3/4 of it "
-                            "(an MFMA-saturated 3M kernel would read 104.8 TFLOP/s here); peak = dense f64 MFMA spec")
+            roof["frac"] = roof["achieved"] / roof["peak"]
+        # HBM bytes per launch of the dominant family from PMC passes over THIS command and THIS build
+        # (tools/pmc_traffic_bench.sh writes profiles/r02_pmc_traffic.json with the library's source hash)
         roof["traffic"] = None
-        # HBM bytes per launch of the dominant family from the committed PMC passes (rocprofv3 --pmc
-        # FETCH_SIZE / WRITE_SIZE over this same command, tools/pmc_traffic_bench.sh): the counters
-        # cannot be read from inside the process, so the last measured value is reported with its source
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
                 pmc = json.load(fh)
-            if FAMILIES[dom] in pmc["families"] and pmc["workload"] == f"si{n}x{n}x{n}_ecut{args.ecut:g}":
-                roof["traffic"] = pmc["families"][FAMILIES[dom]]["bytes_per_launch"]
+            key = FAMILIES[dom]
+            if pmc.get("lib_hash") == library_source_hash() and pmc.get("workload") == workload and key in pmc["families"]:
+                roof["traffic"] = pmc["families"][key]["bytes_per_launch"]
                 roof["traffic_unit"] = "B/launch"
-                roof["traffic_source"] = ("profiles/r01_pmc_traffic.json (" + pmc["collected"] + ")"
-                                          + ("; " + pmc["note"] if pmc.get("note") else ""))
-                roof["algorithmic_bytes_per_launch"] = (prof_get(lib, basis, 10)[1] / max(launches, 1) if dom == 0
-                                                        else work / max(launches, 1))
+                roof["traffic_source"] = "profiles/r02_pmc_traffic.json (" + pmc["collected"] + ")"
         except (OSError, KeyError, ValueError):
             pass
+        roof["algorithmic_bytes_per_launch"] = (fam[10][1] / max(launches, 1)) if dom == 0 else work / max(launches, 1)
         roof["kernel"] = FAMILIES[dom]
         roof["launches"] = launches
         roof["avg_launch_ms"] = ms / max(launches, 1)
         roof["families_ms"] = {FAMILIES[f]: round(fam[f][0], 3) for f in FAMILIES}
         roof["families_launches"] = {FAMILIES[f]: int(fam[f][2]) for f in FAMILIES}
         roof["families_work"] = {FAMILIES[f]: fam[f][1] for f in FAMILIES}   # flops (zgemm) / algorithmic bytes (FFT)
+        roof["families_work"]["zgemm_executed_real_flops"] = fam[12][1]
+        roof["families_work"]["zgemm_operand_bytes"] = fam[10][1]
         roof["families_rate"] = {
-            FAMILIES[f]: (round(fam[f][1] / (fam[f][0] * 1e-3) / (1e12 if f == 0 else 1e9), 2)
-                          if fam[f][0] > 0 and f < 7 else None) for f in FAMILIES}
+            FAMILIES[f]: (round(fam[f][1] / (fam[f][0] * 1e-3) / (1e12 if f in (0, 11) else 1e9), 2)
+                          if fam[f][0] > 0 and (f < 7 or f == 11) else None) for f in FAMILIES}
+        booked = sum(fam[f][0] for f in (0, 11, 1, 2, 3, 4, 5, 6, 7, 8, 13))
+        kp0 = basis.kpoints[0]
         out = {
             "metric": "SCF iterations/sec (Hψ applies/sec) at fixed Ecut·atoms",
-            "value": value, "unit": "SCF iterations/s", "n_gpus": n_gpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "value": value, "unit": "SCF iterations/s", "n_gpus": n_gpus, "steps": steps_run,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / steps_run, "higher_is_better": True,
+            "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "hpsi_applies_per_s": n_matvec / elapsed,
-            "config": {"workload": f"Si {n}x{n}x{n} supercell ({len(atoms)} atoms, {model.n_electrons} e-) LDA "
-                                   f"HGH, Ecut={args.ecut:g} Ha, fft={'x'.join(map(str, basis.fft_size))}, "
-                                   f"{'Gamma-only' if n_gpus == 1 else f'{n_gpus} k-points (1 per GPU)'}",
-                       "n_G": basis.kpoints[0].n_G, "n_bands": int(info["psi"][0].shape[0]),
+            "config": {"workload": workload, "timed": "whole self_consistent_field (scf_full): guess_density -> "
+                                                      f"tol={args.tol:g}, capped at --steps={args.steps}",
+                       "converged": bool(info["converged"]), "scf_wall_s": round(elapsed, 3),
+                       "n_G": kp0.n_G, "n_bands": int(info["psi"][0].shape[0]),
                        "n_proj": int(basis.terms.D.shape[0]) if basis.terms.D is not None else 0,
-                       "parallelism": f"kpt{n_gpus}", "setup_s": round(t_setup, 2),
-                       "lobpcg_iters_per_step": iters,
-                       "host_timers_ms_per_step": {k_: round(1e3 * v_ / args.steps, 2) for k_, v_ in host_timers.items()}, "E_total": info["energies"].total,
-                       "drho": info["history_drho"][-1]},
+                       "parallelism": parallelism, "setup_s": round(t_setup, 2),
+                       "n_matvec": int(n_matvec), "lobpcg_iters_per_step": iters, "n_matvec_per_step": nmv_steps,
+                       "diagtol_per_step": [float(f"{d:.3g}") for d in diagtols],
+                       "step_wall_s": [round(s_, 3) for s_ in step_s],
+                       "host_timers_ms_per_step": {k_: round(1e3 * v_ / steps_run, 2) for k_, v_ in host_timers.items()},
+                       "library_booked_ms": round(booked, 1), "lib_hash": library_source_hash(),
+                       "E_total": info["energies"].total, "drho": info["history_drho"][-1]},
             "roofline": roof,
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(basis, info, args.cpu_sample_bands, float(np.mean(iters)),
-                                                   n_matvec / args.steps)
+                if args.mode == "kpoints":
+                    out["cpu_baseline"] = {"value": None, "unit": "SCF iterations/s", "cores": os.cpu_count(),
+                                           "kind": "port", "sample": "see cfg1_scf_3steps"}
+                else:
+                    per_step = {"n_matvec": n_matvec / steps_run, "zgemm_flops": zg_useful / steps_run}
+                    out["cpu_baseline"] = cpu_baseline_gamma(basis, info, args.cpu_sample_bands, per_step)
+                out["cpu_baseline"]["cfg1_scf_3steps"] = cfg1_scf_3steps(device)
             except Exception as e:  # the baseline is reporting only; never lose the measurement
                 out["cpu_baseline"] = {"value": None, "unit": "SCF iterations/s", "cores": os.cpu_count(),
                                        "kind": "port", "sample": f"failed: {e!r}"}

@@ -12,13 +12,28 @@ LIBPATH = os.path.join(LIBDIR, "libdftk_mi355x.so")
 SOURCES = ["api.cpp", "comm.cpp", "lobpcg.cpp", "fft_kernels.hip", "gemm_kernels.hip", "dense_kernels.hip"]
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIBPATH):
-        return True
-    t = os.path.getmtime(LIBPATH)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + ["common.h"]]
+HASHPATH = LIBPATH + ".srchash"
+
+
+def source_hash() -> str:
+    """sha256 over every source the library is built from (order fixed).  The hash is compiled into the
+    library (``dftk_mi_version()`` ends with ``src=<hash>``) and written next to it, so that a stale binary
+    -- the .so is git-ignored but ships to the GPU box -- is never used silently, whatever its mtime says."""
+    import hashlib
+    h = hashlib.sha256()
+    deps = [os.path.join(CSRC, f) for f in sorted(SOURCES + ["common.h"])]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "dftk_mi355x.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    for d in deps:
+        with open(d, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIBPATH) or not os.path.exists(HASHPATH):
+        return True
+    with open(HASHPATH) as fh:
+        return fh.read().strip() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -29,7 +44,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libdftk_mi355x.so")
     os.makedirs(LIBDIR, exist_ok=True)
+    sh = source_hash()
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           f'-DDFTK_MI_SRC_HASH="{sh}"',
            # keep MFMA accumulators in VGPRs: without it hipcc (ROCm 7.2) shuttles every loop-carried
            # accumulator VGPR<->AGPR around each k-step (256 v_accvgpr moves per 32 f64 MFMAs)
            "-mllvm", "-amdgpu-mfma-vgpr-form=1",
@@ -39,6 +56,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    with open(HASHPATH, "w") as fh:
+        fh.write(sh + "\n")
     return LIBPATH
 
 

@@ -107,6 +107,10 @@ def load(build_if_missing: bool = True):
         fn = getattr(lib, name)    # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    version = lib.dftk_mi_version().decode()
+    if not version.endswith("src=" + _build.source_hash()):
+        raise RuntimeError(f"{path} was built from other sources ({version!r}, expected src={_build.source_hash()}): "
+                           "stale binary, rebuild with python -m dftk_jl_amd._build")
     _lib = lib
     return lib
 

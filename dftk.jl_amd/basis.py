@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .comm import KptComm, distribute_kpoints
+from .comm import KptComm, distribute_kpoints, split_evenly
 from .model import ExplicitKpoints, Model, MonkhorstPack
 
 
@@ -78,12 +78,25 @@ class Kpoint:
         self.Gplusk_cart = Gk[mapping]                                  # (n_G, 3) cartesian, device
         self.kinetic = kin_all[mapping].contiguous()                    # 1/2 |k+G|^2 (kinetic.jl:31-35)
         self.n_G = int(mapping.numel())
+        # plane-wave sharding (comm_pw): this rank holds the rows [row0, row1) of every orbital block of the
+        # k-point (split_evenly over the sphere index); without it the slab is the whole sphere
+        pw = basis.comm_pw
+        self.row_starts = np.array([r.start for r in split_evenly(self.n_G, pw.size)] + [self.n_G], dtype=np.int64)
+        self.row0, self.row1 = int(self.row_starts[pw.rank]), int(self.row_starts[pw.rank + 1])
+        self.n_loc = self.row1 - self.row0
+        self.kinetic_local = self.kinetic[self.row0:self.row1]
         self.handle = C.c_void_p()
         self._keep = {}
+        self._pot_owner = None      # the DftHamiltonianBlock whose potential currently sits in the device handle
         if basis.handle is not None:
             kin_h = np.ascontiguousarray(self.kinetic.cpu().numpy())
             _lib.check(basis.lib.dftk_mi_kblock_create(basis.handle, self.n_G, self.mapping.ctypes.data,
                                                        kin_h.ctypes.data, C.byref(self.handle)))
+            if pw.size > 1:
+                if self.n_loc < 1:
+                    raise ValueError("plane-wave sharding: more ranks than plane waves")
+                _lib.check(basis.lib.dftk_mi_kblock_set_shard(self.handle, pw.abi_handle(basis.device.index),
+                                                              self.row_starts.ctypes.data))
 
     def __del__(self):
         try:
@@ -96,17 +109,23 @@ class Kpoint:
 class PlaneWaveBasis:
     """``PlaneWaveBasis(model; Ecut, kgrid, fft_size, architecture=GPU, comm_kpts)``.
 
+    ``comm_kpts`` shards the k-points over ranks (as the reference); ``comm_pw`` shards the PLANE WAVES of
+    every k-block over ranks (row slabs; what a Gamma-only supercell needs to strong-scale).
     ``device="cuda"`` binds the basis to the MI355X library (required for the hot path);
     ``device="cpu"`` builds the descriptors only (set-up / sharding tests): any hot-path call
     then raises, there is no CPU fallback.
     """
 
     def __init__(self, model: Model, Ecut: float, kgrid=None, fft_size=None, device="cuda",
-                 comm_kpts: KptComm | None = None, build_terms=True):
+                 comm_kpts: KptComm | None = None, build_terms=True, comm_pw: KptComm | None = None):
         self.model = model
         self.Ecut = float(Ecut)
         self.device = torch.device(device)
         self.comm_kpts = comm_kpts if comm_kpts is not None else KptComm.single()
+        # comm_pw: ranks that share every k-block of this basis by plane-wave row slabs (Gamma-only cells)
+        self.comm_pw = comm_pw if comm_pw is not None else KptComm.single()
+        if self.comm_pw.size > 1 and self.comm_kpts.size > 1:
+            raise NotImplementedError("k-point and plane-wave sharding cannot be combined yet")
         self.fft_size = tuple(int(n) for n in (fft_size or compute_fft_size(model, Ecut)))
         nx, ny, nz = self.fft_size
         self.N = nx * ny * nz
@@ -176,6 +195,12 @@ class PlaneWaveBasis:
     def sync(self):
         self._require_gpu()
         _lib.check(self.lib.dftk_mi_basis_sync(self.handle))
+
+    @property
+    def stream_ptr(self):
+        """hipStream_t of the library's stream (collectives of the host mirror are enqueued on it)."""
+        self._require_gpu()
+        return self.lib.dftk_mi_basis_stream(self.handle)
 
     def fft(self, f_real: torch.Tensor) -> torch.Tensor:
         """cube -> Fourier coefficients (c_G = sqrt(Omega)/N sum_r f(r) e^{-iG.r})."""

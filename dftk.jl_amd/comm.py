@@ -1,18 +1,26 @@
-"""``comm_kpts``: the k-point communicator of PlaneWaveBasis (src/PlaneWaveBasis.jl:183-235,
-src/common/mpi.jl:19-53) re-designed for one process per GPU.
+"""Communicators of the hot path, one process per GPU.
 
-* ``KptComm.single()``   -- one rank, no communication.
-* ``KptComm.from_torch()`` -- uses an initialised ``torch.distributed`` group for the rendezvous
-  (rank / size).  The bulk density all-reduce is ``torch.distributed.all_reduce`` -- RCCL over xGMI
-  with the ``nccl`` backend on GPUs, gloo on CPU tensors (tests of the sharding logic).  With
-  ``DFTK_MI_COMM=abi`` GPU reductions go through the library's own RCCL communicator instead
-  (``dftk_mi_allreduce_sum_f64``, the entry point a Julia shim binds; the unique id is shipped
-  through the torch store).
+``comm_kpts`` -- the k-point communicator of ``PlaneWaveBasis`` (src/PlaneWaveBasis.jl:183-235,
+src/common/mpi.jl:19-53): k-points shard over the ranks, one density all-reduce per SCF step.
+``comm_pw``   -- NEW (the reference can only duplicate a k-point on surplus ranks,
+PlaneWaveBasis.jl:190-203): the plane waves of ONE k-block shard over the ranks as row slabs
+(``dftk_mi_kblock_set_shard``), so that a Gamma-only supercell strong-scales over the GPUs of a node.
+
+Both are ``KptComm`` objects.  ``torch.distributed`` provides the rendezvous (rank / size / store);
+the DATA path on GPUs is the library's own communicator (``dftk_mi_comm``):
+
+* ``nccl`` process group  -> RCCL over xGMI, bound by the library itself (``dftk_mi_comm_init_rank``; the
+  unique id travels through the torch store).  This is the default on GPUs.
+* any other process group (gloo) -> the library's host-staged communicator (``dftk_mi_comm_create_host``)
+  with callbacks that run ``torch.distributed`` collectives on the pinned host buffers: the path for
+  MPI-like hosts, and how the test-suite runs two ranks on ONE GPU.
+
+Scalars (energies, counts, eigenvalue lists) are gathered ONCE per use through the host group
+(``gather_lists``) instead of one all-reduce per scalar.
 """
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import numpy as np
 import torch
@@ -32,7 +40,10 @@ def split_evenly(n_items: int, n_parts: int):
 class KptComm:
     def __init__(self, rank=0, size=1, group=None):
         self.rank, self.size, self.group = rank, size, group
-        self._rccl = None
+        self.host_group = None    # gloo twin of an nccl group: host-side scalar / object collectives
+        self._abi = None          # dftk_mi_comm handle (created lazily)
+        self._abi_kind = None
+        self._callbacks = None    # keeps the ctypes callbacks alive
 
     @staticmethod
     def single():
@@ -43,68 +54,129 @@ class KptComm:
         import torch.distributed as dist
         if not dist.is_initialized():
             return KptComm()
-        return KptComm(dist.get_rank(group), dist.get_world_size(group), group if group is not None else True)
+        comm = KptComm(dist.get_rank(group), dist.get_world_size(group), group if group is not None else True)
+        if comm.size > 1 and dist.get_backend(group) == "nccl":
+            # small host-side collectives (eigenvalue / energy gathers) stay off the GPU and off RCCL
+            ranks = [dist.get_global_rank(group, i) for i in range(comm.size)] if group is not None else None
+            comm.host_group = dist.new_group(ranks=ranks, backend="gloo")
+        return comm
 
-    # -- RCCL communicator of the C ABI, created lazily on first GPU reduction
-    def _ensure_rccl(self, device_index: int):
-        if self._rccl is not None or self.size == 1:
-            return
+    def _group(self):
+        return None if self.group is True else self.group
+
+    # -- the C-ABI communicator --------------------------------------------------------------------
+    def abi_handle(self, device_index: int):
+        """``dftk_mi_comm*`` for this group: RCCL when the process group is nccl, host-staged otherwise."""
+        if self.size == 1:
+            return None
+        if self._abi is not None:
+            return self._abi
         import torch.distributed as dist
-        from ._lib import load, check
+        from ._lib import ALLREDUCE_FN, ALLTOALLV_FN, check, load
         lib = load()
-        buf = C.create_string_buffer(128)
-        if self.rank == 0:
-            check(lib.dftk_mi_comm_get_unique_id(buf))
-        obj = [bytes(buf.raw)]
-        dist.broadcast_object_list(obj, src=0, group=None if self.group is True else self.group)
         handle = C.c_void_p()
-        check(lib.dftk_mi_comm_init_rank(obj[0], self.size, self.rank, device_index, C.byref(handle)))
-        self._rccl = handle
+        if dist.get_backend(self._group()) == "nccl":
+            buf = C.create_string_buffer(128)
+            if self.rank == 0:
+                check(lib.dftk_mi_comm_get_unique_id(buf))
+            obj = [bytes(buf.raw)]
+            dist.broadcast_object_list(obj, src=dist.get_global_rank(self._group(), 0) if self._group() else 0,
+                                       group=self.host_group if self.host_group is not None else self._group())
+            check(lib.dftk_mi_comm_init_rank(obj[0], self.size, self.rank, device_index, C.byref(handle)))
+            self._abi_kind = "rccl"
+        else:
+            grp, size = self._group(), self.size
 
+            def allreduce(_user, buf, n):
+                try:
+                    t = torch.from_numpy(np.ctypeslib.as_array(buf, shape=(n,)))
+                    dist.all_reduce(t, group=grp)
+                    return 0
+                except Exception:      # never unwind through the C frames
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+
+            def alltoallv(_user, send, scnt, soff, recv, rcnt, roff):
+                try:
+                    sc = [scnt[i] for i in range(size)]
+                    so = [soff[i] for i in range(size)]
+                    rc = [rcnt[i] for i in range(size)]
+                    ro = [roff[i] for i in range(size)]
+                    stot = max((o + c for o, c in zip(so, sc)), default=0)
+                    rtot = max((o + c for o, c in zip(ro, rc)), default=0)
+                    s = torch.from_numpy(np.ctypeslib.as_array(send, shape=(max(stot, 1),)))
+                    r = torch.from_numpy(np.ctypeslib.as_array(recv, shape=(max(rtot, 1),)))
+                    # gloo has no all_to_all on every build: one broadcast-free exchange with all_gather of
+                    # the padded pieces would waste traffic, so use point-to-point pairs ordered by rank
+                    me = dist.get_rank(grp)
+                    ranks = [dist.get_global_rank(grp, i) if grp else i for i in range(size)]
+                    r[ro[me]:ro[me] + rc[me]] = s[so[me]:so[me] + sc[me]]
+                    reqs = []
+                    for i in range(size):
+                        if i == me:
+                            continue
+                        if sc[i]:
+                            reqs.append(dist.isend(s[so[i]:so[i] + sc[i]], dst=ranks[i], group=grp))
+                        if rc[i]:
+                            reqs.append(dist.irecv(r[ro[i]:ro[i] + rc[i]], src=ranks[i], group=grp))
+                    for q in reqs:
+                        q.wait()
+                    return 0
+                except Exception:
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+
+            self._callbacks = (ALLREDUCE_FN(allreduce), ALLTOALLV_FN(alltoallv))
+            check(lib.dftk_mi_comm_create_host(self.size, self.rank, device_index,
+                                               C.cast(self._callbacks[0], C.c_void_p),
+                                               C.cast(self._callbacks[1], C.c_void_p), None, C.byref(handle)))
+            self._abi_kind = "host"
+        self._abi = handle
+        return handle
+
+    # -- reductions --------------------------------------------------------------------------------
     def sum_(self, t: torch.Tensor, stream_ptr=None) -> torch.Tensor:
-        """mpi_sum!(arr, comm) (common/mpi.jl:19-21), in place."""
+        """mpi_sum!(arr, comm) (common/mpi.jl:19-21), in place.  CUDA float64 tensors go through the C-ABI
+        communicator on ``stream_ptr`` (the basis' stream); anything else through torch.distributed."""
         if self.size == 1:
             return t
-        if t.is_cuda and os.environ.get("DFTK_MI_COMM", "torch") == "abi":
-            # the C-ABI communicator (what a Julia shim uses): dftk_mi_allreduce_sum_f64 -> ncclAllReduce
+        if t.is_cuda:
             if t.dtype != torch.float64 or not t.is_contiguous():
-                raise ValueError("RCCL density all-reduce expects a contiguous float64 tensor")
-            from ._lib import load, check
-            self._ensure_rccl(t.device.index or 0)
-            check(load().dftk_mi_allreduce_sum_f64(self._rccl, t.data_ptr(), t.numel(), stream_ptr))
+                raise ValueError("density all-reduce expects a contiguous float64 tensor")
+            from ._lib import check, load
+            handle = self.abi_handle(t.device.index or 0)
+            check(load().dftk_mi_allreduce_sum_f64(handle, t.data_ptr(), t.numel(), stream_ptr))
             return t
         import torch.distributed as dist
-        dist.all_reduce(t, group=None if self.group is True else self.group)
+        dist.all_reduce(t, group=self._group())
         return t
 
-    def sum_scalar(self, x: float) -> float:
-        if self.size == 1:
-            return x
-        import torch.distributed as dist
-        t = torch.tensor([x], dtype=torch.float64)
-        if dist.get_backend() == "nccl":
-            t = t.cuda()
-        dist.all_reduce(t, group=None if self.group is True else self.group)
-        return float(t.item())
-
-    def max_scalar(self, x: float) -> float:
-        if self.size == 1:
-            return x
-        import torch.distributed as dist
-        t = torch.tensor([x], dtype=torch.float64)
-        if dist.get_backend() == "nccl":
-            t = t.cuda()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=None if self.group is True else self.group)
-        return float(t.item())
-
     def gather_lists(self, local):
-        """All-gather a small picklable object (eigenvalues for the Fermi level)."""
+        """All-gather a small picklable object (eigenvalues, partial energies): ONE collective."""
         if self.size == 1:
             return [local]
         import torch.distributed as dist
         out = [None] * self.size
-        dist.all_gather_object(out, local, group=None if self.group is True else self.group)
+        dist.all_gather_object(out, local, group=self.host_group if self.host_group is not None else self._group())
         return out
+
+    def sum_scalars(self, xs):
+        """Sum a short list of floats over the ranks with one collective; every rank gets the same floats
+        (summed in rank order on the host, so the result is identical everywhere)."""
+        if self.size == 1:
+            return [float(x) for x in xs]
+        parts = self.gather_lists([float(x) for x in xs])
+        return [float(sum(p[i] for p in parts)) for i in range(len(xs))]
+
+    def sum_scalar(self, x: float) -> float:
+        return self.sum_scalars([x])[0]
+
+    def max_scalar(self, x: float) -> float:
+        if self.size == 1:
+            return x
+        return float(max(self.gather_lists(float(x))))
 
 
 def distribute_kpoints(kcoords, kweights, comm: KptComm):

@@ -18,8 +18,12 @@ void dftk_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* dftk_mi_last_error(void) { return g_err; }
+#ifndef DFTK_MI_SRC_HASH
+#define DFTK_MI_SRC_HASH "unknown"
+#endif
 extern "C" const char* dftk_mi_version(void) {
-    return "dftk_mi355x 0.1.0 (gfx950; fp64; pruned batched FFT pipeline, f64-MFMA zgemm, blocked-Jacobi heev)";
+    return "dftk_mi355x 0.2.0 (gfx950; fp64; pruned batched FFT pipeline, f64-MFMA zgemm, blocked-Jacobi heev, "
+           "plane-wave sharded LOBPCG) src=" DFTK_MI_SRC_HASH;
 }
 
 // ------------------------------------------------------------------------------------ profiling

@@ -23,8 +23,10 @@ def compute_density(basis, psi, occupation, occupation_threshold: float = 0.0) -
             raise TypeError("compute_density: complex128 CUDA band-major blocks required")
         _lib.check(basis.lib.dftk_mi_density_accumulate(kpt.handle, len(w), psik.data_ptr(), psik.stride(0),
                                                         w.ctypes.data, rho.data_ptr()))
+    # mpi_sum!(rho, comm_kpts) (:46), enqueued on the library's stream behind the accumulation kernels; with
+    # plane-wave sharding every rank has accumulated its share of the BANDS: the same all-reduce over comm_pw
+    for comm in (basis.comm_pw, basis.comm_kpts):
+        if comm.size > 1:
+            comm.sum_(rho, basis.stream_ptr)
     basis.sync()
-    basis.comm_kpts.sum_(rho, None)                                  # mpi_sum!(rho, comm_kpts) (:46)
-    if basis.comm_kpts.size > 1:
-        torch.cuda.synchronize(basis.device)
     return rho

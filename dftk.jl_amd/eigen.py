@@ -46,11 +46,12 @@ def lobpcg_hyper(A: DftHamiltonianBlock, X0: torch.Tensor, maxiter: int = 100, p
     basis = A.basis
     if not (X0.is_cuda and X0.dtype == torch.complex128):
         raise TypeError("lobpcg_hyper: complex128 CUDA block required (no CPU fallback)")
-    M, n_G = X0.shape
-    if n_G != A.n_G:
-        raise ValueError(f"Mismatch in dimension between guess ({n_G}) and Hamiltonian ({A.n_G})")
+    M, n_loc = X0.shape
+    if n_loc != A.n_loc:
+        raise ValueError(f"Mismatch in dimension between guess ({n_loc}) and Hamiltonian ({A.n_loc})")
     if tol is None:
-        tol = 20 * n_G * EPS                    # diag_lobpcg_hyper.jl:6
+        tol = 20 * A.n_G * EPS                  # diag_lobpcg_hyper.jl:6
+    A.bind()
     X = X0.clone().contiguous()
     lam = np.zeros(M)
     res = np.zeros(M)
@@ -63,6 +64,18 @@ def lobpcg_hyper(A: DftHamiltonianBlock, X0: torch.Tensor, maxiter: int = 100, p
     return EigResult(lam, X, res, n_iter.value, bool(conv.value), int(nmv.value))
 
 
+def lobpcg_residual_history(A: DftHamiltonianBlock):
+    """``resid_history`` of the last ``lobpcg_hyper`` call on this block (lobpcg_hyper_impl.jl:368,443-446):
+    array (M, n_iter + 1), rows ordered like the returned eigenpairs; second value = number of SVD fallbacks."""
+    lib = A.basis.lib
+    M, nit, nsvd = C.c_int(), C.c_int(), C.c_int()
+    _lib.check(lib.dftk_mi_lobpcg_history(A.kpoint.handle, C.byref(M), C.byref(nit), None, 0, C.byref(nsvd)))
+    hist = np.zeros((nit.value + 1, M.value))
+    _lib.check(lib.dftk_mi_lobpcg_history(A.kpoint.handle, C.byref(M), C.byref(nit), hist.ctypes.data, hist.size,
+                                          C.byref(nsvd)))
+    return hist.T.copy(), nsvd.value
+
+
 def _splitmix64(x: torch.Tensor) -> torch.Tensor:
     """splitmix64 finaliser on int64 tensors (wrapping arithmetic; logical shifts emulated with masks)."""
     def lsr(v, k):
@@ -73,11 +86,12 @@ def _splitmix64(x: torch.Tensor) -> torch.Tensor:
     return x ^ lsr(x, 31)
 
 
-def _counter_normal(n: int, seed: int, device) -> torch.Tensor:
-    """n standard normal numbers that depend only on (seed, index): Box-Muller on two splitmix64 streams.
-    torch.randn on the GPU assigns Philox subsequences per launched thread, so its output depends on the
-    number of CUs of the device; this does not (same start vectors on every box)."""
-    idx = torch.arange(n, dtype=torch.int64, device=device)
+def _counter_normal(n, seed: int, device) -> torch.Tensor:
+    """Standard normal numbers that depend only on (seed, index): Box-Muller on two splitmix64 streams; ``n`` is
+    a count (indices 0 .. n-1) or an int64 tensor of indices.  torch.randn on the GPU assigns Philox subsequences
+    per launched thread, so its output depends on the number of CUs of the device; this does not (same start
+    vectors on every box, and a rank of a plane-wave-sharded block can draw exactly its rows)."""
+    idx = n if torch.is_tensor(n) else torch.arange(n, dtype=torch.int64, device=device)
     base = _splitmix64(torch.tensor([seed & (2 ** 63 - 1)], dtype=torch.int64, device=device))
     a = _splitmix64(idx * 2 + base)
     b = _splitmix64(idx * 2 + 1 + base)
@@ -93,7 +107,13 @@ def random_orbitals(basis, kpt, howmany: int, generator: torch.Generator | None 
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     else:   # one draw advances the generator; a single-element draw does not depend on the launch geometry
         seed = int(torch.randint(0, 2 ** 62, (1,), device=generator.device, generator=generator).item())
-    z = _counter_normal(2 * howmany * kpt.n_G, seed, basis.device).reshape(2, howmany, kpt.n_G)
+    if basis.comm_pw.size > 1:
+        # the ranks of comm_pw hold row slabs of ONE random block: same seed everywhere (rank 0's draw)
+        seed = int(basis.comm_pw.gather_lists(seed)[0])
+    # element (c, band, g) of the (2, howmany, n_G) block has index (c * howmany + band) * n_G + g
+    rows = torch.arange(kpt.row0, kpt.row1, dtype=torch.int64, device=basis.device)
+    lead = torch.arange(2 * howmany, dtype=torch.int64, device=basis.device) * kpt.n_G
+    z = _counter_normal((lead[:, None] + rows[None, :]).reshape(-1), seed, basis.device).reshape(2, howmany, kpt.n_loc)
     return torch.complex(z[0], z[1]) / np.sqrt(2 * kpt.n_G)
 
 
@@ -109,8 +129,8 @@ def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None
                              f"{nev_per_kpoint} eigenvalues. Increase Ecut.")
         if psiguess is not None:
             g = psiguess[ik]
-            if g.shape[1] != kpt.n_G:
-                raise ValueError(f"Mismatch in dimension between guess ({g.shape[1]}) and Hamiltonian ({kpt.n_G})")
+            if g.shape[1] != kpt.n_loc:
+                raise ValueError(f"Mismatch in dimension between guess ({g.shape[1]}) and Hamiltonian ({kpt.n_loc})")
             if g.shape[0] > nev_per_kpoint:
                 g = g[:nev_per_kpoint]
             elif g.shape[0] < nev_per_kpoint:

@@ -1,8 +1,10 @@
 """``DftHamiltonianBlock`` and ``mul_`` -- host mirror of src/terms/Hamiltonian.jl:22-57,137-192.
 
-The block owns no arrays: kinetic multiplier, sphere tables and projectors live in the k-block
-handle of the device library; constructing a block uploads the summed local potential
-(operators.jl:213-222) into it, exactly like the reference rebuilds its blocks every SCF step.
+Kinetic multiplier, sphere tables and projectors live in the k-block handle of the device library; the
+block OWNS its summed local potential (operators.jl:213-222) like the reference's block owns its operators.
+The device handle holds one padded copy of a potential at a time: every entry point that applies H
+(``mul_``, ``lobpcg_hyper``) calls ``bind()``, which re-uploads this block's potential when another block
+of the same k-point (an older / newer Hamiltonian that is still alive) was the last one bound.
 """
 from __future__ import annotations
 
@@ -15,17 +17,29 @@ class DftHamiltonianBlock:
     def __init__(self, basis, kpoint, potential):
         basis._require_gpu()
         self.basis, self.kpoint = basis, kpoint
-        self.potential = None
-        if potential is not None:
-            self.potential = potential.to(torch.float64).contiguous()
-            torch.cuda.current_stream(basis.device).synchronize()
-            _lib.check(basis.lib.dftk_mi_kblock_set_potential(kpoint.handle, self.potential.data_ptr()))
+        self.potential = potential.to(torch.float64).contiguous() if potential is not None else None
+        self.bind(force=True)
+
+    def bind(self, force: bool = False):
+        """Make the device handle of the k-point apply THIS block's potential."""
+        kpt = self.kpoint
+        if not force and kpt._pot_owner is self:
+            return
+        if self.potential is not None:
+            torch.cuda.current_stream(self.basis.device).synchronize()
+            _lib.check(self.basis.lib.dftk_mi_kblock_set_potential(kpt.handle, self.potential.data_ptr()))
         else:
-            _lib.check(basis.lib.dftk_mi_kblock_set_potential(kpoint.handle, None))
+            _lib.check(self.basis.lib.dftk_mi_kblock_set_potential(kpt.handle, None))
+        kpt._pot_owner = self
 
     @property
     def n_G(self):
         return self.kpoint.n_G
+
+    @property
+    def n_loc(self):
+        """Rows of an orbital block on this rank (== n_G unless the basis shards plane waves)."""
+        return self.kpoint.n_loc
 
     def size(self):
         return (self.kpoint.n_G, self.kpoint.n_G)
@@ -38,6 +52,9 @@ class DftHamiltonianBlock:
         if psi.dim() != 2 or psi.stride(1) != 1 or Hpsi.stride(1) != 1:
             raise ValueError("mul_: band-major contiguous blocks required")
         nb = psi.shape[0]
+        if psi.shape[1] != self.n_loc or Hpsi.shape != psi.shape:
+            raise ValueError(f"mul_: blocks must be (n_bands, {self.n_loc})")
+        self.bind()
         torch.cuda.current_stream(self.basis.device).synchronize()
         _lib.check(self.basis.lib.dftk_mi_apply_H_parts(self.kpoint.handle, which, nb, psi.data_ptr(), psi.stride(0),
                                                         Hpsi.data_ptr(), Hpsi.stride(0)))

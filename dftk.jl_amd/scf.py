@@ -50,19 +50,23 @@ def _occupations(model, eigenvalues, eF):
 
 
 def compute_occupation(basis, eigenvalues, tol_n_elec: float = 1e-6):
-    """occupation.jl:53-132,160-211.  ``eigenvalues`` are this rank's k-points; the electron count
-    is reduced over ``comm_kpts`` (weighted_ksum, PlaneWaveBasis.jl:509-512)."""
+    """occupation.jl:53-132,160-211.  ``eigenvalues`` are this rank's k-points.  The reference reduces every
+    trial electron count over ``comm_kpts`` (weighted_ksum, PlaneWaveBasis.jl:509-512) -- up to 200 all-reduces
+    per bisection; here the (n_k x n_bands) eigenvalues are gathered ONCE and every rank runs the same search
+    on the host."""
     model, comm = basis.model, basis.comm_kpts
-    kw = np.asarray(basis.kweights)
+    local = [(float(w), np.asarray(e, dtype=float).tolist()) for w, e in zip(basis.kweights, eigenvalues)]
+    parts = comm.gather_lists(local)
+    kw = np.array([w for part in parts for w, _ in part])
+    eig_all = [np.asarray(e, dtype=float) for part in parts for _, e in part]
 
     def excess(eF):
-        occ = _occupations(model, eigenvalues, eF)
-        return comm.sum_scalar(float(sum(w * o.sum() for w, o in zip(kw, occ)))) - model.n_electrons
+        occ = _occupations(model, eig_all, eF)
+        return float(sum(w * o.sum() for w, o in zip(kw, occ))) - model.n_electrons
 
     n_fill = -(-model.n_electrons // (model.n_spin_components * model.filled_occupation))
-    homo = comm.max_scalar(max(float(e[n_fill - 1]) for e in eigenvalues))
-    lumo_local = min((float(np.min(e[n_fill:])) if len(e) > n_fill else math.inf) for e in eigenvalues)
-    lumo = -comm.max_scalar(-lumo_local)
+    homo = max(float(e[n_fill - 1]) for e in eig_all)
+    lumo = min((float(np.min(e[n_fill:])) if len(e) > n_fill else math.inf) for e in eig_all)
     eF = homo + 1 if lumo == math.inf else (homo + lumo) / 2           # guess_fermi_level_intocc_
     if model.temperature == 0:
         if abs(excess(eF)) > tol_n_elec:
@@ -70,9 +74,9 @@ def compute_occupation(basis, eigenvalues, tol_n_elec: float = 1e-6):
                                "electrons. You should add a temperature.")
     elif abs(excess(eF)) >= tol_n_elec / 10:                           # FermiBisection (:99-132)
         if excess(eF) < 0:
-            lo, hi = eF, comm.max_scalar(max(float(np.max(e)) for e in eigenvalues)) + 1
+            lo, hi = eF, max(float(np.max(e)) for e in eig_all) + 1
         else:
-            lo, hi = -comm.max_scalar(-min(float(np.min(e)) for e in eigenvalues)) - 1, eF
+            lo, hi = min(float(np.min(e)) for e in eig_all) - 1, eF
         for _ in range(200):
             mid = 0.5 * (lo + hi)
             if mid == lo or mid == hi:
@@ -149,7 +153,7 @@ def next_density(ham, nbandsalg, eigensolver=lobpcg_hyper, psi=None, eigenvalues
     if timers is not None:
         timers["diagonalization"] = timers.get("diagonalization", 0.0) + t1 - t0
         timers["occupation+density"] = timers.get("occupation+density", 0.0) + time.time() - t1
-    n_matvec = int(basis.comm_kpts.sum_scalar(eig["n_matvec"]))
+    n_matvec = int(basis.comm_kpts.sum_scalar(eig["n_matvec"]))    # (not over comm_pw: those ranks share the blocks)
     return dict(psi=eig["X"], eigenvalues=eig["λ"], occupation=occ, eF=eF, rho=rho, diagonalization=eig,
                 n_bands_converge=n_conv, n_matvec=n_matvec)
 

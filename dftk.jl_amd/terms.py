@@ -66,16 +66,19 @@ def build_projector_form_factors(psp, Gpk_cart):
 
 
 def build_projection_vectors(basis, kpt):
-    """nonlocal.jl:166-199.  Returns P as a (n_p, n_G) tensor == column-major n_G x n_p."""
+    """nonlocal.jl:166-199.  Returns P as a (n_p, n_loc) tensor == column-major n_loc x n_p: the rows of this
+    rank's plane-wave slab (all of the sphere without ``comm_pw``)."""
     model = basis.model
-    Gpk = (kpt.G_vectors.to(torch.float64)
+    rows = slice(kpt.row0, kpt.row1)
+    Gpk = (kpt.G_vectors[rows].to(torch.float64)
            + torch.tensor(kpt.coordinate, dtype=torch.float64, device=basis.device)[None, :])
+    Gpk_cart = kpt.Gplusk_cart[rows]
     rows = []
     for group in model.atom_groups:
         psp = model.atoms[group[0]].psp
         if psp.count_n_proj() == 0:
             continue
-        ff = build_projector_form_factors(psp, kpt.Gplusk_cart) / math.sqrt(model.unit_cell_volume)
+        ff = build_projector_form_factors(psp, Gpk_cart) / math.sqrt(model.unit_cell_volume)
         for ia in group:
             r = torch.tensor(model.positions[ia], dtype=torch.float64, device=basis.device)
             sf = torch.exp(-1j * TWO_PI * (Gpk[:, 0] * r[0] + Gpk[:, 1] * r[1] + Gpk[:, 2] * r[2]))
@@ -329,7 +332,7 @@ def instantiate_terms(basis):
     model = basis.model
     T = Terms()
     T.names = list(model.term_types)
-    T.kinetic = [k.kinetic for k in basis.kpoints] if "Kinetic" in T.names else None
+    T.kinetic = [k.kinetic_local for k in basis.kpoints] if "Kinetic" in T.names else None
     T.P, T.D = None, None
     if "AtomicNonlocal" in T.names:
         P = [build_projection_vectors(basis, k) for k in basis.kpoints]
@@ -351,7 +354,7 @@ def instantiate_terms(basis):
                 kpt._keep["D"] = Dh
                 torch.cuda.current_stream(basis.device).synchronize()
                 _lib.check(basis.lib.dftk_mi_kblock_set_projectors(kpt.handle, T.P[ik].shape[0],
-                                                                   T.P[ik].data_ptr(), kpt.n_G, Dh.ctypes.data))
+                                                                   T.P[ik].data_ptr(), kpt.n_loc, Dh.ctypes.data))
     return T
 
 
@@ -371,13 +374,16 @@ def _band_nonlocal_energy(Ppsi, D):
 
 
 def _PH_psi(basis, Pt, psik):
-    """P' psi through the library's f64-MFMA zgemm; returns a (n_bands, n_p) tensor."""
+    """P' psi through the library's f64-MFMA zgemm; returns a (n_bands, n_p) tensor.  With plane-wave
+    sharding P and psi are row slabs: the partial projections are summed over ``comm_pw``."""
     n_p, n_G = Pt.shape
     nb = psik.shape[0]
     out = torch.empty((nb, n_p), dtype=torch.complex128, device=basis.device)
     torch.cuda.current_stream(basis.device).synchronize()
     _lib.check(basis.lib.dftk_mi_zgemm(basis.handle, b"C", n_p, nb, n_G, _lib.cplx(1.0), Pt.data_ptr(), Pt.stride(0),
                                        psik.data_ptr(), psik.stride(0), _lib.cplx(0.0), out.data_ptr(), n_p))
+    if basis.comm_pw.size > 1:
+        basis.comm_pw.sum_(torch.view_as_real(out).reshape(-1), basis.stream_ptr)
     basis.sync()
     return out
 
@@ -414,6 +420,7 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, ei
     E = Energies()
     pot = None
     have_psi = psi is not None and occupation is not None
+    reduce_kpts = []       # terms that are sums over this rank's k-points: ONE fused reduction at the end
     for name in T.names:
         if name == "Kinetic":
             if have_psi:
@@ -422,7 +429,8 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, ei
                     dots = ((psik.real ** 2 + psik.imag ** 2) * T.kinetic[ik][None, :]).sum(dim=1)   # (n_bands,)
                     occ = torch.as_tensor(occupation[ik], dtype=torch.float64, device=basis.device)
                     e += basis.kweights[ik] * float((occ * dots).sum().item())
-                E[name] = basis.comm_kpts.sum_scalar(e)
+                E[name] = basis.comm_pw.sum_scalar(e)     # slab partial sums; k-points are summed below
+                reduce_kpts.append(name)
             else:
                 E[name] = math.inf
         elif name == "AtomicLocal":
@@ -439,7 +447,8 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, ei
                     band = _band_nonlocal_energy(Ppsi, T.D)
                     occ = torch.as_tensor(occupation[ik], dtype=torch.float64, device=basis.device)
                     e += basis.kweights[ik] * float((band * occ).sum().item())
-                E[name] = basis.comm_kpts.sum_scalar(e)
+                E[name] = e
+                reduce_kpts.append(name)
             else:
                 E[name] = math.inf
         elif name == "Ewald":
@@ -470,9 +479,13 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, ei
                     x = (np.asarray(eigenvalues[ik], dtype=float)[:psik.shape[0]] - eF) / model.temperature
                     e -= (model.temperature * basis.kweights[ik] * model.filled_occupation
                           * float(np.sum(smearing_entropy(model.smearing, x))))
-                E[name] = basis.comm_kpts.sum_scalar(e)
+                E[name] = e
+                reduce_kpts.append(name)
         else:
             raise NotImplementedError(f"term {name} is outside the MI355X hot path")
+    if reduce_kpts and basis.comm_kpts.size > 1:
+        for name, v in zip(reduce_kpts, basis.comm_kpts.sum_scalars([E[n] for n in reduce_kpts])):
+            E[name] = v
     if only_energies:
         return E, None
     ham = [DftHamiltonianBlock(basis, kpt, pot) for kpt in basis.kpoints]

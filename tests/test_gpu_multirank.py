@@ -78,23 +78,125 @@ def test_two_ranks_one_gpu_scf_equals_single_rank(tmp_path):
     assert abs(got["rho_sum"] - 8.0) < 1e-9
 
 
-def test_bench_two_ranks_one_gpu(tmp_path):
-    """bench.py's N = 2 path (torch.distributed.run env contract, one k-point per rank, max-over-ranks
-    timing, whole-job value) on a tiny cell; both ranks on cuda:0 over gloo."""
-    port = str(33000 + os.getpid() % 2000)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--supercell", "1", "--ecut", "10", "--no-cpu-baseline"]
+def _run_bench(extra, port_base):
+    port = str(port_base + os.getpid() % 2000)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"] + extra
     base = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
                 DFTK_MI_BENCH_BACKEND="gloo", DFTK_MI_BENCH_DEVICE="0")
     outs = _spawn([(cmd, dict(base, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)])
     lines = [ln for ln in outs[0].splitlines() if ln.startswith("{")]
     assert len(lines) == 1, outs[0][-2000:]
     assert not [ln for ln in outs[1].splitlines() if ln.startswith("{")]        # only rank 0 prints
-    out = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_one_gpu_weak_kpoints():
+    """bench.py --mode weak, N = 2 (torch.distributed.run env contract, one k-point per rank, max-over-ranks
+    timing, whole-job value) on a tiny cell; both ranks on cuda:0 over gloo; --steps caps the SCF."""
+    out = _run_bench(["--mode", "weak", "--steps", "2", "--warmup", "1", "--supercell", "1", "--ecut", "10"], 33000)
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
-    assert out["config"]["parallelism"] == "kpt2"
+    assert out["config"]["parallelism"] == "kpt2" and not out["config"]["converged"]
     assert abs(out["value"] - 2 * 2 / (out["ms_per_step"] * 2 / 1e3)) < 1e-6 * out["value"]   # 2 k-blocks x steps / time
     assert out["roofline"]["achieved"] > 0 and np.isfinite(out["config"]["E_total"])
+
+
+def test_bench_two_ranks_one_gpu_gamma_sharded_equals_single_rank():
+    """bench.py's DEFAULT N > 1 path: the Gamma-only cell with its plane waves sharded over the ranks (strong
+    scaling, whole SCF to convergence); same converged energy and SCF length class as the one-rank run."""
+    args = ["--steps", "40", "--warmup", "0", "--supercell", "1", "--ecut", "12", "--tol", "1e-8"]
+    out = _run_bench(args, 35000)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["converged"]
+    assert out["config"]["parallelism"].startswith("pw2") and out["steps"] < 40
+    assert out["roofline"]["families_launches"]["collectives"] > 0
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + args
+    one = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
+    ref = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    assert ref["config"]["converged"] and ref["n_gpus"] == 1
+    assert abs(out["config"]["E_total"] - ref["config"]["E_total"]) < 1e-8 * 2      # 1e-8 Ha / atom
+    assert abs(out["steps"] - ref["steps"]) <= 2
+
+
+PW_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, os.environ["REPO"])
+import numpy as np, torch, torch.distributed as dist
+import dftk_jl_amd as dftk
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["PORT"],
+                        rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+comm = dftk.KptComm.from_torch()
+lat, atoms, pos = dftk.silicon_cell((2, 2, 2))
+model = dftk.model_DFT(lat, atoms, pos, functionals=("lda_x", "lda_c_pw"))
+basis = dftk.PlaneWaveBasis(model, 8, dftk.MonkhorstPack((1, 1, 1)), fft_size=(40, 40, 40), device="cuda:0", comm_pw=comm)
+kpt = basis.kpoints[0]
+assert kpt.n_loc < kpt.n_G and comm._abi_kind is not None
+# (1) H psi and the density of a fixed block, slab by slab
+rho0 = dftk.guess_density(basis)
+_, ham = dftk.energy_hamiltonian(basis, None, None, rho=rho0)
+torch.manual_seed(5)
+gen = torch.Generator(device="cuda"); gen.manual_seed(11)
+psi = dftk.random_orbitals(basis, kpt, 9, gen)
+Hpsi = ham[0] @ psi
+occ = [np.array([2.0, 2, 2, 2, 1.5, 0.5, 0, 0, 0])]
+rho = dftk.compute_density(basis, [psi], occ)
+parts = comm.gather_lists((kpt.row0, psi.cpu().numpy(), Hpsi.cpu().numpy()))
+# (2) a whole SCF
+res = dftk.self_consistent_field(basis, tol=1e-9)
+if comm.rank == 0:
+    full_psi = np.concatenate([p[1] for p in sorted(parts, key=lambda t: t[0])], axis=1)
+    full_H = np.concatenate([p[2] for p in sorted(parts, key=lambda t: t[0])], axis=1)
+    np.save(os.environ["OUT"] + "_psi.npy", full_psi); np.save(os.environ["OUT"] + "_H.npy", full_H)
+    np.save(os.environ["OUT"] + "_rho.npy", rho.cpu().numpy())
+    print("RESULT " + json.dumps({"E": res["energies"].total, "terms": dict(res["energies"]),
+                                  "lam": res["eigenvalues"][0].tolist(), "converged": bool(res["converged"]),
+                                  "n_iter": res["n_iter"], "n_matvec": res["n_matvec"],
+                                  "rho_sum": float(res["rho"].sum()) * basis.dvol}))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_planewave_sharded_block_two_ranks_one_gpu(tmp_path):
+    """SURVEY section 8e (Gamma-only cells): the plane waves of ONE k-block shard over two ranks as row slabs
+    (dftk_mi_kblock_set_shard; here both ranks on cuda:0 with the host-staged communicator over gloo).  H psi and
+    the density of a fixed block equal the unsharded ones to round-off; a whole SCF reproduces the single-rank
+    energy terms (1e-8 Ha/atom) and eigenvalues."""
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    script = tmp_path / "pw_worker.py"
+    script.write_text(PW_WORKER)
+    port = str(37000 + os.getpid() % 2000)
+    out_prefix = str(tmp_path / "pw")
+    base = dict(os.environ, WORLD_SIZE="2", PORT=port, REPO=ROOT, MASTER_ADDR="127.0.0.1", OUT=out_prefix)
+    outs = _spawn([([sys.executable, str(script)], dict(base, RANK=str(r))) for r in range(2)])
+    got = json.loads([ln for ln in outs[0].splitlines() if ln.startswith("RESULT ")][-1][len("RESULT "):])
+    assert got["converged"]
+    lat, atoms, pos = dftk.silicon_cell((2, 2, 2))
+    model = dftk.model_DFT(lat, atoms, pos, functionals=("lda_x", "lda_c_pw"))
+    basis = dftk.PlaneWaveBasis(model, 8, dftk.MonkhorstPack((1, 1, 1)), fft_size=(40, 40, 40))
+    rho0 = dftk.guess_density(basis)
+    _, ham = dftk.energy_hamiltonian(basis, None, None, rho=rho0)
+    psi = torch.from_numpy(np.load(out_prefix + "_psi.npy")).cuda()
+    # the slabs of the sharded random block are the rows of the one-rank block drawn from the same generator
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(11)
+    assert torch.equal(psi, dftk.random_orbitals(basis, basis.kpoints[0], 9, gen))
+    Href = (ham[0] @ psi).cpu().numpy()
+    Hgot = np.load(out_prefix + "_H.npy")
+    assert np.linalg.norm(Hgot - Href) / np.linalg.norm(Href) < 1e-13
+    occ = [np.array([2.0, 2, 2, 2, 1.5, 0.5, 0, 0, 0])]
+    rho_ref = dftk.compute_density(basis, [psi], occ).cpu().numpy()
+    rho_got = np.load(out_prefix + "_rho.npy")
+    assert np.linalg.norm(rho_got - rho_ref) / np.linalg.norm(rho_ref) < 1e-13
+    ref = dftk.self_consistent_field(basis, tol=1e-9)
+    assert ref["converged"]
+    n_atoms = 16
+    assert abs(got["E"] - ref["energies"].total) < 1e-8 * n_atoms
+    for name, v in ref["energies"].items():
+        assert abs(got["terms"][name] - v) < 1e-7, name
+    nconv = ref["n_bands_converge"]
+    np.testing.assert_allclose(np.array(got["lam"])[:nconv], ref["eigenvalues"][0][:nconv], atol=1e-7)
+    assert abs(got["rho_sum"] - 64.0) < 1e-8
+    assert abs(got["n_iter"] - ref["n_iter"]) <= 2
 
 
 def test_rccl_c_abi_single_rank_allreduce():

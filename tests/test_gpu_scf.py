@@ -312,3 +312,24 @@ def test_seeded_scf_is_bitwise_reproducible():
     r3 = dftk.self_consistent_field(basis, tol=1e-7, seed=4)                  # another seed: another trajectory ...
     assert r3["history_Etot"] != r1["history_Etot"]
     assert abs(r3["energies"].total - r1["energies"].total) < 1e-8           # ... same fixed point
+
+
+def test_hamiltonian_blocks_own_their_potential():
+    """A DftHamiltonianBlock owns its operators (src/terms/Hamiltonian.jl:22-34): two Hamiltonians of the same basis
+    (H[rho1], H[rho2]) stay independent although the device handle of a k-point holds one padded potential at a
+    time -- applying the older block after a newer one was built must re-bind its own potential."""
+    basis = dftk.PlaneWaveBasis(device_model(), 10, dftk.ExplicitKpoints([[0.0, 0.25, -0.5]], [1.0]), fft_size=(24, 24, 24))
+    rho1 = dftk.guess_density(basis)
+    rho2 = rho1 * (1.0 + 0.3 * torch.cos(torch.arange(24, device="cuda", dtype=torch.float64))[None, None, :])
+    _, ham1 = dftk.energy_hamiltonian(basis, None, None, rho=rho1)
+    psi = dftk.random_orbitals(basis, basis.kpoints[0], 5)
+    want1 = (ham1[0] @ psi).clone()
+    _, ham2 = dftk.energy_hamiltonian(basis, None, None, rho=rho2)          # overwrites the handle's potential
+    want2 = (ham2[0] @ psi).clone()
+    assert (want1 - want2).abs().max() > 1e-3
+    assert torch.equal(ham1[0] @ psi, want1)                                 # the old block still applies ITS potential
+    assert torch.equal(ham2[0] @ psi, want2)
+    r1 = dftk.lobpcg_hyper(ham1[0], psi, prec=dftk.PreconditionerTPA(ham1[0]), tol=1e-8)
+    r2 = dftk.lobpcg_hyper(ham2[0], psi, prec=dftk.PreconditionerTPA(ham2[0]), tol=1e-8)
+    r1b = dftk.lobpcg_hyper(ham1[0], psi, prec=dftk.PreconditionerTPA(ham1[0]), tol=1e-8)
+    assert np.abs(r1.λ - r2.λ).max() > 1e-4 and np.array_equal(r1.λ, r1b.λ)

@@ -18,6 +18,13 @@ void dftk_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* dftk_mi_last_error(void) { return g_err; }
+
+hipError_t dftk_scratch_malloc(void** p, size_t bytes) {
+    static const bool poison = getenv("DFTK_MI_POISON") != nullptr;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess && poison) e = hipMemset(*p, 0xFF, bytes);
+    return e;
+}
 #ifndef DFTK_MI_SRC_HASH
 #define DFTK_MI_SRC_HASH "unknown"
 #endif
@@ -478,7 +485,7 @@ static int shard_buffers(dftk_mi_kblock* kb, int nb, cd** R1, cd** F, cd** G) {
         if (kb->sh_buf) HIPCHK(hipFree(kb->sh_buf));
         kb->sh_buf = nullptr;
         kb->sh_bytes = 0;
-        HIPCHK(hipMalloc((void**)&kb->sh_buf, need));
+        HIPCHK(dftk_scratch_malloc((void**)&kb->sh_buf, need));
         kb->sh_bytes = need;
     }
     *R1 = kb->sh_buf;
@@ -591,7 +598,7 @@ static int apply_nonlocal(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldp
         if (b->T1) HIPCHK(hipFree(b->T1));
         b->T1 = nullptr;
         b->T1_bytes = 0;
-        HIPCHK(hipMalloc((void**)&b->T1, need));
+        HIPCHK(dftk_scratch_malloc((void**)&b->T1, need));
         b->T1_bytes = need;
     }
     cd* Ppsi = b->T1;

@@ -11,6 +11,9 @@
 typedef double2 cd;   // complex fp64, (x, y) = (re, im); layout-compatible with dftk_mi_cplx
 
 void dftk_set_error(const char* fmt, ...);
+// hipMalloc for library-owned scratch; DFTK_MI_POISON=1 fills it with 0xFF bytes (NaN doubles) so that any read
+// of scratch that was not written in the current call shows up as a non-finite result (debugging aid)
+hipError_t dftk_scratch_malloc(void** p, size_t bytes);
 
 #define HIPCHK(expr)                                                                      \
     do {                                                                                  \

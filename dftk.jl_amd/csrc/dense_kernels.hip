@@ -848,7 +848,7 @@ static int dws_ensure(dftk_mi_basis* b, void** buf, size_t* cur, size_t bytes) {
     if (*buf) HIPCHK(hipFree(*buf));
     *buf = nullptr;
     *cur = 0;
-    HIPCHK(hipMalloc(buf, bytes));
+    HIPCHK(dftk_scratch_malloc(buf, bytes));
     *cur = bytes;
     return 0;
 }

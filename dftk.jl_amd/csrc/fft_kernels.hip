@@ -622,13 +622,13 @@ int fft_ensure_scratch(dftk_mi_basis* b, dftk_mi_kblock* kb, int nb) {
     if (t1 > b->T1_bytes) {
         if (b->T1) HIPCHK(hipFree(b->T1));
         b->T1 = nullptr;
-        HIPCHK(hipMalloc(&b->T1, t1));
+        HIPCHK(dftk_scratch_malloc((void**)&b->T1, t1));
         b->T1_bytes = t1;
     }
     if (t2 > b->T2_bytes) {
         if (b->T2) HIPCHK(hipFree(b->T2));
         b->T2 = nullptr;
-        HIPCHK(hipMalloc(&b->T2, t2));
+        HIPCHK(dftk_scratch_malloc((void**)&b->T2, t2));
         b->T2_bytes = t2;
     }
     return 0;

@@ -865,7 +865,7 @@ int ensure_ws(dftk_mi_basis* b, size_t bytes) {
     b->ws = nullptr;
     b->ws_bytes = 0;
     size_t want = bytes + bytes / 4;
-    HIPCHK(hipMalloc(&b->ws, want));
+    HIPCHK(dftk_scratch_malloc(&b->ws, want));
     b->ws_bytes = want;
     return 0;
 }

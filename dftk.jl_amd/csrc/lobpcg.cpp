@@ -8,6 +8,7 @@
 // orthogonalisation loops) runs on the host from a handful of reduced scalars per iteration;
 // every n_G-sized operation is a kernel on the basis' stream.
 #include "common.h"
+#include <cstdio>
 #include <cstdlib>
 #include <algorithm>
 #include <cmath>
@@ -38,9 +39,12 @@ struct Ctx {
     dftk_mi_basis* b;
     // small scratch (device)
     cd *O, *Rw, *invR, *BYX, *tmpS;
+    cd* Vh;                   // m x m: V^H of the SVD fallback (survives the Cholesky-QR polish)
     double *d_a, *d_b;        // M-sized double scratch
     std::vector<double> h;    // host scratch
-    std::mt19937_64 rng;
+    std::mt19937_64 rng;      // re-randomised columns of n_G-sized blocks (per-rank stream: each rank draws its slab)
+    std::mt19937_64 rng_rep;  // ... of REPLICATED small matrices of a sharded run: must be identical on all ranks
+    bool replicated = false;  // inside a NoComm scope
     int n_svd = 0;            // SVD fallbacks taken
     // Row-slab (plane-wave) sharding: every product with the long dimension n_G as its inner dimension and
     // every column reduction is a LOCAL partial sum followed by an all-reduce over the block's communicator
@@ -189,11 +193,11 @@ int svd_polar(Ctx& c, Mat X, cd* scratch, int64_t scratch_ld) {
         CHK(c.reduce_norms(c.d_a, m));
     }
     CHK(ew_scale_cols(c.b, W.rows, m, W.p, W.ld, c.d_a, true));
+    CHK(ew_conj_transpose(c.b, m, c.Rw, m, c.Vh, m));                         // V' (the polish below reuses O, Rw, invR)
     int nch;
     double gr;
     CHK(ortho_X(c, W, X.p, 2 * EPS, &nch, &gr, /*allow_svd=*/false, X.ld));   // X's storage is free now
-    CHK(ew_conj_transpose(c.b, m, c.Rw, m, c.invR, m));                       // V'
-    CHK(zgemm(c.b, 'N', X.rows, m, m, ONE, W.p, W.ld, c.invR, m, ZERO, X.p, X.ld));
+    CHK(zgemm(c.b, 'N', X.rows, m, m, ONE, W.p, W.ld, c.Vh, m, ZERO, X.p, X.ld));
     return 0;
 }
 
@@ -201,7 +205,8 @@ int svd_polar(Ctx& c, Mat X, cd* scratch, int64_t scratch_ld) {
 int randomize_column(Ctx& c, Mat X, int col) {
     std::normal_distribution<double> nd(0.0, 1.0);
     std::vector<double> v(2 * X.rows);
-    for (auto& x : v) x = nd(c.rng);
+    std::mt19937_64& gen = c.replicated ? c.rng_rep : c.rng;
+    for (auto& x : v) x = nd(gen);
     HIPCHK(hipMemcpyAsync(X.p + (int64_t)col * X.ld, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice,
                           c.b->stream));
     HIPCHK(hipStreamSynchronize(c.b->stream));
@@ -322,15 +327,21 @@ int hcat_mul(Ctx& c, const std::vector<Mat>& Ys, const cd* coef, int64_t ldcoef,
 struct NoComm {
     Ctx& c;
     dftk_mi_comm* saved;
-    explicit NoComm(Ctx& ctx) : c(ctx), saved(ctx.comm) { c.comm = nullptr; }
-    ~NoComm() { c.comm = saved; }
+    explicit NoComm(Ctx& ctx) : c(ctx), saved(ctx.comm) {
+        c.comm = nullptr;
+        c.replicated = saved != nullptr;   // (unsharded runs keep drawing from the one generator)
+    }
+    ~NoComm() {
+        c.comm = saved;
+        c.replicated = false;
+    }
 };
 
 }  // namespace
 
 int lobpcg_ortho(dftk_mi_basis* b, int64_t n, int m, cd* X, int64_t ldx, int force_svd, int* n_chol, int* used_svd) {
     if (m <= 0) return 0;
-    const size_t elems = (size_t)n * m + 3 * (size_t)m * m;
+    const size_t elems = (size_t)n * m + 4 * (size_t)m * m;
     void* buf = nullptr;
     HIPCHK(hipMalloc(&buf, elems * sizeof(cd) + 2 * (size_t)(m + 8) * sizeof(double)));
     Ctx c;
@@ -341,8 +352,9 @@ int lobpcg_ortho(dftk_mi_basis* b, int64_t n, int m, cd* X, int64_t ldx, int for
     c.O = w + (size_t)n * m;
     c.Rw = c.O + (size_t)m * m;
     c.invR = c.Rw + (size_t)m * m;
+    c.Vh = c.invR + (size_t)m * m;
     c.BYX = c.tmpS = nullptr;
-    c.d_a = reinterpret_cast<double*>(c.invR + (size_t)m * m);
+    c.d_a = reinterpret_cast<double*>(c.Vh + (size_t)m * m);
     c.d_b = c.d_a + (m + 8);
     c.rng.seed(0x9E3779B97F4A7C15ull);
     int nch = 0;
@@ -381,7 +393,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     const size_t m3 = 3 * (size_t)M;
     const size_t small_elems = m3 * m3 * 2              // G, V
                                + m3 * M * 2             // cP, tmpS
-                               + (size_t)M * M * 3      // O, Rw, invR
+                               + (size_t)M * M * 4      // O, Rw, invR, Vh
                                + (2 * (size_t)M + m3) * (M + 1);   // BYX (+1 scratch column)
     const size_t dbl = 9 * (size_t)(M + 8);
     const size_t need = (nbig * blk + small_elems) * sizeof(cd) + dbl * sizeof(double) + m3 * sizeof(int) + 1024;
@@ -390,7 +402,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
         if (kb->lob_buf) HIPCHK(hipFree(kb->lob_buf));
         kb->lob_buf = nullptr;
         kb->lob_bytes = 0;
-        HIPCHK(hipMalloc((void**)&kb->lob_buf, need));
+        HIPCHK(dftk_scratch_malloc((void**)&kb->lob_buf, need));
         kb->lob_bytes = need;
     }
     cd* w = kb->lob_buf;
@@ -428,6 +440,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     c.O = take((size_t)M * M);
     c.Rw = take((size_t)M * M);
     c.invR = take((size_t)M * M);
+    c.Vh = take((size_t)M * M);
     c.BYX = take((2 * (size_t)M + m3) * (M + 1));
     double* dd = reinterpret_cast<double*>(w);
     c.d_a = dd;
@@ -439,6 +452,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     double* d_rn = dd + 6 * (M + 8);    // (slot 7 holds the final permutation)
     // every rank of a sharded block draws its own slab of a re-randomised column
     c.rng.seed((seed ? seed : 0x9E3779B97F4A7C15ull) + 0x632BE59BD9B4E019ull * (uint64_t)comm_rank(comm));
+    c.rng_rep.seed((seed ? seed : 0x9E3779B97F4A7C15ull) ^ 0xD1B54A32D192ED03ull);
     Mat X = Yb[0].cols_from(0, M), AX = AYb[0].cols_from(0, M);   // views of the CURRENT pair (rebound on swap)
     kb->last_AX = AX.p;
 
@@ -594,8 +608,8 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
         CHK(d2h(c, d_xx, nact));
         for (int i = 0; i < nact; ++i)
             if (!(std::fabs(c.h[i] - 1.0) < std::sqrt(EPS))) {
-                dftk_set_error("LOBPCG is badly failing to keep the vectors normalized (column %d: %g)", lo + i,
-                               c.h[i]);
+                dftk_set_error("LOBPCG is badly failing to keep the vectors normalized (column %d: %g; iteration %d, "
+                               "%d locked, %d active, %d ranks)", lo + i, c.h[i], niter, nlocked, nact, comm_size(comm));
                 return DFTK_MI_NUM_NORMALIZATION;
             }
         // newly locked columns never change again: keep them identical in both pairs
@@ -615,6 +629,27 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
         std::vector<Mat> Zs = {X};
         if (niter > 0) Zs.push_back(nP);
         CHK(ortho_XY(c, Rn, Zs, tmp, ortho_tol, d_rn));
+        static const bool dbg_check = getenv("DFTK_MI_LOBPCG_CHECK") != nullptr;
+        if (dbg_check) {   // debugging aid: || [X P R]' [X P R] - I ||_max after the orthogonalisations of this iteration
+            const int nc = M + (niter > 0 ? 2 : 1) * lenXn;
+            CHK(zgemm(b, 'C', nc, nc, N, ONE, Yb[cur].p, N, Yb[cur].p, N, ZERO, G, nc));
+            CHK(c.reduce_c(G, (size_t)nc * nc));
+            std::vector<double> hg(2 * (size_t)nc * nc);
+            HIPCHK(hipMemcpyAsync(hg.data(), G, hg.size() * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+            HIPCHK(hipStreamSynchronize(b->stream));
+            double worst[3][3] = {{0}};
+            auto blk_of = [&](int j) { return j < M ? 0 : (niter > 0 && j < M + lenXn ? 1 : 2); };
+            for (int j = 0; j < nc; ++j)
+                for (int i = 0; i < nc; ++i) {
+                    const double re = hg[2 * ((size_t)i + (size_t)j * nc)] - (i == j ? 1.0 : 0.0);
+                    const double im = hg[2 * ((size_t)i + (size_t)j * nc) + 1];
+                    double& w = worst[blk_of(i)][blk_of(j)];
+                    w = std::max(w, std::sqrt(re * re + im * im));
+                }
+            fprintf(stderr, "[lobpcg-check rank %d] it %d locked %d act %d  XX %.1e XP %.1e XR %.1e PP %.1e PR %.1e RR %.1e\n",
+                    comm_rank(comm), niter, nlocked, lenXn, worst[0][0], worst[0][1], worst[0][2], worst[1][1],
+                    worst[1][2], worst[2][2]);
+        }
 
         if (niter >= maxiter) break;
         niter += 1;

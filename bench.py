@@ -61,7 +61,10 @@ def parse():
     ap.add_argument("--kgrid", type=int, default=6, help="--mode kpoints: n for the unreduced n x n x n mesh")
     ap.add_argument("--tol", type=float, default=1e-6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-bands", type=int, default=64)
+    ap.add_argument("--prof-all", action="store_true",
+                    help="count kernel-family launches from the warm-up on (lines the counts up with a whole-process "
+                         "rocprofv3 --pmc pass; tools/pmc_traffic_bench.sh)")
+    ap.add_argument("--cpu-sample-bands", type=int, default=0, help="0 = one band per host core (max 256)")
     return ap.parse_args()
 
 
@@ -128,19 +131,48 @@ def cpu_baseline_gamma(basis, info, n_sample, per_step):
     ref = H.mul(psi[:, :2])
     err = float(np.linalg.norm(chk - ref) / np.linalg.norm(ref))
     assert err < 1e-12, f"batched CPU H psi deviates from the oracle: {err}"
-    bsz = 16
-    t0 = time.time()
-    for c0 in range(0, n_sample, bsz):
-        hpsi_batched(psi[:, c0:c0 + bsz])
-    t_hpsi = (time.time() - t0) / n_sample
-    t0 = time.time()
-    for c0 in range(0, n_sample, bsz):
-        nb = min(bsz, n_sample - c0)
-        cube = np.zeros((nb, N), dtype=complex)
-        cube[:, kpt.mapping] = psi[:, c0:c0 + nb].T
-        cube = sfft.ifftn(cube.reshape(nb, nz, ny, nx), axes=(1, 2, 3), workers=cores, norm="forward", overwrite_x=True)
-        (cube.real ** 2 + cube.imag ** 2).sum(axis=0)
-    t_dens = (time.time() - t0) / n_sample
+    # band-parallel like the reference (one band per thread, FFT threads = 1: src/common/threading.jl:12,
+    # src/terms/Hamiltonian.jl:155): a thread pool over bands, each with a single-threaded pocketfft
+    from concurrent.futures import ThreadPoolExecutor
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+    except Exception:
+        avail = 32 << 30
+    threads = int(max(1, min(cores, n_sample, avail // (6 * 16 * N))))
+    P_h = P
+    D_h = T.D
+
+    def hpsi_one(n):
+        cube = np.zeros(N, dtype=complex)
+        cube[kpt.mapping] = psi[:, n]
+        cube = sfft.ifftn(cube.reshape(nz, ny, nx), workers=1, norm="forward", overwrite_x=True).reshape(N)
+        cube *= pot
+        cube = sfft.fftn(cube.reshape(nz, ny, nx), workers=1, norm="backward", overwrite_x=True).reshape(N)
+        return cube[kpt.mapping] + kin * psi[:, n]
+
+    def dens_one(n):
+        cube = np.zeros(N, dtype=complex)
+        cube[kpt.mapping] = psi[:, n]
+        cube = sfft.ifftn(cube.reshape(nz, ny, nx), workers=1, norm="forward", overwrite_x=True)
+        return cube.real ** 2 + cube.imag ** 2
+
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        list(pool.map(hpsi_one, range(min(threads, n_sample))))          # warm
+        t0 = time.time()
+        loc = list(pool.map(hpsi_one, range(n_sample)))
+        if P_h is not None:                                                 # nonlocal part: one threaded zgemm pair
+            nl = P_h @ (D_h @ (P_h.conj().T @ psi))
+        t_hpsi = (time.time() - t0) / n_sample
+        one = np.stack(loc[:2], axis=1) + (nl[:, :2] if P_h is not None else 0.0)
+        err2 = float(np.linalg.norm(one - ref) / np.linalg.norm(ref))
+        assert err2 < 1e-12, f"band-parallel CPU H psi deviates from the oracle: {err2}"
+        t0 = time.time()
+        acc = None
+        for d in pool.map(dens_one, range(n_sample)):
+            acc = d if acc is None else acc + d
+        t_dens = (time.time() - t0) / n_sample
+    bsz = threads
     # dense algebra rate: Gram matrix and rotation of a panel (threaded OpenBLAS zgemm)
     mcols = min(128, M)
     Xs = rng.standard_normal((n_G, mcols)) + 1j * rng.standard_normal((n_G, mcols))
@@ -154,8 +186,8 @@ def cpu_baseline_gamma(basis, info, n_sample, per_step):
     t_step = (per_step["n_matvec"] * t_hpsi + per_step["zgemm_flops"] / rate + n_occ * t_dens)
     return {"value": 1.0 / t_step, "unit": "SCF iterations/s", "cores": cores, "kind": "port",
             "hpsi_applies_per_s": 1.0 / t_hpsi,
-            "sample": (f"NumPy/SciPy oracle arithmetic (not DFTK: no Julia here), bands batched {bsz} at a time with "
-                       f"scipy.fft workers={cores} and threaded OpenBLAS: {n_sample} bands of H psi "
+            "sample": (f"NumPy/SciPy oracle arithmetic (not DFTK: no Julia here), band-parallel as the reference: "
+                       f"{bsz} threads x one band each (pocketfft workers=1) + threaded OpenBLAS: {n_sample} bands of H psi "
                        f"({t_hpsi * 1e3:.2f} ms/band; checked against oracle.HamiltonianBlock.mul to {err:.1e}), "
                        f"{n_sample} density bands ({t_dens * 1e3:.2f} ms/band), a {mcols}-column zgemm panel "
                        f"({rate / 1e9:.0f} GF/s); one SCF step modelled as the device run's per-step averages: "
@@ -260,6 +292,8 @@ def main():
 
     from dftk_jl_amd._lib import check
     # ---- warm-up on a throw-away stepper (same seed: the timed run repeats these steps from the same guess)
+    if args.prof_all:
+        check(lib.dftk_mi_prof_enable(basis.handle, 1))
     if args.warmup > 0:
         warm = dftk.ScfStepper(basis, tol=args.tol)
         for _ in range(args.warmup):
@@ -267,7 +301,8 @@ def main():
                 break
         del warm
     barrier()
-    check(lib.dftk_mi_prof_enable(basis.handle, 1))
+    if not args.prof_all:
+        check(lib.dftk_mi_prof_enable(basis.handle, 1))
     iters, diagtols, step_s, nmv_steps = [], [], [], []
     host_timers = {}
     t0 = time.time()
@@ -375,7 +410,8 @@ def main():
                                            "kind": "port", "sample": "see cfg1_scf_3steps"}
                 else:
                     per_step = {"n_matvec": n_matvec / steps_run, "zgemm_flops": zg_useful / steps_run}
-                    out["cpu_baseline"] = cpu_baseline_gamma(basis, info, args.cpu_sample_bands, per_step)
+                    n_smp = args.cpu_sample_bands or min(os.cpu_count(), 256)
+                    out["cpu_baseline"] = cpu_baseline_gamma(basis, info, n_smp, per_step)
                 out["cpu_baseline"]["cfg1_scf_3steps"] = cfg1_scf_3steps(device)
             except Exception as e:  # the baseline is reporting only; never lose the measurement
                 out["cpu_baseline"] = {"value": None, "unit": "SCF iterations/s", "cores": os.cpu_count(),

@@ -20,5 +20,7 @@ from .hamiltonian import DftHamiltonianBlock, mul_  # noqa: F401,E402
 from .terms import energy_hamiltonian, guess_density  # noqa: F401,E402
 from .eigen import lobpcg_hyper, diagonalize_all_kblocks, PreconditionerTPA, random_orbitals  # noqa: F401,E402
 from .densities import compute_density  # noqa: F401,E402
+from .mixing import (SimpleMixing, KerkerMixing, KerkerDosMixing, DielectricMixing, LdosMixing, HybridMixing,  # noqa: F401,E402
+                     Chi0Mixing, compute_dos, compute_ldos)
 from .scf import (self_consistent_field, next_density, compute_occupation, AdaptiveBands, FixedBands,  # noqa: F401,E402
                   AndersonAcceleration, determine_diagtol, ScfDefaultCallback, ScfStepper)

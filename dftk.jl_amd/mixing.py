@@ -1,0 +1,256 @@
+"""SCF mixing rules on the device (host mirror of src/scf/mixing.jl, src/scf/chi0models.jl, src/postprocess/dos.jl).
+
+``mix_density(mixing, basis, dF; info...) -> d_rho`` approximates the inverse Jacobian of the SCF map
+(mixing.jl:1-20).  Everything cube-sized stays in HBM: the Fourier multipliers run through the library's cube
+FFTs (``basis.fft`` / ``basis.irfft``), the LDOS is a second pass of the density kernel with the weights
+``-f'((e - eF)/T)/T`` (dos.jl:43-62, ``dftk_mi_density_accumulate``), GMRES works on cube-sized torch vectors and
+only its Hessenberg matrix lives on the host.
+
+* ``SimpleMixing`` (:36-39), ``KerkerMixing`` (:54-105), ``KerkerDosMixing`` (:117-137), ``DielectricMixing`` (:152-172)
+* ``LdosMixing`` / ``HybridMixing`` / ``Chi0Mixing`` (:199-290) with ``LdosModel`` and ``DielectricModel``
+  (chi0models.jl:21-80), RPA kernel (hartree.jl:68-81), GMRES as KrylovKit's ``linsolve`` (krylovdim 30,
+  tol = max(1e-12, reltol |b|), zero start vector).  ``LdosMixing()`` is the reference's default and reduces to
+  simple mixing at T = 0 (chi0models.jl:32).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from .densities import compute_density
+
+SQRT_PI = math.sqrt(math.pi)
+EPS = float(np.finfo(np.float64).eps)
+
+
+def occupation_derivative(kind, x):
+    """d/dx of Smearing.occupation (Smearing.jl:29) on host arrays."""
+    x = np.asarray(x, dtype=float)
+    if kind == "gaussian":
+        return -np.exp(-x * x) / SQRT_PI
+    if kind == "fermi_dirac":
+        e = np.exp(-np.abs(x))
+        return -e / (1 + e) ** 2
+    raise NotImplementedError(f"smearing {kind}")
+
+
+def default_smearing_temperature(model):
+    """mixing.jl:296-301."""
+    return "gaussian", max(model.temperature, min(0.1, 100 * model.temperature))
+
+
+def compute_dos(eps, basis, eigenvalues, smearing=None, temperature=None):
+    """Total density of states at ``eps`` (dos.jl:18-34), summed over ``comm_kpts``."""
+    smearing = smearing or basis.model.smearing
+    temperature = basis.model.temperature if temperature is None else temperature
+    if temperature == 0 or smearing == "none":
+        raise ValueError("compute_dos only supports finite temperature")
+    filled = basis.model.filled_occupation
+    D = 0.0
+    for w, ek in zip(basis.kweights, eigenvalues):
+        x = (np.asarray(ek, dtype=float) - eps) / temperature
+        D -= filled * w / temperature * float(np.sum(occupation_derivative(smearing, x)))
+    return basis.comm_kpts.sum_scalar(D)
+
+
+def compute_ldos(eps, basis, eigenvalues, psi, smearing=None, temperature=None, weight_threshold=EPS):
+    """Local density of states in real space (dos.jl:43-62): ``compute_density`` with modified weights."""
+    smearing = smearing or basis.model.smearing
+    temperature = basis.model.temperature if temperature is None else temperature
+    if temperature == 0 or smearing == "none":
+        raise ValueError("compute_ldos only supports finite temperature")
+    filled = basis.model.filled_occupation
+    weights = []
+    for ek, p in zip(eigenvalues, psi):
+        x = (np.asarray(ek, dtype=float)[:p.shape[0]] - eps) / temperature
+        weights.append(-filled / temperature * occupation_derivative(smearing, x))
+    return compute_density(basis, psi, weights, weight_threshold)
+
+
+def gmres(apply, b: torch.Tensor, rtol: float, krylovdim: int = 30, maxiter: int = 100, atol: float = 1e-12):
+    """Restarted GMRES on device vectors (modified Gram-Schmidt; Givens rotations on the host)."""
+    x = torch.zeros_like(b)
+    nb = float(torch.linalg.norm(b).item())
+    tol = max(atol, rtol * nb)
+    r, beta = b.clone(), nb
+    for _ in range(maxiter):
+        if beta <= tol:
+            break
+        V = [r / beta]
+        H = np.zeros((krylovdim + 1, krylovdim))
+        g = np.zeros(krylovdim + 1)
+        g[0] = beta
+        cs, sn = np.zeros(krylovdim), np.zeros(krylovdim)
+        k_used = 0
+        for k in range(krylovdim):
+            w = apply(V[k])
+            for j in range(k + 1):
+                H[j, k] = float((V[j] * w).sum().item())
+                w = w - H[j, k] * V[j]
+            H[k + 1, k] = float(torch.linalg.norm(w).item())
+            for j in range(k):
+                t = cs[j] * H[j, k] + sn[j] * H[j + 1, k]
+                H[j + 1, k] = -sn[j] * H[j, k] + cs[j] * H[j + 1, k]
+                H[j, k] = t
+            d = math.hypot(H[k, k], H[k + 1, k])
+            cs[k], sn[k] = (1.0, 0.0) if d == 0 else (H[k, k] / d, H[k + 1, k] / d)
+            H[k, k] = d
+            hk1 = H[k + 1, k]
+            H[k + 1, k] = 0.0
+            g[k + 1] = -sn[k] * g[k]
+            g[k] = cs[k] * g[k]
+            k_used = k + 1
+            if abs(g[k + 1]) <= tol or hk1 == 0.0:
+                break
+            V.append(w / hk1)
+        y = np.linalg.solve(np.triu(H[:k_used, :k_used]), g[:k_used])
+        for j in range(k_used):
+            x = x + float(y[j]) * V[j]
+        r = b - apply(x)
+        beta = float(torch.linalg.norm(r).item())
+    return x, beta <= tol
+
+
+def _G2(basis):
+    Gc = basis.G_vectors_cart_cube()
+    return (Gc * Gc).sum(dim=-1)
+
+
+class SimpleMixing:
+    """mixing.jl:36-39: J^-1 ~ 1."""
+
+    def mix_density(self, basis, dF, **info):
+        return dF
+
+
+class KerkerMixing:
+    """mixing.jl:54-105 (spin-unpolarised): J^-1 ~ |G|^2 / (kTF^2 + |G|^2)."""
+
+    def __init__(self, kTF: float = 0.8):
+        self.kTF = float(kTF)
+
+    def mix_density(self, basis, dF, **info):
+        G2 = _G2(basis)
+        drho_f = basis.fft(dF) * (G2 / (self.kTF ** 2 + G2)) * basis.enforce_real_mask()
+        drho = basis.irfft(drho_f)
+        return drho + (dF.mean() - drho.mean())      # copy the DC component, otherwise it never gets updated
+
+
+class KerkerDosMixing:
+    """mixing.jl:117-137: Kerker with kTF from the density of states at the Fermi level."""
+
+    def __init__(self, smearing=None, temperature=None):
+        self.smearing, self.temperature = smearing, temperature
+
+    def mix_density(self, basis, dF, eF=None, eigenvalues=None, **info):
+        sm, T = default_smearing_temperature(basis.model)
+        sm = self.smearing or sm
+        T = self.temperature if self.temperature is not None else T
+        if T == 0:
+            return dF
+        dos_per_vol = compute_dos(eF, basis, eigenvalues, sm, T) / basis.model.unit_cell_volume
+        return KerkerMixing(kTF=math.sqrt(4 * math.pi * dos_per_vol)).mix_density(basis, dF)
+
+
+class DielectricMixing:
+    """mixing.jl:152-172: J^-1 ~ (kTF^2 - C0 G^2) / (eps_r kTF^2 - C0 G^2), C0 = 1 - eps_r."""
+
+    def __init__(self, kTF: float = 0.8, eps_r: float = 10.0):
+        self.kTF, self.eps_r = float(kTF), float(eps_r)
+
+    def mix_density(self, basis, dF, **info):
+        er, kTF = self.eps_r, self.kTF
+        if er == 1:
+            return dF
+        if er > 1 / math.sqrt(EPS):
+            return KerkerMixing(kTF).mix_density(basis, dF)
+        C0 = 1 - er
+        G2 = _G2(basis)
+        drho = basis.irfft(basis.fft(dF) * ((kTF ** 2 - C0 * G2) / (er * kTF ** 2 - C0 * G2)))
+        return drho + (dF.mean() - drho.mean())
+
+
+class LdosModel:
+    """chi0models.jl:21-45: chi0 = -Dloc(r) delta(r, r') + Dloc(r) Dloc(r') / D."""
+
+    def __init__(self, smearing=None, temperature=None):
+        self.smearing, self.temperature = smearing, temperature
+
+    def __call__(self, basis, eigenvalues=None, psi=None, eF=None, **info):
+        sm, T = default_smearing_temperature(basis.model)
+        sm = self.smearing or sm
+        T = self.temperature if self.temperature is not None else T
+        if T == 0:
+            return None
+        ldos = compute_ldos(eF, basis, eigenvalues, psi, sm, T)
+        if float(ldos.abs().max().item()) < math.sqrt(EPS):
+            return None
+        tdos = float(ldos.sum().item()) * basis.dvol
+
+        def apply(drho, dV, alpha=1.0):
+            deF = float((ldos * dV).sum().item()) * basis.dvol
+            return drho + alpha * (ldos * (deF / tdos) - ldos * dV)
+        return apply
+
+
+class DielectricModel:
+    """chi0models.jl:54-80 (localization = identity)."""
+
+    def __init__(self, eps_r: float = 10.0, kTF: float = 0.8):
+        self.eps_r, self.kTF = float(eps_r), float(kTF)
+
+    def __call__(self, basis, **info):
+        C0 = 1 - self.eps_r
+        if C0 == 0:
+            return None
+        kTF = self.kTF
+        G2 = _G2(basis)
+        mult = C0 * kTF ** 2 * G2 / (4 * math.pi) / (kTF ** 2 - C0 * G2)
+
+        def apply(drho, dV, alpha=1.0):
+            return drho + alpha * basis.irfft(mult * basis.fft(dV))
+        return apply
+
+
+class Chi0Mixing:
+    """mixing.jl:228-290: GMRES solve of (1 - chi0 vc) d_rho = dF in real space, RPA kernel."""
+
+    def __init__(self, chi0terms, RPA: bool = True, reltol: float = 0.01):
+        if not RPA:
+            raise NotImplementedError("only the RPA (Hartree) kernel is on this path")
+        self.chi0terms, self.reltol = list(chi0terms), float(reltol)
+        self.last_gmres_applies = 0
+
+    def mix_density(self, basis, dF, **info):
+        applies = [a for a in (t(basis, **info) for t in self.chi0terms) if a is not None]
+        if not applies:
+            return dF                                   # "do not bother running GMRES": simple mixing
+        poisson = basis.terms.poisson
+        count = [0]
+
+        def dielectric_adjoint(x):
+            count[0] += 1
+            dV = basis.irfft(poisson * basis.fft(x)) if poisson is not None else torch.zeros_like(x)   # apply_kernel, RPA
+            dV = dV - dV.mean()
+            out = x
+            for a in applies:
+                out = a(out, dV, -1.0)                  # eps dF -= chi0 dV
+            return out - out.mean()
+        dc = dF.mean()
+        drho, _ = gmres(dielectric_adjoint, dF - dc, self.reltol)
+        self.last_gmres_applies = count[0]
+        # (the reference broadcasts d_rho from rank 0, mpi_bcast!: every rank of comm_kpts / comm_pw runs the same
+        #  deterministic kernels on identical inputs here, so the replicas are already numerically identical)
+        return drho + dc
+
+
+def LdosMixing(smearing=None, temperature=None, **kw):
+    """mixing.jl:221-225."""
+    return Chi0Mixing([LdosModel(smearing, temperature)], **kw)
+
+
+def HybridMixing(eps_r=10.0, kTF=0.8, smearing=None, temperature=None, **kw):
+    """mixing.jl:199-205."""
+    return Chi0Mixing([DielectricModel(eps_r, kTF), LdosModel(smearing, temperature)], **kw)

@@ -1,8 +1,8 @@
 """SCF driver glue around the device hot path (host mirror of src/scf/*.jl, src/occupation.jl).
 
 ``self_consistent_field`` (self_consistent_field.jl:164-289) with ``ScfAndersonDensitySolver``
-(scf_solvers.jl:68-102, anderson.jl:36-130), simple mixing (what ``LdosMixing`` reduces to at
-T = 0, chi0models.jl:32, mixing.jl:264-266), ``AdaptiveDiagtol`` (scf_callbacks.jl:191-212),
+(scf_solvers.jl:68-102, anderson.jl:36-130), the mixing rules of mixing.py (default ``LdosMixing``, simple
+mixing at T = 0, chi0models.jl:32, mixing.jl:264-266), ``AdaptiveDiagtol`` (scf_callbacks.jl:191-212),
 ``AdaptiveBands`` (nbands_algorithm.jl:52-110), ``next_density`` (:80-129) and the Fermi-level
 search (occupation.jl:53-211; None / Fermi-Dirac / Gaussian smearing).  Everything cube- or
 block-sized stays in HBM; the host only sees eigenvalues, occupations and scalars.
@@ -18,6 +18,7 @@ from scipy.special import erfc
 
 from .densities import compute_density
 from .eigen import diagonalize_all_kblocks, lobpcg_hyper
+from .mixing import LdosMixing
 from .terms import energy_hamiltonian, guess_density
 
 EPS = float(np.finfo(np.float64).eps)
@@ -246,9 +247,11 @@ class ScfStepper:
     scf_solvers.jl:85-98).  ``step()`` performs exactly one SCF iteration."""
 
     def __init__(self, basis, rho=None, psi=None, tol=1e-6, damping=0.8, nbandsalg=None, is_converged=None,
-                 eigensolver=lobpcg_hyper, anderson_m=10, seed=0, determine_tol=determine_diagtol):
+                 eigensolver=lobpcg_hyper, anderson_m=10, seed=0, determine_tol=determine_diagtol, mixing=None):
         basis._require_gpu()
         self.basis = basis
+        # mixing = LdosMixing() as the reference (self_consistent_field.jl:177): simple mixing at T = 0
+        self.mixing = mixing if mixing is not None else LdosMixing()
         self.gen = torch.Generator(device=basis.device)
         self.gen.manual_seed(seed + 7919 * basis.comm_kpts.rank)
         self.seed = seed
@@ -299,9 +302,11 @@ class ScfStepper:
         info["converged"] = bool(self.is_converged(info))
         info["timings"] = info["timings"] + [time.time() - t_it]
         if not info["converged"]:
-            # rho_next = Anderson(rho_in, beta, rho_out - rho_in); simple mixing: P^-1 = 1
+            # rho_next = Anderson(rho_in, beta, mix_density(mixing, rho_out - rho_in))   (:247, scf_solvers.jl:85-98)
             t = time.time()
-            self.rho_in = self.accel(self.rho_in, self.damping, drho)
+            pf = self.mixing.mix_density(basis, drho, eF=nxt["eF"], eigenvalues=nxt["eigenvalues"], psi=nxt["psi"],
+                                         occupation=nxt["occupation"], rho_in=self.rho_in)
+            self.rho_in = self.accel(self.rho_in, self.damping, pf)
             lap("mixing", t)
         info["timers"] = timers
         self.info = info
@@ -317,13 +322,13 @@ class ScfStepper:
 
 def self_consistent_field(basis, rho=None, psi=None, tol=1e-6, maxiter=100, damping=0.8, nbandsalg=None,
                           is_converged=None, callback=None, eigensolver=lobpcg_hyper, anderson_m=10, seed=0,
-                          determine_tol=determine_diagtol):
+                          determine_tol=determine_diagtol, mixing=None):
     """``self_consistent_field(basis; rho, psi, tol, maxiter, damping, nbandsalg, is_converged, callback,
     eigensolver)`` (self_consistent_field.jl:164-289)."""
     t0 = time.time()
     stepper = ScfStepper(basis, rho=rho, psi=psi, tol=tol, damping=damping, nbandsalg=nbandsalg,
                          is_converged=is_converged, eigensolver=eigensolver, anderson_m=anderson_m, seed=seed,
-                         determine_tol=determine_tol)
+                         determine_tol=determine_tol, mixing=mixing)
     for _ in range(maxiter):
         info = stepper.step()
         if callback is not None:

@@ -22,5 +22,7 @@ from .basis import (Model, ElementPsp, PlaneWaveBasis, Kpoint, compute_fft_size,
                     MonkhorstPack, ExplicitKpoints, model_DFT, model_atomic)
 from .terms import energy_hamiltonian, guess_density, HamiltonianBlock  # noqa: F401
 from .lobpcg import lobpcg_hyper, LOBPCG, PreconditionerTPA, diagonalize_all_kblocks  # noqa: F401
+from .mixing import (SimpleMixing, KerkerMixing, KerkerDosMixing, DielectricMixing, LdosMixing,  # noqa: F401
+                     HybridMixing, Chi0Mixing)
 from .scf import (self_consistent_field, compute_density, compute_occupation,  # noqa: F401
                   AdaptiveBands, next_density)

@@ -3,8 +3,7 @@
 Restates ``src/densities.jl:13-57`` (no symmetrisation: identity symmetry only),
 ``src/occupation.jl:30-211`` + ``src/Smearing.jl`` (None / Fermi-Dirac / Gaussian),
 ``src/scf/nbands_algorithm.jl``, ``src/scf/scf_callbacks.jl:138-230`` (convergence, AdaptiveDiagtol),
-``src/scf/anderson.jl:36-130``, ``src/scf/scf_solvers.jl:68-102``, ``src/scf/mixing.jl:28-39`` (simple
-mixing; LdosMixing degenerates to it at T = 0, chi0models.jl:32) and
+``src/scf/anderson.jl:36-130``, ``src/scf/scf_solvers.jl:68-102`` (mixing rules: oracle/mixing.py) and
 ``src/scf/self_consistent_field.jl:80-289``.
 """
 from __future__ import annotations
@@ -222,9 +221,13 @@ def determine_diagtol(n_iter, history_drho, ratio=0.2, diagtol_max=0.005, diagto
 
 def self_consistent_field(basis, rho=None, psi=None, tol=1e-6, maxiter=100, damping=0.8,
                           nbandsalg=None, is_converged=None, callback=None, rng=None,
-                          anderson_m=10):
-    """self_consistent_field.jl:164-289 with ScfAndersonDensitySolver + simple mixing."""
+                          anderson_m=10, mixing=None):
+    """self_consistent_field.jl:164-289 with ScfAndersonDensitySolver; ``mixing`` defaults to ``LdosMixing()`` as
+    the reference (:177), which is simple mixing at T = 0 (chi0models.jl:32)."""
     rng = np.random.default_rng(0) if rng is None else rng
+    if mixing is None:
+        from .mixing import LdosMixing
+        mixing = LdosMixing()
     if rho is None:
         rho = guess_density(basis)
     if nbandsalg is None:
@@ -258,8 +261,11 @@ def self_consistent_field(basis, rho=None, psi=None, tol=1e-6, maxiter=100, damp
             callback(info)
         if info["converged"]:
             break
-        # fixpoint map returns rho_in + mix(drho) = rho_out; the solver then damps + accelerates
-        rho_in = accel(rho_in, damping, nxt["rho"] - rho_in)
+        # fixpoint map returns rho_in + mix_density(mixing, drho) (:247); the solver damps + accelerates the
+        # preconditioned residual (scf_solvers.jl:85-98)
+        pf = mixing.mix_density(basis, drho, eF=nxt["eF"], eigenvalues=nxt["eigenvalues"], psi=nxt["psi"],
+                                occupation=nxt["occupation"], rho_in=rho_in)
+        rho_in = accel(rho_in, damping, pf)
     energies, ham = energy_hamiltonian(basis, info["psi"], info["occupation"], rho=info["rho"],
                                        eigenvalues=info["eigenvalues"], eF=info["eF"])
     info["energies"] = energies

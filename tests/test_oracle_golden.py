@@ -14,6 +14,7 @@ from oracle import (ElementPsp, ExplicitKpoints, Model, MonkhorstPack, PlaneWave
                     guess_density, load_psp_hgh, model_DFT, self_consistent_field, AdaptiveBands)
 from oracle.psp import (eval_psp_local_fourier, eval_psp_projector_fourier, parse_hgh)
 from oracle.scf import compute_density
+import oracle
 from oracle.terms import energy_ewald
 
 A_SI = 5.131570667152971          # test/testcases.jl:14-16
@@ -553,3 +554,46 @@ def test_hgh_fourier_forms_against_real_space_quadrature(symbol, functional):
     p_small = 1e-3
     lim = eval_psp_local_fourier(psp, np.array([p_small]))[0] + 4 * np.pi * psp.Zion / p_small ** 2
     assert eval_psp_energy_correction(psp) == pytest.approx(lim, abs=1e-3)
+
+
+# ----------------------------------------------------------------------------------- mixing (oracle/mixing.py)
+def test_mixing_gmres_and_limits():
+    """GMRES (KrylovKit linsolve restated) against a dense solve; limiting cases of the mixings
+    (mixing.jl:157-159: eps_r = 1 is simple mixing, eps_r = Inf Kerker; chi0models.jl:32: LDOS at T = 0 drops out)."""
+    from oracle import mixing as om
+    rng = np.random.default_rng(3)
+    A = np.eye(40) + 0.3 * rng.standard_normal((40, 40)) / np.sqrt(40)
+    b = rng.standard_normal(40)
+    x, ok = om.gmres(lambda v: A @ v, b, 1e-10, krylovdim=7)
+    assert ok and np.linalg.norm(A @ x - b) <= 1e-10 * np.linalg.norm(b) * 1.01
+    x2, ok2 = om.gmres(lambda v: A @ v, b, 1e-2)
+    assert ok2 and 1e-6 < np.linalg.norm(A @ x2 - b) <= 1e-2 * np.linalg.norm(b)
+    lat, atoms, pos = oracle.basis.silicon_primitive()
+    basis = oracle.PlaneWaveBasis(oracle.model_DFT(lat, atoms, pos), 5, oracle.MonkhorstPack((1, 1, 1)))
+    dF = rng.standard_normal(basis.fft_size[::-1])
+    assert np.array_equal(om.DielectricMixing(eps_r=1.0).mix_density(basis, dF), dF)
+    np.testing.assert_allclose(om.DielectricMixing(eps_r=1e12).mix_density(basis, dF),
+                               om.KerkerMixing().mix_density(basis, dF), atol=1e-14)
+    assert om.LdosMixing().mix_density(basis, dF, eF=0.1, eigenvalues=[np.zeros(4)], psi=None) is dF   # T = 0
+    k = om.KerkerMixing(kTF=0.8).mix_density(basis, dF)
+    assert abs(k.mean() - dF.mean()) < 1e-14                       # DC component copied
+    assert np.linalg.norm(k - k.mean()) < np.linalg.norm(dF - dF.mean())   # long wavelengths damped
+
+
+def test_metal_scf_same_fixed_point_for_every_mixing():
+    """All mixings are preconditioners of the SAME fixed-point problem: a small fcc-Al 2-atom cell converges to one
+    energy with simple, Kerker, Kerker-DOS, LDOS (the reference's default) and hybrid mixing."""
+    a = 7.6324708938577865
+    lat = a / 2 * np.array([[0, 1, 1.0], [1, 0, 1.0], [1, 1, 0.0]])
+    Al = oracle.ElementPsp("Al", oracle.load_psp_hgh("Al", "lda"))
+    lat2, atoms, pos = oracle.basis.create_supercell(lat, [Al], [np.zeros(3)], (2, 1, 1))
+    m = oracle.model_DFT(lat2, atoms, pos, functionals=("lda_x", "lda_c_vwn"), temperature=0.01, smearing="fermi_dirac")
+    b = oracle.PlaneWaveBasis(m, 5, oracle.MonkhorstPack((1, 2, 2)))
+    E = {}
+    for name, mix in [("simple", oracle.SimpleMixing()), ("kerker", oracle.KerkerMixing()),
+                      ("kerkerdos", oracle.KerkerDosMixing()), ("ldos", None), ("hybrid", oracle.HybridMixing())]:
+        r = oracle.self_consistent_field(b, tol=1e-8, mixing=mix)
+        assert r["converged"] and r["n_iter"] < 30, name
+        E[name] = r["energies"].total
+    for name, e in E.items():
+        assert abs(e - E["simple"]) < 1e-9, (name, e, E["simple"])

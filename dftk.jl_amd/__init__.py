@@ -24,3 +24,4 @@ from .mixing import (SimpleMixing, KerkerMixing, KerkerDosMixing, DielectricMixi
                      Chi0Mixing, compute_dos, compute_ldos)
 from .scf import (self_consistent_field, next_density, compute_occupation, AdaptiveBands, FixedBands,  # noqa: F401,E402
                   AndersonAcceleration, determine_diagtol, ScfDefaultCallback, ScfStepper)
+from .io import scfres_to_dict, save_scfres, load_scfres, basis_to_dict, model_to_dict  # noqa: F401,E402

@@ -656,6 +656,14 @@ extern "C" int dftk_mi_apply_H(dftk_mi_kblock* kb, int n_bands, const dftk_mi_cp
     return dftk_mi_apply_H_parts(kb, 7, n_bands, psi_d, ld_psi, Hpsi_d, ld_Hpsi);
 }
 
+extern "C" int dftk_mi_local_potential(dftk_mi_kblock* cube_kb, const double* rho_d, const double* V_loc_d,
+                                       const double* poisson_green_d, int xc_functionals, double* V_out_d,
+                                       double* energies_h) {
+    if (!cube_kb || !rho_d || !energies_h || (xc_functionals & ~7) || cube_kb->sh_comm) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(cube_kb->basis->device));
+    return local_potential_lda(cube_kb, rho_d, V_loc_d, poisson_green_d, xc_functionals, V_out_d, energies_h);
+}
+
 extern "C" int dftk_mi_ifft_sphere(dftk_mi_kblock* kb, const dftk_mi_cplx* c_d, dftk_mi_cplx* cube_d) {
     if (!kb || !c_d || !cube_d) return DFTK_MI_EINVAL;
     HIPCHK(hipSetDevice(kb->basis->device));

@@ -207,6 +207,10 @@ int comm_allreduce_norms(dftk_mi_comm* c, dftk_mi_basis* b, double* d, size_t n)
 int comm_alltoallv(dftk_mi_comm* c, dftk_mi_basis* b, const cd* send, const size_t* soff, const size_t* scnt,
                    cd* recv, const size_t* roff, const size_t* rcnt);
 
+// xc_kernels.hip
+int local_potential_lda(dftk_mi_kblock* cube_kb, const double* rho, const double* vloc, const double* green,
+                        int fun_mask, double* V_out, double* energies_h);
+
 // lobpcg.cpp
 // ortho!(X) (Cholesky-QR with the reference's shift-and-retry and SVD fallback) on a stand-alone block;
 // force_svd = 1 takes the SVD branch directly (tests)

@@ -1,0 +1,168 @@
+// xc_kernels.hip -- the local-potential pipeline of energy_hamiltonian on the device:
+//   Hartree   src/terms/hartree.jl:50-59   rho -> FFT -> * 4 pi / |G|^2 -> E_H = 1/2 Re <V_H(G), rho(G)> -> irfft
+//   XC (LDA)  src/terms/xc.jl:84-160       e_xc(rho), v_xc(rho) point by point (Slater exchange, VWN5 / PW92
+//                                          correlation: the closed forms libxc evaluates for lda_x, lda_c_vwn, lda_c_pw)
+//   sum       src/terms/operators.jl:213-222   V = V_loc + V_H + v_xc, handed to the k-blocks as ONE potential
+//   energies  src/terms/local.jl:15-16 (E_loc = sum rho V_loc dvol), xc.jl:113 (E_xc = sum e_xc dvol)
+// One pass over the cube for XC + the sum + two energy reductions; the Poisson multiply and the Hartree energy
+// ride on the Fourier-space pass between the two cube FFTs (the library's own pruned pipeline with a full "sphere").
+// Reductions: one partial per workgroup, summed on the host in a fixed order (bitwise reproducible).
+#include "common.h"
+#include <cmath>
+#include <vector>
+
+namespace {
+const int XC_BLOCKS = 1024;
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+    v = wave_sum_d(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_real_to_complex(int64_t n, const double* __restrict__ x, cd* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = make_double2(x[i], 0.0);
+}
+
+// c <- green * c ; partial[block] = sum green |c_old|^2
+__global__ __launch_bounds__(256) void k_poisson(int64_t n, cd* __restrict__ c, const double* __restrict__ green,
+                                                 double* __restrict__ partial) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const cd v = c[i];
+        const double g = green[i];
+        acc += g * (v.x * v.x + v.y * v.y);
+        c[i] = make_double2(g * v.x, g * v.y);
+    }
+    const double s = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// closed forms; eps = energy per particle, returns e = rho * eps and v = d e / d rho
+__device__ __forceinline__ void lda_x(double rho, double& e, double& v) {
+    const double cx = -0.73855876638202240588;   // -3/4 (3/pi)^(1/3)
+    const double r13 = cbrt(rho);
+    e = cx * rho * r13;
+    v = (4.0 / 3.0) * cx * r13;
+}
+__device__ __forceinline__ void lda_c_vwn(double rho, double& e, double& v) {
+    const double A = 0.0310907, b = 3.72744, c = 12.9352, x0 = -0.10498;
+    const double rs = cbrt(3.0 / (4.0 * M_PI * rho));
+    const double x = sqrt(rs);
+    const double X = x * x + b * x + c, X0 = x0 * x0 + b * x0 + c;
+    const double Q = sqrt(4.0 * c - b * b);
+    const double at = atan(Q / (2.0 * x + b));
+    const double eps = A * (log(x * x / X) + 2.0 * b / Q * at -
+                            b * x0 / X0 * (log((x - x0) * (x - x0) / X) + 2.0 * (b + 2.0 * x0) / Q * at));
+    const double dat = -2.0 * Q / (Q * Q + (2.0 * x + b) * (2.0 * x + b));
+    const double deps_dx = A * (2.0 / x - (2.0 * x + b) / X + 2.0 * b / Q * dat -
+                                b * x0 / X0 * (2.0 / (x - x0) - (2.0 * x + b) / X + 2.0 * (b + 2.0 * x0) / Q * dat));
+    e = rho * eps;
+    v = eps - rs / 3.0 * deps_dx / (2.0 * x);
+}
+__device__ __forceinline__ void lda_c_pw(double rho, double& e, double& v) {
+    const double a = 0.031091, a1 = 0.21370, b1 = 7.5957, b2 = 3.5876, b3 = 1.6382, b4 = 0.49294;
+    const double rs = cbrt(3.0 / (4.0 * M_PI * rho));
+    const double sq = sqrt(rs);
+    const double den = 2.0 * a * (b1 * sq + b2 * rs + b3 * rs * sq + b4 * rs * rs);
+    const double lg = log1p(1.0 / den);
+    const double eps = -2.0 * a * (1.0 + a1 * rs) * lg;
+    const double dden = 2.0 * a * (b1 / (2.0 * sq) + b2 + 1.5 * b3 * sq + 2.0 * b4 * rs);
+    const double deps = -2.0 * a * a1 * lg + 2.0 * a * (1.0 + a1 * rs) * dden / (den * den + den);
+    e = rho * eps;
+    v = eps - rs / 3.0 * deps;
+}
+
+// V = V_loc + V_H + v_xc ; partials: [0] sum e_xc, [1] sum rho V_loc
+__global__ __launch_bounds__(256) void k_xc_sum(int64_t n, const double* __restrict__ rho, const cd* __restrict__ vh_cube,
+                                                double vh_scale, const double* __restrict__ vloc, int fun_mask,
+                                                double* __restrict__ V, double* __restrict__ partial) {
+    __shared__ double sh[4];
+    double acc_xc = 0.0, acc_loc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double r = rho[i];
+        double e = 0.0, v = 0.0;
+        if (fun_mask != 0 && r > 1e-300) {
+            double ei, vi;
+            if (fun_mask & 1) { lda_x(r, ei, vi); e += ei; v += vi; }
+            if (fun_mask & 2) { lda_c_vwn(r, ei, vi); e += ei; v += vi; }
+            if (fun_mask & 4) { lda_c_pw(r, ei, vi); e += ei; v += vi; }
+        }
+        acc_xc += e;
+        double tot = v;
+        if (vloc) {
+            const double vl = vloc[i];
+            acc_loc += r * vl;
+            tot += vl;
+        }
+        if (vh_cube) tot += vh_scale * vh_cube[i].x;
+        if (V) V[i] = tot;
+    }
+    const double s0 = block_sum(acc_xc, sh);
+    const double s1 = block_sum(acc_loc, sh);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = s0;
+        partial[XC_BLOCKS + blockIdx.x] = s1;
+    }
+}
+}  // namespace
+
+// cube_kb: a k-block whose "sphere" is the whole cube (mapping = 0 .. N-1), i.e. the library's cube FFT.
+int local_potential_lda(dftk_mi_kblock* cube_kb, const double* rho, const double* vloc, const double* green,
+                        int fun_mask, double* V_out, double* energies_h) {
+    dftk_mi_basis* b = cube_kb->basis;
+    const int64_t N = (int64_t)b->nx * b->ny * b->nz;
+    if (cube_kb->n_G != N) {
+        dftk_set_error("local_potential: the k-block must span the whole cube (n_G = %lld, N = %lld)",
+                       (long long)cube_kb->n_G, (long long)N);
+        return DFTK_MI_EINVAL;
+    }
+    // two complex cubes + reduction partials in the basis' dense workspace
+    const size_t need = 2 * (size_t)N * sizeof(cd) + 3 * XC_BLOCKS * sizeof(double);
+    if (need > b->dense_ws_bytes) {
+        HIPCHK(hipStreamSynchronize(b->stream));
+        if (b->dense_ws) HIPCHK(hipFree(b->dense_ws));
+        b->dense_ws = nullptr;
+        b->dense_ws_bytes = 0;
+        HIPCHK(dftk_scratch_malloc(&b->dense_ws, need));
+        b->dense_ws_bytes = need;
+    }
+    cd* c1 = reinterpret_cast<cd*>(b->dense_ws);
+    cd* c2 = c1 + N;
+    double* partial = reinterpret_cast<double*>(c2 + N);
+    const cd* vh = nullptr;
+    std::vector<double> hp(3 * XC_BLOCKS, 0.0);
+    if (green) {
+        hipLaunchKernelGGL(k_real_to_complex, dim3(XC_BLOCKS), dim3(256), 0, b->stream, N, rho, c1);
+        CHK(launch_fft_from_cube(cube_kb, c1, c2));                       // c2 = F[rho] (unnormalised)
+        hipLaunchKernelGGL(k_poisson, dim3(XC_BLOCKS), dim3(256), 0, b->stream, N, c2, green, partial + 2 * XC_BLOCKS);
+        CHK(launch_ifft_to_cube(cube_kb, c2, c1));                        // c1 = N * V_H(r)
+        vh = c1;
+    }
+    hipLaunchKernelGGL(k_xc_sum, dim3(XC_BLOCKS), dim3(256), 0, b->stream, N, rho, vh, 1.0 / (double)N, vloc, fun_mask,
+                       V_out, partial);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(hp.data(), partial, (green ? 3 : 2) * XC_BLOCKS * sizeof(double), hipMemcpyDeviceToHost,
+                          b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int k = 0; k < 3; ++k)
+        for (int i = 0; i < XC_BLOCKS; ++i) s[k] += hp[(size_t)k * XC_BLOCKS + i];
+    const double dvol = b->volume / (double)N;
+    energies_h[0] = green ? 0.5 * b->volume / ((double)N * (double)N) * s[2] : 0.0;   // Hartree
+    energies_h[1] = s[0] * dvol;                                                        // Xc
+    energies_h[2] = s[1] * dvol;                                                        // AtomicLocal
+    return 0;
+}

@@ -336,7 +336,8 @@ def self_consistent_field(basis, rho=None, psi=None, tol=1e-6, maxiter=100, damp
         if info["converged"]:
             break
     info = stepper.finalize()
-    info["runtime"] = time.time() - t0
+    info.update(runtime=time.time() - t0, basis=basis, mixing=stepper.mixing, damping=damping,
+                occupation_threshold=stepper.nbandsalg.occupation_threshold, algorithm="SCF")
     return info
 
 

@@ -90,6 +90,21 @@ int dftk_mi_apply_H(dftk_mi_kblock* kb, int n_bands, const dftk_mi_cplx* psi_d, 
 int dftk_mi_apply_H_parts(dftk_mi_kblock* kb, int which, int n_bands, const dftk_mi_cplx* psi_d,
                           int64_t ld_psi, dftk_mi_cplx* Hpsi_d, int64_t ld_Hpsi);
 
+/* ---- local-potential pipeline of energy_hamiltonian (src/terms/Hamiltonian.jl:200-227) on the cube ----------
+ * Hartree (src/terms/hartree.jl:50-59: V_H = irfft(green .* fft(rho)), E_H = 1/2 Re<V_H(G), rho(G)>), LDA exchange-
+ * correlation (src/terms/xc.jl:84-160 with lda_x / lda_c_vwn / lda_c_pw, the functionals of `LDA()` and of the
+ * reference's pinned tests), the local pseudopotential energy (src/terms/local.jl:15-16) and the summation into ONE
+ * potential (src/terms/operators.jl:213-222):  V_out = V_loc + V_H + v_xc.
+ * cube_kb: a k-block whose mapping is 0 .. N-1 (the library's cube FFT).  rho_d, V_loc_d, poisson_green_d
+ * (4 pi / |G|^2 with the G = 0 and unpaired-G entries zeroed, hartree.jl:29-45), V_out_d: real cubes on the device;
+ * V_loc_d / poisson_green_d / V_out_d may be NULL (term absent / energies only).  energies_h[3] = Hartree, Xc,
+ * AtomicLocal (host).  Synchronises the basis' stream. */
+#define DFTK_MI_XC_LDA_X     1
+#define DFTK_MI_XC_LDA_C_VWN 2
+#define DFTK_MI_XC_LDA_C_PW  4
+int dftk_mi_local_potential(dftk_mi_kblock* cube_kb, const double* rho_d, const double* V_loc_d,
+                            const double* poisson_green_d, int xc_functionals, double* V_out_d, double* energies_h);
+
 /* ---- sphere <-> cube transforms  (src/fft.jl:110-122 ifft!, :162-172 fft!; normalize=false) --
  * cube_d is nx*ny*nz complex, x fastest.  Test/diagnostic entry points (the hot path never
  * materialises the full cube in the caller's layout). */

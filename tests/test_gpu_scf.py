@@ -333,3 +333,62 @@ def test_hamiltonian_blocks_own_their_potential():
     r2 = dftk.lobpcg_hyper(ham2[0], psi, prec=dftk.PreconditionerTPA(ham2[0]), tol=1e-8)
     r1b = dftk.lobpcg_hyper(ham1[0], psi, prec=dftk.PreconditionerTPA(ham1[0]), tol=1e-8)
     assert np.abs(r1.λ - r2.λ).max() > 1e-4 and np.array_equal(r1.λ, r1b.λ)
+
+
+def test_scfres_wire_formats_and_restart(tmp_path):
+    """save_scfres / load_scfres (src/scf/scfres.jl:69-86, src/input_output.jl:345-386): the JSON carries the keys
+    DFTK's ``scfres_to_dict`` writes (Julia nesting: eigenvalues[spin][kpoint][band]); the npz checkpoint restarts
+    the SCF at the fixed point."""
+    import json
+    basis = dftk.PlaneWaveBasis(device_model(), 10, dftk.MonkhorstPack((2, 2, 2)), fft_size=(24, 24, 24))
+    res = dftk.self_consistent_field(basis, tol=1e-8)
+    fn = str(tmp_path / "scfres.json")
+    dftk.save_scfres(fn, res)
+    d = json.load(open(fn))
+    for key in ("lattice", "recip_lattice", "atomic_positions", "element_symbols", "n_electrons", "temperature",
+                "kcoords", "kweights", "n_kpoints", "fft_size", "dvol", "Ecut", "n_bands", "eigenvalues", "occupation",
+                "εF", "diagonalization", "energies", "converged", "norm_Δρ", "n_iter", "n_matvec", "history_Etot",
+                "history_Δρ", "n_bands_converge", "damping_value", "mixing", "scfres_extra_keys"):
+        assert key in d, key
+    assert "ρ" not in d                                                    # json: save_ρ defaults to false
+    eig = np.array(d["eigenvalues"])
+    assert eig.shape == (1, 8, d["n_bands"])
+    np.testing.assert_allclose(eig[0, 3], res["eigenvalues"][3][:d["n_bands"]], rtol=0, atol=0)
+    assert d["energies"]["total"] == pytest.approx(res["energies"].total, abs=1e-14)
+    assert np.allclose(np.array(d["lattice"]).T, LATTICE) and d["converged"] and d["mixing"] == "Chi0Mixing"
+    fz = str(tmp_path / "scfres.npz")
+    dftk.save_scfres(fz, res)
+    chk = dftk.load_scfres(fz, basis)
+    assert torch.equal(chk["rho"], res["rho"]) and len(chk["psi"]) == 8
+    again = dftk.self_consistent_field(basis, rho=chk["rho"], psi=chk["psi"], tol=1e-8)
+    assert again["converged"] and again["n_iter"] <= 2
+    assert abs(again["energies"].total - res["energies"].total) < 1e-9
+    other = dftk.PlaneWaveBasis(device_model(), 10, dftk.MonkhorstPack((2, 2, 2)), fft_size=(25, 25, 25))
+    with pytest.raises(ValueError):
+        dftk.load_scfres(fz, other)
+
+
+@pytest.mark.parametrize("functionals", [("lda_x", "lda_c_pw"), ("lda_x", "lda_c_vwn"), ("lda_x",)])
+def test_local_potential_pipeline_behind_abi_matches_torch_and_oracle(functionals, monkeypatch):
+    """dftk_mi_local_potential (Hartree multiply between the cube FFTs, LDA e_xc / v_xc closed forms, V = V_loc + V_H +
+    v_xc and the three energies in one pass) against the torch formulation of the same terms and against the
+    oracle, on a density with vacuum-like tiny and slightly negative entries."""
+    basis = dftk.PlaneWaveBasis(device_model(functionals), 12, dftk.MonkhorstPack((1, 1, 1)), fft_size=(24, 25, 27))
+    rho = dftk.guess_density(basis)
+    rho = rho * (1 + 0.2 * torch.sin(torch.arange(24, device="cuda", dtype=torch.float64) * 0.7))[None, None, :]
+    rho[0, 0, :5] = torch.tensor([0.0, 1e-320, -1e-9, 1e-14, 1e-301], device="cuda", dtype=torch.float64)
+    E1, ham1 = dftk.energy_hamiltonian(basis, None, None, rho=rho)
+    monkeypatch.setenv("DFTK_MI_TORCH_LOCAL", "1")
+    E2, ham2 = dftk.energy_hamiltonian(basis, None, None, rho=rho)
+    monkeypatch.delenv("DFTK_MI_TORCH_LOCAL")
+    for name in ("AtomicLocal", "Hartree", "Xc"):
+        assert abs(E1[name] - E2[name]) < 1e-12 * max(1.0, abs(E2[name])), name
+    V1, V2 = ham1[0].potential, ham2[0].potential
+    assert float((V1 - V2).abs().max()) < 1e-12 * float(V2.abs().max())
+    ob = oracle.PlaneWaveBasis(oracle_model(functionals), 12, oracle.MonkhorstPack((1, 1, 1)), fft_size=(24, 25, 27))
+    oE, oham = oracle.energy_hamiltonian(ob, None, None, rho=rho.cpu().numpy())
+    for name in ("AtomicLocal", "Hartree", "Xc"):
+        assert abs(E1[name] - oE[name]) < 1e-11 * max(1.0, abs(oE[name])), name
+    assert np.abs(V1.cpu().numpy() - oham[0].potential).max() < 1e-10
+    Eo, _ = dftk.energy_hamiltonian(basis, None, None, rho=rho, only_energies=True)      # energies only: no V written
+    assert Eo["Xc"] == E1["Xc"] and Eo["Hartree"] == E1["Hartree"]

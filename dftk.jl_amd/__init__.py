@@ -25,3 +25,5 @@ from .mixing import (SimpleMixing, KerkerMixing, KerkerDosMixing, DielectricMixi
 from .scf import (self_consistent_field, next_density, compute_occupation, AdaptiveBands, FixedBands,  # noqa: F401,E402
                   AndersonAcceleration, determine_diagtol, ScfDefaultCallback, ScfStepper)
 from .io import scfres_to_dict, save_scfres, load_scfres, basis_to_dict, model_to_dict  # noqa: F401,E402
+from .symmetry import (SymOp, symmetry_operations, symmetrize_rho, irreducible_kcoords,  # noqa: F401,E402
+                       symmetries_preserving_kgrid, symmetries_preserving_rgrid, check_group)

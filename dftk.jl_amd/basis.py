@@ -117,7 +117,9 @@ class PlaneWaveBasis:
     """
 
     def __init__(self, model: Model, Ecut: float, kgrid=None, fft_size=None, device="cuda",
-                 comm_kpts: KptComm | None = None, build_terms=True, comm_pw: KptComm | None = None):
+                 comm_kpts: KptComm | None = None, build_terms=True, comm_pw: KptComm | None = None,
+                 use_symmetries_for_kpoint_reduction=True):
+        from . import symmetry as _sym
         self.model = model
         self.Ecut = float(Ecut)
         self.device = torch.device(device)
@@ -126,7 +128,16 @@ class PlaneWaveBasis:
         self.comm_pw = comm_pw if comm_pw is not None else KptComm.single()
         if self.comm_pw.size > 1 and self.comm_kpts.size > 1:
             raise NotImplementedError("k-point and plane-wave sharding cannot be combined yet")
-        self.fft_size = tuple(int(n) for n in (fft_size or compute_fft_size(model, Ecut)))
+        symmetries_respect_rgrid = fft_size is None                          # PlaneWaveBasis.jl:330
+        if fft_size is None:
+            # FFT size compatible with the fractional translations of the symmetries (PlaneWaveBasis.jl:349-361)
+            factors = (1,)
+            if any(not s.isone() for s in model.symmetries):
+                from fractions import Fraction
+                den = {Fraction(float(x)).limit_denominator(1000).denominator for s in model.symmetries for x in s.w}
+                factors = tuple(sorted(den & {2, 3, 4, 6})) or (1,)
+            fft_size = compute_fft_size(model, Ecut, factors=factors)
+        self.fft_size = tuple(int(n) for n in fft_size)
         nx, ny, nz = self.fft_size
         self.N = nx * ny * nz
         self.dvol = model.unit_cell_volume / self.N
@@ -144,8 +155,20 @@ class PlaneWaveBasis:
         # k-points: explicit list or unreduced Monkhorst-Pack mesh, split over comm_kpts
         if kgrid is None:
             kgrid = MonkhorstPack((1, 1, 1))
+        # symmetries that survive the discretisation, irreducible k-points (PlaneWaveBasis.jl:161-173)
+        symmetries = list(model.symmetries)
+        if symmetries_respect_rgrid:
+            symmetries = _sym.symmetries_preserving_rgrid(symmetries, self.fft_size)
         if isinstance(kgrid, MonkhorstPack):
-            kgrid = kgrid.reducible()
+            symmetries = _sym.symmetries_preserving_kgrid(symmetries, kgrid.kgrid_size, kgrid.kshift)
+            if use_symmetries_for_kpoint_reduction and any(not s.isone() for s in symmetries):
+                kc, kw = _sym.irreducible_kcoords(kgrid.kgrid_size, symmetries, kgrid.kshift)
+                kgrid = ExplicitKpoints(kc, kw)
+            else:
+                kgrid = kgrid.reducible()
+        else:
+            symmetries = _sym.symmetries_preserving_kcoords(symmetries, kgrid.kcoords)
+        self.symmetries = symmetries
         (kc, kw, self.kcoords_global, self.kweights_global,
          self.krange_allprocs) = distribute_kpoints(kgrid.kcoords, kgrid.kweights, self.comm_kpts)
         self.krange_thisproc = self.krange_allprocs[self.comm_kpts.rank]

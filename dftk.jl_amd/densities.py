@@ -1,6 +1,6 @@
 """``compute_density`` (src/densities.jl:13-57): per-band pruned iFFT + |psi|^2 accumulation on the
-device, one RCCL all-reduce over ``comm_kpts``; no symmetrisation (identity symmetry only, as
-``symmetries=false`` / Gamma-only supercells, symmetry.jl:292-295)."""
+device, one RCCL all-reduce over ``comm_kpts``, then the symmetrisation over ``basis.symmetries``
+(symmetry.jl:346-357; a no-op for ``symmetries=False`` / Gamma-only supercells)."""
 from __future__ import annotations
 
 import numpy as np
@@ -29,4 +29,7 @@ def compute_density(basis, psi, occupation, occupation_threshold: float = 0.0) -
         if comm.size > 1:
             comm.sum_(rho, basis.stream_ptr)
     basis.sync()
+    if any(not s.isone() for s in basis.symmetries):
+        from .symmetry import symmetrize_rho
+        rho = symmetrize_rho(basis, rho, do_lowpass=False)                # densities.jl:47
     return rho

@@ -2,8 +2,8 @@
 
 Mirrors the parts of src/Model.jl, src/elements.jl, src/standard_models.jl:45-61,116-131,220,
 src/supercell.jl:5-20 and src/bzmesh.jl:4-48 that the SCF hot path consumes.  Symmetry
-detection (Spglib) is out of scope: k-points are explicit lists or unreduced Monkhorst-Pack
-meshes (``symmetries=false`` in the reference's terms).
+detection, k-mesh reduction and density symmetrisation live in symmetry.py (``symmetries=True``); the default
+is ``symmetries=False`` (explicit lists / unreduced Monkhorst-Pack meshes).
 """
 from __future__ import annotations
 
@@ -45,7 +45,7 @@ class Model:
     term list, XC functionals, temperature/smearing."""
 
     def __init__(self, lattice, atoms, positions, terms, functionals=("lda_x", "lda_c_pw"),
-                 temperature=0.0, smearing=None, n_electrons=None):
+                 temperature=0.0, smearing=None, n_electrons=None, symmetries=False):
         self.lattice = np.asarray(lattice, dtype=float)
         self.atoms = list(atoms)
         self.positions = [np.asarray(p, dtype=float) for p in positions]
@@ -73,6 +73,15 @@ class Model:
             else:
                 self.atom_groups.append([i])
                 reps.append(a)
+
+        # Model.jl:104-110: True = automatic detection (symmetry.py; the reference asks Spglib), False = identity
+        # only, or an explicit list of SymOp.  Default False: explicit / unreduced k-lists unless asked for.
+        from . import symmetry as _sym
+        if symmetries is True:
+            symmetries = _sym.symmetry_operations(self.lattice, self.atom_groups, self.positions)
+        elif symmetries is False or symmetries is None:
+            symmetries = [_sym.identity()]
+        self.symmetries = list(symmetries)
 
     @property
     def filled_occupation(self):   # Model.jl:352-360

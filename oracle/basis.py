@@ -99,6 +99,9 @@ class Model:
     temperature: float = 0.0
     smearing: str = "none"
     n_electrons: int | None = None
+    # Model.jl:104-110: true = automatic detection, false = identity only, or an explicit list of SymOp.
+    # (Default false here: the pinned reference tests of this oracle run explicit / unreduced k-lists.)
+    symmetries: object = False
 
     def __post_init__(self):
         self.lattice = np.asarray(self.lattice, dtype=float)
@@ -122,6 +125,11 @@ class Model:
         self.filled_occupation = 2  # spin_polarization == :none (Model.jl:352-360)
         if self.temperature > 0 and self.smearing == "none":
             self.smearing = "fermi_dirac"
+        from . import symmetry as _sym
+        if self.symmetries is True:
+            self.symmetries = _sym.symmetry_operations(self.lattice, self.atom_groups, self.positions)
+        elif self.symmetries is False or self.symmetries is None:
+            self.symmetries = [_sym.identity()]
 
 
 def model_atomic(lattice, atoms, positions, extra_terms=(), **kw):
@@ -202,18 +210,39 @@ class Kpoint:
 class PlaneWaveBasis:
     """Subset of PlaneWaveBasis.jl:25-97 / :129-261 (single process, no symmetries)."""
 
-    def __init__(self, model: Model, Ecut: float, kgrid=None, fft_size=None, build_terms=True):
+    def __init__(self, model: Model, Ecut: float, kgrid=None, fft_size=None, build_terms=True,
+                 use_symmetries_for_kpoint_reduction=True):
+        from . import symmetry as _sym
         self.model = model
         self.Ecut = float(Ecut)
+        symmetries_respect_rgrid = fft_size is None                      # PlaneWaveBasis.jl:330
         if fft_size is None:
-            fft_size = compute_fft_size(model.lattice, Ecut)
+            # FFT size compatible with the fractional translations of the symmetries (PlaneWaveBasis.jl:349-361)
+            factors = (1,)
+            if any(not s.isone() for s in model.symmetries):
+                from fractions import Fraction
+                den = {Fraction(float(x)).limit_denominator(1000).denominator for s in model.symmetries for x in s.w}
+                factors = tuple(sorted(den & {2, 3, 4, 6})) or (1,)
+            fft_size = compute_fft_size(model.lattice, Ecut, factors=factors)
         self.fft_size = tuple(int(n) for n in fft_size)
         nx, ny, nz = self.fft_size
         self.N = nx * ny * nz
         if kgrid is None:
             kgrid = MonkhorstPack((1, 1, 1))
+        # symmetries that survive the discretisation (PlaneWaveBasis.jl:161-173)
+        symmetries = list(model.symmetries)
+        if symmetries_respect_rgrid:
+            symmetries = _sym.symmetries_preserving_rgrid(symmetries, self.fft_size)
         if isinstance(kgrid, MonkhorstPack):
-            kgrid = kgrid.reducible()
+            symmetries = _sym.symmetries_preserving_kgrid(symmetries, kgrid.kgrid_size, kgrid.kshift)
+            if use_symmetries_for_kpoint_reduction and any(not s.isone() for s in symmetries):
+                kc, kw = _sym.irreducible_kcoords(kgrid.kgrid_size, symmetries, kgrid.kshift)
+                kgrid = ExplicitKpoints(kc, kw)
+            else:
+                kgrid = kgrid.reducible()        # (full mesh; the density is still symmetrised, as the reference)
+        else:
+            symmetries = _sym.symmetries_preserving_kcoords(symmetries, kgrid.kcoords)   # symmetry.jl:163-174
+        self.symmetries = symmetries
         self.kcoords = [np.asarray(k, dtype=float) for k in kgrid.kcoords]
         self.kweights = [float(w) for w in kgrid.kweights]
         self.dvol = model.unit_cell_volume / self.N

@@ -1,6 +1,6 @@
 """Density, occupation and the SCF driver (oracle restatement).  Test infrastructure only.
 
-Restates ``src/densities.jl:13-57`` (no symmetrisation: identity symmetry only),
+Restates ``src/densities.jl:13-57`` (symmetrisation over ``basis.symmetries``: oracle/symmetry.py),
 ``src/occupation.jl:30-211`` + ``src/Smearing.jl`` (None / Fermi-Dirac / Gaussian),
 ``src/scf/nbands_algorithm.jl``, ``src/scf/scf_callbacks.jl:138-230`` (convergence, AdaptiveDiagtol),
 ``src/scf/anderson.jl:36-130``, ``src/scf/scf_solvers.jl:68-102`` (mixing rules: oracle/mixing.py) and
@@ -31,7 +31,8 @@ def compute_density(basis, psi, occupation, occupation_threshold=0.0):
                 continue
             psi_real = basis.ifft(kpt, psi[ik][:, n], normalize=False)
             rho += occ[n] * basis.kweights[ik] * basis.ifft_normalization ** 2 * np.abs(psi_real) ** 2
-    return rho
+    from .symmetry import symmetrize_rho
+    return symmetrize_rho(basis, rho, do_lowpass=False)          # densities.jl:47
 
 
 # ----------------------------------------------------------------------------- occupations

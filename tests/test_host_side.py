@@ -564,3 +564,50 @@ def test_host_mirror_entropy_term():
     for kind in ("none", "fermi_dirac", "gaussian"):
         np.testing.assert_allclose(smearing_entropy(kind, x), oracle_entropy(kind, x), rtol=0, atol=1e-16)
     assert np.all(smearing_entropy("fermi_dirac", x) >= 0) and smearing_entropy("fermi_dirac", np.array([0.0]))[0] == pytest.approx(np.log(2))
+
+
+def test_symmetry_host_logic_matches_oracle():
+    """The mirror's symmetry detection / k-mesh reduction (dftk.jl_amd/symmetry.py) against the oracle's (which is
+    pinned to the reference's Spglib counts): same operations, same irreducible points and weights, same FFT size."""
+    import oracle
+    from oracle import symmetry as osy
+    lat, atoms, pos = dftk.silicon_cell((2, 1, 1))
+    m = dftk.model_DFT(lat, atoms, pos, symmetries=True)
+    oops = osy.symmetry_operations(lat, [list(range(len(pos)))], pos)
+    assert len(m.symmetries) == len(oops)
+    for a, b in zip(m.symmetries, oops):
+        assert np.array_equal(a.W, b.W) and np.allclose(a.w, b.w) and np.allclose(a.tau, b.tau)
+    dftk.check_group(m.symmetries)
+    lat, atoms, pos = dftk.silicon_cell()
+    m = dftk.model_DFT(lat, atoms, pos, symmetries=True)
+    b = dftk.PlaneWaveBasis(m, 15, dftk.MonkhorstPack((4, 4, 4)), device="cpu", build_terms=False)
+    okc, okw = osy.irreducible_kcoords((4, 4, 4), osy.symmetries_preserving_kgrid(
+        osy.symmetry_operations(lat, [[0, 1]], pos), (4, 4, 4)))
+    assert b.fft_size == (30, 30, 30) and len(b.kpoints) == 8 == len(okc) and len(b.symmetries) == 48
+    assert np.allclose(b.kweights, okw) and all(np.allclose(k.coordinate, q) for k, q in zip(b.kpoints, okc))
+    b2 = dftk.PlaneWaveBasis(m, 15, dftk.MonkhorstPack((4, 4, 4)), device="cpu", build_terms=False,
+                             use_symmetries_for_kpoint_reduction=False)
+    assert len(b2.kpoints) == 64 and len(b2.symmetries) == 48
+    m0 = dftk.model_DFT(lat, atoms, pos)                                   # default: no symmetries
+    b0 = dftk.PlaneWaveBasis(m0, 15, dftk.MonkhorstPack((4, 4, 4)), device="cpu", build_terms=False)
+    assert b0.fft_size == (27, 27, 27) and len(b0.kpoints) == 64 and len(b0.symmetries) == 1
+
+
+def test_scfres_dict_layout_on_host():
+    """scfres_to_dict (src/input_output.jl:345-386) on a hand-made result: keys and Julia nesting."""
+    import torch
+    lat, atoms, pos = dftk.silicon_cell()
+    b = dftk.PlaneWaveBasis(dftk.model_DFT(lat, atoms, pos), 5, dftk.MonkhorstPack((2, 1, 1)), device="cpu",
+                            build_terms=False)
+    E = dftk.terms.Energies(Kinetic=1.0, Hartree=2.0)
+    res = dict(basis=b, eigenvalues=[np.arange(5.0)] * 2, occupation=[np.array([2, 2, 2, 2, 0.0])] * 2, eF=0.3,
+               diagonalization=dict(n_matvec=10, converged=True, residual_norms=[np.zeros(5)] * 2, n_iter=[3, 4]),
+               rho=torch.zeros(b.fft_size[::-1]), energies=E, converged=True, history_drho=[1e-3, 1e-7], n_iter=2,
+               n_matvec=20, history_Etot=[-1.0, -1.1], n_bands_converge=4,
+               psi=[torch.zeros(5, k.n_G) for k in b.kpoints])
+    d = dftk.scfres_to_dict(res, save_psi=True)
+    assert np.array(d["eigenvalues"]).shape == (1, 2, 5) and np.array(d["ρ"]).shape == (1,) + b.fft_size[::-1]
+    assert d["energies"] == {"Kinetic": 1.0, "Hartree": 2.0, "total": 3.0} and d["n_kpoints"] == 2
+    assert d["norm_Δρ"] == 1e-7 and d["εF"] == 0.3 and d["diagonalization"]["n_iter"] == [[3, 4]]
+    import json
+    json.dumps(d)

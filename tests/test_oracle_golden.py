@@ -597,3 +597,61 @@ def test_metal_scf_same_fixed_point_for_every_mixing():
         E[name] = r["energies"].total
     for name, e in E.items():
         assert abs(e - E["simple"]) < 1e-9, (name, e, E["simple"])
+
+
+# ----------------------------------------------------------------------------------- symmetries (oracle/symmetry.py)
+A_SI_TEST = 5.131570667152971
+SI_LAT = np.array([[0, A_SI_TEST, A_SI_TEST], [A_SI_TEST, 0, A_SI_TEST], [A_SI_TEST, A_SI_TEST, 0.0]])
+SI_POS = [np.ones(3) / 8, -np.ones(3) / 8]
+
+
+def test_symmetry_detection_and_kmesh_reduction_reference_counts():
+    """test/bzmesh_symmetry.jl:58-68 (irreducible k-point counts of silicon for several Monkhorst-Pack meshes and
+    shifts, incl. supercells), test/testcases.jl:24-28 (weights 1, 8, 6, 12 / 27 of the 3x3x3 mesh),
+    test/symmetry_issues.jl:9-24 (CuO2: 48 operations) -- Spglib's answers, reproduced by the metric search."""
+    from oracle import symmetry as sy
+    ops = sy.symmetry_operations(SI_LAT, [[0, 1]], SI_POS)
+    assert len(ops) == 48 and ops[0].isone()
+    sy.check_group(ops)
+    for size, shift, n_irr in [((1, 1, 1), (0, 0, 0), 1), ((1, 1, 5), (0, 0, 0), 3), ((2, 3, 2), (0, 0, 0), 6),
+                               ((3, 3, 3), (0, 0, 0), 4), ((2, 3, 4), (0, 0, 0), 14), ((9, 11, 13), (0, 0, 0), 644),
+                               ((3, 3, 3), (.5, .5, .5), 6), ((3, 3, 3), (.5, 0, .5), 6), ((3, 3, 3), (0, .5, 0), 6)]:
+        keep = sy.symmetries_preserving_kgrid(ops, size, shift)
+        sy.check_group(keep)
+        kc, kw = sy.irreducible_kcoords(size, keep, shift)
+        assert len(kc) == n_irr, (size, shift, len(kc))
+        assert abs(sum(kw) - 1) < 1e-14
+        # every mesh point is the image of an irreducible one
+        red = {sy._grid_key(k, np.array(size), shift) for k in sy.reducible_kcoords(size, shift)}
+        img = {sy._grid_key(s.S @ k, np.array(size), shift) for k in kc for s in keep}
+        assert img == red
+    kc, kw = sy.irreducible_kcoords((3, 3, 3), ops)
+    assert sorted(np.round(np.array(kw) * 27).astype(int)) == [1, 6, 8, 12]
+    # supercells (test_reduction(silicon, [1, 4, 4], 7, supercell=(2, 1, 1)); [1, 16, 16] -> 73 for (4, 1, 1))
+    for sc, size, n_irr in [((2, 1, 1), (1, 4, 4), 7), ((4, 1, 1), (1, 16, 16), 73)]:
+        Si = oracle.ElementPsp("Si", oracle.load_psp_hgh("Si", "lda"))
+        lat, atoms, pos = oracle.basis.create_supercell(SI_LAT, [Si, Si], SI_POS, sc)
+        sops = sy.symmetry_operations(lat, [list(range(len(pos)))], pos)
+        keep = sy.symmetries_preserving_kgrid(sops, size)
+        assert len(sy.irreducible_kcoords(size, keep)[0]) == n_irr, (sc, size)
+    a = 4.474
+    latc = np.array([[0, a, a], [a, 0, a], [a, a, 0.0]]).T
+    frac = [np.linalg.solve(latc, c) for c in (np.zeros(3), np.array([6.711, 2.237, 6.711]), np.array([6.711, 2.237, 2.237]))]
+    assert len(sy.symmetry_operations(latc, [[0], [1, 2]], frac)) == 48
+
+
+def test_symmetrised_scf_equals_unsymmetrised():
+    """test/bzmesh_symmetry.jl:95-128: irreducible k-points + density symmetrisation give the same energy (1e-10) and
+    density (1e-8) as the full mesh without symmetries; the symmetric basis picks an FFT size compatible with the
+    fractional translations (PlaneWaveBasis.jl:349-361: 27 -> 30 for silicon at Ecut 15)."""
+    Si = oracle.ElementPsp("Si", oracle.load_psp_hgh("Si", "lda"))
+    m0 = oracle.model_DFT(SI_LAT, [Si, Si], SI_POS, symmetries=False)
+    m1 = oracle.model_DFT(SI_LAT, [Si, Si], SI_POS, symmetries=True)
+    assert oracle.PlaneWaveBasis(m1, 15, oracle.MonkhorstPack((4, 4, 4)), build_terms=False).fft_size == (30, 30, 30)
+    kg = oracle.MonkhorstPack((2, 2, 2), (0.5, 0, 0))
+    b0, b1 = oracle.PlaneWaveBasis(m0, 5, kg), oracle.PlaneWaveBasis(m1, 5, kg)
+    assert (len(b0.kpoints), len(b1.kpoints), len(b1.symmetries)) == (8, 2, 12) and b0.fft_size == b1.fft_size
+    r0 = oracle.self_consistent_field(b0, tol=1e-10)
+    r1 = oracle.self_consistent_field(b1, tol=1e-10)
+    assert abs(r0["energies"].total - r1["energies"].total) < 1e-10
+    assert np.linalg.norm(r0["rho"] - r1["rho"]) * np.sqrt(b0.dvol) < 1e-8

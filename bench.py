@@ -19,9 +19,10 @@ n_matvec / wall time.
 N > 1 (``--gpus N``, one process per GPU, launched by torch.distributed.run):
   --mode gamma   (default) the SAME Gamma-only workload, plane waves of the single k-block sharded over the
                  N GPUs as row slabs (``comm_pw``) -> strong scaling, N = 1 comparable.
-  --mode kpoints BASELINE configs[2]-class k-point workload, fixed for every N: fcc Al, PBE, Ecut 40,
-                 unreduced 6x6x6 Monkhorst-Pack mesh (216 k-points), Gaussian smearing T = 1e-3, split by
-                 ``distribute_kpoints`` with ONE density all-reduce per step -> strong scaling.
+  --mode kpoints BASELINE configs[2], fixed for every N: fcc Al, PBE, Ecut 40, 12x12x12 Monkhorst-Pack mesh with
+                 the crystal symmetries (72 irreducible k-points, as the reference builds it), Gaussian smearing
+                 T = 1e-3, LDOS mixing; split by ``distribute_kpoints`` with ONE density all-reduce per step ->
+                 strong scaling (9 k-points per GPU at N = 8).
   --mode weak    one k-point of the Si supercell per GPU (weak scaling; the round-1 behaviour).
 
 Prints ONE JSON line on rank 0 with ``roofline`` (dominant kernel family, HIP-event timed inside the library
@@ -58,7 +59,8 @@ def parse():
     ap.add_argument("--mode", choices=("gamma", "kpoints", "weak"), default="gamma")
     ap.add_argument("--supercell", type=int, default=5, help="n for the n x n x n Si supercell (5 = 1000 e-, 4 = configs[1])")
     ap.add_argument("--ecut", type=float, default=None)
-    ap.add_argument("--kgrid", type=int, default=6, help="--mode kpoints: n for the unreduced n x n x n mesh")
+    ap.add_argument("--kgrid", type=int, default=12, help="--mode kpoints: n of the n x n x n Monkhorst-Pack mesh")
+    ap.add_argument("--no-symmetries", action="store_true", help="--mode kpoints: unreduced mesh")
     ap.add_argument("--tol", type=float, default=1e-6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-all", action="store_true",
@@ -257,14 +259,15 @@ def main():
         lat = a / 2 * np.array([[0, 1, 1.0], [1, 0, 1.0], [1, 1, 0.0]])
         Al = dftk.ElementPsp("Al", dftk.load_psp("Al", "pbe"))
         model = dftk.model_DFT(lat, [Al], [np.zeros(3)], functionals=("gga_x_pbe", "gga_c_pbe"), temperature=1e-3,
-                               smearing="gaussian")
+                               smearing="gaussian", symmetries=not args.no_symmetries)
         ecut = args.ecut or 40.0
         kg = dftk.MonkhorstPack((args.kgrid,) * 3)
         basis = dftk.PlaneWaveBasis(model, ecut, kg, device=device, comm_kpts=comm)
-        n_kblocks_total = args.kgrid ** 3
+        n_kblocks_total = len(basis.kcoords_global)
         workload = (f"Al fcc (1 atom, 3 e-) PBE HGH, Ecut={ecut:g} Ha, fft={'x'.join(map(str, basis.fft_size))}, "
-                    f"unreduced {args.kgrid}x{args.kgrid}x{args.kgrid} k-mesh ({n_kblocks_total} k-points, "
-                    f"{len(basis.kpoints)} on rank 0), Gaussian smearing T=1e-3")
+                    f"{args.kgrid}x{args.kgrid}x{args.kgrid} k-mesh, {len(basis.symmetries)} symmetries -> "
+                    f"{n_kblocks_total} k-points ({len(basis.kpoints)} on rank 0, {basis.n_lanes} stream lanes), "
+                    f"Gaussian smearing T=1e-3")
         parallelism, scaling = f"kpt{n_gpus}", "strong"
     else:
         n = args.supercell

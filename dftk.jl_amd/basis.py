@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -57,9 +58,10 @@ def G_axis(n):
 class Kpoint:
     """Kpoint.jl:6-18 + the device-side k-block handle (sphere tables, kinetic vector)."""
 
-    def __init__(self, basis, coordinate, spin=1):
+    def __init__(self, basis, coordinate, spin=1, lane=0):
         self.basis = basis
         self.spin = spin
+        self.lane = lane            # which of the basis' library handles (HIP streams) owns this k-block
         self.coordinate = np.asarray(coordinate, dtype=float)
         dev = basis.device
         # enumerate the cube in column-major order, keep |B (G + k)|^2 / 2 <= Ecut (Kpoint.jl:28-35)
@@ -90,7 +92,7 @@ class Kpoint:
         self._pot_owner = None      # the DftHamiltonianBlock whose potential currently sits in the device handle
         if basis.handle is not None:
             kin_h = np.ascontiguousarray(self.kinetic.cpu().numpy())
-            _lib.check(basis.lib.dftk_mi_kblock_create(basis.handle, self.n_G, self.mapping.ctypes.data,
+            _lib.check(basis.lib.dftk_mi_kblock_create(basis.lane_handles[lane], self.n_G, self.mapping.ctypes.data,
                                                        kin_h.ctypes.data, C.byref(self.handle)))
             if pw.size > 1:
                 if self.n_loc < 1:
@@ -118,7 +120,7 @@ class PlaneWaveBasis:
 
     def __init__(self, model: Model, Ecut: float, kgrid=None, fft_size=None, device="cuda",
                  comm_kpts: KptComm | None = None, build_terms=True, comm_pw: KptComm | None = None,
-                 use_symmetries_for_kpoint_reduction=True):
+                 use_symmetries_for_kpoint_reduction=True, n_lanes: int | None = None):
         from . import symmetry as _sym
         self.model = model
         self.Ecut = float(Ecut)
@@ -173,7 +175,21 @@ class PlaneWaveBasis:
          self.krange_allprocs) = distribute_kpoints(kgrid.kcoords, kgrid.kweights, self.comm_kpts)
         self.krange_thisproc = self.krange_allprocs[self.comm_kpts.rank]
         self.kweights = kw
-        self.kpoints = [Kpoint(self, k) for k in kc]
+        # Lanes: k-blocks are tiny on k-point workloads (n_G ~ 1e3, 6-8 bands: launch-latency bound), and the
+        # reference loops over them sequentially (diag.jl:24).  Here the local k-points are dealt round-robin onto
+        # n_lanes library handles = HIP streams with their own scratch; host threads drive the lanes concurrently
+        # (diagonalize_all_kblocks, compute_density), so the small kernels of different k-points overlap on the GPU.
+        if n_lanes is None:
+            n_lanes = int(os.environ.get("DFTK_MI_LANES", "16"))
+        n_lanes = max(1, min(n_lanes, len(kc))) if (self.handle is not None and self.comm_pw.size == 1) else 1
+        self.lane_handles = [self.handle]
+        for _ in range(1, n_lanes):
+            h = C.c_void_p()
+            _lib.check(self.lib.dftk_mi_basis_create(nx, ny, nz, model.unit_cell_volume, self.device.index, C.byref(h)))
+            self.lane_handles.append(h)
+        self.n_lanes = n_lanes
+        self._pool = None
+        self.kpoints = [Kpoint(self, k, lane=i % n_lanes) for i, k in enumerate(kc)]
         # the full cube as a degenerate "sphere": gives hand-written cube FFTs for Hartree etc.
         self._cube_handle = C.c_void_p()
         if self.handle is not None:
@@ -215,9 +231,33 @@ class PlaneWaveBasis:
             raise RuntimeError("PlaneWaveBasis was built with device='cpu': the MI355X hot path is unavailable "
                                "(no CPU fallback)")
 
-    def sync(self):
+    def sync(self, lane=None):
+        """Block until the library's stream(s) are idle: one lane, or all of them."""
         self._require_gpu()
-        _lib.check(self.lib.dftk_mi_basis_sync(self.handle))
+        for h in (self.lane_handles if lane is None else [self.lane_handles[lane]]):
+            _lib.check(self.lib.dftk_mi_basis_sync(h))
+
+    def run_on_lanes(self, fn, items):
+        """``[fn(i, item) for i, item in enumerate(items)]`` with item i executed by the host thread of lane
+        ``kpoints[i].lane`` (items of one lane in order, lanes concurrently).  ctypes releases the GIL inside the
+        library calls, which is where the time goes."""
+        items = list(items)
+        if self.n_lanes == 1 or len(items) <= 1:
+            return [fn(i, it) for i, it in enumerate(items)]
+        from concurrent.futures import ThreadPoolExecutor
+        if self._pool is None:
+            self._pool = ThreadPoolExecutor(max_workers=self.n_lanes, thread_name_prefix="dftk-lane")
+        out = [None] * len(items)
+
+        def work(lane):
+            torch.cuda.set_device(self.device)
+            for i, it in enumerate(items):
+                if self.kpoints[i].lane == lane:
+                    out[i] = fn(i, it)
+        futures = [self._pool.submit(work, lane) for lane in range(self.n_lanes)]
+        for f in futures:
+            f.result()
+        return out
 
     @property
     def stream_ptr(self):
@@ -253,6 +293,9 @@ class PlaneWaveBasis:
                 self.kpoints = []
                 if self._cube_handle:
                     self.lib.dftk_mi_kblock_destroy(self._cube_handle)
-                self.lib.dftk_mi_basis_destroy(self.handle)
+                if self._pool is not None:
+                    self._pool.shutdown(wait=True)
+                for h in self.lane_handles[::-1]:
+                    self.lib.dftk_mi_basis_destroy(h)
         except Exception:
             pass

@@ -12,9 +12,11 @@ from . import _lib
 def compute_density(basis, psi, occupation, occupation_threshold: float = 0.0) -> torch.Tensor:
     basis._require_gpu()
     nx, ny, nz = basis.fft_size
-    rho = torch.zeros((nz, ny, nx), dtype=torch.float64, device=basis.device)
+    # one accumulator per lane (the lanes run concurrently on their own streams), summed in lane order afterwards
+    rhos = [torch.zeros((nz, ny, nx), dtype=torch.float64, device=basis.device) for _ in range(basis.n_lanes)]
     torch.cuda.current_stream(basis.device).synchronize()
-    for ik, kpt in enumerate(basis.kpoints):
+
+    def accumulate(ik, kpt):
         occ = np.asarray(occupation[ik], dtype=np.float64)          # occupations live on the host (:16)
         w = np.where(np.abs(occ) >= occupation_threshold, occ, 0.0) * basis.kweights[ik] * basis.ifft_normalization ** 2
         w = np.ascontiguousarray(w)
@@ -22,7 +24,14 @@ def compute_density(basis, psi, occupation, occupation_threshold: float = 0.0) -
         if not (psik.is_cuda and psik.dtype == torch.complex128 and psik.stride(1) == 1):
             raise TypeError("compute_density: complex128 CUDA band-major blocks required")
         _lib.check(basis.lib.dftk_mi_density_accumulate(kpt.handle, len(w), psik.data_ptr(), psik.stride(0),
-                                                        w.ctypes.data, rho.data_ptr()))
+                                                        w.ctypes.data, rhos[kpt.lane].data_ptr()))
+    basis.run_on_lanes(accumulate, basis.kpoints)
+    rho = rhos[0]
+    if basis.n_lanes > 1:
+        basis.sync()
+        for r in rhos[1:]:
+            rho += r
+        torch.cuda.current_stream(basis.device).synchronize()
     # mpi_sum!(rho, comm_kpts) (:46), enqueued on the library's stream behind the accumulation kernels; with
     # plane-wave sharding every rank has accumulated its share of the BANDS: the same all-reduce over comm_pw
     for comm in (basis.comm_pw, basis.comm_kpts):

@@ -121,8 +121,8 @@ def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None
                             tol: float = 1e-6, miniter: int = 1, maxiter: int = 100, n_conv_check=None,
                             generator: torch.Generator | None = None, seed: int = 0):
     """diag.jl:9-65 with ``interpolate_kpoints=false``."""
-    results = []
-    for ik, Hk in enumerate(ham):
+    guesses = []
+    for ik, Hk in enumerate(ham):                 # start vectors first, in k order: one deterministic RNG stream
         kpt, basis = Hk.kpoint, Hk.basis
         if kpt.n_G < nev_per_kpoint:
             raise ValueError(f"The size of the plane wave basis is {kpt.n_G}, and you are asking for "
@@ -138,9 +138,15 @@ def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None
                 g = torch.cat([g, extra * np.sqrt(2 * kpt.n_G)], dim=0)
         else:
             g = random_orbitals(basis, kpt, nev_per_kpoint, generator)
+        guesses.append(g)
+    if guesses:
+        torch.cuda.synchronize(ham[0].basis.device)
+
+    def solve(ik, Hk):                            # the k loop of diag.jl:24-48, lanes concurrently
         prec = prec_type(Hk) if prec_type is not None else None
-        results.append(eigensolver(Hk, g, prec=prec, tol=tol, miniter=miniter, maxiter=maxiter,
-                                   n_conv_check=n_conv_check, seed=seed + ik))
+        return eigensolver(Hk, guesses[ik], prec=prec, tol=tol, miniter=miniter, maxiter=maxiter,
+                           n_conv_check=n_conv_check, seed=seed + ik)
+    results = ham[0].basis.run_on_lanes(solve, ham) if ham else []
     return dict(λ=[r.λ for r in results], X=[r.X for r in results],
                 residual_norms=[r.residual_norms for r in results], n_iter=[r.n_iter for r in results],
                 converged=all(r.converged for r in results), n_matvec=sum(r.n_matvec for r in results))

@@ -58,7 +58,7 @@ class DftHamiltonianBlock:
         torch.cuda.current_stream(self.basis.device).synchronize()
         _lib.check(self.basis.lib.dftk_mi_apply_H_parts(self.kpoint.handle, which, nb, psi.data_ptr(), psi.stride(0),
                                                         Hpsi.data_ptr(), Hpsi.stride(0)))
-        self.basis.sync()
+        self.basis.sync(self.kpoint.lane)
         return Hpsi
 
     def __matmul__(self, psi):

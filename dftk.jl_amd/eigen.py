@@ -117,10 +117,28 @@ def random_orbitals(basis, kpt, howmany: int, generator: torch.Generator | None 
     return torch.complex(z[0], z[1]) / np.sqrt(2 * kpt.n_G)
 
 
+def interpolate_kpoint(data_in: torch.Tensor, kpoint_in, kpoint_out) -> torch.Tensor:
+    """``interpolate_kpoint`` (src/interpolation.jl:96-115): carry the coefficients of the plane waves both spheres
+    share from one k-point to another (zero elsewhere) -- a fast, inexact guess for the iterative solver.  The
+    re-orthonormalisation (``ortho_qr`` there) is LOBPCG's own first step ``X = ortho!(copy(X))``."""
+    if kpoint_in is kpoint_out:
+        return data_in.clone()
+    m_in, m_out = kpoint_in.mapping_device, kpoint_out.mapping_device
+    pos = torch.searchsorted(m_in, m_out).clamp_(max=m_in.numel() - 1)
+    hit = m_in[pos] == m_out
+    out = torch.zeros((data_in.shape[0], m_out.numel()), dtype=data_in.dtype, device=data_in.device)
+    out[:, hit] = data_in[:, pos[hit]]
+    return out
+
+
 def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None, prec_type=PreconditionerTPA,
                             tol: float = 1e-6, miniter: int = 1, maxiter: int = 100, n_conv_check=None,
-                            generator: torch.Generator | None = None, seed: int = 0):
-    """diag.jl:9-65 with ``interpolate_kpoints=false``."""
+                            generator: torch.Generator | None = None, seed: int = 0, interpolate_kpoints: bool = True):
+    """diag.jl:9-65.  ``interpolate_kpoints`` (default true as the reference): without a guess, a k-point starts
+    from the interpolated solution of the PREVIOUS k-point (:39-42).  The reference's k loop is sequential; here the
+    local k-points run concurrently on the basis' stream lanes, so "previous" means the previous k-point of the same
+    lane (identical to the reference for ``n_lanes = 1``); the first k-point of every lane starts from random
+    orbitals."""
     guesses = []
     for ik, Hk in enumerate(ham):                 # start vectors first, in k order: one deterministic RNG stream
         kpt, basis = Hk.kpoint, Hk.basis
@@ -136,16 +154,25 @@ def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None
             elif g.shape[0] < nev_per_kpoint:
                 extra = random_orbitals(basis, kpt, nev_per_kpoint - g.shape[0], generator)
                 g = torch.cat([g, extra * np.sqrt(2 * kpt.n_G)], dim=0)
+        elif interpolate_kpoints and ik >= basis.n_lanes and basis.comm_pw.size == 1:
+            g = None                                   # filled in by the lane from its previous k-point
         else:
             g = random_orbitals(basis, kpt, nev_per_kpoint, generator)
         guesses.append(g)
     if guesses:
         torch.cuda.synchronize(ham[0].basis.device)
 
+    done = {}
+
     def solve(ik, Hk):                            # the k loop of diag.jl:24-48, lanes concurrently
         prec = prec_type(Hk) if prec_type is not None else None
-        return eigensolver(Hk, guesses[ik], prec=prec, tol=tol, miniter=miniter, maxiter=maxiter,
-                           n_conv_check=n_conv_check, seed=seed + ik)
+        g = guesses[ik]
+        if g is None:
+            prev = ik - Hk.basis.n_lanes           # previous k-point of this lane (already solved: lanes run in order)
+            g = interpolate_kpoint(done[prev].X, ham[prev].kpoint, Hk.kpoint)
+        done[ik] = eigensolver(Hk, g, prec=prec, tol=tol, miniter=miniter, maxiter=maxiter,
+                               n_conv_check=n_conv_check, seed=seed + ik)
+        return done[ik]
     results = ham[0].basis.run_on_lanes(solve, ham) if ham else []
     return dict(λ=[r.λ for r in results], X=[r.X for r in results],
                 residual_norms=[r.residual_norms for r in results], n_iter=[r.n_iter for r in results],

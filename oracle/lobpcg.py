@@ -275,9 +275,22 @@ def random_orbitals(n_G, howmany, rng):
     return Q
 
 
+def interpolate_kpoint(data_in, kpoint_in, kpoint_out):
+    """interpolation.jl:96-115: coefficients of the shared plane waves, zero elsewhere, then ortho_qr."""
+    if kpoint_in is kpoint_out:
+        return data_in.copy()
+    pos = np.searchsorted(kpoint_in.mapping, kpoint_out.mapping)
+    pos = np.minimum(pos, len(kpoint_in.mapping) - 1)
+    hit = kpoint_in.mapping[pos] == kpoint_out.mapping
+    out = np.zeros((len(kpoint_out.mapping), data_in.shape[1]), dtype=complex)
+    out[hit, :] = data_in[pos[hit], :]
+    return np.linalg.qr(out)[0]
+
+
 def diagonalize_all_kblocks(ham, nev_per_kpoint, psiguess=None, tol=1e-6, miniter=1, maxiter=100,
-                            n_conv_check=None, prec=True, rng=None):
-    """diag.jl:9-65 (interpolate_kpoints=false: random guesses unless psiguess is given)."""
+                            n_conv_check=None, prec=True, rng=None, interpolate_kpoints=True):
+    """diag.jl:9-65 (``interpolate_kpoints=true`` by default as the reference: without a guess, k-point ik > 1
+    starts from the interpolated solution of k-point ik - 1)."""
     rng = np.random.default_rng(0) if rng is None else rng
     results = []
     for ik, H in enumerate(ham):
@@ -291,6 +304,8 @@ def diagonalize_all_kblocks(ham, nev_per_kpoint, psiguess=None, tol=1e-6, minite
                 X0 = np.concatenate([g, rng.standard_normal((n_Gk, extra))
                                      + 1j * rng.standard_normal((n_Gk, extra))], axis=1)
                 g = np.linalg.qr(X0)[0]
+        elif interpolate_kpoints and ik > 0:
+            g = interpolate_kpoint(results[ik - 1]["X"], ham[ik - 1].kpoint, H.kpoint)
         else:
             g = random_orbitals(n_Gk, nev_per_kpoint, rng)
         P = PreconditionerTPA(H.kinetic) if (prec and H.kinetic is not None) else None

@@ -34,7 +34,7 @@ def state():
     db = dftk.PlaneWaveBasis(dm, 6, dftk.MonkhorstPack(kg))
     assert db.fft_size == ob.fft_size
     _, oham = oracle.energy_hamiltonian(ob, None, None, rho=oracle.guess_density(ob))
-    eig = oracle.diagonalize_all_kblocks(oham, 9, tol=1e-8, n_conv_check=6)
+    eig = oracle.diagonalize_all_kblocks(oham, 9, tol=1e-8, n_conv_check=6, interpolate_kpoints=False)
     occ, eF = oracle.compute_occupation(ob, eig["λ"])
     rho_out = oracle.compute_density(ob, eig["X"], occ)
     dF = rho_out - oracle.guess_density(ob)

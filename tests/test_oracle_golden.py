@@ -129,12 +129,12 @@ def test_lobpcg_free_electron():
     model = Model(LATTICE, si_atoms(), POSITIONS, terms=("Kinetic",))
     basis = PlaneWaveBasis(model, 5, KGRID, fft_size=(15, 15, 15))
     _, ham = energy_hamiltonian(basis, None, None)
-    res = diagonalize_all_kblocks(ham, 10, tol=1e-8)
+    res = diagonalize_all_kblocks(ham, 10, tol=1e-8, interpolate_kpoints=False)
     assert res["converged"]
     for lam, r, nit, rn in zip(res["λ"], ref, res["n_iter"], res["residual_norms"]):
         np.testing.assert_allclose(lam, r, atol=1e-9)
         assert nit < 50 and rn.max() < 100 * 1e-8
-    res = diagonalize_all_kblocks(ham, 10, tol=1e-4, prec=False)      # without preconditioner
+    res = diagonalize_all_kblocks(ham, 10, tol=1e-4, prec=False, interpolate_kpoints=False)      # without preconditioner
     for lam, r in zip(res["λ"], ref):
         np.testing.assert_allclose(lam, r, atol=1e-4)
 
@@ -150,7 +150,7 @@ def test_lobpcg_core_hamiltonian():
     model = Model(LATTICE, si_atoms(), POSITIONS, terms=("Kinetic", "AtomicLocal", "AtomicNonlocal"))
     basis = PlaneWaveBasis(model, 10, KGRID, fft_size=(21, 21, 21))
     _, ham = energy_hamiltonian(basis, None, None)
-    res = diagonalize_all_kblocks(ham, 5, tol=1e-8)
+    res = diagonalize_all_kblocks(ham, 5, tol=1e-8, interpolate_kpoints=False)
     for lam, r in zip(res["λ"], ref):
         np.testing.assert_allclose(lam, r, atol=0.02)
     # LOBPCG == dense diagonalisation (test/lobpcg.jl:106-122)
@@ -170,7 +170,7 @@ def test_lobpcg_kinetic_local_tight():
     model = Model(LATTICE, si_atoms(), POSITIONS, terms=("Kinetic", "AtomicLocal"))
     basis = PlaneWaveBasis(model, 25, KGRID, fft_size=(33, 33, 33))
     _, ham = energy_hamiltonian(basis, None, None)
-    res = diagonalize_all_kblocks(ham, 6, tol=1e-8)
+    res = diagonalize_all_kblocks(ham, 6, tol=1e-8, interpolate_kpoints=False)
     for lam, r in zip(res["λ"], ref):
         np.testing.assert_allclose(lam[:5], r, atol=5e-7)
 
@@ -183,7 +183,7 @@ def test_energies_guess_density():
     E, H = energy_hamiltonian(basis, None, None, rho=rho0)
     assert E["Hartree"] == pytest.approx(0.3527293727197568, abs=5e-8)
     assert E["Xc"] == pytest.approx(-2.3033165870558165, abs=5e-8)
-    res = diagonalize_all_kblocks(H, 8, tol=1e-9)
+    res = diagonalize_all_kblocks(H, 8, tol=1e-9, interpolate_kpoints=False)
     occ = [[2.0, 2.0, 2.0, 2.0, 0.0, 0.0, 0.0, 0.0] for _ in basis.kpoints]
     rho = compute_density(basis, res["X"], occ)
     E, _ = energy_hamiltonian(basis, res["X"], occ, rho=rho)

@@ -42,6 +42,8 @@ _SIGNATURES = {
     "dftk_mi_apply_H_parts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, _i64, C.c_void_p, _i64]),
     "dftk_mi_local_potential": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                           C.c_void_p]),
+    "dftk_mi_xc_gga": (C.c_int, [C.c_void_p, _i64, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
+                                 C.c_void_p]),
     "dftk_mi_ifft_sphere": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dftk_mi_fft_sphere": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dftk_mi_density_accumulate": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, C.c_void_p]),

@@ -664,6 +664,15 @@ extern "C" int dftk_mi_local_potential(dftk_mi_kblock* cube_kb, const double* rh
     return local_potential_lda(cube_kb, rho_d, V_loc_d, poisson_green_d, xc_functionals, V_out_d, energies_h);
 }
 
+extern "C" int dftk_mi_xc_gga(dftk_mi_basis* b, int64_t n, const double* rho_d, const double* sigma_d, int xc_functionals,
+                              double density_threshold, double* e_d, double* vrho_d, double* vsigma_d) {
+    if (!b || n < 0 || !rho_d || !sigma_d || !e_d || !vrho_d || !vsigma_d || (xc_functionals & ~24) || !xc_functionals)
+        return DFTK_MI_EINVAL;
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(b->device));
+    return xc_gga_pointwise(b, n, rho_d, sigma_d, xc_functionals, density_threshold, e_d, vrho_d, vsigma_d);
+}
+
 extern "C" int dftk_mi_ifft_sphere(dftk_mi_kblock* kb, const dftk_mi_cplx* c_d, dftk_mi_cplx* cube_d) {
     if (!kb || !c_d || !cube_d) return DFTK_MI_EINVAL;
     HIPCHK(hipSetDevice(kb->basis->device));

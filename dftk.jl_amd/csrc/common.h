@@ -210,6 +210,8 @@ int comm_alltoallv(dftk_mi_comm* c, dftk_mi_basis* b, const cd* send, const size
 // xc_kernels.hip
 int local_potential_lda(dftk_mi_kblock* cube_kb, const double* rho, const double* vloc, const double* green,
                         int fun_mask, double* V_out, double* energies_h);
+int xc_gga_pointwise(dftk_mi_basis* b, int64_t n, const double* rho, const double* sigma, int fun_mask,
+                     double threshold, double* e, double* vrho, double* vsigma);
 
 // lobpcg.cpp
 // ortho!(X) (Cholesky-QR with the reference's shift-and-retry and SVD fallback) on a stand-alone block;

@@ -269,15 +269,26 @@ def xc_energy_potential(basis, rho):
         grad = [basis.irfft(1j * G[..., a] * rho_f) for a in range(3)]
         sigma = grad[0] ** 2 + grad[1] ** 2 + grad[2] ** 2
         ok = rho > _DENSITY_THRESHOLD
-        rho_s = torch.where(ok, rho, torch.ones_like(rho)).detach().requires_grad_(True)
-        sig_s = torch.where(ok, sigma, torch.zeros_like(sigma)).detach().requires_grad_(True)
-        with torch.enable_grad():
-            eg = sum(_GGA_FUNCTIONALS[name](rho_s, sig_s) for name in gga)
-            vr, vs = torch.autograd.grad(eg.sum(), (rho_s, sig_s))
         zero = torch.zeros_like(rho)
-        e = e + torch.where(ok, eg.detach(), zero)
-        v = v + torch.where(ok, vr, zero)
-        vsig = torch.where(ok, vs, zero)
+        if os.environ.get("DFTK_MI_TORCH_LOCAL") is None:
+            # e, de/drho, de/dsigma by the library (forward-mode derivatives of the closed forms on the device)
+            mask = sum({"gga_x_pbe": 8, "gga_c_pbe": 16}[name] for name in gga)
+            rho_c, sig_c = rho.contiguous(), sigma.contiguous()
+            eg, vr, vsig = torch.empty_like(rho_c), torch.empty_like(rho_c), torch.empty_like(rho_c)
+            torch.cuda.current_stream(basis.device).synchronize()
+            _lib.check(basis.lib.dftk_mi_xc_gga(basis.handle, rho_c.numel(), rho_c.data_ptr(), sig_c.data_ptr(), mask,
+                                                _DENSITY_THRESHOLD, eg.data_ptr(), vr.data_ptr(), vsig.data_ptr()))
+            e = e + eg
+            v = v + vr
+        else:   # torch formulation (autograd), the parity twin of the kernel
+            rho_s = torch.where(ok, rho, torch.ones_like(rho)).detach().requires_grad_(True)
+            sig_s = torch.where(ok, sigma, torch.zeros_like(sigma)).detach().requires_grad_(True)
+            with torch.enable_grad():
+                eg = sum(_GGA_FUNCTIONALS[name](rho_s, sig_s) for name in gga)
+                vr, vs = torch.autograd.grad(eg.sum(), (rho_s, sig_s))
+            e = e + torch.where(ok, eg.detach(), zero)
+            v = v + torch.where(ok, vr, zero)
+            vsig = torch.where(ok, vs, zero)
         div = sum(1j * G[..., a] * basis.fft(vsig * grad[a]) for a in range(3))
         v = v - 2.0 * basis.irfft(div)
     return float(e.sum().item() * basis.dvol), v

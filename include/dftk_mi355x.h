@@ -105,6 +105,15 @@ int dftk_mi_apply_H_parts(dftk_mi_kblock* kb, int which, int n_bands, const dftk
 int dftk_mi_local_potential(dftk_mi_kblock* cube_kb, const double* rho_d, const double* V_loc_d,
                             const double* poisson_green_d, int xc_functionals, double* V_out_d, double* energies_h);
 
+/* GGA exchange-correlation point by point (the libxc call of src/terms/xc.jl:111 for PBE(): gga_x_pbe + gga_c_pbe):
+ * e_d = energy density per volume, vrho_d = de/drho, vsigma_d = de/dsigma (sigma = |grad rho|^2) for n grid points;
+ * derivatives by forward-mode differentiation of the closed forms on the device.  Points with rho <= density_threshold
+ * give zeros.  The gradient / divergence of xc.jl:356-409,576-584 stay with the caller (cube FFTs). */
+#define DFTK_MI_XC_GGA_X_PBE 8
+#define DFTK_MI_XC_GGA_C_PBE 16
+int dftk_mi_xc_gga(dftk_mi_basis* basis, int64_t n, const double* rho_d, const double* sigma_d, int xc_functionals,
+                   double density_threshold, double* e_d, double* vrho_d, double* vsigma_d);
+
 /* ---- sphere <-> cube transforms  (src/fft.jl:110-122 ifft!, :162-172 fft!; normalize=false) --
  * cube_d is nx*ny*nz complex, x fastest.  Test/diagnostic entry points (the hot path never
  * materialises the full cube in the caller's layout). */

@@ -392,3 +392,19 @@ def test_local_potential_pipeline_behind_abi_matches_torch_and_oracle(functional
     assert np.abs(V1.cpu().numpy() - oham[0].potential).max() < 1e-10
     Eo, _ = dftk.energy_hamiltonian(basis, None, None, rho=rho, only_energies=True)      # energies only: no V written
     assert Eo["Xc"] == E1["Xc"] and Eo["Hartree"] == E1["Hartree"]
+
+
+def test_pbe_pointwise_kernel_matches_autograd(monkeypatch):
+    """dftk_mi_xc_gga (gga_x_pbe + gga_c_pbe: energy density and de/drho, de/dsigma by forward-mode differentiation of
+    the closed forms on the device) against torch autograd of the same expressions, through xc_energy_potential
+    (the oracle's complex-step derivatives are compared in test_pbe_xc_potential_matches_oracle)."""
+    model, _ = _pbe_models("Si", LATTICE, POSITIONS)
+    basis = dftk.PlaneWaveBasis(model, 12, dftk.MonkhorstPack((1, 1, 1)), fft_size=(24, 24, 24))
+    rho = dftk.guess_density(basis)
+    rho = rho * (1 + 0.3 * torch.cos(torch.arange(24, device="cuda", dtype=torch.float64) * 0.9))[None, :, None]
+    rho[1, 2, :4] = torch.tensor([0.0, 1e-13, -1e-6, 5e-12], device="cuda", dtype=torch.float64)   # below the threshold
+    E1, v1 = dftk.terms.xc_energy_potential(basis, rho)
+    monkeypatch.setenv("DFTK_MI_TORCH_LOCAL", "1")
+    E2, v2 = dftk.terms.xc_energy_potential(basis, rho)
+    assert abs(E1 - E2) < 1e-12 * abs(E2)
+    assert float((v1 - v2).abs().max()) < 1e-11 * float(v2.abs().max())

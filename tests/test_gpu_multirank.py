@@ -100,6 +100,24 @@ def test_bench_two_ranks_one_gpu_weak_kpoints():
     assert out["roofline"]["achieved"] > 0 and np.isfinite(out["config"]["E_total"])
 
 
+def test_bench_two_ranks_one_gpu_kpoints_strong_equals_single_rank():
+    """bench.py --mode kpoints (BASELINE configs[2] class: Al PBE, symmetry-reduced Monkhorst-Pack mesh, LDOS mixing,
+    k-points split over the ranks, one density all-reduce per step + one for the LDOS): the 2-rank run does the SAME
+    fixed workload as the 1-rank run (strong scaling) and converges to the same energy."""
+    args = ["--mode", "kpoints", "--kgrid", "4", "--ecut", "12", "--steps", "40", "--warmup", "0", "--tol", "1e-8"]
+    out = _run_bench(args, 39000)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["converged"]
+    assert out["config"]["parallelism"] == "kpt2" and "8 k-points (4 on rank 0" in out["config"]["workload"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + args
+    one = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
+    ref = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    assert ref["config"]["converged"] and "8 k-points (8 on rank 0" in ref["config"]["workload"]
+    assert abs(out["config"]["E_total"] - ref["config"]["E_total"]) < 1e-8
+    assert abs(out["steps"] - ref["steps"]) <= 2
+    assert out["config"]["n_matvec"] > 0 and abs(out["config"]["n_matvec"] / ref["config"]["n_matvec"] - 1) < 0.3
+
+
 def test_bench_two_ranks_one_gpu_gamma_sharded_equals_single_rank():
     """bench.py's DEFAULT N > 1 path: the Gamma-only cell with its plane waves sharded over the ranks (strong
     scaling, whole SCF to convergence); same converged energy and SCF length class as the one-rank run."""

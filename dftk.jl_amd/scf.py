@@ -10,6 +10,7 @@ block-sized stays in HBM; the host only sees eigenvalues, occupations and scalar
 from __future__ import annotations
 
 import math
+import os
 import time
 
 import numpy as np
@@ -252,6 +253,9 @@ class ScfStepper:
         self.basis = basis
         # mixing = LdosMixing() as the reference (self_consistent_field.jl:177): simple mixing at T = 0
         self.mixing = mixing if mixing is not None else LdosMixing()
+        # per-step nonlocal energy from the Ritz values (terms.energy_hamiltonian); the energies returned by
+        # finalize() / self_consistent_field always come from the projections themselves
+        self.ritz_energies = os.environ.get("DFTK_MI_EXACT_STEP_ENERGIES") is None
         self.gen = torch.Generator(device=basis.device)
         self.gen.manual_seed(seed + 7919 * basis.comm_kpts.rank)
         self.seed = seed
@@ -290,7 +294,8 @@ class ScfStepper:
                            timers=timers)
         t = time.time()
         energies, _ = energy_hamiltonian(basis, nxt["psi"], nxt["occupation"], rho=nxt["rho"], only_energies=True,
-                                         eigenvalues=nxt["eigenvalues"], eF=nxt["eF"])
+                                         eigenvalues=nxt["eigenvalues"], eF=nxt["eF"],
+                                         ritz_potential=ham[0].potential if self.ritz_energies else None)
         t = lap("energies", t)
         drho = nxt["rho"] - self.rho_in
         n_matvec_total = info["n_matvec"] + nxt["n_matvec"]

@@ -451,7 +451,8 @@ def smearing_entropy(kind, x):
     raise NotImplementedError(f"smearing {kind}")
 
 
-def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, eigenvalues=None, eF=None):
+def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, eigenvalues=None, eF=None,
+                       ritz_potential=None):
     """``energy_hamiltonian(basis, psi, occupation; rho, eigenvalues, eF)`` (Hamiltonian.jl:200-227); with
     ``only_energies`` it is ``energy(...)`` (:232-236).  Returns (Energies, [DftHamiltonianBlock]).  The entropy
     term -TS (terms/entropy.jl:11-42) needs this rank's eigenvalues and the Fermi level, else it is Inf."""
@@ -461,6 +462,7 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, ei
     pot = None
     have_psi = psi is not None and occupation is not None
     reduce_kpts = []       # terms that are sums over this rank's k-points: ONE fused reduction at the end
+    ritz_fix = None
     # local-potential pipeline behind the C ABI (LDA); DFTK_MI_TORCH_LOCAL=1 keeps the torch formulation (the
     # parity reference of tests/test_gpu_scf.py and the only path for GGA functionals)
     fused = None
@@ -491,6 +493,18 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, ei
         elif name == "AtomicNonlocal":
             if T.P is None:
                 E[name] = 0.0
+            elif have_psi and ritz_potential is not None and eigenvalues is not None and "Kinetic" in E:
+                # psi are the Ritz vectors of H[V_in] with Ritz values eps_n = <psi_n|H|psi_n> (kinetic + local +
+                # nonlocal): sum_n f_n <psi_n|V_nl|psi_n> = sum f eps - E_kin - int V_in rho[psi].  Exact up to the
+                # round-off LOBPCG carries in A X (~1e-13 relative); saves the n_p x n_bands x n_G projection GEMM of
+                # nonlocal.jl:38-44 on every SCF step.  (finalize() and callers without Ritz data take the GEMM.)
+                e = 0.0
+                for ik, psik in enumerate(psi):
+                    occ = np.asarray(occupation[ik], dtype=float)
+                    e += basis.kweights[ik] * float(np.dot(occ, np.asarray(eigenvalues[ik], dtype=float)[:len(occ)]))
+                E[name] = e
+                reduce_kpts.append(name)
+                ritz_fix = float((rho * ritz_potential).sum().item() * basis.dvol)
             elif have_psi:
                 e = 0.0
                 for ik, psik in enumerate(psi):
@@ -537,6 +551,8 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, ei
     if reduce_kpts and basis.comm_kpts.size > 1:
         for name, v in zip(reduce_kpts, basis.comm_kpts.sum_scalars([E[n] for n in reduce_kpts])):
             E[name] = v
+    if ritz_fix is not None:
+        E["AtomicNonlocal"] = E["AtomicNonlocal"] - E["Kinetic"] - ritz_fix
     if only_energies:
         return E, None
     ham = [DftHamiltonianBlock(basis, kpt, pot) for kpt in basis.kpoints]

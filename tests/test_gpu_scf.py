@@ -78,6 +78,9 @@ def test_scf_matches_oracle_small():
     drho = np.linalg.norm(res["rho"].cpu().numpy() - ores["rho"]) * np.sqrt(ob.dvol)
     assert drho < 1e-7
     assert res["n_matvec"] > 0 and res["n_iter"] < 30
+    # the per-step energies take the nonlocal term from the Ritz values (sum f eps - E_kin - int V_in rho); the final
+    # ones from the projections P' psi themselves: same state, so they must agree to LOBPCG's round-off in A X
+    assert abs(res["history_Etot"][-1] - res["energies"].total) < 1e-9
 
 
 REF_LDA = [   # test/silicon_lda.jl:10-20 (ABINIT, Ecut 25)

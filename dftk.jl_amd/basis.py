@@ -64,21 +64,45 @@ class Kpoint:
         self.lane = lane            # which of the basis' library handles (HIP streams) owns this k-block
         self.coordinate = np.asarray(coordinate, dtype=float)
         dev = basis.device
-        # enumerate the cube in column-major order, keep |B (G + k)|^2 / 2 <= Ecut (Kpoint.jl:28-35)
-        gx, gy, gz = basis.G_vectors_cube()
         B = torch.tensor(basis.model.recip_lattice, dtype=torch.float64, device=dev)
         k = torch.tensor(self.coordinate, dtype=torch.float64, device=dev)
-        G = torch.stack([gx.reshape(-1), gy.reshape(-1), gz.reshape(-1)], dim=1).to(torch.float64)
-        Gp = G + k[None, :]
-        # B (G + k) spelled out (keeps the set-up free of BLAS calls with degenerate 3-wide shapes)
-        Gk = Gp[:, 0:1] * B[:, 0][None, :] + Gp[:, 1:2] * B[:, 1][None, :] + Gp[:, 2:3] * B[:, 2][None, :]
-        kin_all = (Gk * Gk).sum(dim=1) / 2
-        mapping = torch.nonzero(kin_all <= basis.Ecut).reshape(-1)
-        self.mapping = mapping.cpu().numpy().astype(np.int64)            # 0-based, ascending
-        self.mapping_device = mapping
-        self.G_vectors = G[mapping].to(torch.int64)                     # (n_G, 3) on device
-        self.Gplusk_cart = Gk[mapping]                                  # (n_G, 3) cartesian, device
-        self.kinetic = kin_all[mapping].contiguous()                    # 1/2 |k+G|^2 (kinetic.jl:31-35)
+        if basis.lib is not None:
+            # sphere enumeration behind the ABI (dftk_mi_kpoint_sphere_host, Kpoint.jl:28-35): one native pass over
+            # the cube in index order, no cube-sized temporaries
+            nx, ny, nz = basis.fft_size
+            Bh = np.asfortranarray(basis.model.recip_lattice, dtype=np.float64)
+            kh = np.ascontiguousarray(self.coordinate, dtype=np.float64)
+            n = C.c_int64()
+            _lib.check(basis.lib.dftk_mi_kpoint_sphere_host(nx, ny, nz, Bh.ctypes.data, kh.ctypes.data, basis.Ecut, 0,
+                                                            C.byref(n), None, None, None))
+            map_h = np.zeros(n.value, dtype=np.int64)
+            kin_h = np.zeros(n.value, dtype=np.float64)
+            G_h = np.zeros((n.value, 3), dtype=np.int32)
+            _lib.check(basis.lib.dftk_mi_kpoint_sphere_host(nx, ny, nz, Bh.ctypes.data, kh.ctypes.data, basis.Ecut,
+                                                            n.value, C.byref(n), map_h.ctypes.data, kin_h.ctypes.data,
+                                                            G_h.ctypes.data))
+            mapping = torch.from_numpy(map_h).to(dev)
+            self.mapping = map_h
+            self.mapping_device = mapping
+            self.G_vectors = torch.from_numpy(G_h).to(dev).to(torch.int64)            # (n_G, 3) on device
+            Gp = self.G_vectors.to(torch.float64) + k[None, :]
+            self.Gplusk_cart = Gp[:, 0:1] * B[:, 0][None, :] + Gp[:, 1:2] * B[:, 1][None, :] + Gp[:, 2:3] * B[:, 2][None, :]
+            self.kinetic = torch.from_numpy(kin_h).to(dev)                            # 1/2 |k+G|^2 (kinetic.jl:31-35)
+        else:
+            # descriptor-only basis (device="cpu"): the same enumeration with torch
+            # enumerate the cube in column-major order, keep |B (G + k)|^2 / 2 <= Ecut (Kpoint.jl:28-35)
+            gx, gy, gz = basis.G_vectors_cube()
+            G = torch.stack([gx.reshape(-1), gy.reshape(-1), gz.reshape(-1)], dim=1).to(torch.float64)
+            Gp = G + k[None, :]
+            # B (G + k) spelled out (keeps the set-up free of BLAS calls with degenerate 3-wide shapes)
+            Gk = Gp[:, 0:1] * B[:, 0][None, :] + Gp[:, 1:2] * B[:, 1][None, :] + Gp[:, 2:3] * B[:, 2][None, :]
+            kin_all = (Gk * Gk).sum(dim=1) / 2
+            mapping = torch.nonzero(kin_all <= basis.Ecut).reshape(-1)
+            self.mapping = mapping.cpu().numpy().astype(np.int64)            # 0-based, ascending
+            self.mapping_device = mapping
+            self.G_vectors = G[mapping].to(torch.int64)                     # (n_G, 3) on device
+            self.Gplusk_cart = Gk[mapping]                                  # (n_G, 3) cartesian, device
+            self.kinetic = kin_all[mapping].contiguous()                    # 1/2 |k+G|^2 (kinetic.jl:31-35)
         self.n_G = int(mapping.numel())
         # plane-wave sharding (comm_pw): this rank holds the rows [row0, row1) of every orbital block of the
         # k-point (split_evenly over the sphere index); without it the slab is the whole sphere

@@ -664,6 +664,27 @@ extern "C" int dftk_mi_local_potential(dftk_mi_kblock* cube_kb, const double* rh
     return local_potential_lda(cube_kb, rho_d, V_loc_d, poisson_green_d, xc_functionals, V_out_d, energies_h);
 }
 
+extern "C" int dftk_mi_kpoint_sphere_host(int nx, int ny, int nz, const double* recip_lattice_h, const double* kcoord_h,
+                                          double Ecut, int64_t cap, int64_t* n_G, int64_t* mapping0_h,
+                                          double* kinetic_h, int32_t* G_h) {
+    if (nx < 1 || ny < 1 || nz < 1 || !recip_lattice_h || !kcoord_h || !n_G || cap < 0) return DFTK_MI_EINVAL;
+    return sphere_enumerate_host(nx, ny, nz, recip_lattice_h, kcoord_h, Ecut, cap, n_G, mapping0_h, kinetic_h, G_h);
+}
+
+extern "C" int dftk_mi_build_projectors_hgh(dftk_mi_basis* b, int64_t n_rows, const int32_t* G_d,
+                                            const double* recip_lattice_h, const double* kcoord_h,
+                                            double unit_cell_volume, int n_species, const double* rp_h,
+                                            const int* n_proj_h, int n_atoms, const int* species_of_atom_h,
+                                            const double* positions_h, dftk_mi_cplx* P_d, int64_t ldP, int* n_p) {
+    if (!b || n_rows < 0 || !recip_lattice_h || !kcoord_h || !(unit_cell_volume > 0) || n_species < 1 || !rp_h ||
+        !n_proj_h || n_atoms < 0 || (n_atoms > 0 && (!species_of_atom_h || !positions_h)) || !n_p ||
+        (P_d && !G_d))
+        return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(b->device));
+    return build_projectors_hgh(b, n_rows, G_d, recip_lattice_h, kcoord_h, unit_cell_volume, n_species, rp_h, n_proj_h,
+                                n_atoms, species_of_atom_h, positions_h, reinterpret_cast<cd*>(P_d), ldP, n_p);
+}
+
 extern "C" int dftk_mi_xc_gga(dftk_mi_basis* b, int64_t n, const double* rho_d, const double* sigma_d, int xc_functionals,
                               double density_threshold, double* e_d, double* vrho_d, double* vsigma_d) {
     if (!b || n < 0 || !rho_d || !sigma_d || !e_d || !vrho_d || !vsigma_d || (xc_functionals & ~24) || !xc_functionals)

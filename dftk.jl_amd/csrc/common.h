@@ -213,6 +213,13 @@ int local_potential_lda(dftk_mi_kblock* cube_kb, const double* rho, const double
 int xc_gga_pointwise(dftk_mi_basis* b, int64_t n, const double* rho, const double* sigma, int fun_mask,
                      double threshold, double* e, double* vrho, double* vsigma);
 
+// setup_kernels.hip
+int sphere_enumerate_host(int nx, int ny, int nz, const double* B, const double* k, double Ecut, int64_t cap,
+                          int64_t* n_G_out, int64_t* mapping0, double* kinetic, int32_t* G_out);
+int build_projectors_hgh(dftk_mi_basis* b, int64_t n_rows, const int32_t* G_d, const double* recip_h, const double* k_h,
+                         double volume, int n_species, const double* rp_h, const int* nproj_h, int n_atoms,
+                         const int* species_of_atom_h, const double* positions_h, cd* P_d, int64_t ldP, int* n_p_out);
+
 // lobpcg.cpp
 // ortho!(X) (Cholesky-QR with the reference's shift-and-retry and SVD fallback) on a stand-alone block;
 // force_svd = 1 takes the SVD branch directly (tests)

@@ -66,9 +66,45 @@ def build_projector_form_factors(psp, Gpk_cart):
     return out      # (n_proj_psp, n_G)
 
 
+def build_projection_vectors_abi(basis, kpt):
+    """``build_projection_vectors`` (nonlocal.jl:166-244) written by ONE device kernel of the library
+    (``dftk_mi_build_projectors_hgh``: HGH radial parts, real solid harmonics, (-i)^l, structure factors), straight
+    into P; same column order as the torch construction below (species groups, atoms, (l, m, i))."""
+    import ctypes as C
+    model = basis.model
+    groups = [g for g in model.atom_groups if model.atoms[g[0]].psp.count_n_proj() > 0]
+    if not groups:
+        return None
+    rp = np.zeros((len(groups), 4))
+    nproj = np.zeros((len(groups), 4), dtype=np.int32)
+    species, positions = [], []
+    for s_idx, g in enumerate(groups):
+        psp = model.atoms[g[0]].psp
+        for l in range(psp.lmax + 1):
+            rp[s_idx, l] = psp.rp[l]
+            nproj[s_idx, l] = psp.count_n_proj_radial(l)
+        for ia in g:
+            species.append(s_idx)
+            positions.append(np.asarray(model.positions[ia], dtype=float))
+    species = np.asarray(species, dtype=np.int32)
+    positions = np.ascontiguousarray(np.asarray(positions, dtype=np.float64))
+    G32 = kpt.G_vectors[kpt.row0:kpt.row1].to(torch.int32).contiguous()
+    Bh = np.asfortranarray(model.recip_lattice, dtype=np.float64)
+    kh = np.ascontiguousarray(kpt.coordinate, dtype=np.float64)
+    n_p = C.c_int()
+    args = (basis.handle, kpt.n_loc, G32.data_ptr(), Bh.ctypes.data, kh.ctypes.data, model.unit_cell_volume,
+            len(groups), rp.ctypes.data, nproj.ctypes.data, len(species), species.ctypes.data, positions.ctypes.data)
+    _lib.check(basis.lib.dftk_mi_build_projectors_hgh(*args, None, kpt.n_loc, C.byref(n_p)))
+    P = torch.empty((n_p.value, kpt.n_loc), dtype=torch.complex128, device=basis.device)
+    torch.cuda.current_stream(basis.device).synchronize()
+    _lib.check(basis.lib.dftk_mi_build_projectors_hgh(*args, P.data_ptr(), kpt.n_loc, C.byref(n_p)))
+    return P
+
+
 def build_projection_vectors(basis, kpt):
-    """nonlocal.jl:166-199.  Returns P as a (n_p, n_loc) tensor == column-major n_loc x n_p: the rows of this
-    rank's plane-wave slab (all of the sphere without ``comm_pw``)."""
+    """nonlocal.jl:166-199 with torch ops (descriptor-only bases and the parity twin of the kernel above).
+    Returns P as a (n_p, n_loc) tensor == column-major n_loc x n_p: the rows of this rank's plane-wave slab (all
+    of the sphere without ``comm_pw``)."""
     model = basis.model
     rows = slice(kpt.row0, kpt.row1)
     Gpk = (kpt.G_vectors[rows].to(torch.float64)
@@ -347,7 +383,9 @@ def instantiate_terms(basis):
     T.kinetic = [k.kinetic_local for k in basis.kpoints] if "Kinetic" in T.names else None
     T.P, T.D = None, None
     if "AtomicNonlocal" in T.names:
-        P = [build_projection_vectors(basis, k) for k in basis.kpoints]
+        build = build_projection_vectors_abi if (basis.handle is not None and os.environ.get("DFTK_MI_TORCH_SETUP") is None) \
+            else build_projection_vectors
+        P = [build(basis, k) for k in basis.kpoints]
         if P and P[0] is not None:
             T.P, T.D = P, build_projection_coefficients(model)
     T.E_ewald = (energy_ewald(model.lattice, [a.charge_ionic for a in model.atoms], model.positions)

@@ -90,6 +90,25 @@ int dftk_mi_apply_H(dftk_mi_kblock* kb, int n_bands, const dftk_mi_cplx* psi_d, 
 int dftk_mi_apply_H_parts(dftk_mi_kblock* kb, int which, int n_bands, const dftk_mi_cplx* psi_d,
                           int64_t ld_psi, dftk_mi_cplx* Hpsi_d, int64_t ld_Hpsi);
 
+/* ---- basis / term set-up ------------------------------------------------------------------
+ * Kpoint(...) sphere enumeration (src/Kpoint.jl:20-41): all cube points with |B (G + k)|^2 / 2 <= Ecut in ascending
+ * 0-based x-fastest linear index, their kinetic multipliers (src/terms/kinetic.jl:31-35) and integer G vectors
+ * (3 per plane wave).  recip_lattice_h: 3x3 column-major (Julia's `model.recip_lattice`).  Host routine (no GPU
+ * needed): call with cap = 0 / NULL buffers to get *n_G, then with buffers of that size. */
+int dftk_mi_kpoint_sphere_host(int nx, int ny, int nz, const double* recip_lattice_h, const double* kcoord_h,
+                               double Ecut, int64_t cap, int64_t* n_G, int64_t* mapping0_h, double* kinetic_h,
+                               int32_t* G_h);
+/* build_projection_vectors (src/terms/nonlocal.jl:166-244) for HGH pseudopotentials, written on the device:
+ * P[g, c] = f_{l,i}(|q|) Y_lm(q) (-i)^l / sqrt(Omega) exp(-2 pi i (G + k).r_atom), q = B (G + k); columns atom by atom
+ * in the order given, within an atom (l, m, i) as nonlocal.jl:228-229.  G_d: 3 ints per row (the rows of this rank's
+ * slab for a sharded block); rp_h / n_proj_h: 4 entries (l = 0..3) per species: r_l and the number of radial
+ * projectors; positions_h: 3 reduced coordinates per atom.  *n_p = number of columns (P_d may be NULL to query). */
+int dftk_mi_build_projectors_hgh(dftk_mi_basis* basis, int64_t n_rows, const int32_t* G_d,
+                                 const double* recip_lattice_h, const double* kcoord_h, double unit_cell_volume,
+                                 int n_species, const double* rp_h, const int* n_proj_h, int n_atoms,
+                                 const int* species_of_atom_h, const double* positions_h, dftk_mi_cplx* P_d,
+                                 int64_t ldP, int* n_p);
+
 /* ---- local-potential pipeline of energy_hamiltonian (src/terms/Hamiltonian.jl:200-227) on the cube ----------
  * Hartree (src/terms/hartree.jl:50-59: V_H = irfft(green .* fft(rho)), E_H = 1/2 Re<V_H(G), rho(G)>), LDA exchange-
  * correlation (src/terms/xc.jl:84-160 with lda_x / lda_c_vwn / lda_c_pw, the functionals of `LDA()` and of the

@@ -411,3 +411,25 @@ def test_pbe_pointwise_kernel_matches_autograd(monkeypatch):
     E2, v2 = dftk.terms.xc_energy_potential(basis, rho)
     assert abs(E1 - E2) < 1e-12 * abs(E2)
     assert float((v1 - v2).abs().max()) < 1e-11 * float(v2.abs().max())
+
+
+def test_setup_behind_abi_matches_torch_construction(monkeypatch):
+    """the k-point sphere (dftk_mi_kpoint_sphere_host) and the projector matrix
+    (dftk_mi_build_projectors_hgh, one device kernel) against the torch construction of the same objects and the
+    oracle's: Si (s, p projectors, 2 radial functions) in a supercell at a general k-point."""
+    lat, atoms, pos = dftk.silicon_cell((2, 1, 1))
+    model = dftk.model_DFT(lat, atoms, pos)
+    kg = dftk.ExplicitKpoints([[0.25, -0.5, 0.125]], [1.0])
+    basis = dftk.PlaneWaveBasis(model, 12, kg)
+    monkeypatch.setenv("DFTK_MI_TORCH_SETUP", "1")
+    twin = dftk.PlaneWaveBasis(model, 12, kg)
+    cpu = dftk.PlaneWaveBasis(model, 12, kg, device="cpu", build_terms=False)
+    kpt, kt, kc = basis.kpoints[0], twin.kpoints[0], cpu.kpoints[0]
+    assert np.array_equal(kpt.mapping, kc.mapping) and torch.equal(kpt.G_vectors.cpu(), kc.G_vectors)
+    assert torch.equal(kpt.kinetic.cpu(), kc.kinetic)
+    P, Pt = basis.terms.P[0], twin.terms.P[0]
+    assert P.shape == Pt.shape == (20, kpt.n_G)
+    assert float((P - Pt).abs().max()) < 1e-13 * float(Pt.abs().max())
+    Si = oracle.ElementPsp("Si", oracle.load_psp_hgh("Si", "lda"))
+    ob = oracle.PlaneWaveBasis(oracle.model_DFT(lat, [Si] * 4, pos), 12, oracle.ExplicitKpoints(kg.kcoords, kg.kweights))
+    assert np.abs(P.cpu().numpy().T - ob.terms.P[0]).max() < 1e-13

@@ -47,6 +47,8 @@ _SIGNATURES = {
     "dftk_mi_build_projectors_hgh": (C.c_int, [C.c_void_p, _i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
                                                C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _i64,
                                                C.POINTER(C.c_int)]),
+    "dftk_mi_atomic_superposition": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                               C.c_void_p, C.c_void_p]),
     "dftk_mi_xc_gga": (C.c_int, [C.c_void_p, _i64, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
                                  C.c_void_p]),
     "dftk_mi_ifft_sphere": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -685,6 +685,17 @@ extern "C" int dftk_mi_build_projectors_hgh(dftk_mi_basis* b, int64_t n_rows, co
                                 n_atoms, species_of_atom_h, positions_h, reinterpret_cast<cd*>(P_d), ldP, n_p);
 }
 
+extern "C" int dftk_mi_atomic_superposition(dftk_mi_kblock* cube_kb, int kind, const double* recip_lattice_h,
+                                            int n_species, const double* params_h, int n_atoms,
+                                            const int* species_of_atom_h, const double* positions_h, double* out_d) {
+    if (!cube_kb || (kind != 0 && kind != 1) || !recip_lattice_h || n_species < 1 || !params_h || n_atoms < 1 ||
+        !species_of_atom_h || !positions_h || !out_d || cube_kb->sh_comm)
+        return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(cube_kb->basis->device));
+    return atomic_superposition(cube_kb, kind, recip_lattice_h, n_species, params_h, n_atoms, species_of_atom_h,
+                                positions_h, out_d);
+}
+
 extern "C" int dftk_mi_xc_gga(dftk_mi_basis* b, int64_t n, const double* rho_d, const double* sigma_d, int xc_functionals,
                               double density_threshold, double* e_d, double* vrho_d, double* vsigma_d) {
     if (!b || n < 0 || !rho_d || !sigma_d || !e_d || !vrho_d || !vsigma_d || (xc_functionals & ~24) || !xc_functionals)

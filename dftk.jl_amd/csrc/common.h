@@ -220,6 +220,9 @@ int build_projectors_hgh(dftk_mi_basis* b, int64_t n_rows, const int32_t* G_d, c
                          double volume, int n_species, const double* rp_h, const int* nproj_h, int n_atoms,
                          const int* species_of_atom_h, const double* positions_h, cd* P_d, int64_t ldP, int* n_p_out);
 
+int atomic_superposition(dftk_mi_kblock* cube_kb, int kind, const double* recip_h, int n_species, const double* par_h,
+                         int n_atoms, const int* species_of_atom_h, const double* positions_h, double* out_d);
+
 // lobpcg.cpp
 // ortho!(X) (Cholesky-QR with the reference's shift-and-retry and SVD fallback) on a stand-alone block;
 // force_svd = 1 takes the SVD branch directly (tests)

@@ -176,3 +176,118 @@ int build_projectors_hgh(dftk_mi_basis* b, int64_t n_rows, const int32_t* G_d, c
     HIPCHK(hipStreamSynchronize(b->stream));   // cols (host vector) and b->ws are reused by the next call
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ atomic superpositions
+// f(G) = sum_species ff_s(|G|) sum_{a in s} e^{-2 pi i G.r_a} / sqrt(Omega) on the whole cube, entries whose -G partner
+// is not on the grid zeroed (enforce_real!, symmetry.jl:318-337), then the inverse cube FFT:
+//   kind 0: compute_local_potential (src/terms/local.jl:108-138) with the HGH local form factor
+//           (eval_psp_local_fourier, src/pseudo/PspHgh.jl:110-124); params = {rloc, Zion, c1, c2, c3, c4}
+//   kind 1: Gaussian valence-density superposition (src/density_methods.jl:111-125,158-181,236-244);
+//           params = {decay length, valence charge}
+struct AtomPar {
+    double rx, ry, rz;
+    int species;
+};
+__global__ __launch_bounds__(256) void k_atomic_sum(int nx, int ny, int nz, Mat3 B, int kind, int n_atoms,
+                                                    const AtomPar* __restrict__ atoms, const double* __restrict__ par,
+                                                    double inv_sqrt_vol, cd* __restrict__ out) {
+    const int64_t N = (int64_t)nx * ny * nz;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= N) return;
+    const int ix = (int)(idx % nx), iy = (int)((idx / nx) % ny), iz = (int)(idx / ((int64_t)nx * ny));
+    const bool unpaired = ((nx % 2 == 0) && ix == nx / 2) || ((ny % 2 == 0) && iy == ny / 2) || ((nz % 2 == 0) && iz == nz / 2);
+    if (unpaired) {
+        out[idx] = make_double2(0.0, 0.0);
+        return;
+    }
+    const double gx = (double)(ix <= (nx - 1) / 2 ? ix : ix - nx), gy = (double)(iy <= (ny - 1) / 2 ? iy : iy - ny),
+                 gz = (double)(iz <= (nz - 1) / 2 ? iz : iz - nz);
+    const double qx = gx * B.b[0] + gy * B.b[3] + gz * B.b[6];
+    const double qy = gx * B.b[1] + gy * B.b[4] + gz * B.b[7];
+    const double qz = gx * B.b[2] + gy * B.b[5] + gz * B.b[8];
+    const double p = sqrt(qx * qx + qy * qy + qz * qz);
+    double re = 0.0, im = 0.0;
+    int cur = -1;
+    double ff = 0.0;
+    for (int a = 0; a < n_atoms; ++a) {
+        const AtomPar at = atoms[a];
+        if (at.species != cur) {      // atoms arrive grouped by species: one form-factor evaluation per species
+            cur = at.species;
+            const double* q = par + 8 * cur;
+            if (kind == 0) {
+                const double rloc = q[0], Zion = q[1];
+                const double t2 = (p * rloc) * (p * rloc);
+                if (t2 > 0.0) {
+                    const double P = q[2] + q[3] * (3.0 - t2) + q[4] * (15.0 - 10.0 * t2 + t2 * t2) +
+                                     q[5] * (105.0 - 105.0 * t2 + 21.0 * t2 * t2 - t2 * t2 * t2);
+                    ff = 4.0 * M_PI * rloc * rloc * (-Zion + sqrt(M_PI / 2.0) * rloc * t2 * P) * exp(-t2 / 2.0) / t2;
+                } else {
+                    ff = 0.0;                  // compensating background
+                }
+            } else {
+                const double x = p * q[0];
+                ff = q[1] * exp(-x * x);
+            }
+            ff *= inv_sqrt_vol;
+        }
+        double sn, cs;
+        sincos(-2.0 * M_PI * (gx * at.rx + gy * at.ry + gz * at.rz), &sn, &cs);
+        re += ff * cs;
+        im += ff * sn;
+    }
+    out[idx] = make_double2(re, im);
+}
+
+__global__ __launch_bounds__(256) void k_real_part_scaled(int64_t n, const cd* __restrict__ c, double scale,
+                                                          double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = scale * c[i].x;
+}
+
+int atomic_superposition(dftk_mi_kblock* cube_kb, int kind, const double* recip_h, int n_species, const double* par_h,
+                         int n_atoms, const int* species_of_atom_h, const double* positions_h, double* out_d) {
+    dftk_mi_basis* b = cube_kb->basis;
+    const int64_t N = (int64_t)b->nx * b->ny * b->nz;
+    if (cube_kb->n_G != N) {
+        dftk_set_error("atomic_superposition: the k-block must span the whole cube");
+        return DFTK_MI_EINVAL;
+    }
+    std::vector<AtomPar> atoms(n_atoms);
+    for (int a = 0; a < n_atoms; ++a) {
+        if (species_of_atom_h[a] < 0 || species_of_atom_h[a] >= n_species) return DFTK_MI_EINVAL;
+        if (a > 0 && species_of_atom_h[a] < species_of_atom_h[a - 1]) {
+            dftk_set_error("atomic_superposition: atoms must be grouped by species");
+            return DFTK_MI_EINVAL;
+        }
+        atoms[a] = AtomPar{positions_h[3 * a], positions_h[3 * a + 1], positions_h[3 * a + 2], species_of_atom_h[a]};
+    }
+    const size_t need = 2 * (size_t)N * sizeof(cd);
+    if (need > b->dense_ws_bytes) {
+        HIPCHK(hipStreamSynchronize(b->stream));
+        if (b->dense_ws) HIPCHK(hipFree(b->dense_ws));
+        b->dense_ws = nullptr;
+        b->dense_ws_bytes = 0;
+        HIPCHK(dftk_scratch_malloc(&b->dense_ws, need));
+        b->dense_ws_bytes = need;
+    }
+    cd* c1 = reinterpret_cast<cd*>(b->dense_ws);
+    cd* c2 = c1 + N;
+    const size_t tab = (size_t)n_atoms * sizeof(AtomPar) + (size_t)n_species * 8 * sizeof(double);
+    CHK(ensure_ws(b, tab));
+    AtomPar* d_atoms = reinterpret_cast<AtomPar*>(b->ws);
+    double* d_par = reinterpret_cast<double*>(d_atoms + n_atoms);
+    HIPCHK(hipMemcpyAsync(d_atoms, atoms.data(), (size_t)n_atoms * sizeof(AtomPar), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(d_par, par_h, (size_t)n_species * 8 * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    Mat3 B;
+    for (int i = 0; i < 9; ++i) B.b[i] = recip_h[i];
+    hipLaunchKernelGGL(k_atomic_sum, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, b->stream, b->nx, b->ny, b->nz, B,
+                       kind, n_atoms, d_atoms, d_par, 1.0 / sqrt(b->volume), c1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(b->stream));      // host tables and b->ws are free again (the FFT below reuses ws-free paths)
+    CHK(launch_ifft_to_cube(cube_kb, c1, c2));
+    hipLaunchKernelGGL(k_real_part_scaled, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, b->stream, N, c2,
+                       1.0 / sqrt(b->volume), out_d);   // ifft_normalization (fft.jl:87)
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}

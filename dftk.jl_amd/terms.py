@@ -36,9 +36,38 @@ def _structure_factor_cube(basis, r):
     return pz[:, None, None] * py[None, :, None] * px[None, None, :]
 
 
+def _atomic_superposition_abi(basis, kind, params_of):
+    """One library call (``dftk_mi_atomic_superposition``) for sum_s ff_s(|G|) sum_a e^{-2 pi i G.r_a} -> real cube."""
+    model = basis.model
+    par = np.zeros((len(model.atom_groups), 8))
+    species, positions = [], []
+    for s_idx, g in enumerate(model.atom_groups):
+        vals = params_of(model.atoms[g[0]])
+        par[s_idx, :len(vals)] = vals
+        for ia in g:
+            species.append(s_idx)
+            positions.append(np.asarray(model.positions[ia], dtype=float))
+    species = np.asarray(species, dtype=np.int32)
+    positions = np.ascontiguousarray(np.asarray(positions, dtype=np.float64))
+    Bh = np.asfortranarray(model.recip_lattice, dtype=np.float64)
+    nx, ny, nz = basis.fft_size
+    out = torch.empty((nz, ny, nx), dtype=torch.float64, device=basis.device)
+    torch.cuda.current_stream(basis.device).synchronize()
+    _lib.check(basis.lib.dftk_mi_atomic_superposition(basis._cube_handle, kind, Bh.ctypes.data, par.shape[0],
+                                                      par.ctypes.data, len(species), species.ctypes.data,
+                                                      positions.ctypes.data, out.data_ptr()))
+    return out
+
+
+def _use_setup_abi(basis):
+    return basis.handle is not None and os.environ.get("DFTK_MI_TORCH_SETUP") is None
+
+
 def compute_local_potential(basis):
     """local.jl:108-138."""
     model = basis.model
+    if _use_setup_abi(basis):
+        return _atomic_superposition_abi(basis, 0, lambda el: [el.psp.rloc, float(el.psp.Zion)] + list(el.psp.cloc)[:4])
     Gnorm = torch.linalg.norm(basis.G_vectors_cart_cube(), dim=-1)
     pot = torch.zeros(Gnorm.shape, dtype=torch.complex128, device=basis.device)
     for group in model.atom_groups:
@@ -355,6 +384,11 @@ def atom_decay_length(n_core, n_val):
 def guess_density(basis):
     """``guess_density(basis, ValenceDensityGaussian())`` (density_methods.jl:111-125,158-181,236-244)."""
     model = basis.model
+    if _use_setup_abi(basis):
+        rho = _atomic_superposition_abi(basis, 1, lambda el: [atom_decay_length(el.n_elec_core, el.charge_ionic),
+                                                              float(el.charge_ionic)])
+        N = float(rho.sum().item()) * model.unit_cell_volume / basis.N
+        return rho * (model.n_electrons / N) if N > 0 else rho
     Gnorm = torch.linalg.norm(basis.G_vectors_cart_cube(), dim=-1)
     rho_G = torch.zeros(Gnorm.shape, dtype=torch.complex128, device=basis.device)
     for group in model.atom_groups:
@@ -383,8 +417,7 @@ def instantiate_terms(basis):
     T.kinetic = [k.kinetic_local for k in basis.kpoints] if "Kinetic" in T.names else None
     T.P, T.D = None, None
     if "AtomicNonlocal" in T.names:
-        build = build_projection_vectors_abi if (basis.handle is not None and os.environ.get("DFTK_MI_TORCH_SETUP") is None) \
-            else build_projection_vectors
+        build = build_projection_vectors_abi if _use_setup_abi(basis) else build_projection_vectors
         P = [build(basis, k) for k in basis.kpoints]
         if P and P[0] is not None:
             T.P, T.D = P, build_projection_coefficients(model)

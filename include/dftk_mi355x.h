@@ -109,6 +109,17 @@ int dftk_mi_build_projectors_hgh(dftk_mi_basis* basis, int64_t n_rows, const int
                                  const int* species_of_atom_h, const double* positions_h, dftk_mi_cplx* P_d,
                                  int64_t ldP, int* n_p);
 
+/* Superposition of atomic form factors on the cube, real-space result:
+ *   out(r) = irfft( enforce_real( sum_species ff_s(|G|) sum_{a in s} e^{-2 pi i G.r_a} / sqrt(Omega) ) )
+ * kind 0: compute_local_potential (src/terms/local.jl:108-138) with the HGH local form factor
+ *         (src/pseudo/PspHgh.jl:110-124); params_h[8 s + 0..5] = rloc, Zion, c1..c4
+ * kind 1: Gaussian valence-density superposition of guess_density (src/density_methods.jl:111-125,158-181,236-244,
+ *         un-normalised); params_h[8 s + 0..1] = decay length, valence charge.
+ * Atoms grouped by species (species_of_atom_h non-decreasing); cube_kb spans the whole cube. */
+int dftk_mi_atomic_superposition(dftk_mi_kblock* cube_kb, int kind, const double* recip_lattice_h, int n_species,
+                                 const double* params_h, int n_atoms, const int* species_of_atom_h,
+                                 const double* positions_h, double* out_d);
+
 /* ---- local-potential pipeline of energy_hamiltonian (src/terms/Hamiltonian.jl:200-227) on the cube ----------
  * Hartree (src/terms/hartree.jl:50-59: V_H = irfft(green .* fft(rho)), E_H = 1/2 Re<V_H(G), rho(G)>), LDA exchange-
  * correlation (src/terms/xc.jl:84-160 with lda_x / lda_c_vwn / lda_c_pw, the functionals of `LDA()` and of the

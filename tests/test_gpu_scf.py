@@ -433,3 +433,12 @@ def test_setup_behind_abi_matches_torch_construction(monkeypatch):
     Si = oracle.ElementPsp("Si", oracle.load_psp_hgh("Si", "lda"))
     ob = oracle.PlaneWaveBasis(oracle.model_DFT(lat, [Si] * 4, pos), 12, oracle.ExplicitKpoints(kg.kcoords, kg.kweights))
     assert np.abs(P.cpu().numpy().T - ob.terms.P[0]).max() < 1e-13
+    # local potential and Gaussian guess density: dftk_mi_atomic_superposition vs the torch construction vs the oracle
+    V, Vt = basis.terms.V_loc, twin.terms.V_loc
+    assert float((V - Vt).abs().max()) < 1e-12 * float(Vt.abs().max())
+    assert np.abs(V.cpu().numpy() - ob.terms.V_loc).max() < 1e-11 * np.abs(ob.terms.V_loc).max()
+    g_twin = dftk.guess_density(twin)
+    monkeypatch.delenv("DFTK_MI_TORCH_SETUP")
+    g_abi = dftk.guess_density(basis)
+    assert float((g_abi - g_twin).abs().max()) < 1e-12 * float(g_twin.abs().max())
+    assert np.abs(g_abi.cpu().numpy() - oracle.guess_density(ob)).max() < 1e-12

@@ -88,5 +88,28 @@ def main(which):
         run("cfg4_graphene_pbe_ecut40_k3", model, 40, oracle.MonkhorstPack((3, 3, 1)), None)
 
 
+def main_full(which):
+    """The k-point configs EXACTLY as the reference's constructor builds them: crystal symmetries on, irreducible
+    Monkhorst-Pack points, symmetry-adapted FFT size, LDOS mixing (the SCF default)."""
+    if "cfg3full" in which:
+        a = 7.6324708938577865
+        lat = a / 2 * np.array([[0, 1, 1.0], [1, 0, 1.0], [1, 1, 0.0]])
+        Al = oracle.ElementPsp("Al", oracle.load_psp_hgh("Al", "pbe"))
+        model = oracle.model_DFT(lat, [Al], [np.zeros(3)], functionals=("gga_x_pbe", "gga_c_pbe"), temperature=1e-3,
+                                 smearing="gaussian", symmetries=True)
+        run("cfg3_al_pbe_ecut40_k12_sym", model, 40, oracle.MonkhorstPack((12, 12, 12)), None,
+            note="BASELINE configs[2] in full: 12x12x12 mesh, 48 symmetries -> 72 irreducible k-points")
+    if "cfg4full" in which:
+        a, L = 4.66, 20.0
+        lat = np.array([[a / 2, a / 2, 0.0], [-a * np.sqrt(3) / 2, a * np.sqrt(3) / 2, 0.0], [0.0, 0.0, L]])
+        C_ = oracle.ElementPsp("C", oracle.load_psp_hgh("C", "pbe"))
+        pos = [np.array([1 / 3, -1 / 3, 0.0]), np.array([-1 / 3, 1 / 3, 0.0])]
+        model = oracle.model_DFT(lat, [C_, C_], pos, functionals=("gga_x_pbe", "gga_c_pbe"), temperature=1e-3,
+                                 smearing="fermi_dirac", symmetries=True)
+        run("cfg4_graphene_pbe_ecut40_k9_sym", model, 40, oracle.MonkhorstPack((9, 9, 1)), None,
+            note="BASELINE configs[3] in full: 9x9x1 mesh with the crystal symmetries")
+
+
 if __name__ == "__main__":
+    main_full(sys.argv[1:])
     main(sys.argv[1:] or ["cfg2", "cfg1", "cfg3", "cfg4"])

@@ -444,7 +444,7 @@ extern "C" int dftk_mi_kblock_set_shard(dftk_mi_kblock* kb, dftk_mi_comm* comm, 
     if (!kb) return DFTK_MI_EINVAL;
     HIPCHK(hipSetDevice(kb->basis->device));
     HIPCHK(hipStreamSynchronize(kb->basis->stream));
-    if (!comm) {
+    if (!comm || comm_size(comm) == 1) {      // a one-rank communicator owns the whole sphere: nothing to shard
         kb->sh_comm = nullptr;
         return 0;
     }

@@ -611,3 +611,37 @@ def test_scfres_dict_layout_on_host():
     assert d["norm_Δρ"] == 1e-7 and d["εF"] == 0.3 and d["diagonalization"]["n_iter"] == [[3, 4]]
     import json
     json.dumps(d)
+
+
+def test_kpoint_sphere_host_matches_oracle_and_torch():
+    """dftk_mi_kpoint_sphere_host (src/Kpoint.jl:20-41 behind the ABI; a host routine, no GPU needed): mapping,
+    kinetic multipliers and integer G vectors identical to the oracle's and to the mirror's torch enumeration, for
+    Gamma, a general k-point, an anisotropic cell and a cube with an even axis."""
+    import ctypes as C
+    import oracle
+    from dftk_jl_amd._lib import check
+    lib = dftk.load_library()
+    cases = [((1, 1, 1), 9.0, [0.0, 0.0, 0.0], None), ((2, 1, 1), 7.0, [0.25, -0.5, 0.125], None),
+             ((1, 1, 2), 6.0, [1 / 3, 0.0, -1 / 3], (16, 18, 40))]
+    for sc, ecut, k, fft in cases:
+        lat, atoms, pos = dftk.silicon_cell(sc)
+        m = dftk.model_DFT(lat, atoms, pos)
+        b = dftk.PlaneWaveBasis(m, ecut, dftk.ExplicitKpoints([k], [1.0]), device="cpu", build_terms=False, fft_size=fft)
+        kp = b.kpoints[0]
+        nx, ny, nz = b.fft_size
+        B = np.asfortranarray(m.recip_lattice)
+        kk = np.asarray(k, dtype=float)
+        n = C.c_int64()
+        check(lib.dftk_mi_kpoint_sphere_host(nx, ny, nz, B.ctypes.data, kk.ctypes.data, ecut, 0, C.byref(n), None, None, None))
+        assert n.value == kp.n_G
+        mp, kin, G = np.zeros(n.value, dtype=np.int64), np.zeros(n.value), np.zeros((n.value, 3), dtype=np.int32)
+        check(lib.dftk_mi_kpoint_sphere_host(nx, ny, nz, B.ctypes.data, kk.ctypes.data, ecut, n.value, C.byref(n),
+                                             mp.ctypes.data, kin.ctypes.data, G.ctypes.data))
+        assert np.array_equal(mp, kp.mapping) and np.array_equal(G, kp.G_vectors.numpy())
+        assert np.array_equal(kin, kp.kinetic.numpy())
+        Si = oracle.ElementPsp("Si", oracle.load_psp_hgh("Si", "lda"))
+        ob = oracle.PlaneWaveBasis(oracle.model_DFT(lat, [Si] * len(pos), pos), ecut, oracle.ExplicitKpoints([k], [1.0]),
+                                   fft_size=fft, build_terms=False)
+        assert np.array_equal(mp, ob.kpoints[0].mapping) and np.array_equal(G, ob.kpoints[0].G_vectors)
+        assert lib.dftk_mi_kpoint_sphere_host(nx, ny, nz, B.ctypes.data, kk.ctypes.data, ecut, 3, C.byref(n),
+                                              mp.ctypes.data, None, None) == -1          # buffers too small: reported

@@ -304,7 +304,13 @@ class ScfStepper:
                     energies=energies, ham=ham, rho_in=self.rho_in, diagtol=diagtol,
                     history_Etot=info["history_Etot"] + [energies.total],
                     history_drho=info["history_drho"] + [float(torch.linalg.norm(drho).item()) * self.sqrt_dvol])
-        info["converged"] = bool(self.is_converged(info))
+        # rank 0 decides for everybody (mpi_bcast(converged, comm_kpts), self_consistent_field.jl:249): the ranks
+        # hold bit-identical densities, but a control-flow split on a last-bit difference must never deadlock
+        conv = bool(self.is_converged(info))
+        for comm in (basis.comm_kpts, basis.comm_pw):
+            if comm.size > 1:
+                conv = bool(comm.gather_lists(conv)[0])
+        info["converged"] = conv
         info["timings"] = info["timings"] + [time.time() - t_it]
         if not info["converged"]:
             # rho_next = Anderson(rho_in, beta, mix_density(mixing, rho_out - rho_in))   (:247, scf_solvers.jl:85-98)

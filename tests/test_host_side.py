@@ -645,3 +645,19 @@ def test_kpoint_sphere_host_matches_oracle_and_torch():
         assert np.array_equal(mp, ob.kpoints[0].mapping) and np.array_equal(G, ob.kpoints[0].G_vectors)
         assert lib.dftk_mi_kpoint_sphere_host(nx, ny, nz, B.ctypes.data, kk.ctypes.data, ecut, 3, C.byref(n),
                                               mp.ctypes.data, None, None) == -1          # buffers too small: reported
+
+
+def test_bench_cli_contract_without_gpu():
+    """bench.py parses the driver's flags and refuses to run without a GPU (no CPU fallback, no silent skip)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True)
+    assert h.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--mode", "--supercell", "--no-cpu-baseline"):
+        assert flag in h.stdout
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1"],
+                           capture_output=True, text=True)
+        assert r.returncode != 0 and "needs a GPU" in (r.stdout + r.stderr)

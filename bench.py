@@ -366,7 +366,8 @@ def main():
             with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
                 pmc = json.load(fh)
             key = FAMILIES[dom]
-            if pmc.get("lib_hash") == library_source_hash() and pmc.get("workload") == workload and key in pmc["families"]:
+            if (n_gpus == 1 and pmc.get("lib_hash") == library_source_hash() and pmc.get("workload") == workload
+                    and key in pmc["families"]):       # (collected on one GPU: says nothing about a sharded launch mix)
                 roof["traffic"] = pmc["families"][key]["bytes_per_launch"]
                 roof["traffic_unit"] = "B/launch"
                 roof["traffic_source"] = "profiles/r02_pmc_traffic.json (" + pmc["collected"] + ")"

@@ -68,6 +68,8 @@ _SIGNATURES = {
     "dftk_mi_tpa_ldiv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, C.c_double, C.c_void_p, _i64]),
     "dftk_mi_block_residual": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, _i64, C.c_void_p,
                                          C.c_void_p, _i64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dftk_mi_shard_plan_host": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
     "dftk_mi_kblock_set_shard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dftk_mi_zgemm": (C.c_int, [C.c_void_p, C.c_char, _i64, _i64, _i64, dftk_mi_cplx, C.c_void_p, _i64,
                                 C.c_void_p, _i64, dftk_mi_cplx, C.c_void_p, _i64]),

@@ -494,6 +494,44 @@ static int shard_buffers(dftk_mi_kblock* kb, int nb, cd** R1, cd** F, cd** G) {
     return 0;
 }
 
+// Offsets / counts (complex elements) of the two layouts of an nb-band block of a sharded k-block on rank `me`:
+// slab side  -- this rank's rows of all bands, packed n_loc x nb: the columns of destination s are one contiguous piece;
+// band side  -- all rows of this rank's bands: the piece from source r is its rows x mine columns, packed.
+static void shard_plan(const std::vector<int64_t>& rows, int p, int me, int nb, std::vector<int>& c0,
+                       std::vector<size_t>& slab_off, std::vector<size_t>& slab_cnt, std::vector<size_t>& band_off,
+                       std::vector<size_t>& band_cnt) {
+    band_split(nb, p, c0);
+    const int64_t nloc = rows[me + 1] - rows[me];
+    const int mine = c0[me + 1] - c0[me];
+    slab_off.resize(p), slab_cnt.resize(p), band_off.resize(p), band_cnt.resize(p);
+    for (int s = 0; s < p; ++s) {
+        slab_off[s] = (size_t)c0[s] * nloc;
+        slab_cnt[s] = (size_t)(c0[s + 1] - c0[s]) * nloc;
+        band_off[s] = (size_t)rows[s] * mine;
+        band_cnt[s] = (size_t)(rows[s + 1] - rows[s]) * mine;
+    }
+}
+
+extern "C" int dftk_mi_shard_plan_host(int n_ranks, int rank, int n_bands, const int64_t* row_starts_h,
+                                       int* band_starts /* [n_ranks + 1] */, int64_t* slab_off, int64_t* slab_cnt,
+                                       int64_t* band_off, int64_t* band_cnt /* [n_ranks] each */) {
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks || n_bands < 0 || !row_starts_h || !band_starts || !slab_off ||
+        !slab_cnt || !band_off || !band_cnt)
+        return DFTK_MI_EINVAL;
+    std::vector<int64_t> rows(row_starts_h, row_starts_h + n_ranks + 1);
+    std::vector<int> c0;
+    std::vector<size_t> so, sc, bo, bc;
+    shard_plan(rows, n_ranks, rank, n_bands, c0, so, sc, bo, bc);
+    for (int s = 0; s <= n_ranks; ++s) band_starts[s] = c0[s];
+    for (int s = 0; s < n_ranks; ++s) {
+        slab_off[s] = (int64_t)so[s];
+        slab_cnt[s] = (int64_t)sc[s];
+        band_off[s] = (int64_t)bo[s];
+        band_cnt[s] = (int64_t)bc[s];
+    }
+    return 0;
+}
+
 // slab layout (n_loc x nb, this rank's rows of every band) -> band layout (n_G x mine, all rows of this rank's
 // bands) and back: one all-to-all each way, pieces are contiguous column groups on the slab side
 struct Transposer {
@@ -506,16 +544,8 @@ struct Transposer {
         p = comm_size(kb->sh_comm);
         me = comm_rank(kb->sh_comm);
         nloc = local_rows(kb);
-        band_split(nb, p, c0);
+        shard_plan(*kb->sh_rows, p, me, nb, c0, slab_off, slab_cnt, band_off, band_cnt);
         mine = c0[me + 1] - c0[me];
-        slab_off.resize(p), slab_cnt.resize(p), band_off.resize(p), band_cnt.resize(p);
-        for (int s = 0; s < p; ++s) {
-            slab_off[s] = (size_t)c0[s] * nloc;
-            slab_cnt[s] = (size_t)(c0[s + 1] - c0[s]) * nloc;
-            const int64_t rows = (*kb->sh_rows)[s + 1] - (*kb->sh_rows)[s];
-            band_off[s] = (size_t)(*kb->sh_rows)[s] * mine;
-            band_cnt[s] = (size_t)rows * mine;
-        }
     }
     // psi_loc (ld == nloc required by the caller) -> F (n_G x mine, ld n_G); R1 is scratch
     int to_bands(const cd* slab, cd* R1, cd* F) {

@@ -263,6 +263,13 @@ int dftk_mi_allreduce_sum_f64(dftk_mi_comm* comm, double* buf_d, size_t n, void*
  * communicator.  Call before set_projectors; comm = NULL un-shards.  The communicator is borrowed. */
 int dftk_mi_kblock_set_shard(dftk_mi_kblock* kb, dftk_mi_comm* comm, const int64_t* row_starts_h);
 
+/* Host-only view of the slab <-> band transposition plan of a sharded block (CPU test-suite): for `rank` of
+ * `n_ranks`, an n_bands block: band_starts[s] .. band_starts[s+1] = bands transformed by rank s; slab_off/cnt[s] =
+ * piece of the packed n_loc x n_bands slab that goes to rank s; band_off/cnt[r] = piece of the packed band layout that
+ * comes from rank r (offsets / counts in complex elements). */
+int dftk_mi_shard_plan_host(int n_ranks, int rank, int n_bands, const int64_t* row_starts_h, int* band_starts,
+                            int64_t* slab_off, int64_t* slab_cnt, int64_t* band_off, int64_t* band_cnt);
+
 /* ---- per-family kernel timing with HIP events on the basis' stream (used by bench.py) ----------
  * family: 0 UNSTRUCTURED zgemm calls (work = 8mnk flops), 1..5 FFT stages A..E (work = algorithmic bytes of
  * the pruned pipeline), 6 density z-pass, 7 heev, 8 potrf+trtri, 9 whole apply_H

@@ -661,3 +661,99 @@ def test_bench_cli_contract_without_gpu():
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1"],
                            capture_output=True, text=True)
         assert r.returncode != 0 and "needs a GPU" in (r.stdout + r.stderr)
+
+
+def test_shard_plan_transposes_slabs_to_bands_and_back():
+    """Plane-wave sharding, host logic (dftk_mi_shard_plan_host = the plan the device Transposer uses): emulate the
+    slab -> band all-to-all of apply_H for p ranks in NumPy and check that every rank ends up with all rows of exactly
+    its bands, and that the way back restores the slabs -- for even / ragged splits, more ranks than bands, 1 rank."""
+    import ctypes as C
+    from dftk_jl_amd._lib import check
+    from dftk_jl_amd.comm import split_evenly
+    lib = dftk.load_library()
+    rng = np.random.default_rng(0)
+    for n_G, p, nb in [(101, 2, 7), (64, 4, 8), (37, 3, 2), (50, 1, 5), (23, 8, 3)]:
+        rows = np.array([r.start for r in split_evenly(n_G, p)] + [n_G], dtype=np.int64)
+        X = rng.standard_normal((n_G, nb)) + 1j * rng.standard_normal((n_G, nb))
+        plans = []
+        for me in range(p):
+            c0 = np.zeros(p + 1, dtype=np.int32)
+            arrs = [np.zeros(p, dtype=np.int64) for _ in range(4)]
+            check(lib.dftk_mi_shard_plan_host(p, me, nb, rows.ctypes.data, c0.ctypes.data, *[a.ctypes.data for a in arrs]))
+            plans.append((c0, *arrs))
+        assert all(np.array_equal(pl[0], plans[0][0]) for pl in plans) and plans[0][0][-1] == nb
+        c0 = plans[0][0]
+        # packed slabs (column-major n_loc x nb) and the emulated all-to-all
+        slabs = [X[rows[r]:rows[r + 1], :].flatten(order="F") for r in range(p)]
+        bands = []
+        for me in range(p):
+            _, so, sc, bo, bc = plans[me]
+            mine = c0[me + 1] - c0[me]
+            recv = np.zeros(n_G * mine, dtype=complex)
+            for r in range(p):
+                _, so_r, sc_r, _, _ = plans[r]
+                piece = slabs[r][so_r[me]:so_r[me] + sc_r[me]]           # what rank r sends to me
+                assert len(piece) == bc[r]
+                recv[bo[r]:bo[r] + bc[r]] = piece
+            full = np.zeros((n_G, mine), dtype=complex)
+            for r in range(p):                                             # the device's strided copies
+                nr = rows[r + 1] - rows[r]
+                full[rows[r]:rows[r + 1], :] = recv[bo[r]:bo[r] + bc[r]].reshape((nr, mine), order="F")
+            assert np.array_equal(full, X[:, c0[me]:c0[me + 1]])
+            bands.append(recv)
+        for me in range(p):                                                # and back: band pieces -> slab columns
+            _, so, sc, bo, bc = plans[me]
+            back = np.zeros((rows[me + 1] - rows[me]) * nb, dtype=complex)
+            for s_ in range(p):
+                _, _, _, bo_s, bc_s = plans[s_]
+                back[so[s_]:so[s_] + sc[s_]] = bands[s_][bo_s[me]:bo_s[me] + bc_s[me]]
+            assert np.array_equal(back, slabs[me])
+
+
+PW_GLOO_WORKER = r"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.environ["REPO"])
+import numpy as np, torch, torch.distributed as dist
+import dftk_jl_amd as dftk
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["PORT"],
+                        rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+comm = dftk.KptComm.from_torch()
+handle = comm.abi_handle(0)                     # host-staged dftk_mi_comm over gloo: no GPU needed to create it
+lib = dftk.load_library()
+assert comm._abi_kind == "host" and lib.dftk_mi_comm_size(handle) == comm.size and lib.dftk_mi_comm_rank(handle) == comm.rank
+allreduce, alltoallv = comm._callbacks
+buf = np.arange(6, dtype=np.float64) * (comm.rank + 1)
+assert allreduce(None, buf.ctypes.data_as(C.POINTER(C.c_double)), 6) == 0
+assert np.array_equal(buf, np.arange(6) * sum(range(1, comm.size + 1)))
+# ragged all-to-all: rank r sends (r + 1) * (s + 1) doubles with value 100 r + s to rank s
+p, me = comm.size, comm.rank
+scnt = np.array([(me + 1) * (s + 1) for s in range(p)], dtype=np.uint64); soff = np.concatenate([[0], np.cumsum(scnt)[:-1]]).astype(np.uint64)
+rcnt = np.array([(r + 1) * (me + 1) for r in range(p)], dtype=np.uint64); roff = np.concatenate([[0], np.cumsum(rcnt)[:-1]]).astype(np.uint64)
+send = np.concatenate([np.full(int(scnt[s]), 100.0 * me + s) for s in range(p)])
+recv = np.zeros(int(rcnt.sum()))
+sz = C.POINTER(C.c_size_t); dp = C.POINTER(C.c_double)
+assert alltoallv(None, send.ctypes.data_as(dp), scnt.ctypes.data_as(sz), soff.ctypes.data_as(sz),
+                 recv.ctypes.data_as(dp), rcnt.ctypes.data_as(sz), roff.ctypes.data_as(sz)) == 0
+want = np.concatenate([np.full(int(rcnt[r]), 100.0 * r + me) for r in range(p)])
+assert np.array_equal(recv, want)
+assert comm.sum_scalars([1.0, float(me)]) == [float(p), float(sum(range(p)))]
+dist.barrier(); dist.destroy_process_group()
+print("rank", me, "ok")
+"""
+
+
+def test_host_staged_communicator_callbacks_gloo_world2(tmp_path):
+    """The host-staged communicator (dftk_mi_comm_create_host + the gloo callbacks of KptComm: what a plane-wave
+    sharded block reduces and transposes through when the process group is not nccl) with 2 ranks on the CPU."""
+    script = tmp_path / "pw_worker.py"
+    script.write_text(PW_GLOO_WORKER)
+    port = str(27500 + os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", PORT=port, REPO=ROOT, MASTER_ADDR="127.0.0.1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o}"
+        assert f"rank {r} ok" in o

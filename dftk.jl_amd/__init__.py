@@ -18,7 +18,8 @@ from .comm import KptComm, split_evenly, distribute_kpoints  # noqa: F401,E402
 from .basis import PlaneWaveBasis, Kpoint, compute_fft_size  # noqa: F401,E402
 from .hamiltonian import DftHamiltonianBlock, mul_  # noqa: F401,E402
 from .terms import energy_hamiltonian, guess_density  # noqa: F401,E402
-from .eigen import lobpcg_hyper, diagonalize_all_kblocks, PreconditionerTPA, random_orbitals  # noqa: F401,E402
+from .eigen import (lobpcg_hyper, diagonalize_all_kblocks, PreconditionerTPA, random_orbitals,  # noqa: F401,E402
+                    columnwise_norms, columnwise_dots, ortho_qr, interpolate_kpoint, lobpcg_residual_history)
 from .densities import compute_density  # noqa: F401,E402
 from .mixing import (SimpleMixing, KerkerMixing, KerkerDosMixing, DielectricMixing, LdosMixing, HybridMixing,  # noqa: F401,E402
                      Chi0Mixing, compute_dos, compute_ldos)

@@ -21,12 +21,63 @@ EPS = float(np.finfo(np.float64).eps)
 
 
 class PreconditionerTPA:
-    """Marker for the Teter-Payne-Allan preconditioner (src/eigen/preconditioners.jl:27-78); the
-    kinetic vector it needs already lives in the k-block, so the object carries no data."""
+    """Teter-Payne-Allan preconditioner (src/eigen/preconditioners.jl:27-78).  The kinetic vector lives in the
+    k-block of the library, ``mean_kin`` (set by ``precondprep_``) on the host; inside ``lobpcg_hyper`` the library
+    applies the same two kernels fused into its residual pass."""
 
     def __init__(self, ham_block: DftHamiltonianBlock | None = None, default_shift: float = 1.0):
         self.ham_block = ham_block
         self.default_shift = default_shift
+        self.mean_kin = None
+
+    def precondprep_(self, X: torch.Tensor):
+        """``precondprep!(P, X)`` (:75-77): mean kinetic energy of every band of X (bands = rows)."""
+        H = self.ham_block
+        mk = np.zeros(X.shape[0])
+        torch.cuda.current_stream(H.basis.device).synchronize()
+        _lib.check(H.basis.lib.dftk_mi_tpa_precondprep(H.kpoint.handle, X.shape[0], X.data_ptr(), X.stride(0),
+                                                       mk.ctypes.data))
+        self.mean_kin = mk
+        return self
+
+    def ldiv_(self, Y: torch.Tensor, R: torch.Tensor) -> torch.Tensor:
+        """``ldiv!(Y, P, R)`` (:50-60): Y = mean_kin / (mean_kin + kin) .* R, or R ./ (kin + default_shift) before
+        the first ``precondprep_``."""
+        H = self.ham_block
+        torch.cuda.current_stream(H.basis.device).synchronize()
+        mk = self.mean_kin.ctypes.data if self.mean_kin is not None else None
+        _lib.check(H.basis.lib.dftk_mi_tpa_ldiv(H.kpoint.handle, R.shape[0], R.data_ptr(), R.stride(0), mk,
+                                                float(self.default_shift), Y.data_ptr(), Y.stride(0)))
+        H.basis.sync(H.kpoint.lane)
+        return Y
+
+
+def columnwise_norms(basis, X: torch.Tensor) -> np.ndarray:
+    """``columnwise_norms(X)`` (src/common/linalg.jl:2-4) of a band-major block through the library."""
+    out = np.zeros(X.shape[0])
+    torch.cuda.current_stream(basis.device).synchronize()
+    _lib.check(basis.lib.dftk_mi_columnwise_norms(basis.handle, X.shape[1], X.shape[0], X.data_ptr(), X.stride(0),
+                                                  out.ctypes.data))
+    return out
+
+
+def columnwise_dots(basis, A: torch.Tensor, B: torch.Tensor) -> np.ndarray:
+    """``columnwise_dots(A, B)`` (src/common/linalg.jl:7-9, src/gpu/linalg.jl:17-19): dot(A[:, i], B[:, i])."""
+    out = (_lib.dftk_mi_cplx * A.shape[0])()
+    torch.cuda.current_stream(basis.device).synchronize()
+    _lib.check(basis.lib.dftk_mi_columnwise_dots(basis.handle, A.shape[1], A.shape[0], A.data_ptr(), A.stride(0),
+                                                 B.data_ptr(), B.stride(0), out))
+    return np.array([complex(d.re, d.im) for d in out])
+
+
+def ortho_qr(basis, X: torch.Tensor) -> torch.Tensor:
+    """``ortho_qr(X)`` (src/common/ortho.jl:1-9): orthonormal columns spanning those of X (Cholesky-QR with the
+    reference's safeguards instead of Householder: Q differs from LAPACK's by a unitary diagonal)."""
+    Q = X.clone().contiguous()
+    torch.cuda.current_stream(basis.device).synchronize()
+    _lib.check(basis.lib.dftk_mi_ortho_qr(basis.handle, Q.shape[1], Q.shape[0], Q.data_ptr(), Q.stride(0), 0,
+                                          C.byref(C.c_int()), C.byref(C.c_int())))
+    return Q
 
 
 @dataclass

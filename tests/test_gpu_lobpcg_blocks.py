@@ -209,3 +209,29 @@ def test_lobpcg_residual_history_matches_oracle(lib, use_tpa):
     assert dev_rel.max() < 1e-4
     assert abs(nit - nit_o) <= 2 + nit_o // 10, (nit, nit_o)
     assert abs(nmv - ores["n_matvec"]) <= M * (2 + nit_o // 10)
+
+
+def test_host_mirror_helpers_match_oracle():
+    """The reference-named helpers of the host mirror (PreconditionerTPA.precondprep_ / ldiv_, columnwise_norms,
+    columnwise_dots, ortho_qr) on band-major torch blocks against the oracle."""
+    lat, atoms, pos = dftk.silicon_cell()
+    basis = dftk.PlaneWaveBasis(dftk.model_DFT(lat, atoms, pos), 10, dftk.ExplicitKpoints([[0.1, -0.2, 0.3]], [1.0]))
+    rho = dftk.guess_density(basis)
+    _, ham = dftk.energy_hamiltonian(basis, None, None, rho=rho)
+    H, kpt = ham[0], basis.kpoints[0]
+    X = dftk.random_orbitals(basis, kpt, 6)
+    R = dftk.random_orbitals(basis, kpt, 6)
+    Xn, Rn = X.cpu().numpy().T, R.cpu().numpy().T
+    np.testing.assert_allclose(dftk.columnwise_norms(basis, X), columnwise_norms(Xn), rtol=1e-13)
+    np.testing.assert_allclose(dftk.columnwise_dots(basis, X, R), columnwise_dots(Xn, Rn), atol=1e-14)
+    P, oP = dftk.PreconditionerTPA(H), PreconditionerTPA(kpt.kinetic.cpu().numpy())
+    Y = torch.empty_like(R)
+    assert relerr(P.ldiv_(Y, R).cpu().numpy().T, oP.ldiv(Rn)) < 1e-14           # default_shift form
+    P.precondprep_(X)
+    oP.precondprep(Xn)
+    np.testing.assert_allclose(P.mean_kin, oP.mean_kin, rtol=1e-13)
+    assert relerr(P.ldiv_(Y, R).cpu().numpy().T, oP.ldiv(Rn)) < 1e-14
+    Q = dftk.ortho_qr(basis, X).cpu().numpy().T
+    assert np.linalg.norm(Q.conj().T @ Q - np.eye(6)) < 1e-12
+    Qref = np.linalg.qr(Xn)[0]
+    assert np.linalg.norm(Q - Qref @ (Qref.conj().T @ Q)) < 1e-12                # same column space

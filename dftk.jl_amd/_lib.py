@@ -68,6 +68,14 @@ _SIGNATURES = {
     "dftk_mi_tpa_ldiv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, C.c_double, C.c_void_p, _i64]),
     "dftk_mi_block_residual": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, _i64, C.c_void_p,
                                          C.c_void_p, _i64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dftk_mi_kblock_set_gamma_real": (C.c_int, [C.c_void_p, C.c_int]),
+    "dftk_mi_gamma_half_size": (C.c_int, [C.c_void_p, C.POINTER(_i64)]),
+    "dftk_mi_gamma_tables_host": (C.c_int, [C.c_int, C.c_int, C.c_int, _i64, C.c_void_p, C.POINTER(_i64), C.c_void_p,
+                                            C.c_void_p]),
+    "dftk_mi_gamma_compress": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, _i64]),
+    "dftk_mi_gamma_expand": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, _i64]),
+    "dftk_mi_gamma_apply_H": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, _i64, C.c_void_p, _i64]),
+    "dftk_mi_density_accumulate_real": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, C.c_void_p]),
     "dftk_mi_shard_plan_host": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p]),
     "dftk_mi_kblock_set_shard": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

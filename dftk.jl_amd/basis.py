@@ -123,6 +123,16 @@ class Kpoint:
                     raise ValueError("plane-wave sharding: more ranks than plane waves")
                 _lib.check(basis.lib.dftk_mi_kblock_set_shard(self.handle, pw.abi_handle(basis.device.index),
                                                               self.row_starts.ctypes.data))
+        # Gamma point: LOBPCG iterates real-symmetric orbitals psi(-G) = conj(psi(G)) in the library's half-sphere
+        # format (dftk_mi_kblock_set_gamma_real: real matrix products over half the rows, two bands per FFT pass).
+        # An extension over the reference (no Gamma special case there); eigenvalues / density / energies unchanged.
+        self.gamma_real = False
+        if (basis.gamma_real is not False and self.handle and pw.size == 1 and not self.coordinate.any()):
+            st = basis.lib.dftk_mi_kblock_set_gamma_real(self.handle, 1)
+            if st == 0:
+                self.gamma_real = True
+            elif basis.gamma_real is True:          # explicitly requested: report why it is impossible
+                _lib.check(st)
 
     def __del__(self):
         try:
@@ -144,8 +154,12 @@ class PlaneWaveBasis:
 
     def __init__(self, model: Model, Ecut: float, kgrid=None, fft_size=None, device="cuda",
                  comm_kpts: KptComm | None = None, build_terms=True, comm_pw: KptComm | None = None,
-                 use_symmetries_for_kpoint_reduction=True, n_lanes: int | None = None):
+                 use_symmetries_for_kpoint_reduction=True, n_lanes: int | None = None, gamma_real: bool | None = None):
         from . import symmetry as _sym
+        # gamma_real: None = automatic at k = 0 (env DFTK_MI_GAMMA_REAL=0 switches it off), True = required, False = off
+        if gamma_real is None and os.environ.get("DFTK_MI_GAMMA_REAL", "1") == "0":
+            gamma_real = False
+        self.gamma_real = gamma_real
         self.model = model
         self.Ecut = float(Ecut)
         self.device = torch.device(device)

@@ -414,6 +414,8 @@ extern "C" int dftk_mi_kblock_create(dftk_mi_basis* b, int64_t n_G, const int64_
     std::vector<double> kin(n_G, 0.0);
     if (kinetic_h) std::copy(kinetic_h, kinetic_h + n_G, kin.begin());
     CHK(upload(kin, &kb->d_kin));
+    kb->h_mapping = new std::vector<int64_t>(mapping0_h, mapping0_h + n_G);
+    kb->h_kin = new std::vector<double>(kin);
     *out = kb;
     return 0;
 }
@@ -429,6 +431,9 @@ extern "C" int dftk_mi_kblock_destroy(dftk_mi_kblock* kb) {
     if (kb->sh_buf) hipFree(kb->sh_buf);
     delete kb->sh_rows;
     delete kb->lob_hist;
+    delete kb->h_mapping;
+    delete kb->h_kin;
+    gamma_destroy(kb->gr);
     delete kb;
     return 0;
 }
@@ -447,6 +452,10 @@ extern "C" int dftk_mi_kblock_set_shard(dftk_mi_kblock* kb, dftk_mi_comm* comm, 
     if (!comm || comm_size(comm) == 1) {      // a one-rank communicator owns the whole sphere: nothing to shard
         kb->sh_comm = nullptr;
         return 0;
+    }
+    if (kb->gr && kb->gr->on) {
+        dftk_set_error("set_shard: the block iterates real-symmetric orbitals (dftk_mi_kblock_set_gamma_real); switch that off first");
+        return DFTK_MI_EINVAL;
     }
     const int p = comm_size(comm);
     if (!row_starts_h || row_starts_h[0] != 0 || row_starts_h[p] != kb->n_G) {
@@ -580,6 +589,7 @@ extern "C" int dftk_mi_kblock_set_projectors(dftk_mi_kblock* kb, int n_p, const 
     }
     kb->n_p = 0;
     kb->P = nullptr;
+    if (kb->gr) kb->gr->P_src = nullptr;   // the half-format copy is rebuilt on its next use
     if (n_p == 0) return 0;
     if (!P_d || !D_h || ldP < local_rows(kb)) return DFTK_MI_EINVAL;
     int bw = 0;
@@ -610,15 +620,15 @@ extern "C" int dftk_mi_kblock_set_potential(dftk_mi_kblock* kb, const double* V_
 }
 
 // ------------------------------------------------------------------------------------ H psi
-static int apply_nonlocal(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, cd* Hpsi, int64_t ldH,
-                          bool accumulate) {
+int apply_nonlocal_rows(dftk_mi_kblock* kb, int nb, const cd* P, int64_t ldP, int64_t rows, const cd* psi,
+                        int64_t ldpsi, cd* Hpsi, int64_t ldH, bool accumulate, int gemm_flags, dftk_mi_comm* comm) {
     // Hpsi (+)= P (D (P' psi))   (operators.jl:126-128)
     dftk_mi_basis* b = kb->basis;
     const cd one = {1.0, 0.0}, zero = {0.0, 0.0};
     if (kb->n_p == 0) {
         if (!accumulate)
             for (int c = 0; c < nb; ++c)
-                HIPCHK(hipMemsetAsync(Hpsi + (int64_t)c * ldH, 0, local_rows(kb) * sizeof(cd), b->stream));
+                HIPCHK(hipMemsetAsync(Hpsi + (int64_t)c * ldH, 0, rows * sizeof(cd), b->stream));
         return 0;
     }
     // scratch for the two n_p x nb panels lives in T1 (free outside the FFT pipeline)
@@ -634,12 +644,16 @@ static int apply_nonlocal(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldp
     cd* Ppsi = b->T1;
     cd* DPpsi = b->T1 + (size_t)kb->n_p * nb;
     // (sharded block: P, psi, Hpsi are row slabs; the projections are partial sums -> one small all-reduce)
-    const int64_t rows = local_rows(kb);
-    CHK(zgemm(b, 'C', kb->n_p, nb, rows, one, kb->P, kb->ldP, psi, ldpsi, zero, Ppsi, kb->n_p));
-    if (kb->sh_comm) CHK(comm_allreduce(kb->sh_comm, b, reinterpret_cast<double*>(Ppsi), 2 * (size_t)kb->n_p * nb));
+    CHK(zgemm(b, 'C', kb->n_p, nb, rows, one, P, ldP, psi, ldpsi, zero, Ppsi, kb->n_p, gemm_flags));
+    if (comm) CHK(comm_allreduce(comm, b, reinterpret_cast<double*>(Ppsi), 2 * (size_t)kb->n_p * nb));
     CHK(apply_D(kb, nb, Ppsi, DPpsi));
-    CHK(zgemm(b, 'N', rows, nb, kb->n_p, one, kb->P, kb->ldP, DPpsi, kb->n_p, accumulate ? one : zero, Hpsi, ldH));
+    CHK(zgemm(b, 'N', rows, nb, kb->n_p, one, P, ldP, DPpsi, kb->n_p, accumulate ? one : zero, Hpsi, ldH, gemm_flags));
     return 0;
+}
+
+static int apply_nonlocal(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, cd* Hpsi, int64_t ldH,
+                          bool accumulate) {
+    return apply_nonlocal_rows(kb, nb, kb->P, kb->ldP, local_rows(kb), psi, ldpsi, Hpsi, ldH, accumulate, 0, kb->sh_comm);
 }
 
 extern "C" int dftk_mi_apply_H_parts(dftk_mi_kblock* kb, int which, int n_bands, const dftk_mi_cplx* psi_d,
@@ -767,6 +781,69 @@ extern "C" int dftk_mi_density_accumulate(dftk_mi_kblock* kb, int n_bands, const
     return launch_density(kb, t.mine, F, kb->n_G, weight_h + t.c0[t.me], rho_d);
 }
 
+// ------------------------------------------------------------------------------------ Gamma-real extension
+extern "C" int dftk_mi_kblock_set_gamma_real(dftk_mi_kblock* kb, int on) {
+    if (!kb) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(kb->basis->device));
+    return gamma_enable(kb, on);
+}
+
+extern "C" int dftk_mi_gamma_tables_host(int nx, int ny, int nz, int64_t n_G, const int64_t* mapping0_h,
+                                         int64_t* n_half, int32_t* row_h, int32_t* partner_row_h) {
+    if (nx < 1 || ny < 1 || nz < 1 || n_G < 1 || !mapping0_h || !n_half) return DFTK_MI_EINVAL;
+    if ((row_h == nullptr) != (partner_row_h == nullptr)) return DFTK_MI_EINVAL;
+    return gamma_tables_host(nx, ny, nz, n_G, mapping0_h, n_half, row_h, partner_row_h);
+}
+
+static int gamma_ready(dftk_mi_kblock* kb) {
+    if (!kb || !kb->gr || !kb->gr->d_g) {
+        dftk_set_error("gamma_real: call dftk_mi_kblock_set_gamma_real(kb, 1) first");
+        return DFTK_MI_EINVAL;
+    }
+    return 0;
+}
+
+extern "C" int dftk_mi_gamma_half_size(dftk_mi_kblock* kb, int64_t* n_half) {
+    if (!n_half) return DFTK_MI_EINVAL;
+    CHK(gamma_ready(kb));
+    *n_half = kb->gr->n_half;
+    return 0;
+}
+
+extern "C" int dftk_mi_gamma_compress(dftk_mi_kblock* kb, int m, const dftk_mi_cplx* X_d, int64_t ldx,
+                                      dftk_mi_cplx* Xh_d, int64_t ldh) {
+    CHK(gamma_ready(kb));
+    if (m < 0 || !X_d || !Xh_d || ldx < kb->n_G || ldh < kb->gr->n_half) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(kb->basis->device));
+    return gamma_compress(kb, m, reinterpret_cast<const cd*>(X_d), ldx, reinterpret_cast<cd*>(Xh_d), ldh);
+}
+
+extern "C" int dftk_mi_gamma_expand(dftk_mi_kblock* kb, int m, const dftk_mi_cplx* Xh_d, int64_t ldh,
+                                    dftk_mi_cplx* X_d, int64_t ldx) {
+    CHK(gamma_ready(kb));
+    if (m < 0 || !X_d || !Xh_d || ldx < kb->n_G || ldh < kb->gr->n_half) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(kb->basis->device));
+    return gamma_expand(kb, m, reinterpret_cast<const cd*>(Xh_d), ldh, reinterpret_cast<cd*>(X_d), ldx);
+}
+
+extern "C" int dftk_mi_gamma_apply_H(dftk_mi_kblock* kb, int which, int n_bands, const dftk_mi_cplx* psih_d,
+                                     int64_t ld_psi, dftk_mi_cplx* Hpsih_d, int64_t ld_Hpsi) {
+    CHK(gamma_ready(kb));
+    if (!psih_d || !Hpsih_d || n_bands < 0 || (which & ~7) || ld_psi < kb->gr->n_half || ld_Hpsi < kb->gr->n_half)
+        return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(kb->basis->device));
+    return gamma_apply_H(kb, which, n_bands, reinterpret_cast<const cd*>(psih_d), ld_psi,
+                         reinterpret_cast<cd*>(Hpsih_d), ld_Hpsi);
+}
+
+extern "C" int dftk_mi_density_accumulate_real(dftk_mi_kblock* kb, int n_bands, const dftk_mi_cplx* psi_d,
+                                               int64_t ld_psi, const double* weight_h, double* rho_d) {
+    if (!kb || !psi_d || !weight_h || !rho_d || n_bands < 0 || ld_psi < kb->n_G || kb->sh_comm) return DFTK_MI_EINVAL;
+    if (n_bands == 0) return 0;
+    HIPCHK(hipSetDevice(kb->basis->device));
+    return gamma_density(kb, n_bands, reinterpret_cast<const cd*>(psi_d), ld_psi, weight_h, rho_d);
+}
+
 extern "C" int dftk_mi_lobpcg(dftk_mi_kblock* kb, int M, dftk_mi_cplx* X_d, int64_t ldX, double tol, int miniter,
                               int maxiter, int n_conv_check, int use_tpa, uint64_t seed, double* lambda_h,
                               double* resid_h, int* n_iter, int* converged, int64_t* n_matvec) {
@@ -801,7 +878,7 @@ extern "C" int dftk_mi_zgemm_plan_host(char transA, int64_t m, int64_t n, int64_
 extern "C" int dftk_mi_zgemm_ex(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, dftk_mi_cplx alpha,
                                 const dftk_mi_cplx* A_d, int64_t lda, const dftk_mi_cplx* B_d, int64_t ldb,
                                 dftk_mi_cplx beta, dftk_mi_cplx* C_d, int64_t ldc, int flags) {
-    if (!b || m < 0 || n < 0 || k < 0 || !C_d || (flags & ~3)) return DFTK_MI_EINVAL;
+    if (!b || m < 0 || n < 0 || k < 0 || !C_d || (flags & ~(3 | DFTK_MI_GEMM_REAL))) return DFTK_MI_EINVAL;
     HIPCHK(hipSetDevice(b->device));
     cd al = {alpha.re, alpha.im}, be = {beta.re, beta.im};
     return zgemm(b, transA, m, n, k, al, reinterpret_cast<const cd*>(A_d), lda, reinterpret_cast<const cd*>(B_d), ldb,

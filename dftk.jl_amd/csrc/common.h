@@ -86,6 +86,8 @@ enum ProfFamily {
     PROF_ZGEMM_EXEC = 12,    // no timing: real flops the launched tiles execute on the matrix pipe, all zgemm calls
                              // (3M kernel: 6 per complex multiply-add, 4M: 8; full tiles incl. shifted/border recompute)
     PROF_COMM = 13,          // collectives of a sharded k-block (work = bytes handed to the communicator)
+    PROF_ZGEMM_CPLX = 14,    // no timing: useful flops of all zgemm calls as if none were REAL (a DFTK_MI_GEMM_REAL call
+                             // stands for a complex product of twice its flops): what the general complex path needs
     PROF_NFAM = 16
 };
 struct Prof {
@@ -103,6 +105,19 @@ struct Prof {
 int prof_begin(dftk_mi_basis* b, int fam, double work, uint64_t tag = 0);   // returns slot index or -1
 void prof_end(dftk_mi_basis* b, int slot);
 int prof_resolve(dftk_mi_basis* b);
+
+// real-symmetric orbitals of a Gamma-point block (gamma_kernels.hip)
+struct GammaReal {
+    bool on = false;              // dftk_mi_lobpcg iterates in the half-sphere format
+    int64_t n_half = 0;           // (n_G + 1) / 2
+    int *d_g = nullptr, *d_mg = nullptr;   // [n_half] sphere rows of G_j and -G_j (j = 0: G = 0)
+    double* d_kin_half = nullptr;
+    cd* P_half = nullptr;         // n_half x n_p, scaled like the vectors (built on first use)
+    const cd* P_src = nullptr;
+    int P_n_p = 0;
+    cd* buf = nullptr;            // pack / unpack scratch
+    size_t buf_bytes = 0;
+};
 
 struct dftk_mi_kblock {
     dftk_mi_basis* basis;
@@ -138,6 +153,10 @@ struct dftk_mi_kblock {
     cd* sh_buf; size_t sh_bytes;     // transpose buffers (owned, grown on demand)
     // residual history of the last dftk_mi_lobpcg call: hist[i + M * it], it = 0 .. n_iter (host, owned)
     std::vector<double>* lob_hist; int lob_hist_M, lob_hist_iters, lob_n_svd;
+    // host copies of the sphere (pair tables of the Gamma-real format are built from them on demand)
+    std::vector<int64_t>* h_mapping;
+    std::vector<double>* h_kin;
+    GammaReal* gr;                   // owned; null until dftk_mi_kblock_set_gamma_real / density_accumulate_real
 };
 
 // ------------------------------------------------------------------------------------ internal API
@@ -147,8 +166,9 @@ int launch_local_apply(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi,
                        int64_t ldout, bool add_kinetic, bool have_local);
 int launch_ifft_to_cube(dftk_mi_kblock* kb, const cd* c, cd* cube);
 int launch_fft_from_cube(dftk_mi_kblock* kb, const cd* cube, cd* c);
+// w_im_h (optional): separate weights for the squared IMAGINARY parts (two real bands packed into one transform)
 int launch_density(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, const double* w_h,
-                   double* rho);
+                   double* rho, const double* w_im_h = nullptr);
 int launch_pad_potential(dftk_mi_kblock* kb, const double* V);
 int launch_kinetic_only(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, cd* out,
                         int64_t ldout, bool accumulate, bool use_kin);
@@ -222,6 +242,20 @@ int build_projectors_hgh(dftk_mi_basis* b, int64_t n_rows, const int32_t* G_d, c
 
 int atomic_superposition(dftk_mi_kblock* cube_kb, int kind, const double* recip_h, int n_species, const double* par_h,
                          int n_atoms, const int* species_of_atom_h, const double* positions_h, double* out_d);
+
+// gamma_kernels.hip
+int gamma_tables_host(int nx, int ny, int nz, int64_t n_G, const int64_t* mapping, int64_t* n_half_out, int32_t* g,
+                      int32_t* mg);
+int gamma_enable(dftk_mi_kblock* kb, int on);
+void gamma_destroy(GammaReal* gr);
+int gamma_compress(dftk_mi_kblock* kb, int m, const cd* X, int64_t ldx, cd* H, int64_t ldh);
+int gamma_expand(dftk_mi_kblock* kb, int m, const cd* H, int64_t ldh, cd* X, int64_t ldx);
+int gamma_apply_H(dftk_mi_kblock* kb, int which, int nb, const cd* psi, int64_t ldpsi, cd* Hpsi, int64_t ldH);
+int gamma_density(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, const double* w_h, double* rho);
+// api.cpp: Hpsi (+)= P D P' psi on `rows` rows of projector storage P (leading dimension ldP); gemm_flags is OR-ed
+// into the two products (DFTK_MI_GEMM_REAL for half-format blocks); comm (nullable) all-reduces the projections
+int apply_nonlocal_rows(dftk_mi_kblock* kb, int nb, const cd* P, int64_t ldP, int64_t rows, const cd* psi,
+                        int64_t ldpsi, cd* Hpsi, int64_t ldH, bool accumulate, int gemm_flags, dftk_mi_comm* comm);
 
 // lobpcg.cpp
 // ortho!(X) (Cholesky-QR with the reference's shift-and-retry and SVD fallback) on a stand-alone block;

@@ -540,10 +540,13 @@ __global__ __launch_bounds__(FFT_THREADS, YFWD_MIN_BLOCKS) void k_xfwd_gather(Ff
 
 // ---------------------------------------------------------------------------------------- density
 // rho[z,y,x] += sum_band w[band] |BFFT_z(T2[band])|^2 ; one workgroup owns an (x-tile, y) column set.
+// wim (nullable): the squared imaginary part is weighted with wim[band] instead (two real-symmetric orbitals packed
+// as a + i b into one transform, gamma_kernels.hip: rho += w Re^2 + wim Im^2).
 template <bool GEN>
 __global__ __launch_bounds__(FFT_THREADS, DENS_MIN_BLOCKS) void k_zdensity(FftAxis az, int nx, int nxp, int ny, int nzx,
                                                           const int* __restrict__ zpos, int nb,
                                                           const double* __restrict__ w,
+                                                          const double* __restrict__ wim,
                                                           const cd* __restrict__ T2, int64_t T2_stride,
                                                           double* __restrict__ rho) {
     constexpr int FFT_LS = FFT_LS_YZ;
@@ -560,7 +563,8 @@ __global__ __launch_bounds__(FFT_THREADS, DENS_MIN_BLOCKS) void k_zdensity(FftAx
     for (int t = tid; t < nz; t += FFT_THREADS) tw[t] = az.tw[t];
     for (int ib = 0; ib < nb; ++ib) {
         const double wb = w[ib];
-        if (wb == 0.0) continue;   // uniform across the block
+        const double wi = wim ? wim[ib] : wb;
+        if (wb == 0.0 && wi == 0.0) continue;   // uniform across the block
         const cd z0 = make_double2(0.0, 0.0);
         for (int t = tid; t < nz * FFT_LS; t += FFT_THREADS) buf[t] = z0;
         __syncthreads();
@@ -573,7 +577,7 @@ __global__ __launch_bounds__(FFT_THREADS, DENS_MIN_BLOCKS) void k_zdensity(FftAx
             const int z = j + k * FFT_TPL;
             if (z < nz) {
                 const cd v = buf[z * FFT_LS + l];
-                acc[k] = fma(wb, fma(v.x, v.x, v.y * v.y), acc[k]);
+                acc[k] = fma(wb, v.x * v.x, fma(wi, v.y * v.y, acc[k]));
             }
         }
         __syncthreads();
@@ -799,7 +803,8 @@ int launch_fft_from_cube(dftk_mi_kblock* kb, const cd* cube, cd* c) {
     return 0;
 }
 
-int launch_density(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, const double* w_h, double* rho) {
+int launch_density(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, const double* w_h, double* rho,
+                   const double* w_im_h) {
     dftk_mi_basis* b = kb->basis;
     CHK(check_lds(b));
     if (b->nz > DENS_MAXACC * FFT_TPL) {
@@ -811,19 +816,21 @@ int launch_density(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, con
     const Strides st = strides(kb);
     // all weights go to the device once (general workspace; the copy from the caller's pageable array is
     // staged by the runtime before the call returns) -- no host synchronisation between the band batches
-    CHK(ensure_ws(b, (size_t)nb * sizeof(double)));
+    CHK(ensure_ws(b, 2 * (size_t)nb * sizeof(double)));
     double* w_d = reinterpret_cast<double*>(b->ws);
+    double* wim_d = w_im_h ? w_d + nb : nullptr;
     HIPCHK(hipMemcpyAsync(w_d, w_h, (size_t)nb * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    if (w_im_h) HIPCHK(hipMemcpyAsync(wim_d, w_im_h, (size_t)nb * sizeof(double), hipMemcpyHostToDevice, b->stream));
     for (int b0 = 0; b0 < nb; b0 += batch) {
         const int nbb = (nb - b0) < batch ? (nb - b0) : batch;
         bool any = false;
-        for (int i = 0; i < nbb; ++i) any = any || (w_h[b0 + i] != 0.0);
+        for (int i = 0; i < nbb; ++i) any = any || (w_h[b0 + i] != 0.0) || (w_im_h && w_im_h[b0 + i] != 0.0);
         if (!any) continue;
         CHK(run_AB(kb, nbb, psi + (int64_t)b0 * ldpsi, ldpsi));
         const int pz = prof_begin(b, PROF_DENS_Z, 16.0 * (double)kb->nzx * b->ny * b->nxp * nbb +
                                                       16.0 * (double)b->nx * b->ny * b->nz);   // T2 per band + rho read-modify-write
-        LAUNCH_FFT(k_zdensity, b->ax[2], dim3(b->nxp / FFT_L, b->ny), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, kb->d_zpos, nbb, w_d + b0, b->T2, st.s2,
-                           rho);
+        LAUNCH_FFT(k_zdensity, b->ax[2], dim3(b->nxp / FFT_L, b->ny), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, kb->d_zpos, nbb, w_d + b0,
+                           wim_d ? wim_d + b0 : (const double*)nullptr, b->T2, st.s2, rho);
         prof_end(b, pz);
     }
     HIPCHK(hipGetLastError());

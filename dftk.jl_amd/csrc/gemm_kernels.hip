@@ -399,6 +399,8 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_lds(int m, int n, int
 #define M3_HINT(a, b, c) __builtin_amdgcn_sched_group_barrier(a, b, c)
 #endif
 #define M3_BN (16 * M3_RN)
+#define M3_RN_REAL 4
+#define M3_BN_REAL (16 * M3_RN_REAL)
 // workgroups per CU the kernel is compiled for.  3 for the M-major variant (168 VGPRs) is as fast as 2,
 // but with 12 instead of 8 row panels in flight per XCD the column tiles of a panel drift apart in k and
 // re-fetch their A tiles: FETCH_SIZE 4.0x the operand bytes against 1.55x -> 2.  The K-major variant
@@ -407,15 +409,23 @@ __global__ __launch_bounds__(GEMM_WAVES * 64) void k_zgemm_lds(int m, int n, int
 #define M3_N_BLOCKS 2
 #endif
 #define M3_MIN_BLOCKS(CONJA) ((CONJA) ? 2 : M3_N_BLOCKS)
-template <bool CONJA, int MODE>
+// REAL (flag DFTK_MI_GEMM_REAL of zgemm): the operands are blocks of REAL-SYMMETRIC plane-wave vectors in the
+// half-sphere format (gamma_kernels.hip), i.e. really REAL matrices with two real rows per complex entry:
+//   conj(A)' B -> Re(A^H B) = Ar' Br + Ai' Bi   (the imaginary part vanishes mathematically; stored as 0)
+//   A B        -> A * Re(B): Re = Ar Br, Im = Ai Br   (B is a real coefficient matrix stored as complex)
+// TWO real MFMA streams per complex entry instead of three -- exactly the flops of the equivalent dgemm.
+template <bool CONJA, int MODE, bool REAL, int RN>
 __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm_3m(int m, int n, int K, int kchunk, int gm, int gn,
                                                                int rt0, int ct0, int lsplit, int upper,
-                                                               int shift_ct, int nsplit, const cd* __restrict__ A, int64_t lda,
+                                                               int shift_ct, int shift_rt, int nsplit, const cd* __restrict__ A, int64_t lda,
                                                                const cd* __restrict__ B, int64_t ldb,
                                                                cd* __restrict__ C, int64_t ldc, cd alpha, cd beta,
                                                                cd* __restrict__ slab) {
+    constexpr int BN = 16 * RN;      // column-tile width: 32 (3M complex), 64 (REAL: the third product's registers
+                                     // hold a second pair of accumulator columns -> 1.7x the flops per operand byte)
+    static_assert(RN == 2 || RN == 4, "B staging handles one or two columns per thread");
     __shared__ cd sA[2][LT_KT][GEMM_BM];
-    __shared__ cd sB[2][LT_KT][M3_BN];
+    __shared__ cd sB[2][LT_KT][BN];
     const int id = blockIdx.x;
     const int xcd = id & 7, slot = id >> 3;
     int z, row_t, col_t;
@@ -454,27 +464,31 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm
     // its neighbour, recomputes up to 31 columns and stores only columns >= jmin.  A ragged n then needs no
     // right-strip launch (which would stream all of A a second time for a handful of columns).
     const bool shifted = tcn == shift_ct;
-    const int I0 = tr * GEMM_BM, J0 = shifted ? n - M3_BN : tcn * M3_BN;
-    const int jmin = shifted ? tcn * M3_BN : 0;
-    if ((upper & 1) && I0 >= J0 + M3_BN) return;   // tile strictly below the diagonal (whole workgroup)
+    // likewise tile row shift_rt (the one past the last full row) is SHIFTED UP to end at row m and stores only
+    // rows >= imin: a ragged m needs no bottom-strip launch (a second, serialized launch of slow predicated
+    // workgroups whose k chains are as long as the interior's)
+    const bool rshifted = tr == shift_rt;
+    const int I0 = rshifted ? m - GEMM_BM : tr * GEMM_BM, J0 = shifted ? n - BN : tcn * BN;
+    const int jmin = shifted ? tcn * BN : 0, imin = tr * GEMM_BM;
+    if ((upper & 1) && imin >= J0 + BN) return;   // no needed entry (i <= j) in this tile (whole workgroup)
     const int i0 = I0 + wave * (GEMM_RM * 16);
     const int kbeg = z * kchunk;
     // bit 1 of `upper`: B is upper triangular (B[k][j] = 0 for k > j) -> this tile column stops at k = J0 + BN
-    const int kend = min(min(K, kbeg + kchunk), (upper & 2) ? J0 + M3_BN : K);
+    const int kend = min(min(K, kbeg + kchunk), (upper & 2) ? J0 + BN : K);
     // MODE 1: every tile of the launch is full (no predicates anywhere).  MODE 0: predicated only.
     constexpr bool FULL = MODE == 1;
     const int rmv = FULL ? GEMM_RM : min(GEMM_RM, max(0, (m - i0 + 15) >> 4));
-    const int rnv = FULL ? M3_RN : min(M3_RN, max(0, (n - J0 + 15) >> 4));
+    const int rnv = FULL ? RN : min(RN, max(0, (n - J0 + 15) >> 4));
     const bool active = FULL || (rmv > 0 && rnv > 0);
 
     // three real products per complex one (Karatsuba / "3M"):
     //   P1 = sum Ar Br, P2 = sum Ai Bi, P3 = sum (Ar +/- Ai)(Br + Bi)   (- for conj(A))
     //   A B      : Re = P1 - P2, Im = P3 - P1 - P2 ;   conj(A) B: Re = P1 + P2, Im = P3 - P1 + P2
-    v4d acc1[GEMM_RM][M3_RN], acc2[GEMM_RM][M3_RN], acc3[GEMM_RM][M3_RN];
+    v4d acc1[GEMM_RM][RN], acc2[GEMM_RM][RN], acc3[GEMM_RM][RN];
 #pragma unroll
     for (int a = 0; a < GEMM_RM; ++a)
 #pragma unroll
-        for (int b = 0; b < M3_RN; ++b) {
+        for (int b = 0; b < RN; ++b) {
             acc1[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
             acc2[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
             acc3[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -486,7 +500,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm
     const int tk = tid & 7, tc = tid >> 3;
     // running per-thread source pointers (named scalars: arrays captured by lambdas end up in scratch);
     // every load advances them by one k-tile
-    const cd *pA0, *pA1, *pA2, *pA3, *pB0;
+    const cd *pA0, *pA1, *pA2, *pA3, *pB0, *pB1;
     {
         auto a_ptr = [&](int r) -> const cd* {
             if (CONJA) {
@@ -509,10 +523,11 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm
         pA2 = a_ptr(2);
         pA3 = a_ptr(3);
         pB0 = b_ptr(0);
+        pB1 = b_ptr(RN == 4 ? 1 : 0);
     }
     const int64_t stepA = CONJA ? (int64_t)LT_KT : (int64_t)LT_KT * lda;
     struct Stage {
-        cd a0, a1, a2, a3, b0;
+        cd a0, a1, a2, a3, b0, b1;
     };
     auto advance = [&]() {
         pA0 += stepA;
@@ -520,6 +535,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm
         pA2 += stepA;
         pA3 += stepA;
         pB0 += LT_KT;
+        if (RN == 4) pB1 += LT_KT;
     };
     // tile entirely inside [kbeg, kend): plain loads
     auto load_fast = [&]() -> Stage {
@@ -529,6 +545,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm
         st.a2 = *pA2;
         st.a3 = *pA3;
         st.b0 = *pB0;
+        if (RN == 4) st.b1 = *pB1;
         advance();
         return st;
     };
@@ -549,6 +566,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm
             st.a3 = *(pA3 - (int64_t)max(0, kk + 6) * lda);
         }
         st.b0 = *(pB0 - oB);
+        if (RN == 4) st.b1 = *(pB1 - oB);
         advance();
         return st;
     };
@@ -565,7 +583,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm
             if (kk + 4 >= kend) st.a2 = czero;
             if (kk + 6 >= kend) st.a3 = czero;
         }
-        if (!vB) st.b0 = czero;
+        if (!vB) st.b0 = st.b1 = czero;
         return st;
     };
     auto store_tile = [&](int buf, const Stage& st) {
@@ -582,10 +600,11 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm
             sA[buf][kk + 6][ii] = st.a3;
         }
         sB[buf][tk][(tc) ^ tk] = st.b0;
+        if (RN == 4) sB[buf][tk][(tc + 32) ^ tk] = st.b1;
     };
     // MFMA fragments of one k-half of a tile: half h holds k = 2*lk + h (lk = lane >> 4)
     struct Frag {
-        cd a[GEMM_RM], b[M3_RN];
+        cd a[GEMM_RM], b[RN];
     };
     auto read_frag = [&](int buf, int h) -> Frag {
         Frag f;
@@ -596,7 +615,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm
             f.a[a] = sA[buf][kk][CONJA ? (c ^ kk) : c];
         }
 #pragma unroll
-        for (int b = 0; b < M3_RN; ++b) {
+        for (int b = 0; b < RN; ++b) {
             const int c = b * 16 + li;
             f.b[b] = sB[buf][kk][c ^ kk];
         }
@@ -604,23 +623,31 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm
     };
     auto mfma_half = [&](const Frag& f, auto nopred_tag) {
         constexpr bool NOPRED = decltype(nopred_tag)::value;
-        double bs[M3_RN];
+        double bs[RN];
 #pragma unroll
-        for (int b = 0; b < M3_RN; ++b) bs[b] = f.b[b].x + f.b[b].y;
+        for (int b = 0; b < RN; ++b) bs[b] = f.b[b].x + f.b[b].y;
 #pragma unroll
         for (int a = 0; a < GEMM_RM; ++a) {
             if (NOPRED || a < rmv) {
                 const double ar = f.a[a].x, ai = f.a[a].y;
                 const double as = CONJA ? ar - ai : ar + ai;
 #pragma unroll
-                for (int b = 0; b < M3_RN; ++b)
+                for (int b = 0; b < RN; ++b)
                     if (NOPRED || b < rnv) acc1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, f.b[b].x, acc1[a][b], 0, 0, 0);
 #pragma unroll
-                for (int b = 0; b < M3_RN; ++b)
-                    if (NOPRED || b < rnv) acc2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, f.b[b].y, acc2[a][b], 0, 0, 0);
+                for (int b = 0; b < RN; ++b)
+                    if (NOPRED || b < rnv) {
+                        if (REAL && CONJA)   // Re(conj(a) b) = ar br + ai bi: ONE accumulator
+                            acc1[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, f.b[b].y, acc1[a][b], 0, 0, 0);
+                        else
+                            acc2[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, REAL ? f.b[b].x : f.b[b].y, acc2[a][b],
+                                                                              0, 0, 0);
+                    }
+                if (!REAL) {
 #pragma unroll
-                for (int b = 0; b < M3_RN; ++b)
-                    if (NOPRED || b < rnv) acc3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, bs[b], acc3[a][b], 0, 0, 0);
+                    for (int b = 0; b < RN; ++b)
+                        if (NOPRED || b < rnv) acc3[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, bs[b], acc3[a][b], 0, 0, 0);
+                }
             }
         }
     };
@@ -650,12 +677,12 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm
                 st = load_fast();
                 mfma_half(f0, std::true_type{});
 #pragma unroll
-                for (int i = 0; i < GEMM_RM + M3_RN; ++i) {
+                for (int i = 0; i < GEMM_RM + RN; ++i) {
                     M3_HINT(0x008, 1, 0);   // 1 MFMA
                     M3_HINT(0x100, 1, 0);   // 1 DS read
                 }
 #pragma unroll
-                for (int i = 0; i < 5; ++i) {
+                for (int i = 0; i < 4 + RN / 2; ++i) {
                     M3_HINT(0x008, 1, 0);   // 1 MFMA
                     M3_HINT(0x200, 1, 0);   // 1 DS write
                     M3_HINT(0x020, 1, 0);   // 1 VMEM read
@@ -665,7 +692,7 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm
                 f0 = read_frag((t + 1) & 1, 0);
                 mfma_half(f1, std::true_type{});
 #pragma unroll
-                for (int i = 0; i < GEMM_RM + M3_RN; ++i) {
+                for (int i = 0; i < GEMM_RM + RN; ++i) {
                     M3_HINT(0x008, 2, 1);
                     M3_HINT(0x100, 1, 1);
                 }
@@ -703,15 +730,15 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm
 #pragma unroll
     for (int a = 0; a < GEMM_RM; ++a)
 #pragma unroll
-        for (int b = 0; b < M3_RN; ++b)
+        for (int b = 0; b < RN; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gi = i0 + a * 16 + lk + 4 * r;
                 const int gj = j0 + b * 16 + li;
-                if (gi < m && gj < n && gj >= jmin) {
+                if (gi < m && gj < n && gj >= jmin && gi >= imin) {
                     const double p1 = acc1[a][b][r], p2 = acc2[a][b][r], p3 = acc3[a][b][r];
-                    const double vr = CONJA ? p1 + p2 : p1 - p2;
-                    const double vi = CONJA ? p3 - p1 + p2 : p3 - p1 - p2;
+                    const double vr = REAL ? p1 : (CONJA ? p1 + p2 : p1 - p2);
+                    const double vi = REAL ? (CONJA ? 0.0 : p2) : (CONJA ? p3 - p1 + p2 : p3 - p1 - p2);
                     if (direct) {
                         cd* c = C + gi + (int64_t)gj * ldc;
                         cd o = make_double2(alpha.x * vr - alpha.y * vi, alpha.x * vi + alpha.y * vr);
@@ -763,7 +790,7 @@ __global__ void k_zgemm_reduce(int m, int n, int mi, int nj, int nsI, const cd* 
 template <bool CONJA>
 __global__ void k_zgemm_naive(int m, int n, int K, const cd* __restrict__ A, int64_t lda,
                               const cd* __restrict__ B, int64_t ldb, cd* __restrict__ C, int64_t ldc, cd alpha,
-                              cd beta) {
+                              cd beta, int real) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)m * n) return;
     const int j = (int)(idx / m);
@@ -772,10 +799,12 @@ __global__ void k_zgemm_naive(int m, int n, int K, const cd* __restrict__ A, int
     for (int k = 0; k < K; ++k) {
         cd a = CONJA ? A[k + (int64_t)i * lda] : A[i + (int64_t)k * lda];
         if (CONJA) a.y = -a.y;
-        const cd b = B[k + (int64_t)j * ldb];
+        cd b = B[k + (int64_t)j * ldb];
+        if (real && !CONJA) b.y = 0.0;
         sr += a.x * b.x - a.y * b.y;
         si += a.x * b.y + a.y * b.x;
     }
+    if (real && CONJA) si = 0.0;
     cd* c = C + i + (int64_t)j * ldc;
     cd o = make_double2(alpha.x * sr - alpha.y * si, alpha.x * si + alpha.y * sr);
     if (beta.x != 0.0 || beta.y != 0.0) {
@@ -907,7 +936,7 @@ static Split gemm_plan_split(int64_t m, int64_t n, int64_t k, int upper, const s
         } else {
             int64_t max_ns = k >= 2048 ? k / 256 : k / 64;
             if (max_ns > 1024) max_ns = 1024;
-            const int64_t max_by_ws = (int64_t)(256ull << 20) / plane;   // each slab <= 256 MiB
+            const int64_t max_by_ws = (int64_t)(1024ull << 20) / plane;   // all slabs of a launch <= 1 GiB
             if (max_ns > max_by_ws) max_ns = max_by_ws;
             if (max_ns > 2 * slots / total + 8) max_ns = 2 * slots / total + 8;
             if (max_ns < 1) max_ns = 1;
@@ -942,6 +971,11 @@ static Split gemm_plan_split(int64_t m, int64_t n, int64_t k, int upper, const s
             plan_cache[key] = {best_ns, best_zm};
         }
     }
+    static const int force_ns = getenv("DFTK_MI_GEMM_FORCE_NS") ? atoi(getenv("DFTK_MI_GEMM_FORCE_NS")) : 0;   // experiments
+    if (force_ns > 0 && kind >= 3 && (kind & 1) && k >= 4096) {
+        best_ns = force_ns;
+        best_zm = 0;
+    }
     int kc = (int)((k + best_ns - 1) / best_ns);
     kc = (kc + 7) & ~7;
     const int ns = (int)((k + kc - 1) / kc);
@@ -954,12 +988,21 @@ struct GemmTiling {
     int BNt, gm, gmf, gnf, gnt, nright, nbottom;
     int shift;   // 1: the ragged last tile column is a full tile shifted left (3M kernel), no right strip
     int gnI;     // tile columns of the interior launch = gnf + shift
+    int shift_r; // 1: the ragged last tile row is a full tile shifted up, no bottom strip
+    int gmI;     // tile rows of the interior launch = gmf + shift_r
     Split I, B;
 };
-static GemmTiling gemm_tiling(bool conja, int64_t m, int64_t n, int64_t k, int upper, bool use3m) {
+// column tiles of the REAL kernels: 16 * RN wide; RN per operand layout (env DFTK_MI_REAL_RN_C / _N = 2 | 4)
+static int real_rn(bool conja) {
+    static const int rc = getenv("DFTK_MI_REAL_RN_C") ? atoi(getenv("DFTK_MI_REAL_RN_C")) : M3_RN_REAL;
+    static const int rn = getenv("DFTK_MI_REAL_RN_N") ? atoi(getenv("DFTK_MI_REAL_RN_N")) : M3_RN_REAL;
+    const int v = conja ? rc : rn;
+    return v == 2 ? 2 : 4;
+}
+static GemmTiling gemm_tiling(bool conja, int64_t m, int64_t n, int64_t k, int upper, bool use3m, bool real = false) {
     GemmTiling t;
     const int64_t slots2 = gemm_slots2();
-    t.BNt = use3m ? M3_BN : GEMM_BN;                            // column-tile width of this kernel family
+    t.BNt = real ? 16 * real_rn(conja) : use3m ? M3_BN : GEMM_BN;   // column-tile width of this kernel family
     t.gm = (int)((m + GEMM_BM - 1) / GEMM_BM);
     t.gnt = (int)((n + t.BNt - 1) / t.BNt);
     t.gmf = (int)(m / GEMM_BM);
@@ -967,15 +1010,17 @@ static GemmTiling gemm_tiling(bool conja, int64_t m, int64_t n, int64_t k, int u
     static const bool no_shift = getenv("DFTK_MI_GEMM_NO_SHIFT") != nullptr;
     t.shift = (use3m && !no_shift && t.gnt > t.gnf && t.gnf >= 1) ? 1 : 0;
     t.gnI = t.gnf + t.shift;
+    t.shift_r = (use3m && !no_shift && t.gm > t.gmf && t.gmf >= 1) ? 1 : 0;
+    t.gmI = t.gmf + t.shift_r;
     t.nright = (t.gnt > t.gnf && !t.shift) ? t.gm : 0;
-    t.nbottom = (t.gm > t.gmf) ? t.gnI : 0;
+    t.nbottom = (t.gm > t.gmf && !t.shift_r) ? t.gnI : 0;
     // live column tiles per tile row of each launch (upper: only tiles that intersect the upper triangle)
     auto live = [&](int tr, int tc) {
         const int64_t jend = (t.shift && tc == t.gnf) ? n : (int64_t)tc * t.BNt + t.BNt;
         return !(upper & 1) || (int64_t)tr * GEMM_BM < jend;
     };
-    std::vector<int> rowsI(t.gmf, 0), rowsB(t.nright + t.nbottom, 0);
-    for (int tr = 0; tr < t.gmf; ++tr)
+    std::vector<int> rowsI(t.gmI, 0), rowsB(t.nright + t.nbottom, 0);
+    for (int tr = 0; tr < t.gmI; ++tr)
         for (int tc = 0; tc < t.gnI; ++tc) rowsI[tr] += live(tr, tc) ? 1 : 0;
     for (int e = 0; e < t.nright; ++e) rowsB[e] = live(e, t.gnf) ? 1 : 0;
     for (int e = 0; e < t.nbottom; ++e) rowsB[t.nright + e] = live(t.gmf, e) ? 1 : 0;
@@ -986,9 +1031,11 @@ static GemmTiling gemm_tiling(bool conja, int64_t m, int64_t n, int64_t k, int u
     return t;
 }
 int zgemm_plan_host(char transA, int64_t m, int64_t n, int64_t k, int flags, int* out) {
-    if (m <= 0 || n <= 0 || k <= 0 || (flags & ~3) || !out) return DFTK_MI_EINVAL;
+    if (m <= 0 || n <= 0 || k <= 0 || (flags & ~(3 | DFTK_MI_GEMM_REAL)) || !out) return DFTK_MI_EINVAL;
     const bool conja = (transA == 'C' || transA == 'c');
-    const GemmTiling t = gemm_tiling(conja, m, n, k, flags, getenv("DFTK_MI_GEMM_4M") == nullptr);
+    const GemmTiling t = gemm_tiling(conja, m, n, k, flags & 3,
+                                     getenv("DFTK_MI_GEMM_4M") == nullptr || (flags & DFTK_MI_GEMM_REAL),
+                                     (flags & DFTK_MI_GEMM_REAL) != 0);
     const int v[12] = {t.BNt, t.gmf, t.gnf, t.nright, t.nbottom, t.I.nsplit, t.I.kchunk, t.I.zmajor ? 1 : 0,
                        t.B.nsplit, t.B.kchunk, t.B.zmajor ? 1 : 0, t.shift};
     for (int i = 0; i < 12; ++i) out[i] = v[i];
@@ -997,7 +1044,8 @@ int zgemm_plan_host(char transA, int64_t m, int64_t n, int64_t k, int flags, int
 
 int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alpha, const cd* A, int64_t lda,
           const cd* B, int64_t ldb, cd beta, cd* C, int64_t ldc, int upper_in) {
-    const int upper = upper_in;
+    const int upper = upper_in & 3;
+    const bool real = (upper_in & DFTK_MI_GEMM_REAL) != 0;   // operands are real-symmetric half-sphere blocks
     if (m <= 0 || n <= 0) return 0;
     const bool conja = (transA == 'C' || transA == 'c');
     if (!conja && !(transA == 'N' || transA == 'n')) {
@@ -1017,24 +1065,27 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
     const uint64_t tag = !shapes ? 0
                                  : ((uint64_t)conja << 63) | ((uint64_t)(m & 0xFFFFF) << 42) |
                                        ((uint64_t)(n & 0xFFFFF) << 22) | (uint64_t)(k & 0x3FFFFF) | (1ull << 62);
-    static const bool use3m = getenv("DFTK_MI_GEMM_4M") == nullptr;   // DFTK_MI_GEMM_4M=1: classic 4-product kernels
-    const GemmTiling til = gemm_tiling(conja, m, n, k, upper, use3m);
+    static const bool use3m_env = getenv("DFTK_MI_GEMM_4M") == nullptr;   // DFTK_MI_GEMM_4M=1: classic 4-product kernels
+    const bool use3m = use3m_env || real;                                  // (the REAL product only exists in the 3M family)
+    const GemmTiling til = gemm_tiling(conja, m, n, k, upper, use3m, real);
     // Flop booking (bench.py roofline).  `useful` = the part of the product that is mathematically needed:
     // 8mnk for an unstructured call, only the (i <= j) entries of C for UPPER, only k <= j for a triangular B.
     // `executed` = what the launched tiles really run on the matrix pipe (whole tiles, shifted-tile and border
     // recompute included; 6 real flops per complex multiply-add in the 3M kernels, 8 in the 4M ones).
     double useful = 0.0, executed = 0.0;
     if (b->prof && b->prof->on) {
+        // a REAL call is a real GEMM with twice the rows (or inner dimension): 2 * (2 m n k) flops, no 3M saving
+        const double mac_useful = real ? 4.0 : 8.0;
         if (!(upper & 3)) {
-            useful = 8.0 * (double)m * (double)n * (double)k;
+            useful = mac_useful * (double)m * (double)n * (double)k;
         } else {
             for (int64_t j = 0; j < n; ++j) {
                 const double rows = (upper & 1) ? (double)std::min<int64_t>(m, j + 1) : (double)m;
                 const double kk = (upper & 2) ? (double)std::min<int64_t>(k, j + 1) : (double)k;
-                useful += 8.0 * rows * kk;
+                useful += mac_useful * rows * kk;
             }
         }
-        const double per_mac = (b->use_mfma && use3m) ? 6.0 : 8.0;
+        const double per_mac = real ? 4.0 : (b->use_mfma && use3m) ? 6.0 : 8.0;
         const int BNt = til.BNt;
         auto kext = [&](int tc) {   // k range a tile column runs (triangular B stops at the diagonal)
             const int64_t j0 = (til.shift && tc == til.gnf) ? n - BNt : (int64_t)tc * BNt;
@@ -1044,7 +1095,7 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
             const int64_t jend = (til.shift && tc == til.gnf) ? n : std::min<int64_t>(n, (int64_t)tc * BNt + BNt);
             return !(upper & 1) || i0 < jend;
         };
-        for (int tr = 0; tr < til.gmf; ++tr)
+        for (int tr = 0; tr < til.gmI; ++tr)
             for (int tc = 0; tc < til.gnI; ++tc)
                 if (live((int64_t)tr * GEMM_BM, tc)) executed += per_mac * GEMM_BM * BNt * kext(tc);
         const int64_t mrem = m - (int64_t)til.gmf * GEMM_BM;
@@ -1062,6 +1113,7 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
         b->prof->work[PROF_ZGEMM_BYTES] += 16.0 * ((double)m * k + (double)k * n +
                                                    (double)m * n * ((beta.x != 0.0 || beta.y != 0.0) ? 2.0 : 1.0));
         b->prof->work[PROF_ZGEMM_EXEC] += executed;
+        b->prof->work[PROF_ZGEMM_CPLX] += real ? 2.0 * useful : useful;
     }
     struct ProfGuard {
         dftk_mi_basis* b;
@@ -1072,10 +1124,10 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
         const unsigned blocks = (unsigned)((m * n + 255) / 256);
         if (conja)
             hipLaunchKernelGGL(k_zgemm_naive<true>, dim3(blocks), dim3(256), 0, b->stream, (int)m, (int)n, (int)k, A,
-                               lda, B, ldb, C, ldc, alpha, beta);
+                               lda, B, ldb, C, ldc, alpha, beta, real ? 1 : 0);
         else
             hipLaunchKernelGGL(k_zgemm_naive<false>, dim3(blocks), dim3(256), 0, b->stream, (int)m, (int)n, (int)k,
-                               A, lda, B, ldb, C, ldc, alpha, beta);
+                               A, lda, B, ldb, C, ldc, alpha, beta, real ? 1 : 0);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -1105,22 +1157,27 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
         const int64_t nblk = zmajor ? (int64_t)((sp.nsplit + 7) / 8) * 8 * gm_s * gn_s : grid_for(gm_s, gn_s, sp.nsplit);
         if (nblk > INT32_MAX) return DFTK_MI_EINVAL;
         dim3 grid((unsigned)nblk);
-        const int upper = upper_in | (zmajor ? 4 : 0);
+        const int upper = (upper_in & 3) | (zmajor ? 4 : 0);
 #define DFTK_LAUNCH_LDS(CJ, FL)                                                                                        \
     hipLaunchKernelGGL((k_zgemm_lds<CJ, FL>), grid, dim3(GEMM_WAVES * 64), pad_lds, b->stream, (int)m, (int)n, (int)k, \
                        sp.kchunk, gm_s, gn_s, rt0, ct0, lsplit, upper, sp.nsplit, A, lda, B, ldb, C, ldc, alpha, beta, sp.slab)
 #define DFTK_LAUNCH_3M(CJ, MD)                                                                                         \
-    hipLaunchKernelGGL((k_zgemm_3m<CJ, MD>), grid, dim3(GEMM_WAVES * 64), pad_lds, b->stream, (int)m, (int)n, (int)k,  \
-                       sp.kchunk, gm_s, gn_s, rt0, ct0, lsplit, upper, til.shift ? gnf : -1, sp.nsplit, A, lda, B, ldb, C, \
+    if (real && BNt == 64) DFTK_LAUNCH_3M_(CJ, MD, true, 4);                                                           \
+    else if (real) DFTK_LAUNCH_3M_(CJ, MD, true, 2);                                                                   \
+    else DFTK_LAUNCH_3M_(CJ, MD, false, M3_RN)
+#define DFTK_LAUNCH_3M_(CJ, MD, RL, RNN)                                                                               \
+    hipLaunchKernelGGL((k_zgemm_3m<CJ, MD, RL, RNN>), grid, dim3(GEMM_WAVES * 64), pad_lds, b->stream, (int)m, (int)n, (int)k,  \
+                       sp.kchunk, gm_s, gn_s, rt0, ct0, lsplit, upper, til.shift ? gnf : -1,                           \
+                       (til.shift_r && lsplit < 0) ? gmf : -1, sp.nsplit, A, lda, B, ldb, C,                           \
                        ldc, alpha, beta, sp.slab)
         // mode 1 = full tiles, 0 = predicated border
         if (use3m) {
             if (conja) {
-                if (mode == 1) DFTK_LAUNCH_3M(true, 1);
-                else DFTK_LAUNCH_3M(true, 0);
+                if (mode == 1) { DFTK_LAUNCH_3M(true, 1); }
+                else { DFTK_LAUNCH_3M(true, 0); }
             } else {
-                if (mode == 1) DFTK_LAUNCH_3M(false, 1);
-                else DFTK_LAUNCH_3M(false, 0);
+                if (mode == 1) { DFTK_LAUNCH_3M(false, 1); }
+                else { DFTK_LAUNCH_3M(false, 0); }
             }
         } else if (conja) {
             if (mode == 1) DFTK_LAUNCH_LDS(true, 1);
@@ -1130,14 +1187,15 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
             else DFTK_LAUNCH_LDS(false, 0);
         }
 #undef DFTK_LAUNCH_3M
+#undef DFTK_LAUNCH_3M_
 #undef DFTK_LAUNCH_LDS
         return 0;
     };
-    CHK(launch(1, gmf, til.gnI, 0, 0, -1, spI));
+    CHK(launch(1, til.gmI, til.gnI, 0, 0, -1, spI));
     CHK(launch(0, nright + nbottom, 1, gmf, gnf, nright, spB));
     if (spI.slab || spB.slab)
         hipLaunchKernelGGL(k_zgemm_reduce, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, b->stream, (int)m,
-                           (int)n, gmf * GEMM_BM, til.shift ? (int)n : gnf * BNt, spI.slab ? spI.nsplit : -1, spI.slab,
+                           (int)n, til.shift_r ? (int)m : gmf * GEMM_BM, til.shift ? (int)n : gnf * BNt, spI.slab ? spI.nsplit : -1, spI.slab,
                            spB.slab ? spB.nsplit : -1, spB.slab, C, ldc, alpha, beta, upper);
     HIPCHK(hipGetLastError());
     return 0;

@@ -45,7 +45,17 @@ struct Ctx {
     std::mt19937_64 rng;      // re-randomised columns of n_G-sized blocks (per-rank stream: each rank draws its slab)
     std::mt19937_64 rng_rep;  // ... of REPLICATED small matrices of a sharded run: must be identical on all ranks
     bool replicated = false;  // inside a NoComm scope
+    bool small = false;       // inside a NoComm scope (sharded or not): the operands are small replicated matrices
     int n_svd = 0;            // SVD fallbacks taken
+    // Gamma-real mode (gamma_kernels.hip): the n_G-sized blocks are half-sphere images of real-symmetric vectors.
+    // rf = DFTK_MI_GEMM_REAL is OR-ed into every product that involves them; small matrices are real (stored as
+    // complex with zero imaginary parts) and keep the general complex kernels (rf = 0 inside NoComm).
+    bool real_mode = false;
+    int rf = 0;
+    int mm(char transA, int64_t m, int64_t n, int64_t k, cd alpha, const cd* A, int64_t lda, const cd* B, int64_t ldb,
+           cd beta, cd* C, int64_t ldc, int upper = 0) {
+        return zgemm(b, transA, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, upper | rf);
+    }
     // Row-slab (plane-wave) sharding: every product with the long dimension n_G as its inner dimension and
     // every column reduction is a LOCAL partial sum followed by an all-reduce over the block's communicator
     // (no-ops for an unsharded block).  reduce_norms: the buffer holds sqrt(local sums).
@@ -127,7 +137,7 @@ int ortho_X(Ctx& c, Mat X, cd* tmp, double tol, int* nchol_total_out, double* gr
             dftk_set_error("ortho!(X) did not reach the orthogonality tolerance in 30 Cholesky-QR passes");
             return DFTK_MI_NUM_CHOLESKY;
         }
-        CHK(zgemm(c.b, 'C', m, m, src.rows, ONE, src.p, src.ld, src.p, src.ld, ZERO, c.O, m, /*upper=*/1));
+        CHK(c.mm('C', m, m, src.rows, ONE, src.p, src.ld, src.p, src.ld, ZERO, c.O, m, /*upper=*/1));
         CHK(c.reduce_c(c.O, (size_t)m * m));
         CHK(ew_hermitize_upper(c.b, m, c.O, m));
         int nchol = 10000;
@@ -148,7 +158,7 @@ int ortho_X(Ctx& c, Mat X, cd* tmp, double tol, int* nchol_total_out, double* gr
             return 0;
         }
         // X <- X * invR
-        CHK(zgemm(c.b, 'N', src.rows, m, m, ONE, src.p, src.ld, c.invR, m, ZERO, dst.p, dst.ld,
+        CHK(c.mm('N', src.rows, m, m, ONE, src.p, src.ld, c.invR, m, ZERO, dst.p, dst.ld,
                   /*B upper triangular=*/2));
         std::swap(src, dst);
         growth *= nI;
@@ -166,13 +176,13 @@ int svd_polar(Ctx& c, Mat X, cd* scratch, int64_t scratch_ld) {
     const int m = X.cols;
     // c.O holds the hermitised Gram matrix X'X (ortho_X computed it; the shifts of safe_cholesky may have
     // touched it, so recompute)
-    CHK(zgemm(c.b, 'C', m, m, X.rows, ONE, X.p, X.ld, X.p, X.ld, ZERO, c.O, m, /*upper=*/1));
+    CHK(c.mm('C', m, m, X.rows, ONE, X.p, X.ld, X.p, X.ld, ZERO, c.O, m, /*upper=*/1));
     CHK(c.reduce_c(c.O, (size_t)m * m));
     CHK(ew_hermitize_upper(c.b, m, c.O, m));
     std::vector<double> w(m);
     CHK(dense_heev(c.b, m, c.O, m, w.data(), c.Rw, m));          // V in Rw (O is destroyed)
     Mat W{scratch, scratch_ld, X.rows, m};
-    CHK(zgemm(c.b, 'N', X.rows, m, m, ONE, X.p, X.ld, c.Rw, m, ZERO, W.p, W.ld));
+    CHK(c.mm('N', X.rows, m, m, ONE, X.p, X.ld, c.Rw, m, ZERO, W.p, W.ld));
     CHK(ew_colnorms(c.b, W.rows, m, W.p, W.ld, c.d_a));
     CHK(c.reduce_norms(c.d_a, m));
     CHK(d2h(c, c.d_a, m));
@@ -197,7 +207,7 @@ int svd_polar(Ctx& c, Mat X, cd* scratch, int64_t scratch_ld) {
     int nch;
     double gr;
     CHK(ortho_X(c, W, X.p, 2 * EPS, &nch, &gr, /*allow_svd=*/false, X.ld));   // X's storage is free now
-    CHK(zgemm(c.b, 'N', X.rows, m, m, ONE, W.p, W.ld, c.Vh, m, ZERO, X.p, X.ld));
+    CHK(c.mm('N', X.rows, m, m, ONE, W.p, W.ld, c.Vh, m, ZERO, X.p, X.ld));
     return 0;
 }
 
@@ -207,6 +217,13 @@ int randomize_column(Ctx& c, Mat X, int col) {
     std::vector<double> v(2 * X.rows);
     std::mt19937_64& gen = c.replicated ? c.rng_rep : c.rng;
     for (auto& x : v) x = nd(gen);
+    if (c.real_mode) {
+        // small matrices are real; a half-sphere vector is free except for the imaginary part of its G = 0 row
+        if (c.small)
+            for (size_t i = 1; i < v.size(); i += 2) v[i] = 0.0;
+        else
+            v[1] = 0.0;
+    }
     HIPCHK(hipMemcpyAsync(X.p + (int64_t)col * X.ld, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice,
                           c.b->stream));
     HIPCHK(hipStreamSynchronize(c.b->stream));
@@ -249,14 +266,14 @@ int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol, con
         int off = 0;
         for (auto& Y : Yl) {
             if (Y.cols == 0) continue;
-            CHK(zgemm(c.b, 'C', Y.cols, X.cols, X.rows, ONE, Y.p, Y.ld, X.p, X.ld, ZERO, c.BYX + off, ny));
+            CHK(c.mm('C', Y.cols, X.cols, X.rows, ONE, Y.p, Y.ld, X.p, X.ld, ZERO, c.BYX + off, ny));
             off += Y.cols;
         }
         CHK(c.reduce_c(c.BYX, (size_t)ny * X.cols));
         off = 0;
         for (auto& Y : Yl) {
             if (Y.cols == 0) continue;
-            CHK(zgemm(c.b, 'N', X.rows, X.cols, Y.cols, MONE, Y.p, Y.ld, c.BYX + off, ny, ONE, X.p, X.ld));
+            CHK(c.mm('N', X.rows, X.cols, Y.cols, MONE, Y.p, Y.ld, c.BYX + off, ny, ONE, X.p, X.ld));
             off += Y.cols;
         }
         // drop_small!
@@ -276,14 +293,14 @@ int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol, con
             cd* scr = c.BYX + (int64_t)ny * X.cols;
             for (auto& Y : Yl) {
                 if (Y.cols == 0) continue;
-                CHK(zgemm(c.b, 'C', Y.cols, 1, X.rows, ONE, Y.p, Y.ld, xj.p, xj.ld, ZERO, scr + o2, ny));
+                CHK(c.mm('C', Y.cols, 1, X.rows, ONE, Y.p, Y.ld, xj.p, xj.ld, ZERO, scr + o2, ny));
                 o2 += Y.cols;
             }
             CHK(c.reduce_c(scr, (size_t)ny));
             o2 = 0;
             for (auto& Y : Yl) {
                 if (Y.cols == 0) continue;
-                CHK(zgemm(c.b, 'N', X.rows, 1, Y.cols, MONE, Y.p, Y.ld, scr + o2, ny, ONE, xj.p, xj.ld));
+                CHK(c.mm('N', X.rows, 1, Y.cols, MONE, Y.p, Y.ld, scr + o2, ny, ONE, xj.p, xj.ld));
                 o2 += Y.cols;
             }
         }
@@ -310,13 +327,13 @@ int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol, con
 // with k = sum of the block widths; the per-block loop only serves non-adjacent callers.
 int hcat_mul(Ctx& c, const std::vector<Mat>& Ys, const cd* coef, int64_t ldcoef, int ncols, Mat C) {
     if (contiguous(Ys))
-        return zgemm(c.b, 'N', Ys[0].rows, ncols, total_cols(Ys), ONE, Ys[0].p, Ys[0].ld, coef, ldcoef, ZERO, C.p,
+        return c.mm('N', Ys[0].rows, ncols, total_cols(Ys), ONE, Ys[0].p, Ys[0].ld, coef, ldcoef, ZERO, C.p,
                      C.ld);
     int64_t off = 0;
     bool first = true;
     for (auto& Y : Ys) {
         if (Y.cols == 0) continue;
-        CHK(zgemm(c.b, 'N', Y.rows, ncols, Y.cols, ONE, Y.p, Y.ld, coef + off, ldcoef, first ? ZERO : ONE, C.p, C.ld));
+        CHK(c.mm('N', Y.rows, ncols, Y.cols, ONE, Y.p, Y.ld, coef + off, ldcoef, first ? ZERO : ONE, C.p, C.ld));
         first = false;
         off += Y.cols;
     }
@@ -327,13 +344,18 @@ int hcat_mul(Ctx& c, const std::vector<Mat>& Ys, const cd* coef, int64_t ldcoef,
 struct NoComm {
     Ctx& c;
     dftk_mi_comm* saved;
-    explicit NoComm(Ctx& ctx) : c(ctx), saved(ctx.comm) {
+    int saved_rf;
+    explicit NoComm(Ctx& ctx) : c(ctx), saved(ctx.comm), saved_rf(ctx.rf) {
         c.comm = nullptr;
         c.replicated = saved != nullptr;   // (unsharded runs keep drawing from the one generator)
+        c.small = true;
+        c.rf = 0;
     }
     ~NoComm() {
         c.comm = saved;
         c.replicated = false;
+        c.small = false;
+        c.rf = saved_rf;
     }
 };
 
@@ -378,8 +400,16 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     // a sharded block works on this rank's row slab of every n_G-sized array (see Ctx::reduce_*)
     dftk_mi_comm* comm = (kb->sh_comm && comm_size(kb->sh_comm) > 1) ? kb->sh_comm : nullptr;
     const int64_t row0 = comm ? (*kb->sh_rows)[comm_rank(comm)] : 0;
-    const int64_t N = comm ? (*kb->sh_rows)[comm_rank(comm) + 1] - row0 : kb->n_G;
-    const double* kin = use_tpa ? kb->d_kin + row0 : nullptr;
+    // Gamma-real block: iterate on the half-sphere images of real-symmetric vectors (the caller's X is projected
+    // onto that subspace on entry and expanded back to the full sphere on exit)
+    const bool real_mode = !comm && kb->gr && kb->gr->on;
+    const int64_t N = real_mode ? kb->gr->n_half : comm ? (*kb->sh_rows)[comm_rank(comm) + 1] - row0 : kb->n_G;
+    const double* kin = !use_tpa ? nullptr : real_mode ? kb->gr->d_kin_half : kb->d_kin + row0;
+    auto apply_H = [&](int nb, const cd* in, int64_t ldin, cd* out, int64_t ldout) -> int {
+        if (real_mode) return gamma_apply_H(kb, 7, nb, in, ldin, out, ldout);
+        return dftk_mi_apply_H(kb, nb, reinterpret_cast<const dftk_mi_cplx*>(in), ldin,
+                               reinterpret_cast<dftk_mi_cplx*>(out), ldout);
+    };
     if (N < 1) {
         dftk_set_error("sharded k-block: empty row slab on rank %d", comm_rank(comm));
         return DFTK_MI_EINVAL;
@@ -436,6 +466,8 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     c.kb = kb;
     c.b = b;
     c.comm = comm;
+    c.real_mode = real_mode;
+    c.rf = real_mode ? DFTK_MI_GEMM_REAL : 0;
     c.tmpS = take(m3 * M);
     c.O = take((size_t)M * M);
     c.Rw = take((size_t)M * M);
@@ -454,10 +486,13 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     c.rng.seed((seed ? seed : 0x9E3779B97F4A7C15ull) + 0x632BE59BD9B4E019ull * (uint64_t)comm_rank(comm));
     c.rng_rep.seed((seed ? seed : 0x9E3779B97F4A7C15ull) ^ 0xD1B54A32D192ED03ull);
     Mat X = Yb[0].cols_from(0, M), AX = AYb[0].cols_from(0, M);   // views of the CURRENT pair (rebound on swap)
-    kb->last_AX = AX.p;
+    kb->last_AX = real_mode ? nullptr : AX.p;
 
     Mat Xuser{Xp, ldX, N, M};
-    CHK(ew_copy(b, N, M, Xuser.p, Xuser.ld, X.p, X.ld));
+    if (real_mode)
+        CHK(gamma_compress(kb, M, Xp, ldX, X.p, X.ld));
+    else
+        CHK(ew_copy(b, N, M, Xuser.p, Xuser.ld, X.p, X.ld));
     std::vector<double> resid_history((size_t)M * (maxiter + 1), 0.0);
     auto RH = [&](int i, int it) -> double& { return resid_history[(size_t)i + (size_t)M * it]; };
     std::vector<double> full_lam(M, 0.0);
@@ -469,8 +504,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
         CHK(ortho_X(c, X, tmp, ortho_tol, &nch, &gr));
     }
     int64_t n_matvec = M;
-    CHK(dftk_mi_apply_H(kb, M, reinterpret_cast<const dftk_mi_cplx*>(X.p), X.ld,
-                        reinterpret_cast<dftk_mi_cplx*>(AX.p), AX.ld));
+    CHK(apply_H(M, X.p, X.ld, AX.p, AX.ld));
     // (R is written at the end of iteration 0 and P at the end of iteration 1, before their first use)
     // lambda = Re(X'AX)/(X'X) column-wise.  The reference's "any(!isfinite, AX)" check (:380) rides on the same
     // pass: a non-finite entry of AX makes its column's dot non-finite (0 * inf and x * nan are nan).
@@ -506,8 +540,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
         int nY = 0;
         cd* cX = V;
         if (niter > 0) {
-            CHK(dftk_mi_apply_H(kb, nact, reinterpret_cast<const dftk_mi_cplx*>(Ra.p), Ra.ld,
-                                reinterpret_cast<dftk_mi_cplx*>(ARa.p), ARa.ld));
+            CHK(apply_H(nact, Ra.p, Ra.ld, ARa.p, ARa.ld));
             n_matvec += nact;
             if (niter > 1) {
                 Ys = {Xa, Pa, Ra};
@@ -519,12 +552,12 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
             nY = (int)Ys.size() * nact;
             // rayleigh_ritz: G = Y' AY (upper triangle), eigen, take the lowest nact
             if (contiguous(Ys) && contiguous(AYs)) {
-                CHK(zgemm(b, 'C', nY, nY, N, ONE, Ys[0].p, Ys[0].ld, AYs[0].p, AYs[0].ld, ZERO, G, nY, /*upper=*/1));
+                CHK(c.mm('C', nY, nY, N, ONE, Ys[0].p, Ys[0].ld, AYs[0].p, AYs[0].ld, ZERO, G, nY, /*upper=*/1));
                 CHK(c.reduce_c(G, (size_t)nY * nY));
             } else {
                 for (size_t ib = 0; ib < Ys.size(); ++ib)
                     for (size_t ia = 0; ia <= ib; ++ia)
-                        CHK(zgemm(b, 'C', nact, nact, N, ONE, Ys[ia].p, Ys[ia].ld, AYs[ib].p, AYs[ib].ld, ZERO,
+                        CHK(c.mm('C', nact, nact, N, ONE, Ys[ia].p, Ys[ia].ld, AYs[ib].p, AYs[ib].ld, ZERO,
                                   G + (int64_t)ia * nact + (int64_t)ib * nact * nY, nY));
                 CHK(c.reduce_c(G, (size_t)nY * nY));
             }
@@ -632,7 +665,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
         static const bool dbg_check = getenv("DFTK_MI_LOBPCG_CHECK") != nullptr;
         if (dbg_check) {   // debugging aid: || [X P R]' [X P R] - I ||_max after the orthogonalisations of this iteration
             const int nc = M + (niter > 0 ? 2 : 1) * lenXn;
-            CHK(zgemm(b, 'C', nc, nc, N, ONE, Yb[cur].p, N, Yb[cur].p, N, ZERO, G, nc));
+            CHK(c.mm('C', nc, nc, N, ONE, Yb[cur].p, N, Yb[cur].p, N, ZERO, G, nc));
             CHK(c.reduce_c(G, (size_t)nc * nc));
             std::vector<double> hg(2 * (size_t)nc * nc);
             HIPCHK(hipMemcpyAsync(hg.data(), G, hg.size() * sizeof(double), hipMemcpyDeviceToHost, b->stream));
@@ -656,7 +689,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     }
     X = Yb[cur].cols_from(0, M);
     AX = AYb[cur].cols_from(0, M);
-    kb->last_AX = AX.p;
+    kb->last_AX = real_mode ? nullptr : AX.p;   // (half-format blocks are not handed out)
     if (!finished) final_iter = maxiter;
     (void)status_final;
 
@@ -674,7 +707,11 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
         CHK(ew_copy(b, N, M, tmp, N, AX.p, AX.ld));
         HIPCHK(hipStreamSynchronize(b->stream));
     }
-    CHK(ew_copy(b, N, M, X.p, X.ld, Xuser.p, Xuser.ld));   // hand the eigenvectors back to the caller's array
+    // hand the eigenvectors back to the caller's array
+    if (real_mode)
+        CHK(gamma_expand(kb, M, X.p, X.ld, Xp, ldX));
+    else
+        CHK(ew_copy(b, N, M, X.p, X.ld, Xuser.p, Xuser.ld));
     double maxres = 0.0;
     for (int i = 0; i < M; ++i) {
         lambda_h[i] = full_lam[perm[i]];

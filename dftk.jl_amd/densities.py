@@ -9,7 +9,9 @@ import torch
 from . import _lib
 
 
-def compute_density(basis, psi, occupation, occupation_threshold: float = 0.0) -> torch.Tensor:
+def compute_density(basis, psi, occupation, occupation_threshold: float = 0.0, real_symmetric=None) -> torch.Tensor:
+    """``real_symmetric`` (list of bools per k-point, from ``diagonalize_all_kblocks``): the orbitals of that k-point
+    satisfy psi(-G) = conj(psi(G)) -- two bands then share one transform (dftk_mi_density_accumulate_real)."""
     basis._require_gpu()
     nx, ny, nz = basis.fft_size
     # one accumulator per lane (the lanes run concurrently on their own streams), summed in lane order afterwards
@@ -23,8 +25,9 @@ def compute_density(basis, psi, occupation, occupation_threshold: float = 0.0) -
         psik = psi[ik]
         if not (psik.is_cuda and psik.dtype == torch.complex128 and psik.stride(1) == 1):
             raise TypeError("compute_density: complex128 CUDA band-major blocks required")
-        _lib.check(basis.lib.dftk_mi_density_accumulate(kpt.handle, len(w), psik.data_ptr(), psik.stride(0),
-                                                        w.ctypes.data, rhos[kpt.lane].data_ptr()))
+        paired = real_symmetric is not None and real_symmetric[ik] and basis.comm_pw.size == 1
+        fn = basis.lib.dftk_mi_density_accumulate_real if paired else basis.lib.dftk_mi_density_accumulate
+        _lib.check(fn(kpt.handle, len(w), psik.data_ptr(), psik.stride(0), w.ctypes.data, rhos[kpt.lane].data_ptr()))
     basis.run_on_lanes(accumulate, basis.kpoints)
     rho = rhos[0]
     if basis.n_lanes > 1:

@@ -88,6 +88,7 @@ class EigResult:
     n_iter: int
     converged: bool
     n_matvec: int
+    real_symmetric: bool = False     # X satisfies psi(-G) = conj(psi(G)) (Gamma-real iteration of the library)
 
 
 def lobpcg_hyper(A: DftHamiltonianBlock, X0: torch.Tensor, maxiter: int = 100, prec=None, tol: float | None = None,
@@ -112,7 +113,8 @@ def lobpcg_hyper(A: DftHamiltonianBlock, X0: torch.Tensor, maxiter: int = 100, p
                                         int(maxiter), int(n_conv_check or 0), 1 if prec is not None else 0,
                                         int(seed) & (2 ** 64 - 1), lam.ctypes.data, res.ctypes.data,
                                         C.byref(n_iter), C.byref(conv), C.byref(nmv)))
-    return EigResult(lam, X, res, n_iter.value, bool(conv.value), int(nmv.value))
+    return EigResult(lam, X, res, n_iter.value, bool(conv.value), int(nmv.value),
+                     real_symmetric=bool(getattr(A.kpoint, "gamma_real", False)))
 
 
 def lobpcg_residual_history(A: DftHamiltonianBlock):
@@ -227,4 +229,5 @@ def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None
     results = ham[0].basis.run_on_lanes(solve, ham) if ham else []
     return dict(λ=[r.λ for r in results], X=[r.X for r in results],
                 residual_norms=[r.residual_norms for r in results], n_iter=[r.n_iter for r in results],
-                converged=all(r.converged for r in results), n_matvec=sum(r.n_matvec for r in results))
+                converged=all(r.converged for r in results), n_matvec=sum(r.n_matvec for r in results),
+                real_symmetric=[bool(getattr(r, "real_symmetric", False)) for r in results])

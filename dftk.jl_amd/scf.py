@@ -151,7 +151,8 @@ def next_density(ham, nbandsalg, eigensolver=lobpcg_hyper, psi=None, eigenvalues
                                   miniter=1, generator=generator, seed=seed)
     t1 = time.time()
     occ, eF = compute_occupation(basis, eig["λ"], tol_n_elec=nbandsalg.occupation_threshold)
-    rho = compute_density(basis, eig["X"], occ, nbandsalg.occupation_threshold)
+    rho = compute_density(basis, eig["X"], occ, nbandsalg.occupation_threshold,
+                          real_symmetric=eig.get("real_symmetric"))
     if timers is not None:
         timers["diagonalization"] = timers.get("diagonalization", 0.0) + t1 - t0
         timers["occupation+density"] = timers.get("occupation+density", 0.0) + time.time() - t1

@@ -213,9 +213,14 @@ int dftk_mi_zgemm(dftk_mi_basis* basis, char transA, int64_t m, int64_t n, int64
  * hermitised afterwards, :216-261 X*inv(R)); flags (may be combined):
  *   DFTK_MI_GEMM_UPPER     only the 128x64 tiles of C that intersect the upper triangle (i <= j) are
  *                          computed and written, the rest of C is left untouched;
- *   DFTK_MI_GEMM_B_UPPER   B is upper triangular (B[k][j] = 0 for k > j): the k loop stops at the diagonal. */
+ *   DFTK_MI_GEMM_B_UPPER   B is upper triangular (B[k][j] = 0 for k > j): the k loop stops at the diagonal;
+ *   DFTK_MI_GEMM_REAL      the long operands are blocks of real-symmetric vectors in the half-sphere format of
+ *                          dftk_mi_kblock_set_gamma_real, i.e. real matrices with two real rows per complex entry:
+ *                          'C' computes Re(A^H B) (imaginary part stored as 0), 'N' computes A * Re(B); two real
+ *                          matrix-core products per complex entry instead of three. */
 #define DFTK_MI_GEMM_UPPER 1
 #define DFTK_MI_GEMM_B_UPPER 2
+#define DFTK_MI_GEMM_REAL 8
 int dftk_mi_zgemm_ex(dftk_mi_basis* basis, char transA, int64_t m, int64_t n, int64_t k,
                      dftk_mi_cplx alpha, const dftk_mi_cplx* A_d, int64_t lda,
                      const dftk_mi_cplx* B_d, int64_t ldb, dftk_mi_cplx beta,
@@ -263,6 +268,40 @@ int dftk_mi_allreduce_sum_f64(dftk_mi_comm* comm, double* buf_d, size_t n, void*
  * communicator.  Call before set_projectors; comm = NULL un-shards.  The communicator is borrowed. */
 int dftk_mi_kblock_set_shard(dftk_mi_kblock* kb, dftk_mi_comm* comm, const int64_t* row_starts_h);
 
+/* ---- real-symmetric orbitals of a Gamma-point block (EXTENSION: the reference has no Gamma special case) -------
+ * At k = 0 the Hamiltonian of the reference's models (real local potential, projectors of real functions)
+ * commutes with complex conjugation in real space: its eigenvectors can be chosen with psi(-G) = conj(psi(G)).
+ * After dftk_mi_kblock_set_gamma_real(kb, 1), dftk_mi_lobpcg on this block projects the caller's X onto that
+ * invariant subspace, iterates on its HALF-SPHERE image (row 0 = x(G = 0), real; row j > 0 = sqrt(2) x(G_j) for one
+ * representative of every pair {G, -G}; n_half = (n_G + 1) / 2 rows), and hands back full-sphere vectors.
+ * Eigenvalues, residual norms, density and energies are those of the general complex iteration (same operator,
+ * same spectrum and multiplicities); every n_G-long product runs as a REAL matrix product over half the rows
+ * (DFTK_MI_GEMM_REAL: a third of the matrix-core flops) and two bands share one FFT pipeline pass (a + i b).
+ * Errors (DFTK_MI_EINVAL): sphere without inversion symmetry / with a Nyquist point, kinetic(G) != kinetic(-G)
+ * (k != 0), projectors that are not real-symmetric (checked when they are first used), sharded block.
+ * dftk_mi_apply_H / dftk_mi_density_accumulate on the block keep their general complex semantics.
+ * dftk_mi_lobpcg_last_AX returns NULL after a real-mode run. */
+int dftk_mi_kblock_set_gamma_real(dftk_mi_kblock* kb, int on);
+int dftk_mi_gamma_half_size(dftk_mi_kblock* kb, int64_t* n_half);
+/* Host-only pair tables (CPU test-suite): row_h[j] / partner_row_h[j] = sphere rows of G_j / -G_j, j = 0 is G = 0;
+ * pairs ascending in row_h.  NULL tables: only count. */
+int dftk_mi_gamma_tables_host(int nx, int ny, int nz, int64_t n_G, const int64_t* mapping0_h, int64_t* n_half,
+                              int32_t* row_h, int32_t* partner_row_h);
+/* full sphere (n_G x m) -> half format (n_half x m): the real-symmetric part (x(G) + conj x(-G)) / 2, scaled; and
+ * back (exact inverse on real-symmetric vectors). */
+int dftk_mi_gamma_compress(dftk_mi_kblock* kb, int m, const dftk_mi_cplx* X_d, int64_t ldx, dftk_mi_cplx* Xh_d,
+                           int64_t ldh);
+int dftk_mi_gamma_expand(dftk_mi_kblock* kb, int m, const dftk_mi_cplx* Xh_d, int64_t ldh, dftk_mi_cplx* X_d,
+                         int64_t ldx);
+/* H psi on half-format blocks (`which` as dftk_mi_apply_H_parts). */
+int dftk_mi_gamma_apply_H(dftk_mi_kblock* kb, int which, int n_bands, const dftk_mi_cplx* psih_d, int64_t ld_psi,
+                          dftk_mi_cplx* Hpsih_d, int64_t ld_Hpsi);
+/* dftk_mi_density_accumulate for REAL-SYMMETRIC columns in the full-sphere layout (what a real-mode dftk_mi_lobpcg
+ * returns): bands 2p and 2p + 1 share one transform (rho += w_2p Re^2 + w_2p+1 Im^2).  The caller vouches for the
+ * symmetry; general complex columns give a wrong density.  Needs no prior set_gamma_real. */
+int dftk_mi_density_accumulate_real(dftk_mi_kblock* kb, int n_bands, const dftk_mi_cplx* psi_d, int64_t ld_psi,
+                                    const double* weight_h, double* rho_d);
+
 /* Host-only view of the slab <-> band transposition plan of a sharded block (CPU test-suite): for `rank` of
  * `n_ranks`, an n_bands block: band_starts[s] .. band_starts[s+1] = bands transformed by rank s; slab_off/cnt[s] =
  * piece of the packed n_loc x n_bands slab that goes to rank s; band_off/cnt[r] = piece of the packed band layout that
@@ -271,11 +310,14 @@ int dftk_mi_shard_plan_host(int n_ranks, int rank, int n_bands, const int64_t* r
                             int64_t* slab_off, int64_t* slab_cnt, int64_t* band_off, int64_t* band_cnt);
 
 /* ---- per-family kernel timing with HIP events on the basis' stream (used by bench.py) ----------
- * family: 0 UNSTRUCTURED zgemm calls (work = 8mnk flops), 1..5 FFT stages A..E (work = algorithmic bytes of
+ * family: 0 UNSTRUCTURED zgemm calls (work = 8mnk flops; 4mnk for a DFTK_MI_GEMM_REAL call = the flops of the
+ * equivalent real product), 1..5 FFT stages A..E (work = algorithmic bytes of
  * the pruned pipeline), 6 density z-pass, 7 heev, 8 potrf+trtri, 9 whole apply_H
  * (work = bands), 10 zgemm operand bytes (no time), 11 STRUCTURED zgemm calls (UPPER / B_UPPER; work = flops of
  * the mathematically needed part only), 12 real flops the launched zgemm tiles execute (no time; 6 per complex
- * multiply-add in the 3M kernels), 13 collectives of a sharded block (work = bytes).  enable(1) resets. */
+ * multiply-add in the 3M kernels, 4 in the REAL ones), 13 collectives of a sharded block (work = bytes), 14 useful
+ * flops of all zgemm calls counted as complex products (no time; a REAL call counts twice its flops: what the
+ * general complex iteration would need).  enable(1) resets. */
 int dftk_mi_prof_enable(dftk_mi_basis* basis, int on);
 int dftk_mi_prof_get(dftk_mi_basis* basis, int family, double* total_ms, double* work, int64_t* launches);
 

@@ -166,7 +166,7 @@ def test_zgemm_upper_triangular_B(lib, m, n):
     bs.sync()
     assert relerr(Cd.cpu().numpy().T, A @ R) < 1e-13
     assert lib.dftk_mi_zgemm_ex(bs.h, b"N", m, n, n, cplx(1.0), Ad.data_ptr(), m, Bd.data_ptr(), n, cplx(0.0),
-                                Cd.data_ptr(), m, 8) < 0   # unknown flag
+                                Cd.data_ptr(), m, 16) < 0   # unknown flag
 
 
 def test_zgemm_random_shapes_against_torch(lib):

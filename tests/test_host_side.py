@@ -357,11 +357,13 @@ def test_zgemm_launch_plan_invariants(lib, trans, m, n, k):
         shift = 1 if (n % 32 and n >= 32) else 0
         assert p["shift"] == shift
         assert p["nright"] == (-(-m // 128) if (n % 32 and not shift) else 0)
-        assert p["nbottom"] == (n // 32 + shift if m % 128 else 0)
+        # likewise a ragged m >= 128 is covered by a full tile row shifted up to end at row m: no bottom strip
+        shift_r = 1 if (m % 128 and m >= 128) else 0
+        assert p["nbottom"] == (n // 32 + shift if (m % 128 and not shift_r) else 0)
         for ns, kc in ((p["nsI"], p["kcI"]), (p["nsB"], p["kcB"])):
             assert ns >= 1 and kc % 8 == 0 and ns * kc >= k and (ns - 1) * kc < k     # chunks tile [0, k) exactly
             assert ns == 1 or kc >= 64                                                   # no degenerate chunks
-        full = p["gmf"] * (p["gnf"] + p["shift"])
+        full = (p["gmf"] + shift_r) * (p["gnf"] + p["shift"])
         if 0 < full < 512 and k >= 2048 and not flags:
             # at least half a round of the 512 resident workgroups, at most a few balanced rounds
             assert 256 <= full * p["nsI"] <= 4 * 512
@@ -369,9 +371,9 @@ def test_zgemm_launch_plan_invariants(lib, trans, m, n, k):
             assert p["nsI"] >= 8 and k >= 2048
     if trans == "N" and m > 100000:
         assert _gemm_plan(lib, trans, m, n, k)["nsI"] == 1      # thousands of tiles: no K split
-    if trans == "C" and m == n and m >= 256:
-        # the upper-only product has fewer live tiles, so at least as many chunks fit into one round
-        assert _gemm_plan(lib, trans, m, n, k, 1)["nsI"] >= _gemm_plan(lib, trans, m, n, k, 0)["nsI"]
+    # the REAL (half-sphere) products run 128 x 64 tiles
+    pr = _gemm_plan(lib, trans, m, n, k, 8)
+    assert pr["bn"] == 64 and pr["gnf"] == n // 64 and pr["shift"] == (1 if (n % 64 and n >= 64) else 0)
 
 
 @pytest.mark.parametrize("n", [1, 16, 33, 100, 259, 518, 777, 1509])
@@ -452,7 +454,8 @@ def test_jacobi_lookahead_identity(lib):
                                           ("N", 127, 31, 64), ("C", 128, 64, 64), ("C", 5, 5, 100), ("N", 300, 1, 259)])
 def test_zgemm_tiling_covers_every_entry_once(lib, trans, m, n, k):
     """The launches the planner describes -- full 128 x 32 tiles (a ragged last column as a tile shifted left
-    that stores only its new columns), right strip, bottom strip -- write every entry of C exactly once; with
+    that stores only its new columns, a ragged last row as a tile shifted up that stores only its new rows), right
+    strip, bottom strip (m < 128 only) -- write every entry of C exactly once; with
     the upper-only flag every entry on or above the diagonal exactly once (tiles strictly below are skipped)."""
     BM = 128
     for flags in (0, 1):
@@ -474,10 +477,11 @@ def test_zgemm_tiling_covers_every_entry_once(lib, trans, m, n, k):
             else:
                 tile(tr, tc * bn, min(n, tc * bn + bn), tc * bn + bn)
 
-        for tr in range(gmf):                                       # interior launch
+        shift_r = 1 if (m % BM and m >= BM) else 0                 # ragged last tile row as a tile shifted up
+        for tr in range(gmf + shift_r):                             # interior launch
             for tc in range(gnf + shift):
                 column_tile(tr, tc)
-        assert p["nright"] in (0, gm) and p["nbottom"] in (0, gnf + shift)
+        assert p["nright"] in (0, gm) and p["nbottom"] == (0 if shift_r or not m % BM else gnf + shift)
         for e in range(p["nright"]):                                # border list: right strip, then bottom strip
             column_tile(e, gnf)
         for e in range(p["nbottom"]):

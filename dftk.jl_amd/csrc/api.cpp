@@ -98,9 +98,9 @@ extern "C" int dftk_mi_prof_enable(dftk_mi_basis* b, int on) {
         // DFTK_MI_GEMM_SHAPES: per-shape zgemm table (tag = trans | m | n | k)
         for (auto& kv : b->prof->shapes) {
             const uint64_t t = kv.first;
-            fprintf(stderr, "[zgemm-shape] %c m=%llu n=%llu k=%llu calls=%lld ms=%.3f TF/s=%.2f\n",
+            fprintf(stderr, "[zgemm-shape] %c m=%llu n=%llu k=%llu flags=%d calls=%lld ms=%.3f TF/s=%.2f\n",
                     (t >> 63) ? 'C' : 'N', (unsigned long long)((t >> 42) & 0xFFFFF),
-                    (unsigned long long)((t >> 22) & 0xFFFFF), (unsigned long long)(t & 0x3FFFFF),
+                    (unsigned long long)((t >> 22) & 0x3FFFF), (unsigned long long)(t & 0x3FFFFF), (int)((t >> 40) & 3),
                     (long long)kv.second.n, kv.second.ms, kv.second.work / (kv.second.ms * 1e9));
         }
         b->prof->shapes.clear();

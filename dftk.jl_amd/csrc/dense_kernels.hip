@@ -450,6 +450,20 @@ __global__ __launch_bounds__(256) void k_normest_upper(int n, const cd* __restri
 // latency-bound pair solve is the whole critical path: one launch of ~22 us per round instead of two
 // (18 + 13 us).
 typedef double v4d_t __attribute__((ext_vector_type(4)));
+// storage type of the work matrices W, V and the rotation blocks: complex, or plain doubles for a real symmetric
+// input (REAL: half the bytes per round -- at n = 1509 a round streams all of W and V through the memory side)
+template <bool REAL>
+struct JacEl {
+    typedef cd T;
+};
+template <>
+struct JacEl<true> {
+    typedef double T;
+};
+__device__ __forceinline__ cd jac_ld(const cd& v) { return v; }
+__device__ __forceinline__ cd jac_ld(const double& v) { return make_double2(v, 0.0); }
+__device__ __forceinline__ void jac_st(cd& dst, double re, double im) { dst = make_double2(re, im); }
+__device__ __forceinline__ void jac_st(double& dst, double re, double) { dst = re; }
 #define JB 16
 #define J2B (2 * JB)
 
@@ -502,10 +516,16 @@ __host__ __device__ __forceinline__ void tournament_find(int nb, int round, int 
 // Look-ahead (have_prev): A is the matrix BEFORE round prev_round and Uprev that round's rotations; the
 // 2 x 2 block problem of this round is  S[r][c] = u_r^H A[rows(P(r)), cols(P(c))] u_c  with P(.) the
 // prev_round pair a block belonged to and u the matching 16 columns of that pair's U.
+// REAL: the matrix is real symmetric stored as complex with zero imaginary parts (Rayleigh-Ritz of the Gamma-real
+// LOBPCG): one real MFMA per complex quadruple, real rotations; imaginary parts are written as exact zeros.
+template <bool REAL>
 __device__ __forceinline__ void jacobi_pair_part(int pair_id, int nb, int round, int prev_round, bool have_prev,
-                                                 const cd* __restrict__ A, int64_t lda,
-                                                 const cd* __restrict__ Uprev, cd* __restrict__ Ubuf,
-                                                 cd (*S)[J2B][J2B + 1], cd (*U)[J2B + 1]) {
+                                                 const typename JacEl<REAL>::T* __restrict__ A, int64_t lda,
+                                                 const typename JacEl<REAL>::T* __restrict__ Uprev,
+                                                 typename JacEl<REAL>::T* __restrict__ Ubuf,
+                                                 typename JacEl<REAL>::T (*S)[J2B][J2B + 1],
+                                                 typename JacEl<REAL>::T (*U)[J2B + 1]) {
+    typedef typename JacEl<REAL>::T ET;
     const int mode = round < 0 ? 1 : 0;
     int bp, bq;
     tournament_pair(nb, round, pair_id, bp, bq);
@@ -532,17 +552,17 @@ __device__ __forceinline__ void jacobi_pair_part(int pair_id, int nb, int round,
         if (wave < 3) {
             const bool rb = wave == 2, cb = wave >= 1;
             const int rp = rb ? pb : pa, rq = rb ? qb : qa, cp = cb ? pb : pa, cq = cb ? qb : qa;
-            const cd* UR = Uprev + (int64_t)(rb ? kb : ka) * J2B * J2B + (int64_t)(JB * (rb ? hb : ha)) * J2B;
-            const cd* UC = Uprev + (int64_t)(cb ? kb : ka) * J2B * J2B + (int64_t)(JB * (cb ? hb : ha)) * J2B;
+            const ET* UR = Uprev + (int64_t)(rb ? kb : ka) * J2B * J2B + (int64_t)(JB * (rb ? hb : ha)) * J2B;
+            const ET* UC = Uprev + (int64_t)(cb ? kb : ka) * J2B * J2B + (int64_t)(JB * (cb ? hb : ha)) * J2B;
             cd fa[2][8], uc[8], ur[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const int k = 4 * t + lk;
                 const int64_t gc = (k < JB ? cp * JB + k : cq * JB + (k - JB));
-                fa[0][t] = A[(rp * JB + li) + gc * lda];
-                fa[1][t] = A[(rq * JB + li) + gc * lda];
-                uc[t] = UC[k + li * J2B];
-                ur[t] = UR[k + li * J2B];   // A operand of the second product: conj(U_row[k][row li])
+                fa[0][t] = jac_ld(A[(rp * JB + li) + gc * lda]);
+                fa[1][t] = jac_ld(A[(rq * JB + li) + gc * lda]);
+                uc[t] = jac_ld(UC[k + li * J2B]);
+                ur[t] = jac_ld(UR[k + li * J2B]);   // A operand of the second product: conj(U_row[k][row li])
             }
             v4d_t yR[2], yI[2];
 #pragma unroll
@@ -552,9 +572,11 @@ __device__ __forceinline__ void jacobi_pair_part(int pair_id, int nb, int round,
                 for (int t = 0; t < 8; ++t) {
                     const double ar = fa[h][t].x, ai = fa[h][t].y, nai = -ai;
                     yR[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, uc[t].x, yR[h], 0, 0, 0);
-                    yI[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, uc[t].y, yI[h], 0, 0, 0);
-                    yR[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, uc[t].y, yR[h], 0, 0, 0);
-                    yI[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, uc[t].x, yI[h], 0, 0, 0);
+                    if (!REAL) {
+                        yI[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, uc[t].y, yI[h], 0, 0, 0);
+                        yR[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, uc[t].y, yR[h], 0, 0, 0);
+                        yI[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, uc[t].x, yI[h], 0, 0, 0);
+                    }
                 }
             }
             v4d_t zR = (v4d_t){0.0, 0.0, 0.0, 0.0}, zI = (v4d_t){0.0, 0.0, 0.0, 0.0};
@@ -565,29 +587,31 @@ __device__ __forceinline__ void jacobi_pair_part(int pair_id, int nb, int round,
                     const cd u = ur[4 * h + r];
                     const double br = yR[h][r], bi = yI[h][r], nui = -u.y;
                     zR = __builtin_amdgcn_mfma_f64_16x16x4f64(u.x, br, zR, 0, 0, 0);
-                    zI = __builtin_amdgcn_mfma_f64_16x16x4f64(u.x, bi, zI, 0, 0, 0);
-                    zR = __builtin_amdgcn_mfma_f64_16x16x4f64(u.y, bi, zR, 0, 0, 0);
-                    zI = __builtin_amdgcn_mfma_f64_16x16x4f64(nui, br, zI, 0, 0, 0);
+                    if (!REAL) {
+                        zI = __builtin_amdgcn_mfma_f64_16x16x4f64(u.x, bi, zI, 0, 0, 0);
+                        zR = __builtin_amdgcn_mfma_f64_16x16x4f64(u.y, bi, zR, 0, 0, 0);
+                        zI = __builtin_amdgcn_mfma_f64_16x16x4f64(nui, br, zI, 0, 0, 0);
+                    }
                 }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = lk + 4 * r;
-                S[0][JB * (rb ? 1 : 0) + i][JB * (cb ? 1 : 0) + li] = make_double2(zR[r], zI[r]);
-                if (wave == 1) S[0][JB + li][i] = make_double2(zR[r], -zI[r]);
+                jac_st(S[0][JB * (rb ? 1 : 0) + i][JB * (cb ? 1 : 0) + li], zR[r], zI[r]);
+                if (wave == 1) jac_st(S[0][JB + li][i], zR[r], -zI[r]);
             }
         }
     }
     for (int e = tid; e < J2B * J2B; e += 256) {
         const int c = e / J2B, r = e - c * J2B;
-        U[r][c] = make_double2(r == c ? 1.0 : 0.0, 0.0);
+        jac_st(U[r][c], r == c ? 1.0 : 0.0, 0.0);
     }
     __syncthreads();
     const int k1 = tid >> 4, k2 = tid & 15;
     const int nrounds = mode == 0 ? JB : JB - 1;
     int cur = 0;
     for (int rd = 0; rd < nrounds; ++rd) {
-        const cd(*Sc)[J2B + 1] = S[cur];
-        cd(*Sn)[J2B + 1] = S[cur ^ 1];
+        const ET(*Sc)[J2B + 1] = S[cur];
+        ET(*Sn)[J2B + 1] = S[cur ^ 1];
         // index pair (p, q) and Jacobi rotation (c, s) of rotation slot k in this round
         auto pair_of = [&](int k, int& p, int& q) {
             if (mode == 0) {
@@ -607,9 +631,10 @@ __device__ __forceinline__ void jacobi_pair_part(int pair_id, int nb, int round,
         // evaluates two of these per round, so they must be short; c gets two steps (c^2 + |s|^2 = 1 to
         // round-off keeps U unitary), the angle itself needs far less than full precision.
         auto rotation = [&](int p, int q, double& c, cd& s) {
-            const cd beta = Sc[p][q];
-            const double al = Sc[p][p].x, ga = Sc[q][q].x;
-            const double b2 = beta.x * beta.x + beta.y * beta.y;
+            cd beta;
+            beta = jac_ld(Sc[p][q]);
+            const double al = jac_ld(Sc[p][p]).x, ga = jac_ld(Sc[q][q]).x;
+            const double b2 = REAL ? beta.x * beta.x : beta.x * beta.x + beta.y * beta.y;
             c = 1.0;
             s = make_double2(0.0, 0.0);
             if (b2 > 1e-300 && b2 > 1e-36 * (fabs(al * ga) + 1e-300)) {
@@ -626,7 +651,7 @@ __device__ __forceinline__ void jacobi_pair_part(int pair_id, int nb, int round,
                 cc = cc * fma(-0.5 * y * cc, cc, 1.5);
                 c = cc;
                 const double f = (d >= 0.0 ? cc : -cc) * u;
-                s = make_double2(f * beta.x, f * beta.y);
+                s = make_double2(f * beta.x, REAL ? 0.0 : f * beta.y);
             }
         };
         int p1, q1, p2, q2;
@@ -641,7 +666,22 @@ __device__ __forceinline__ void jacobi_pair_part(int pair_id, int nb, int round,
         } else {
             rotation(p2, q2, c2, s2);
         }
-        {
+        if constexpr (REAL) {
+            const double a = Sc[p1][p2], b2 = Sc[p1][q2], c3 = Sc[q1][p2], d = Sc[q1][q2];
+            const double ra = c1 * a - s1.x * c3, rb = c1 * b2 - s1.x * d;
+            const double rc = s1.x * a + c1 * c3, rdd = s1.x * b2 + c1 * d;
+            Sn[p1][p2] = c2 * ra - s2.x * rb;
+            Sn[p1][q2] = s2.x * ra + c2 * rb;
+            Sn[q1][p2] = c2 * rc - s2.x * rdd;
+            Sn[q1][q2] = s2.x * rc + c2 * rdd;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = k2 + JB * h;
+                const double xp = U[r][p1], xq = U[r][q1];
+                U[r][p1] = c1 * xp - s1.x * xq;
+                U[r][q1] = s1.x * xp + c1 * xq;
+            }
+        } else {
             const cd a = Sc[p1][p2], b2 = Sc[p1][q2], c3 = Sc[q1][p2], d = Sc[q1][q2];
             // rows: (row_p, row_q) <- (c row_p - s row_q, conj(s) row_p + c row_q)
             const cd ra = make_double2(c1 * a.x - (s1.x * c3.x - s1.y * c3.y), c1 * a.y - (s1.x * c3.y + s1.y * c3.x));
@@ -653,19 +693,19 @@ __device__ __forceinline__ void jacobi_pair_part(int pair_id, int nb, int round,
             Sn[p1][q2] = make_double2(s2.x * ra.x - s2.y * ra.y + c2 * rb.x, s2.x * ra.y + s2.y * ra.x + c2 * rb.y);
             Sn[q1][p2] = make_double2(c2 * rc.x - (s2.x * rdd.x + s2.y * rdd.y), c2 * rc.y - (s2.x * rdd.y - s2.y * rdd.x));
             Sn[q1][q2] = make_double2(s2.x * rc.x - s2.y * rc.y + c2 * rdd.x, s2.x * rc.y + s2.y * rc.x + c2 * rdd.y);
-        }
-        // column rotations of U: rows k2 and k2 + 16, rotation k1
+            // column rotations of U: rows k2 and k2 + 16, rotation k1
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int r = k2 + JB * h;
-            const cd xp = U[r][p1], xq = U[r][q1];
-            U[r][p1] = make_double2(c1 * xp.x - (s1.x * xq.x + s1.y * xq.y), c1 * xp.y - (s1.x * xq.y - s1.y * xq.x));
-            U[r][q1] = make_double2(s1.x * xp.x - s1.y * xp.y + c1 * xq.x, s1.x * xp.y + s1.y * xp.x + c1 * xq.y);
+            for (int h = 0; h < 2; ++h) {
+                const int r = k2 + JB * h;
+                const cd xp = U[r][p1], xq = U[r][q1];
+                U[r][p1] = make_double2(c1 * xp.x - (s1.x * xq.x + s1.y * xq.y), c1 * xp.y - (s1.x * xq.y - s1.y * xq.x));
+                U[r][q1] = make_double2(s1.x * xp.x - s1.y * xp.y + c1 * xq.x, s1.x * xp.y + s1.y * xp.x + c1 * xq.y);
+            }
         }
         __syncthreads();
         cur ^= 1;
     }
-    cd* Uo = Ubuf + (int64_t)pair_id * J2B * J2B;
+    ET* Uo = Ubuf + (int64_t)pair_id * J2B * J2B;
     for (int e = tid; e < J2B * J2B; e += 256) {
         const int c = e / J2B, r = e - c * J2B;
         Uo[e] = U[r][c];   // column-major 2b x 2b
@@ -682,10 +722,14 @@ __device__ __forceinline__ int pair_index(int bp, int bq, int kk) {
 //                     tile Aout_ji = Aout_ij^H is written along with it;  wave w owns the output quadrant
 //                     (w >> 1, w & 1): 32 MFMAs for T = A_ij U_j (through LDS), 32 for U_i^H T;
 //   ids [ntiles, ..): V[:, cols(pair)] <- V[:, cols(pair)] U_pair (in place), one wave per 16-row strip.
-__device__ __forceinline__ void jacobi_update_part(int id, int n, int nb, int round, const cd* __restrict__ A,
-                                                   cd* __restrict__ Aout, int64_t lda, cd* __restrict__ V,
-                                                   int64_t ldv, const cd* __restrict__ Ubuf, int ntiles, int vblocks,
-                                                   cd (*Ts)[J2B + 1]) {
+template <bool REAL>
+__device__ __forceinline__ void jacobi_update_part(int id, int n, int nb, int round,
+                                                   const typename JacEl<REAL>::T* __restrict__ A,
+                                                   typename JacEl<REAL>::T* __restrict__ Aout, int64_t lda,
+                                                   typename JacEl<REAL>::T* __restrict__ V, int64_t ldv,
+                                                   const typename JacEl<REAL>::T* __restrict__ Ubuf, int ntiles,
+                                                   int vblocks, typename JacEl<REAL>::T (*Ts)[J2B + 1]) {
+    typedef typename JacEl<REAL>::T ET;
     const int npairs = nb / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -697,30 +741,37 @@ __device__ __forceinline__ void jacobi_update_part(int id, int n, int nb, int ro
         if (r0 >= n) return;
         int bp, bq;
         tournament_pair(nb, round, pj, bp, bq);
-        const cd* U = Ubuf + (int64_t)pj * J2B * J2B;
+        const ET* U = Ubuf + (int64_t)pj * J2B * J2B;
         v4d_t accR[2], accI[2];
         accR[0] = accR[1] = accI[0] = accI[1] = (v4d_t){0.0, 0.0, 0.0, 0.0};
         cd fa[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) fa[t] = V[r0 + li + (int64_t)pair_index(bp, bq, 4 * t + lk) * ldv];
+        for (int t = 0; t < 8; ++t) fa[t] = jac_ld(V[r0 + li + (int64_t)pair_index(bp, bq, 4 * t + lk) * ldv]);
 #pragma unroll
+        // the TRANSPOSED product (V U)^T = U^T V^T: same registers with the MFMA operands swapped; its accumulator
+        // layout (value r = column 16c + lk + 4r of the pair, lane li = row r0 + li) makes the stores below 16
+        // consecutive rows per column instead of 16 elements a whole column apart
         for (int t = 0; t < 8; ++t) {
-            const double ar = fa[t].x, ai = fa[t].y, nai = -ai;
+            const double ar = fa[t].x, ai = fa[t].y;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const cd u = U[(4 * t + lk) + (16 * c + li) * J2B];
-                accR[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, u.x, accR[c], 0, 0, 0);
-                accI[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, u.y, accI[c], 0, 0, 0);
-                accR[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, u.y, accR[c], 0, 0, 0);
-                accI[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, u.x, accI[c], 0, 0, 0);
+                const cd u = jac_ld(U[(4 * t + lk) + (16 * c + li) * J2B]);
+                accR[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(u.x, ar, accR[c], 0, 0, 0);
+                if (!REAL) {
+                    const double nuy = -u.y;
+                    accI[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(u.x, ai, accI[c], 0, 0, 0);
+                    accR[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(nuy, ai, accR[c], 0, 0, 0);
+                    accI[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(u.y, ar, accI[c], 0, 0, 0);
+                }
             }
         }
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int64_t gc = pair_index(bp, bq, 16 * c + li);
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) V[r0 + lk + 4 * r + gc * ldv] = make_double2(accR[c][r], accI[c][r]);
-        }
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gc = pair_index(bp, bq, 16 * c + lk + 4 * r);
+                jac_st(V[r0 + li + gc * ldv], accR[c][r], accI[c][r]);
+            }
         return;
     }
     // ---- tile (pi <= pj): linear index -> (pi, pj) of the upper triangle (row by row)
@@ -733,8 +784,8 @@ __device__ __forceinline__ void jacobi_update_part(int id, int n, int nb, int ro
     int bpi, bqi, bpj, bqj;
     tournament_pair(nb, round, pi, bpi, bqi);
     tournament_pair(nb, round, pj, bpj, bqj);
-    const cd* Ui = Ubuf + (int64_t)pi * J2B * J2B;
-    const cd* Uj = Ubuf + (int64_t)pj * J2B * J2B;
+    const ET* Ui = Ubuf + (int64_t)pi * J2B * J2B;
+    const ET* Uj = Ubuf + (int64_t)pj * J2B * J2B;
     const int qi = wave >> 1, qj = wave & 1;
     // stage 1: T[qi, qj] = A_ij[qi rows, :] * U_j[:, qj cols]
     {
@@ -742,67 +793,94 @@ __device__ __forceinline__ void jacobi_update_part(int id, int n, int nb, int ro
         const int gr = pair_index(bpi, bqi, 16 * qi + li);
         cd fa[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) fa[t] = A[gr + (int64_t)pair_index(bpj, bqj, 4 * t + lk) * lda];
+        for (int t = 0; t < 8; ++t) fa[t] = jac_ld(A[gr + (int64_t)pair_index(bpj, bqj, 4 * t + lk) * lda]);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const double ar = fa[t].x, ai = fa[t].y, nai = -ai;
-            const cd u = Uj[(4 * t + lk) + (16 * qj + li) * J2B];
+            const cd u = jac_ld(Uj[(4 * t + lk) + (16 * qj + li) * J2B]);
             tR = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, u.x, tR, 0, 0, 0);
-            tI = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, u.y, tI, 0, 0, 0);
-            tR = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, u.y, tR, 0, 0, 0);
-            tI = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, u.x, tI, 0, 0, 0);
+            if (!REAL) {
+                tI = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, u.y, tI, 0, 0, 0);
+                tR = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, u.y, tR, 0, 0, 0);
+                tI = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, u.x, tI, 0, 0, 0);
+            }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Ts[16 * qi + lk + 4 * r][16 * qj + li] = make_double2(tR[r], tI[r]);
+        for (int r = 0; r < 4; ++r) jac_st(Ts[16 * qi + lk + 4 * r][16 * qj + li], tR[r], tI[r]);
     }
     __syncthreads();
     // stage 2: R[qi, qj] = U_i[:, qi cols]^H * T[:, qj cols]
     v4d_t rR = (v4d_t){0.0, 0.0, 0.0, 0.0}, rI = (v4d_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        const cd u = Ui[(4 * t + lk) + (16 * qi + li) * J2B];   // A operand: conj(U_i[k][row])
-        const cd b = Ts[4 * t + lk][16 * qj + li];
+        const cd u = jac_ld(Ui[(4 * t + lk) + (16 * qi + li) * J2B]);   // A operand: conj(U_i[k][row])
+        const cd b = jac_ld(Ts[4 * t + lk][16 * qj + li]);
         const double nui = -u.y;
         rR = __builtin_amdgcn_mfma_f64_16x16x4f64(u.x, b.x, rR, 0, 0, 0);
-        rI = __builtin_amdgcn_mfma_f64_16x16x4f64(u.x, b.y, rI, 0, 0, 0);
-        rR = __builtin_amdgcn_mfma_f64_16x16x4f64(u.y, b.y, rR, 0, 0, 0);
-        rI = __builtin_amdgcn_mfma_f64_16x16x4f64(nui, b.x, rI, 0, 0, 0);
+        if (!REAL) {
+            rI = __builtin_amdgcn_mfma_f64_16x16x4f64(u.x, b.y, rI, 0, 0, 0);
+            rR = __builtin_amdgcn_mfma_f64_16x16x4f64(u.y, b.y, rR, 0, 0, 0);
+            rI = __builtin_amdgcn_mfma_f64_16x16x4f64(nui, b.x, rI, 0, 0, 0);
+        }
     }
     const int64_t gc = pair_index(bpj, bqj, 16 * qj + li);
+    if constexpr (REAL) {
+        // R^T = T^T U_i from the same registers with swapped operands (8 cheap MFMAs): value r = column
+        // 16 qj + lk + 4r, lane li = row 16 qi + li -> the direct tile is stored as runs of 16 consecutive rows, like
+        // the mirror tile (the accumulator layout of R itself would scatter 16 lanes over 16 columns)
+        v4d_t rT = (v4d_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int64_t gr = pair_index(bpi, bqi, 16 * qi + lk + 4 * r);
-        Aout[gr + gc * lda] = make_double2(rR[r], rI[r]);
-        if (pi != pj) Aout[gc + gr * lda] = make_double2(rR[r], -rI[r]);   // mirror tile A_ji = A_ij^H
+        for (int t = 0; t < 8; ++t)
+            rT = __builtin_amdgcn_mfma_f64_16x16x4f64(Ts[4 * t + lk][16 * qj + li], Ui[(4 * t + lk) + (16 * qi + li) * J2B],
+                                                      rT, 0, 0, 0);
+        const int64_t grl = pair_index(bpi, bqi, 16 * qi + li);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            Aout[grl + (int64_t)pair_index(bpj, bqj, 16 * qj + lk + 4 * r) * lda] = rT[r];
+            if (pi != pj) Aout[gc + (int64_t)pair_index(bpi, bqi, 16 * qi + lk + 4 * r) * lda] = rR[r];   // mirror
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t gr = pair_index(bpi, bqi, 16 * qi + lk + 4 * r);
+            jac_st(Aout[gr + gc * lda], rR[r], rI[r]);
+            if (pi != pj) jac_st(Aout[gc + gr * lda], rR[r], -rI[r]);   // mirror tile A_ji = A_ij^H
+        }
     }
 }
 
 // One launch per round: pair workgroups of `round` first (they are the critical path), then the update
 // workgroups of `prev_round`.  flags bit 0: pair part present, bit 1: a previous round is pending.
+template <bool REAL>
 __global__ __launch_bounds__(256) void k_jacobi_round(int n, int nb, int round, int prev_round, int flags,
-                                                      const cd* __restrict__ Win, cd* __restrict__ Wout, int64_t lda,
-                                                      cd* __restrict__ V, int64_t ldv, const cd* __restrict__ Uprev,
-                                                      cd* __restrict__ Uout, int ntiles, int vblocks) {
-    __shared__ cd S[2][J2B][J2B + 1];
-    __shared__ cd U[J2B][J2B + 1];
+                                                      const typename JacEl<REAL>::T* __restrict__ Win,
+                                                      typename JacEl<REAL>::T* __restrict__ Wout, int64_t lda,
+                                                      typename JacEl<REAL>::T* __restrict__ V, int64_t ldv,
+                                                      const typename JacEl<REAL>::T* __restrict__ Uprev,
+                                                      typename JacEl<REAL>::T* __restrict__ Uout, int ntiles,
+                                                      int vblocks) {
+    __shared__ typename JacEl<REAL>::T S[2][J2B][J2B + 1];
+    __shared__ typename JacEl<REAL>::T U[J2B][J2B + 1];
     const int npair_wg = (flags & 1) ? nb / 2 : 0;
     if ((int)blockIdx.x < npair_wg)
-        jacobi_pair_part(blockIdx.x, nb, round, prev_round, (flags & 2) != 0, Win, lda, Uprev, Uout, S, U);
+        jacobi_pair_part<REAL>(blockIdx.x, nb, round, prev_round, (flags & 2) != 0, Win, lda, Uprev, Uout, S, U);
     else
-        jacobi_update_part(blockIdx.x - npair_wg, n, nb, prev_round, Win, Wout, lda, V, ldv, Uprev, ntiles, vblocks,
+        jacobi_update_part<REAL>(blockIdx.x - npair_wg, n, nb, prev_round, Win, Wout, lda, V, ldv, Uprev, ntiles, vblocks,
                            S[0]);
 }
 
-// out[0] = sum |offdiag|^2, out[1] = sum |diag|^2   (whole matrix)
-__global__ __launch_bounds__(256) void k_offdiag_norm(int n, const cd* __restrict__ A, int64_t lda,
+// out[0] = sum |offdiag|^2, out[1] = sum |diag|^2   (whole matrix); out[2 nblocks + block] = sum Im^2
+template <typename ET>
+__global__ __launch_bounds__(256) void k_offdiag_norm(int n, const ET* __restrict__ A, int64_t lda,
                                                       double* __restrict__ out) {
     __shared__ double sh[4];
-    double off = 0.0, dg = 0.0;
+    double off = 0.0, dg = 0.0, im2 = 0.0;
     const int64_t total = (int64_t)n * n;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int c = (int)(e / n), r = (int)(e - (int64_t)c * n);
-        const cd v = A[r + (int64_t)c * lda];
+        const cd v = jac_ld(A[r + (int64_t)c * lda]);
         const double a2 = v.x * v.x + v.y * v.y;
+        im2 += v.y * v.y;
         if (r == c)
             dg += a2;
         else
@@ -810,21 +888,25 @@ __global__ __launch_bounds__(256) void k_offdiag_norm(int n, const cd* __restric
     }
     const double o = block_sum256(off, sh);
     const double d = block_sum256(dg, sh);
+    const double i2 = block_sum256(im2, sh);
     if (threadIdx.x == 0) {
         out[2 * blockIdx.x] = o;
         out[2 * blockIdx.x + 1] = d;
+        out[2 * gridDim.x + blockIdx.x] = i2;
     }
 }
 
-__global__ void k_set_identity(int n, cd* __restrict__ V, int64_t ldv) {
+template <typename ET>
+__global__ void k_set_identity(int n, ET* __restrict__ V, int64_t ldv) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)n * n) return;
     const int j = (int)(idx / n), i = (int)(idx - (int64_t)j * n);
-    V[i + (int64_t)j * ldv] = make_double2(i == j ? 1.0 : 0.0, 0.0);
+    jac_st(V[i + (int64_t)j * ldv], i == j ? 1.0 : 0.0, 0.0);
 }
 
 // copy A (n x n) into the padded work matrix W (np x np), padding diagonal with `big` values
-__global__ void k_pad_matrix(int n, int np, const cd* __restrict__ A, int64_t lda, cd* __restrict__ W, double big) {
+template <typename ET>
+__global__ void k_pad_matrix(int n, int np, const cd* __restrict__ A, int64_t lda, ET* __restrict__ W, double big) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)np * np) return;
     const int j = (int)(idx / np), i = (int)(idx - (int64_t)j * np);
@@ -833,12 +915,20 @@ __global__ void k_pad_matrix(int n, int np, const cd* __restrict__ A, int64_t ld
         v = A[i + (int64_t)j * lda];
     else if (i == j)
         v = make_double2(big * (1.0 + 1e-3 * (i - n)), 0.0);
-    W[idx] = v;
+    jac_st(W[idx], v.x, v.y);
 }
 
-__global__ void k_extract_diag(int n, const cd* __restrict__ W, int64_t ldw, double* __restrict__ d) {
+template <typename ET>
+__global__ void k_extract_diag(int n, const ET* __restrict__ W, int64_t ldw, double* __restrict__ d) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) d[i] = W[i + (int64_t)i * ldw].x;
+    if (i < n) d[i] = jac_ld(W[i + (int64_t)i * ldw]).x;
+}
+// eigenvector columns of the real path back into the caller's complex array, sorted
+__global__ void k_gather_cols_real(int64_t n, const double* __restrict__ X, int64_t ldx, const int* __restrict__ perm,
+                                   cd* __restrict__ Y, int64_t ldy) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (i < n) Y[(int64_t)c * ldy + i] = make_double2(X[(int64_t)perm[c] * ldx + i], 0.0);
 }
 
 // ======================================================================================== host side
@@ -927,50 +1017,39 @@ int jacobi_schedule_host(int n, int round, int* nb_out, int* pairs, int* where) 
     return 0;
 }
 
-int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, int64_t ldv) {
-    if (n <= 0) return 0;
-    const int pslot = prof_begin(b, PROF_HEEV, (double)n);
-    struct ProfGuard {
-        dftk_mi_basis* b;
-        int s;
-        ~ProfGuard() { prof_end(b, s); }
-    } guard{b, pslot};
+// REAL = true: real symmetric input (every imaginary part exactly zero); the work matrices are plain doubles
+template <bool REAL>
+static int heev_impl(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, int64_t ldv, double off2,
+                     double dg2) {
+    typedef typename JacEl<REAL>::T ET;
     int nb = (n + JB - 1) / JB;
     if (nb % 2) nb += 1;
     if (nb < 2) nb = 2;
     const int np = nb * JB;
     const int npairs = nb / 2;
     // workspace: W, W2 (np x np, ping-pong), Vw (np x np), 2 x Ubuf (npairs x 2b x 2b), diag (np doubles), perm (np ints)
+    // (sized for complex elements; the real path uses half of each array)
     const size_t szW = (size_t)np * np * sizeof(cd);
     const size_t szU = (size_t)npairs * J2B * J2B * sizeof(cd);
     const size_t total = 3 * szW + 2 * szU + (size_t)np * (sizeof(double) + sizeof(int)) + 4096 * sizeof(double);
     CHK(dws_ensure(b, &b->dense_ws, &b->dense_ws_bytes, total));   // per basis: one stream, one device
     char* base = reinterpret_cast<char*>(b->dense_ws);
-    cd* W = reinterpret_cast<cd*>(base);
-    cd* Vw = reinterpret_cast<cd*>(base + szW);
-    cd* Wb[2] = {W, reinterpret_cast<cd*>(base + 2 * szW)};
-    cd* Ub[2] = {reinterpret_cast<cd*>(base + 3 * szW), reinterpret_cast<cd*>(base + 3 * szW + szU)};
+    ET* W = reinterpret_cast<ET*>(base);
+    ET* Vw = reinterpret_cast<ET*>(base + szW);
+    ET* Wb[2] = {W, reinterpret_cast<ET*>(base + 2 * szW)};
+    ET* Ub[2] = {reinterpret_cast<ET*>(base + 3 * szW), reinterpret_cast<ET*>(base + 3 * szW + szU)};
     double* d_diag = reinterpret_cast<double*>(base + 3 * szW + 2 * szU);
     int* d_perm = reinterpret_cast<int*>(d_diag + np);
     double* d_red = reinterpret_cast<double*>(d_perm + np + (np & 1));
+    const int redblocks = 64;
+    std::vector<double> hred(3 * redblocks);
 
     // scale for the padding: Gershgorin-like bound from the Frobenius norm
-    const int redblocks = 64;
-    hipLaunchKernelGGL(k_offdiag_norm, dim3(redblocks), dim3(256), 0, b->stream, n, A, lda, d_red);
-    std::vector<double> hred(2 * redblocks);
-    HIPCHK(hipMemcpyAsync(hred.data(), d_red, hred.size() * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
-    double off2 = 0.0, dg2 = 0.0;
-    for (int i = 0; i < redblocks; ++i) {
-        off2 += hred[2 * i];
-        dg2 += hred[2 * i + 1];
-    }
     const double fro = sqrt(off2 + dg2);
-    if (!std::isfinite(fro)) return DFTK_MI_NUM_NONFINITE;
     const double big = 2.0 * fro + 1.0;
-    hipLaunchKernelGGL(k_pad_matrix, dim3((unsigned)(((size_t)np * np + 255) / 256)), dim3(256), 0, b->stream, n, np,
+    hipLaunchKernelGGL(k_pad_matrix<ET>, dim3((unsigned)(((size_t)np * np + 255) / 256)), dim3(256), 0, b->stream, n, np,
                        A, lda, W, big);
-    hipLaunchKernelGGL(k_set_identity, dim3((unsigned)(((size_t)np * np + 255) / 256)), dim3(256), 0, b->stream, np,
+    hipLaunchKernelGGL(k_set_identity<ET>, dim3((unsigned)(((size_t)np * np + 255) / 256)), dim3(256), 0, b->stream, np,
                        Vw, (int64_t)np);
     // off-diagonal Frobenius norm relative to ||A||_F; the round-off floor of the blocked sweeps
     // grows like eps*sqrt(n), so accept 1e-14 outright or a stagnated sweep below 1e-12
@@ -988,7 +1067,7 @@ int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, 
         const int flags = (do_pair ? 1 : 0) | (pending ? 2 : 0);
         const int grid = (do_pair ? npairs : 0) + (pending ? ntiles + npairs * vblocks : 0);
         if (grid == 0) return;
-        hipLaunchKernelGGL(k_jacobi_round, dim3(grid), dim3(256), 0, b->stream, np, nb, round, pending_round, flags,
+        hipLaunchKernelGGL(k_jacobi_round<REAL>, dim3(grid), dim3(256), 0, b->stream, np, nb, round, pending_round, flags,
                            Wb[cur], Wb[cur ^ 1], (int64_t)np, Vw, (int64_t)np, Ub[uw ^ 1], Ub[uw], ntiles, vblocks);
         if (pending) cur ^= 1;      // the update of the pending round has been written to the other copy
         pending = do_pair;
@@ -1007,7 +1086,7 @@ int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, 
             continue;
         }
         launch_round(false, 0);   // drain the pipeline: the check needs the matrix after the last round
-        hipLaunchKernelGGL(k_offdiag_norm, dim3(redblocks), dim3(256), 0, b->stream, np, Wb[cur], (int64_t)np, d_red);
+        hipLaunchKernelGGL(k_offdiag_norm<ET>, dim3(redblocks), dim3(256), 0, b->stream, np, Wb[cur], (int64_t)np, d_red);
         HIPCHK(hipMemcpyAsync(hred.data(), d_red, hred.size() * sizeof(double), hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
         double o2 = 0.0;
@@ -1015,7 +1094,7 @@ int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, 
         if (!std::isfinite(o2)) return DFTK_MI_NUM_NONFINITE;
         const double off = sqrt(o2);
         static const bool trace = getenv("DFTK_MI_HEEV_TRACE") != nullptr;   // convergence history per sweep
-        if (trace) fprintf(stderr, "[heev] n=%d sweep %d off/fro=%.3e\n", n, sweep + 1, off / fro);
+        if (trace) fprintf(stderr, "[heev%s] n=%d sweep %d off/fro=%.3e\n", REAL ? " real" : "", n, sweep + 1, off / fro);
         if (off <= tol * fro) done = true;
         if (!done && prev_off >= 0.0 && off > 0.5 * prev_off && off <= 1e-12 * fro) done = true;
         prev_off = off;
@@ -1027,7 +1106,7 @@ int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, 
         return DFTK_MI_NUM_EIGEN;
     }
     // eigenvalues = diag(W); sort ascending on the host, gather eigenvector columns
-    hipLaunchKernelGGL(k_extract_diag, dim3((np + 255) / 256), dim3(256), 0, b->stream, np, Wb[cur], (int64_t)np, d_diag);
+    hipLaunchKernelGGL(k_extract_diag<ET>, dim3((np + 255) / 256), dim3(256), 0, b->stream, np, Wb[cur], (int64_t)np, d_diag);
     std::vector<double> diag(np);
     HIPCHK(hipMemcpyAsync(diag.data(), d_diag, np * sizeof(double), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -1036,11 +1115,46 @@ int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, 
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int c) { return diag[a] < diag[c]; });
     for (int i = 0; i < n; ++i) W_h[i] = diag[perm[i]];
     HIPCHK(hipMemcpyAsync(d_perm, perm.data(), n * sizeof(int), hipMemcpyHostToDevice, b->stream));
-    hipLaunchKernelGGL(k_gather_cols, dim3((n + 255) / 256, n), dim3(256), 0, b->stream, (int64_t)n, Vw, (int64_t)np,
-                       d_perm, V, ldv);
+    if constexpr (REAL)
+        hipLaunchKernelGGL(k_gather_cols_real, dim3((n + 255) / 256, n), dim3(256), 0, b->stream, (int64_t)n, Vw,
+                           (int64_t)np, d_perm, V, ldv);
+    else
+        hipLaunchKernelGGL(k_gather_cols, dim3((n + 255) / 256, n), dim3(256), 0, b->stream, (int64_t)n, Vw, (int64_t)np,
+                           d_perm, V, ldv);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(b->stream));   // perm (host vector) must outlive the copy
     return 0;
+}
+
+int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, int64_t ldv) {
+    if (n <= 0) return 0;
+    const int pslot = prof_begin(b, PROF_HEEV, (double)n);
+    struct ProfGuard {
+        dftk_mi_basis* b;
+        int s;
+        ~ProfGuard() { prof_end(b, s); }
+    } guard{b, pslot};
+    // norms of the input (scale of the padding, early exit for a diagonal matrix) and sum Im^2
+    const int redblocks = 64;
+    CHK(dws_ensure(b, &b->dense_ws, &b->dense_ws_bytes, 4096 * sizeof(double)));
+    double* d_red = reinterpret_cast<double*>(b->dense_ws);
+    hipLaunchKernelGGL(k_offdiag_norm<cd>, dim3(redblocks), dim3(256), 0, b->stream, n, A, lda, d_red);
+    std::vector<double> hred(3 * redblocks);
+    HIPCHK(hipMemcpyAsync(hred.data(), d_red, hred.size() * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    double off2 = 0.0, dg2 = 0.0, im2 = 0.0;
+    for (int i = 0; i < redblocks; ++i) {
+        off2 += hred[2 * i];
+        dg2 += hred[2 * i + 1];
+        im2 += hred[2 * redblocks + i];
+    }
+    if (!std::isfinite(off2 + dg2)) return DFTK_MI_NUM_NONFINITE;
+    // every imaginary part exactly zero (real symmetric input, e.g. the Rayleigh-Ritz matrices of the Gamma-real
+    // LOBPCG): real rotations on plain-double work matrices -- a quarter of the matrix-core work and half the bytes
+    // per round; the eigenvectors come back with exact zeros in their imaginary parts
+    static const bool no_real = getenv("DFTK_MI_HEEV_NO_REAL") != nullptr;
+    if (im2 == 0.0 && !no_real) return heev_impl<true>(b, n, A, lda, W_h, V, ldv, off2, dg2);
+    return heev_impl<false>(b, n, A, lda, W_h, V, ldv, off2, dg2);
 }
 
 int apply_D(dftk_mi_kblock* kb, int n_bands, const cd* X, cd* Y) {

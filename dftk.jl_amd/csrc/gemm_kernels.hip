@@ -1064,7 +1064,8 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
     static const bool shapes = getenv("DFTK_MI_GEMM_SHAPES") != nullptr;
     const uint64_t tag = !shapes ? 0
                                  : ((uint64_t)conja << 63) | ((uint64_t)(m & 0xFFFFF) << 42) |
-                                       ((uint64_t)(n & 0xFFFFF) << 22) | (uint64_t)(k & 0x3FFFFF) | (1ull << 62);
+                                       ((uint64_t)(n & 0x3FFFF) << 22) | ((uint64_t)(upper_in & 3) << 40) |
+                                       (uint64_t)(k & 0x3FFFFF) | (1ull << 62);
     static const bool use3m_env = getenv("DFTK_MI_GEMM_4M") == nullptr;   // DFTK_MI_GEMM_4M=1: classic 4-product kernels
     const bool use3m = use3m_env || real;                                  // (the REAL product only exists in the 3M family)
     const GemmTiling til = gemm_tiling(conja, m, n, k, upper, use3m, real);

@@ -272,3 +272,23 @@ def test_gamma_real_refusals(lib):
     out = torch.empty_like(hd)
     assert lib.dftk_mi_gamma_apply_H(kb3.h, 7, 2, hd.data_ptr(), nh, out.data_ptr(), nh) == EINVAL
     assert b"real-symmetric" in lib.dftk_mi_last_error()
+
+
+@pytest.mark.parametrize("n", [5, 33, 259, 1006, 1509])
+def test_heev_real_symmetric_input(lib, n):
+    """dftk_mi_heev on a real symmetric matrix (zero imaginary parts, what the Gamma-real Rayleigh-Ritz hands it):
+    the real-rotation Jacobi path -- eigenvalues against LAPACK, real orthonormal eigenvectors, A V = V diag(w)."""
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n))
+    A = (A + A.T) / 2 + np.diag(np.linspace(-3, 3, n))
+    Ad = dev(A.astype(complex).T.copy())
+    Vd = torch.full((n, n), float("nan"), dtype=torch.complex128, device="cuda")
+    w = np.zeros(n)
+    bs = Basis(lib, 8, 8, 8)
+    check(lib.dftk_mi_heev(bs.h, n, Ad.data_ptr(), n, w.ctypes.data, Vd.data_ptr(), n))
+    bs.sync()
+    V = Vd.cpu().numpy().T
+    np.testing.assert_allclose(w, np.linalg.eigvalsh(A), atol=1e-12 * max(1.0, np.abs(A).max()) * n)
+    assert not V.imag.any()
+    assert np.linalg.norm(V.T @ V - np.eye(n)) < 1e-12 * n
+    assert np.linalg.norm(A @ V.real - V.real * w[None, :]) < 1e-12 * n * np.linalg.norm(A)

@@ -1,8 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_gamma_real.py tests/test_gpu_kernels.py -x -q -k "zgemm or gamma or lobpcg or potrf or heev" 2>&1 | tail -8
-python tools/gemm_real_bench.py 264859 503 gramscan 2>&1 | grep -v amdgpu
-python tools/gemm_real_bench.py 264859 503 2>&1 | grep -v amdgpu
+timeout 900 python -m pytest tests/test_gpu_gamma_real.py tests/test_gpu_kernels.py -x -q -k "heev or lobpcg or scf" 2>&1 | tail -8
+python tools/heev_bench.py 503 1006 1509 2>&1 | grep -v amdgpu; DFTK_MI_HEEV_TRACE=1 python tools/heev_bench.py real 503 1006 1509 2>&1 | grep -v amdgpu
 timeout 600 python bench.py --no-cpu-baseline > gpurun_out/bench_cfg5_real.json 2> gpurun_out/bench_cfg5_real.err
 tail -c 300 gpurun_out/bench_cfg5_real.err
 python - <<'PY'

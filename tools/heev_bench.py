@@ -15,9 +15,10 @@ from dftk_jl_amd._lib import check  # noqa: E402
 lib = dftk.load_library()
 h = C.c_void_p()
 check(lib.dftk_mi_basis_create(8, 8, 8, 1.0, 0, C.byref(h)))
-for n in [int(a) for a in sys.argv[1:]] or [259, 518, 777]:
+real = "real" in sys.argv[1:]        # real symmetric input (zero imaginary parts): the real-rotation path
+for n in [int(a) for a in sys.argv[1:] if a != "real"] or [259, 518, 777]:
     rng = np.random.default_rng(n)
-    A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    A = rng.standard_normal((n, n)) + (0 if real else 1j) * rng.standard_normal((n, n))
     A = (A + A.conj().T) / 2 + np.diag(np.linspace(-1, 30, n)) * 3
     Ad0 = torch.tensor(A.T.copy(), dtype=torch.complex128, device="cuda")
     V = torch.empty_like(Ad0)
@@ -30,4 +31,4 @@ for n in [int(a) for a in sys.argv[1:]] or [259, 518, 777]:
         torch.cuda.synchronize()
         dt = time.time() - t0
     ref = np.linalg.eigvalsh(A)
-    print(f"n={n}: {dt * 1e3:.2f} ms per call, max |dW| = {np.abs(W - ref).max():.2e}")
+    print(f"n={n}{' real' if real else ''}: {dt * 1e3:.2f} ms per call, max |dW| = {np.abs(W - ref).max():.2e}")

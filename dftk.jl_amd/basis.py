@@ -127,7 +127,7 @@ class Kpoint:
         # format (dftk_mi_kblock_set_gamma_real: real matrix products over half the rows, two bands per FFT pass).
         # An extension over the reference (no Gamma special case there); eigenvalues / density / energies unchanged.
         self.gamma_real = False
-        if (basis.gamma_real is not False and self.handle and pw.size == 1 and not self.coordinate.any()):
+        if (basis.gamma_real is not False and self.handle and not self.coordinate.any()):
             st = basis.lib.dftk_mi_kblock_set_gamma_real(self.handle, 1)
             if st == 0:
                 self.gamma_real = True

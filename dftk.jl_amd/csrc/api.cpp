@@ -454,7 +454,7 @@ extern "C" int dftk_mi_kblock_set_shard(dftk_mi_kblock* kb, dftk_mi_comm* comm, 
         return 0;
     }
     if (kb->gr && kb->gr->on) {
-        dftk_set_error("set_shard: the block iterates real-symmetric orbitals (dftk_mi_kblock_set_gamma_real); switch that off first");
+        dftk_set_error("set_shard: call before dftk_mi_kblock_set_gamma_real (the half-format rows are split when it is switched on)");
         return DFTK_MI_EINVAL;
     }
     const int p = comm_size(comm);
@@ -546,37 +546,162 @@ extern "C" int dftk_mi_shard_plan_host(int n_ranks, int rank, int n_bands, const
 struct Transposer {
     dftk_mi_kblock* kb;
     int p, me, nb, mine;
-    int64_t nloc;
+    int64_t nloc, ntot;
+    const std::vector<int64_t>* rows;   // [p + 1] row offsets of the sharded dimension (full sphere, or half format)
     std::vector<int> c0;
     std::vector<size_t> slab_off, slab_cnt, band_off, band_cnt;
-    Transposer(dftk_mi_kblock* k, int nbands) : kb(k), nb(nbands) {
+    Transposer(dftk_mi_kblock* k, int nbands, const std::vector<int64_t>* row_offsets = nullptr)
+        : kb(k), nb(nbands), rows(row_offsets ? row_offsets : k->sh_rows) {
         p = comm_size(kb->sh_comm);
         me = comm_rank(kb->sh_comm);
-        nloc = local_rows(kb);
-        shard_plan(*kb->sh_rows, p, me, nb, c0, slab_off, slab_cnt, band_off, band_cnt);
+        nloc = (*rows)[me + 1] - (*rows)[me];
+        ntot = (*rows)[p];
+        shard_plan(*rows, p, me, nb, c0, slab_off, slab_cnt, band_off, band_cnt);
         mine = c0[me + 1] - c0[me];
     }
-    // psi_loc (ld == nloc required by the caller) -> F (n_G x mine, ld n_G); R1 is scratch
+    // psi_loc (ld == nloc required by the caller) -> F (ntot x mine, ld ntot); R1 is scratch
     int to_bands(const cd* slab, cd* R1, cd* F) {
         dftk_mi_basis* b = kb->basis;
         CHK(comm_alltoallv(kb->sh_comm, b, slab, slab_off.data(), slab_cnt.data(), R1, band_off.data(),
                            band_cnt.data()));
         for (int r = 0; r < p; ++r) {
-            const int64_t rows = (*kb->sh_rows)[r + 1] - (*kb->sh_rows)[r];
-            CHK(ew_copy(b, rows, mine, R1 + band_off[r], rows, F + (*kb->sh_rows)[r], kb->n_G));
+            const int64_t nr = (*rows)[r + 1] - (*rows)[r];
+            CHK(ew_copy(b, nr, mine, R1 + band_off[r], nr, F + (*rows)[r], ntot));
         }
         return 0;
     }
     int to_slabs(const cd* Gfull, cd* R1, cd* slab) {
         dftk_mi_basis* b = kb->basis;
         for (int r = 0; r < p; ++r) {
-            const int64_t rows = (*kb->sh_rows)[r + 1] - (*kb->sh_rows)[r];
-            CHK(ew_copy(b, rows, mine, Gfull + (*kb->sh_rows)[r], kb->n_G, R1 + band_off[r], rows));
+            const int64_t nr = (*rows)[r + 1] - (*rows)[r];
+            CHK(ew_copy(b, nr, mine, Gfull + (*rows)[r], ntot, R1 + band_off[r], nr));
         }
         return comm_alltoallv(kb->sh_comm, b, R1, band_off.data(), band_cnt.data(), slab, slab_off.data(),
                               slab_cnt.data());
     }
 };
+
+// ---- real-symmetric Gamma orbitals on a plane-wave sharded block (gamma_kernels.hip has the local pieces) ----------
+// Half-format blocks are sharded by half-format rows; whole bands exist only between two all-to-alls, where the
+// pair packing / FFT pipeline / compress / expand kernels run on this rank's share of the bands.
+int gamma_apply_H_sharded(dftk_mi_kblock* kb, int which, int nb, const cd* psi, int64_t ldpsi, cd* Hpsi, int64_t ldH) {
+    GammaReal* gr = kb->gr;
+    dftk_mi_basis* b = kb->basis;
+    const int64_t hl = gamma_local_rows(kb);
+    if (ldpsi != hl || ldH != hl) {
+        dftk_set_error("sharded gamma apply_H: blocks must be packed (leading dimension == local half rows %lld)", (long long)hl);
+        return DFTK_MI_EINVAL;
+    }
+    const int slot = prof_begin(b, PROF_APPLY_H, (double)nb);
+    struct G {
+        dftk_mi_basis* b;
+        int s;
+        ~G() { prof_end(b, s); }
+    } guard{b, slot};
+    const bool local = (which & 1) && kb->d_Vs != nullptr;
+    const bool kinetic = which & 2;
+    if ((which & 4) && kb->n_p > 0) CHK(gamma_projectors_sharded(kb));   // (first: it may regrow the shared buffers)
+    cd *R1, *F, *Gf;
+    CHK(shard_buffers(kb, nb, &R1, &F, &Gf));
+    Transposer t(kb, nb, &gr->half_rows);
+    const int mine2 = (t.mine + 1) / 2;
+    CHK(gamma_ensure_buf(kb, 2 * (size_t)kb->n_G * (mine2 ? mine2 : 1)));
+    cd* Z = gr->buf;
+    cd* W = gr->buf + (size_t)kb->n_G * (mine2 ? mine2 : 1);
+    CHK(t.to_bands(psi, R1, F));                                   // F: n_half x mine
+    if (t.mine > 0) {
+        CHK(gamma_pack_pairs(kb, t.mine, F, gr->n_half, Z, kb->n_G));
+        CHK(launch_local_apply(kb, mine2, Z, kb->n_G, W, kb->n_G, kinetic, local));
+        CHK(gamma_unpack_pairs(kb, t.mine, W, kb->n_G, Gf, gr->n_half));
+    }
+    CHK(t.to_slabs(Gf, R1, Hpsi));
+    if ((which & 4) && kb->n_p > 0)
+        CHK(apply_nonlocal_rows(kb, nb, gr->P_half, hl, hl, psi, ldpsi, Hpsi, ldH, true, DFTK_MI_GEMM_REAL, kb->sh_comm));
+    return 0;
+}
+
+// this rank's slab of the half-format projectors from its slab of the full-sphere ones (two all-to-alls, once)
+int gamma_projectors_sharded(dftk_mi_kblock* kb) {
+    GammaReal* gr = kb->gr;
+    if (gr->P_src == kb->P && gr->P_n_p == kb->n_p && gr->P_half) return 0;
+    dftk_mi_basis* b = kb->basis;
+    const int64_t hl = gamma_local_rows(kb), fl = local_rows(kb);
+    const int n_p = kb->n_p;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (gr->P_half) HIPCHK(hipFree(gr->P_half));
+    gr->P_half = nullptr;
+    HIPCHK(hipMalloc((void**)&gr->P_half, (size_t)hl * n_p * sizeof(cd)));
+    cd *R1, *F, *Gf;
+    CHK(shard_buffers(kb, n_p, &R1, &F, &Gf));
+    Transposer tf(kb, n_p), th(kb, n_p, &gr->half_rows);
+    // packed copy of the slab (the caller's leading dimension may exceed the local rows)
+    CHK(gamma_ensure_buf(kb, (size_t)fl * n_p));
+    CHK(ew_copy(b, fl, n_p, kb->P, kb->ldP, gr->buf, fl));
+    CHK(tf.to_bands(gr->buf, R1, F));                              // F: n_G x mine columns of P
+    double h[2] = {0.0, 0.0};
+    CHK(gamma_gather_P(kb, tf.mine, F, kb->n_G, Gf, gr->n_half, h));
+    double bad = (h[0] <= 1e-10 * (h[1] > 0 ? h[1] : 1.0)) ? 0.0 : 1.0;
+    HIPCHK(hipMemcpyAsync(b->d_scalars, &bad, sizeof(double), hipMemcpyHostToDevice, b->stream));
+    CHK(comm_allreduce(kb->sh_comm, b, b->d_scalars, 1));
+    HIPCHK(hipMemcpyAsync(&bad, b->d_scalars, sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (bad != 0.0) {
+        dftk_set_error("gamma_real: the projectors are not real-symmetric (max |P(-G) - conj P(G)| = %.3e on this rank)", h[0]);
+        HIPCHK(hipFree(gr->P_half));
+        gr->P_half = nullptr;
+        return DFTK_MI_EINVAL;
+    }
+    CHK(th.to_slabs(Gf, R1, gr->P_half));
+    gr->P_src = kb->P;
+    gr->P_n_p = n_p;
+    return 0;
+}
+
+int gamma_density_sharded(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, const double* w_h, double* rho) {
+    if (ldpsi != local_rows(kb)) {
+        dftk_set_error("sharded density: blocks must be packed (leading dimension == local rows)");
+        return DFTK_MI_EINVAL;
+    }
+    cd *R1, *F, *Gf;
+    CHK(shard_buffers(kb, nb, &R1, &F, &Gf));
+    Transposer t(kb, nb);
+    CHK(t.to_bands(psi, R1, F));
+    if (t.mine == 0) return 0;
+    return gamma_density_bands(kb, t.mine, F, kb->n_G, w_h + t.c0[t.me], rho);
+}
+
+// caller's full-sphere block (row slab of it on a sharded block) -> half-format block of dftk_mi_lobpcg, and back
+int gamma_lobpcg_load(dftk_mi_kblock* kb, int M, const cd* Xuser, int64_t ldX, cd* Xh, int64_t ldh) {
+    if (!kb->sh_comm) return gamma_compress(kb, M, Xuser, ldX, Xh, ldh);
+    GammaReal* gr = kb->gr;
+    dftk_mi_basis* b = kb->basis;
+    const int64_t hl = gamma_local_rows(kb), fl = local_rows(kb);
+    if (ldh != hl) return DFTK_MI_EINVAL;
+    cd *R1, *F, *Gf;
+    CHK(shard_buffers(kb, M, &R1, &F, &Gf));
+    Transposer tf(kb, M), th(kb, M, &gr->half_rows);
+    CHK(gamma_ensure_buf(kb, (size_t)fl * M));
+    CHK(ew_copy(b, fl, M, Xuser, ldX, gr->buf, fl));
+    CHK(tf.to_bands(gr->buf, R1, F));
+    CHK(gamma_compress(kb, tf.mine, F, kb->n_G, Gf, gr->n_half));
+    return th.to_slabs(Gf, R1, Xh);
+}
+
+int gamma_lobpcg_store(dftk_mi_kblock* kb, int M, const cd* Xh, int64_t ldh, cd* Xuser, int64_t ldX) {
+    if (!kb->sh_comm) return gamma_expand(kb, M, Xh, ldh, Xuser, ldX);
+    GammaReal* gr = kb->gr;
+    dftk_mi_basis* b = kb->basis;
+    const int64_t hl = gamma_local_rows(kb), fl = local_rows(kb);
+    if (ldh != hl) return DFTK_MI_EINVAL;
+    cd *R1, *F, *Gf;
+    CHK(shard_buffers(kb, M, &R1, &F, &Gf));
+    Transposer tf(kb, M), th(kb, M, &gr->half_rows);
+    CHK(th.to_bands(Xh, R1, F));                                   // F: n_half x mine
+    CHK(gamma_expand(kb, th.mine, F, gr->n_half, Gf, kb->n_G));    // Gf: n_G x mine
+    CHK(gamma_ensure_buf(kb, (size_t)fl * M));
+    CHK(tf.to_slabs(Gf, R1, gr->buf));
+    return ew_copy(b, fl, M, gr->buf, fl, Xuser, ldX);
+}
 
 extern "C" int dftk_mi_kblock_set_projectors(dftk_mi_kblock* kb, int n_p, const dftk_mi_cplx* P_d, int64_t ldP,
                                              const double* D_h) {
@@ -806,30 +931,35 @@ static int gamma_ready(dftk_mi_kblock* kb) {
 extern "C" int dftk_mi_gamma_half_size(dftk_mi_kblock* kb, int64_t* n_half) {
     if (!n_half) return DFTK_MI_EINVAL;
     CHK(gamma_ready(kb));
-    *n_half = kb->gr->n_half;
+    *n_half = gamma_local_rows(kb);     // (the rows of this rank on a plane-wave sharded block)
     return 0;
 }
 
 extern "C" int dftk_mi_gamma_compress(dftk_mi_kblock* kb, int m, const dftk_mi_cplx* X_d, int64_t ldx,
                                       dftk_mi_cplx* Xh_d, int64_t ldh) {
     CHK(gamma_ready(kb));
-    if (m < 0 || !X_d || !Xh_d || ldx < kb->n_G || ldh < kb->gr->n_half) return DFTK_MI_EINVAL;
+    if (m < 0 || !X_d || !Xh_d || ldx < local_rows(kb) || ldh < gamma_local_rows(kb)) return DFTK_MI_EINVAL;
     HIPCHK(hipSetDevice(kb->basis->device));
+    if (kb->sh_comm)   // row slabs in, row slabs out (collective over the block's communicator)
+        return gamma_lobpcg_load(kb, m, reinterpret_cast<const cd*>(X_d), ldx, reinterpret_cast<cd*>(Xh_d), ldh);
     return gamma_compress(kb, m, reinterpret_cast<const cd*>(X_d), ldx, reinterpret_cast<cd*>(Xh_d), ldh);
 }
 
 extern "C" int dftk_mi_gamma_expand(dftk_mi_kblock* kb, int m, const dftk_mi_cplx* Xh_d, int64_t ldh,
                                     dftk_mi_cplx* X_d, int64_t ldx) {
     CHK(gamma_ready(kb));
-    if (m < 0 || !X_d || !Xh_d || ldx < kb->n_G || ldh < kb->gr->n_half) return DFTK_MI_EINVAL;
+    if (m < 0 || !X_d || !Xh_d || ldx < local_rows(kb) || ldh < gamma_local_rows(kb)) return DFTK_MI_EINVAL;
     HIPCHK(hipSetDevice(kb->basis->device));
+    if (kb->sh_comm)
+        return gamma_lobpcg_store(kb, m, reinterpret_cast<const cd*>(Xh_d), ldh, reinterpret_cast<cd*>(X_d), ldx);
     return gamma_expand(kb, m, reinterpret_cast<const cd*>(Xh_d), ldh, reinterpret_cast<cd*>(X_d), ldx);
 }
 
 extern "C" int dftk_mi_gamma_apply_H(dftk_mi_kblock* kb, int which, int n_bands, const dftk_mi_cplx* psih_d,
                                      int64_t ld_psi, dftk_mi_cplx* Hpsih_d, int64_t ld_Hpsi) {
     CHK(gamma_ready(kb));
-    if (!psih_d || !Hpsih_d || n_bands < 0 || (which & ~7) || ld_psi < kb->gr->n_half || ld_Hpsi < kb->gr->n_half)
+    if (!psih_d || !Hpsih_d || n_bands < 0 || (which & ~7) || ld_psi < gamma_local_rows(kb) ||
+        ld_Hpsi < gamma_local_rows(kb))
         return DFTK_MI_EINVAL;
     HIPCHK(hipSetDevice(kb->basis->device));
     return gamma_apply_H(kb, which, n_bands, reinterpret_cast<const cd*>(psih_d), ld_psi,
@@ -838,7 +968,7 @@ extern "C" int dftk_mi_gamma_apply_H(dftk_mi_kblock* kb, int which, int n_bands,
 
 extern "C" int dftk_mi_density_accumulate_real(dftk_mi_kblock* kb, int n_bands, const dftk_mi_cplx* psi_d,
                                                int64_t ld_psi, const double* weight_h, double* rho_d) {
-    if (!kb || !psi_d || !weight_h || !rho_d || n_bands < 0 || ld_psi < kb->n_G || kb->sh_comm) return DFTK_MI_EINVAL;
+    if (!kb || !psi_d || !weight_h || !rho_d || n_bands < 0 || ld_psi < local_rows(kb)) return DFTK_MI_EINVAL;
     if (n_bands == 0) return 0;
     HIPCHK(hipSetDevice(kb->basis->device));
     return gamma_density(kb, n_bands, reinterpret_cast<const cd*>(psi_d), ld_psi, weight_h, rho_d);

@@ -117,6 +117,9 @@ struct GammaReal {
     int P_n_p = 0;
     cd* buf = nullptr;            // pack / unpack scratch
     size_t buf_bytes = 0;
+    // plane-wave sharded block: rank r owns the half-format rows [half_rows[r], half_rows[r + 1]) (split evenly);
+    // P_half is then this rank's slab of the half-format projectors
+    std::vector<int64_t> half_rows;
 };
 
 struct dftk_mi_kblock {
@@ -252,6 +255,22 @@ int gamma_compress(dftk_mi_kblock* kb, int m, const cd* X, int64_t ldx, cd* H, i
 int gamma_expand(dftk_mi_kblock* kb, int m, const cd* H, int64_t ldh, cd* X, int64_t ldx);
 int gamma_apply_H(dftk_mi_kblock* kb, int which, int nb, const cd* psi, int64_t ldpsi, cd* Hpsi, int64_t ldH);
 int gamma_density(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, const double* w_h, double* rho);
+// local building blocks (whole bands on this rank)
+int gamma_ensure_buf(dftk_mi_kblock* kb, size_t elems);
+int gamma_pack_pairs(dftk_mi_kblock* kb, int nb, const cd* H, int64_t ldh, cd* Z, int64_t ldz);
+int gamma_unpack_pairs(dftk_mi_kblock* kb, int nb, const cd* W, int64_t ldw, cd* H, int64_t ldh);
+int gamma_pack_full(dftk_mi_kblock* kb, int nb, const cd* X, int64_t ldx, cd* Z, int64_t ldz);
+int gamma_gather_P(dftk_mi_kblock* kb, int ncols, const cd* P, int64_t ldP, cd* Ph, int64_t ldh, double* asym_mag_h);
+int gamma_density_bands(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, const double* w_h, double* rho);
+int64_t gamma_local_rows(const dftk_mi_kblock* kb);     // half-format rows held by this rank
+int64_t gamma_row0(const dftk_mi_kblock* kb);
+// api.cpp: the plane-wave sharded variants (slab <-> band all-to-alls around the local building blocks) and the
+// entry / exit conversions of dftk_mi_lobpcg (caller's full-sphere block <-> half-format block, sharded or not)
+int gamma_apply_H_sharded(dftk_mi_kblock* kb, int which, int nb, const cd* psi, int64_t ldpsi, cd* Hpsi, int64_t ldH);
+int gamma_projectors_sharded(dftk_mi_kblock* kb);
+int gamma_density_sharded(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, const double* w_h, double* rho);
+int gamma_lobpcg_load(dftk_mi_kblock* kb, int M, const cd* Xuser, int64_t ldX, cd* Xh, int64_t ldh);
+int gamma_lobpcg_store(dftk_mi_kblock* kb, int M, const cd* Xh, int64_t ldh, cd* Xuser, int64_t ldX);
 // api.cpp: Hpsi (+)= P D P' psi on `rows` rows of projector storage P (leading dimension ldP); gemm_flags is OR-ed
 // into the two products (DFTK_MI_GEMM_REAL for half-format blocks); comm (nullable) all-reduces the projections
 int apply_nonlocal_rows(dftk_mi_kblock* kb, int nb, const cd* P, int64_t ldP, int64_t rows, const cd* psi,

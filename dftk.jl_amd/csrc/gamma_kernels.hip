@@ -155,10 +155,6 @@ int gamma_enable(dftk_mi_kblock* kb, int on) {
         if (kb->gr) kb->gr->on = false;
         return 0;
     }
-    if (kb->sh_comm) {
-        dftk_set_error("gamma_real: not available on a plane-wave sharded block");
-        return DFTK_MI_EINVAL;
-    }
     if (kb->gr && kb->gr->d_g) {
         kb->gr->on = true;
         return 0;
@@ -184,10 +180,31 @@ int gamma_enable(dftk_mi_kblock* kb, int on) {
     HIPCHK(hipMemcpy(gr->d_g, g.data(), nh * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(gr->d_mg, mg.data(), nh * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(gr->d_kin_half, kin.data(), nh * sizeof(double), hipMemcpyHostToDevice));
+    // plane-wave sharded block (set_shard comes first): the half-format rows are split evenly over the ranks
+    gr->half_rows.clear();
+    if (kb->sh_comm) {
+        const int p = comm_size(kb->sh_comm);
+        if (nh < p) {
+            dftk_set_error("gamma_real: more ranks than half-sphere rows");
+            if (!kb->gr) delete gr;
+            return DFTK_MI_EINVAL;
+        }
+        gr->half_rows.assign(p + 1, 0);
+        const int64_t base = nh / p, rem = nh % p;
+        for (int r = 0; r < p; ++r) gr->half_rows[r + 1] = gr->half_rows[r] + base + (r < rem ? 1 : 0);
+    }
     gr->on = true;
     kb->gr = gr;
     return 0;
 }
+
+int64_t gamma_local_rows(const dftk_mi_kblock* kb) {
+    const GammaReal* gr = kb->gr;
+    if (!kb->sh_comm) return gr->n_half;
+    const int r = comm_rank(kb->sh_comm);
+    return gr->half_rows[r + 1] - gr->half_rows[r];
+}
+int64_t gamma_row0(const dftk_mi_kblock* kb) { return kb->sh_comm ? kb->gr->half_rows[comm_rank(kb->sh_comm)] : 0; }
 
 void gamma_destroy(GammaReal* gr) {
     if (!gr) return;
@@ -197,7 +214,7 @@ void gamma_destroy(GammaReal* gr) {
     delete gr;
 }
 
-static int gr_ensure_buf(dftk_mi_kblock* kb, size_t elems) {
+int gamma_ensure_buf(dftk_mi_kblock* kb, size_t elems) {
     GammaReal* gr = kb->gr;
     const size_t need = elems * sizeof(cd);
     if (need <= gr->buf_bytes) return 0;
@@ -230,22 +247,32 @@ int gamma_expand(dftk_mi_kblock* kb, int m, const cd* H, int64_t ldh, cd* X, int
 
 // half-format projectors (built on first use after dftk_mi_kblock_set_projectors); refuses projectors that are
 // not Fourier transforms of real functions
+int gamma_gather_P(dftk_mi_kblock* kb, int ncols, const cd* P, int64_t ldP, cd* Ph, int64_t ldh, double* asym_mag_h) {
+    GammaReal* gr = kb->gr;
+    dftk_mi_basis* b = kb->basis;
+    unsigned long long* d_out = reinterpret_cast<unsigned long long*>(b->d_scalars);
+    HIPCHK(hipMemsetAsync(d_out, 0, 2 * sizeof(unsigned long long), b->stream));
+    if (ncols > 0) {
+        hipLaunchKernelGGL(k_gr_gather_P, gr_grid(gr->n_half, ncols), dim3(256), 0, b->stream, gr->n_half, gr->d_g,
+                           gr->d_mg, P, ldP, Ph, ldh, d_out);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(asym_mag_h, d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
 static int gr_projectors(dftk_mi_kblock* kb) {
     GammaReal* gr = kb->gr;
     if (gr->P_src == kb->P && gr->P_n_p == kb->n_p && gr->P_half) return 0;
+    if (kb->sh_comm) return gamma_projectors_sharded(kb);
     dftk_mi_basis* b = kb->basis;
     HIPCHK(hipStreamSynchronize(b->stream));
     if (gr->P_half) HIPCHK(hipFree(gr->P_half));
     gr->P_half = nullptr;
     HIPCHK(hipMalloc((void**)&gr->P_half, (size_t)gr->n_half * kb->n_p * sizeof(cd)));
-    unsigned long long* d_out = reinterpret_cast<unsigned long long*>(b->d_scalars);
-    HIPCHK(hipMemsetAsync(d_out, 0, 2 * sizeof(unsigned long long), b->stream));
-    hipLaunchKernelGGL(k_gr_gather_P, gr_grid(gr->n_half, kb->n_p), dim3(256), 0, b->stream, gr->n_half, gr->d_g,
-                       gr->d_mg, kb->P, kb->ldP, gr->P_half, gr->n_half, d_out);
-    HIPCHK(hipGetLastError());
     double h[2];
-    HIPCHK(hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
+    CHK(gamma_gather_P(kb, kb->n_p, kb->P, kb->ldP, gr->P_half, gr->n_half, h));
     if (!(h[0] <= 1e-10 * (h[1] > 0 ? h[1] : 1.0))) {
         dftk_set_error("gamma_real: the projectors are not real-symmetric (max |P(-G) - conj P(G)| = %.3e, max |P| = %.3e)",
                        h[0], h[1]);
@@ -258,9 +285,34 @@ static int gr_projectors(dftk_mi_kblock* kb) {
     return 0;
 }
 
+int gamma_pack_pairs(dftk_mi_kblock* kb, int nb, const cd* H, int64_t ldh, cd* Z, int64_t ldz) {
+    if (nb <= 0) return 0;
+    GammaReal* gr = kb->gr;
+    hipLaunchKernelGGL(k_gr_pack, gr_grid(gr->n_half, (nb + 1) / 2), dim3(256), 0, kb->basis->stream, gr->n_half, nb,
+                       gr->d_g, gr->d_mg, H, ldh, Z, ldz);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int gamma_unpack_pairs(dftk_mi_kblock* kb, int nb, const cd* W, int64_t ldw, cd* H, int64_t ldh) {
+    if (nb <= 0) return 0;
+    GammaReal* gr = kb->gr;
+    hipLaunchKernelGGL(k_gr_unpack, gr_grid(gr->n_half, (nb + 1) / 2), dim3(256), 0, kb->basis->stream, gr->n_half, nb,
+                       gr->d_g, gr->d_mg, W, ldw, H, ldh);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int gamma_pack_full(dftk_mi_kblock* kb, int nb, const cd* X, int64_t ldx, cd* Z, int64_t ldz) {
+    if (nb <= 0) return 0;
+    hipLaunchKernelGGL(k_gr_pack_full, gr_grid(kb->n_G, (nb + 1) / 2), dim3(256), 0, kb->basis->stream, kb->n_G, nb, X,
+                       ldx, Z, ldz);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // H psi in the half-sphere format (which: bit 0 local, 1 kinetic, 2 nonlocal as dftk_mi_apply_H_parts)
 int gamma_apply_H(dftk_mi_kblock* kb, int which, int nb, const cd* psi, int64_t ldpsi, cd* Hpsi, int64_t ldH) {
     if (nb <= 0) return 0;
+    if (kb->sh_comm) return gamma_apply_H_sharded(kb, which, nb, psi, ldpsi, Hpsi, ldH);
     GammaReal* gr = kb->gr;
     dftk_mi_basis* b = kb->basis;
     const int nb2 = (nb + 1) / 2;
@@ -272,16 +324,12 @@ int gamma_apply_H(dftk_mi_kblock* kb, int which, int nb, const cd* psi, int64_t 
         int s;
         ~G() { prof_end(b, s); }
     } guard{b, slot};
-    CHK(gr_ensure_buf(kb, 2 * (size_t)kb->n_G * nb2));
+    CHK(gamma_ensure_buf(kb, 2 * (size_t)kb->n_G * nb2));
     cd* Z = gr->buf;
     cd* W = gr->buf + (size_t)kb->n_G * nb2;
-    hipLaunchKernelGGL(k_gr_pack, gr_grid(gr->n_half, nb2), dim3(256), 0, b->stream, gr->n_half, nb, gr->d_g, gr->d_mg,
-                       psi, ldpsi, Z, kb->n_G);
-    HIPCHK(hipGetLastError());
+    CHK(gamma_pack_pairs(kb, nb, psi, ldpsi, Z, kb->n_G));
     CHK(launch_local_apply(kb, nb2, Z, kb->n_G, W, kb->n_G, kinetic, local));
-    hipLaunchKernelGGL(k_gr_unpack, gr_grid(gr->n_half, nb2), dim3(256), 0, b->stream, gr->n_half, nb, gr->d_g,
-                       gr->d_mg, W, kb->n_G, Hpsi, ldH);
-    HIPCHK(hipGetLastError());
+    CHK(gamma_unpack_pairs(kb, nb, W, kb->n_G, Hpsi, ldH));
     if ((which & 4) && kb->n_p > 0) {
         CHK(gr_projectors(kb));
         CHK(apply_nonlocal_rows(kb, nb, gr->P_half, gr->n_half, gr->n_half, psi, ldpsi, Hpsi, ldH, true,
@@ -294,16 +342,20 @@ int gamma_apply_H(dftk_mi_kblock* kb, int which, int nb, const cd* psi, int64_t 
 // transform (the real part of the transformed pair is band 2p, the imaginary part band 2p + 1)
 int gamma_density(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, const double* w_h, double* rho) {
     if (nb <= 0) return 0;
-    dftk_mi_basis* b = kb->basis;
-    const int nb2 = (nb + 1) / 2;
     if (!kb->gr) {                       // only the scratch buffer of the structure is needed here
         kb->gr = new GammaReal();
         kb->gr->on = false;
     }
-    CHK(gr_ensure_buf(kb, (size_t)kb->n_G * nb2));
-    hipLaunchKernelGGL(k_gr_pack_full, gr_grid(kb->n_G, nb2), dim3(256), 0, b->stream, kb->n_G, nb, psi, ldpsi,
-                       kb->gr->buf, kb->n_G);
-    HIPCHK(hipGetLastError());
+    if (kb->sh_comm) return gamma_density_sharded(kb, nb, psi, ldpsi, w_h, rho);
+    return gamma_density_bands(kb, nb, psi, ldpsi, w_h, rho);
+}
+
+// whole bands on this rank (full-sphere layout)
+int gamma_density_bands(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, const double* w_h, double* rho) {
+    if (nb <= 0) return 0;
+    const int nb2 = (nb + 1) / 2;
+    CHK(gamma_ensure_buf(kb, (size_t)kb->n_G * nb2));
+    CHK(gamma_pack_full(kb, nb, psi, ldpsi, kb->gr->buf, kb->n_G));
     std::vector<double> wre(nb2), wim(nb2);
     for (int p = 0; p < nb2; ++p) {
         wre[p] = w_h[2 * p];

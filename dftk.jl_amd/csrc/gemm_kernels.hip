@@ -1010,7 +1010,8 @@ static GemmTiling gemm_tiling(bool conja, int64_t m, int64_t n, int64_t k, int u
     static const bool no_shift = getenv("DFTK_MI_GEMM_NO_SHIFT") != nullptr;
     t.shift = (use3m && !no_shift && t.gnt > t.gnf && t.gnf >= 1) ? 1 : 0;
     t.gnI = t.gnf + t.shift;
-    t.shift_r = (use3m && !no_shift && t.gm > t.gmf && t.gmf >= 1) ? 1 : 0;
+    static const bool no_rshift = getenv("DFTK_MI_GEMM_NO_ROWSHIFT") != nullptr;
+    t.shift_r = (use3m && !no_shift && !no_rshift && t.gm > t.gmf && t.gmf >= 1) ? 1 : 0;
     t.gmI = t.gmf + t.shift_r;
     t.nright = (t.gnt > t.gnf && !t.shift) ? t.gm : 0;
     t.nbottom = (t.gm > t.gmf && !t.shift_r) ? t.gnI : 0;

@@ -51,6 +51,7 @@ struct Ctx {
     // rf = DFTK_MI_GEMM_REAL is OR-ed into every product that involves them; small matrices are real (stored as
     // complex with zero imaginary parts) and keep the general complex kernels (rf = 0 inside NoComm).
     bool real_mode = false;
+    bool holds_g0 = false;    // this rank's slab starts with the G = 0 row (whose imaginary part must stay zero)
     int rf = 0;
     int mm(char transA, int64_t m, int64_t n, int64_t k, cd alpha, const cd* A, int64_t lda, const cd* B, int64_t ldb,
            cd beta, cd* C, int64_t ldc, int upper = 0) {
@@ -221,7 +222,7 @@ int randomize_column(Ctx& c, Mat X, int col) {
         // small matrices are real; a half-sphere vector is free except for the imaginary part of its G = 0 row
         if (c.small)
             for (size_t i = 1; i < v.size(); i += 2) v[i] = 0.0;
-        else
+        else if (c.holds_g0)
             v[1] = 0.0;
     }
     HIPCHK(hipMemcpyAsync(X.p + (int64_t)col * X.ld, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice,
@@ -402,9 +403,9 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     const int64_t row0 = comm ? (*kb->sh_rows)[comm_rank(comm)] : 0;
     // Gamma-real block: iterate on the half-sphere images of real-symmetric vectors (the caller's X is projected
     // onto that subspace on entry and expanded back to the full sphere on exit)
-    const bool real_mode = !comm && kb->gr && kb->gr->on;
-    const int64_t N = real_mode ? kb->gr->n_half : comm ? (*kb->sh_rows)[comm_rank(comm) + 1] - row0 : kb->n_G;
-    const double* kin = !use_tpa ? nullptr : real_mode ? kb->gr->d_kin_half : kb->d_kin + row0;
+    const bool real_mode = kb->gr && kb->gr->on;
+    const int64_t N = real_mode ? gamma_local_rows(kb) : comm ? (*kb->sh_rows)[comm_rank(comm) + 1] - row0 : kb->n_G;
+    const double* kin = !use_tpa ? nullptr : real_mode ? kb->gr->d_kin_half + gamma_row0(kb) : kb->d_kin + row0;
     auto apply_H = [&](int nb, const cd* in, int64_t ldin, cd* out, int64_t ldout) -> int {
         if (real_mode) return gamma_apply_H(kb, 7, nb, in, ldin, out, ldout);
         return dftk_mi_apply_H(kb, nb, reinterpret_cast<const dftk_mi_cplx*>(in), ldin,
@@ -467,6 +468,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     c.b = b;
     c.comm = comm;
     c.real_mode = real_mode;
+    c.holds_g0 = real_mode && gamma_row0(kb) == 0;
     c.rf = real_mode ? DFTK_MI_GEMM_REAL : 0;
     c.tmpS = take(m3 * M);
     c.O = take((size_t)M * M);
@@ -490,7 +492,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
 
     Mat Xuser{Xp, ldX, N, M};
     if (real_mode)
-        CHK(gamma_compress(kb, M, Xp, ldX, X.p, X.ld));
+        CHK(gamma_lobpcg_load(kb, M, Xp, ldX, X.p, X.ld));
     else
         CHK(ew_copy(b, N, M, Xuser.p, Xuser.ld, X.p, X.ld));
     std::vector<double> resid_history((size_t)M * (maxiter + 1), 0.0);
@@ -709,7 +711,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     }
     // hand the eigenvectors back to the caller's array
     if (real_mode)
-        CHK(gamma_expand(kb, M, X.p, X.ld, Xp, ldX));
+        CHK(gamma_lobpcg_store(kb, M, X.p, X.ld, Xp, ldX));
     else
         CHK(ew_copy(b, N, M, X.p, X.ld, Xuser.p, Xuser.ld));
     double maxres = 0.0;

@@ -25,7 +25,7 @@ def compute_density(basis, psi, occupation, occupation_threshold: float = 0.0, r
         psik = psi[ik]
         if not (psik.is_cuda and psik.dtype == torch.complex128 and psik.stride(1) == 1):
             raise TypeError("compute_density: complex128 CUDA band-major blocks required")
-        paired = real_symmetric is not None and real_symmetric[ik] and basis.comm_pw.size == 1
+        paired = real_symmetric is not None and real_symmetric[ik]
         fn = basis.lib.dftk_mi_density_accumulate_real if paired else basis.lib.dftk_mi_density_accumulate
         _lib.check(fn(kpt.handle, len(w), psik.data_ptr(), psik.stride(0), w.ctypes.data, rhos[kpt.lane].data_ptr()))
     basis.run_on_lanes(accumulate, basis.kpoints)

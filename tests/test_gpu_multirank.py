@@ -125,6 +125,7 @@ def test_bench_two_ranks_one_gpu_gamma_sharded_equals_single_rank():
     out = _run_bench(args, 35000)
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["converged"]
     assert out["config"]["parallelism"].startswith("pw2") and out["steps"] < 40
+    assert out["config"]["orbitals"].startswith("real-symmetric")
     assert out["roofline"]["families_launches"]["collectives"] > 0
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + args
     one = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900)
@@ -149,6 +150,7 @@ model = dftk.model_DFT(lat, atoms, pos, functionals=("lda_x", "lda_c_pw"))
 basis = dftk.PlaneWaveBasis(model, 8, dftk.MonkhorstPack((1, 1, 1)), fft_size=(40, 40, 40), device="cuda:0", comm_pw=comm)
 kpt = basis.kpoints[0]
 assert kpt.n_loc < kpt.n_G and comm._abi_kind is not None
+assert kpt.gamma_real          # real-symmetric Gamma orbitals also on the sharded block (half-format row slabs)
 # (1) H psi and the density of a fixed block, slab by slab
 rho0 = dftk.guess_density(basis)
 _, ham = dftk.energy_hamiltonian(basis, None, None, rho=rho0)

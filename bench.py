@@ -364,6 +364,7 @@ def main():
                             "MFMA peak.  complex_equivalent_tflops = what the same calls would cost the general "
                             "complex iteration (REAL calls counted twice) / time")
             roof["complex_equivalent_tflops"] = fam[14][1] / (ms * 1e-3) / 1e12
+            roof["frac_complex_equivalent"] = roof["complex_equivalent_tflops"] / F64_MFMA_PEAK_TF
         else:
             ms, work, launches = fam[dom]
             roof = {"bound": "hbm", "achieved": work / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}

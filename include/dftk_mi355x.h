@@ -278,7 +278,10 @@ int dftk_mi_kblock_set_shard(dftk_mi_kblock* kb, dftk_mi_comm* comm, const int64
  * same spectrum and multiplicities); every n_G-long product runs as a REAL matrix product over half the rows
  * (DFTK_MI_GEMM_REAL: a third of the matrix-core flops) and two bands share one FFT pipeline pass (a + i b).
  * Errors (DFTK_MI_EINVAL): sphere without inversion symmetry / with a Nyquist point, kinetic(G) != kinetic(-G)
- * (k != 0), projectors that are not real-symmetric (checked when they are first used), sharded block.
+ * (k != 0), projectors that are not real-symmetric (checked when they are first used).
+ * Plane-wave sharded block: call AFTER dftk_mi_kblock_set_shard; the half-format rows are then split evenly over
+ * the ranks (dftk_mi_gamma_half_size returns this rank's count; dftk_mi_gamma_compress / _expand / _apply_H become
+ * collective and work on packed row slabs), the caller keeps handing full-sphere row slabs to dftk_mi_lobpcg.
  * dftk_mi_apply_H / dftk_mi_density_accumulate on the block keep their general complex semantics.
  * dftk_mi_lobpcg_last_AX returns NULL after a real-mode run. */
 int dftk_mi_kblock_set_gamma_real(dftk_mi_kblock* kb, int on);

@@ -761,3 +761,32 @@ def test_host_staged_communicator_callbacks_gloo_world2(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o}"
         assert f"rank {r} ok" in o
+
+
+def test_gamma_pair_tables_host(lib):
+    """Host side of the Gamma-real extension (dftk_mi_gamma_tables_host): every row of a k = 0 sphere is paired with
+    its -G row exactly once, G = 0 first and alone; a sphere around k != 0 and a cube with Nyquist points are refused."""
+    import oracle
+    lat = 10.26 / 2 * np.array([[0, 1, 1.0], [1, 0, 1.0], [1, 1, 0.0]])
+    model = oracle.Model(lat, [], [], terms=("Kinetic",), n_electrons=8)
+    for fft in ((21, 21, 21), (24, 25, 27), (30, 30, 30)):
+        basis = oracle.PlaneWaveBasis(model, 10, oracle.ExplicitKpoints([[0, 0, 0], [0.25, 0, 0]], [0.5, 0.5]), fft_size=fft)
+        nx, ny, nz = fft
+        m = np.ascontiguousarray(basis.kpoints[0].mapping, dtype=np.int64)
+        n = len(m)
+        cnt = C.c_int64()
+        check(lib.dftk_mi_gamma_tables_host(nx, ny, nz, n, m.ctypes.data, C.byref(cnt), None, None))
+        nh = cnt.value
+        assert 2 * nh - 1 == n
+        g, mg = np.zeros(nh, dtype=np.int32), np.zeros(nh, dtype=np.int32)
+        check(lib.dftk_mi_gamma_tables_host(nx, ny, nz, n, m.ctypes.data, C.byref(cnt), g.ctypes.data, mg.ctypes.data))
+        assert g[0] == mg[0] == 0 and np.all(np.diff(g) > 0) and np.all(mg[1:] > g[1:])
+        assert sorted(np.concatenate([g, mg[1:]]).tolist()) == list(range(n))          # a partition of the sphere
+        G = basis.kpoints[0].G_vectors
+        assert np.array_equal(G[g], -G[mg])
+        m2 = np.ascontiguousarray(basis.kpoints[1].mapping, dtype=np.int64)               # k != 0: no inversion symmetry
+        st = lib.dftk_mi_gamma_tables_host(nx, ny, nz, len(m2), m2.ctypes.data, C.byref(cnt), None, None)
+        assert st == -1 and b"gamma_real" in lib.dftk_mi_last_error()
+    full = np.arange(8 ** 3, dtype=np.int64)
+    assert lib.dftk_mi_gamma_tables_host(8, 8, 8, len(full), full.ctypes.data, C.byref(cnt), None, None) == -1
+    assert b"Nyquist" in lib.dftk_mi_last_error()

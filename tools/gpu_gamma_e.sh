@@ -1,4 +1,2 @@
 #!/bin/bash
-mkdir -p gpurun_out
-export HSA_ENABLE_IPC_MODE_LEGACY=0
-timeout 1200 python -m pytest tests/test_gpu_multirank.py -x -q 2>&1 | tail -40
+python tools/late_step_profile.py 2>&1 | grep -v amdgpu

@@ -15,6 +15,9 @@ timeout 1500 bash $R/tools/pmc_traffic_bench.sh > $O/pmc.log 2>&1
 cp $R/gpurun_out/r02_pmc_traffic.json $R/gpurun_out/r02_pmc_fetch_size.txt $R/gpurun_out/r02_pmc_write_size.txt $O/ 2>/dev/null
 tail -5 $O/pmc.log
 cd $R
+# the reference's own iteration (general complex orbitals at Gamma) on the same cell, for comparison
+timeout 900 python bench.py --no-gamma-real --no-cpu-baseline > $O/r02_bench_cfg5_complex_$TAG.json 2> $O/bench_cfg5_complex.err
+cut -c1-300 $O/r02_bench_cfg5_complex_$TAG.json
 timeout 600 python bench.py --supercell 4 --no-cpu-baseline > $O/r02_bench_cfg2_$TAG.json 2> $O/bench_cfg2.err
 cut -c1-400 $O/r02_bench_cfg2_$TAG.json
 timeout 600 python bench.py --mode kpoints --no-cpu-baseline > $O/r02_bench_cfg3_kpoints_$TAG.json 2> $O/bench_cfg3.err

@@ -640,7 +640,7 @@ int gamma_projectors_sharded(dftk_mi_kblock* kb) {
     CHK(tf.to_bands(gr->buf, R1, F));                              // F: n_G x mine columns of P
     double h[2] = {0.0, 0.0};
     CHK(gamma_gather_P(kb, tf.mine, F, kb->n_G, Gf, gr->n_half, h));
-    double bad = (h[0] <= 1e-10 * (h[1] > 0 ? h[1] : 1.0)) ? 0.0 : 1.0;
+    double bad = (std::isfinite(h[1]) && h[0] <= 1e-10 * (h[1] > 0 ? h[1] : 1.0)) ? 0.0 : 1.0;
     HIPCHK(hipMemcpyAsync(b->d_scalars, &bad, sizeof(double), hipMemcpyHostToDevice, b->stream));
     CHK(comm_allreduce(kb->sh_comm, b, b->d_scalars, 1));
     HIPCHK(hipMemcpyAsync(&bad, b->d_scalars, sizeof(double), hipMemcpyDeviceToHost, b->stream));

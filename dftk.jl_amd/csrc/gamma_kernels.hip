@@ -134,17 +134,34 @@ __global__ void k_gr_pack_full(int64_t n, int nb, const cd* __restrict__ X, int6
 
 // Ph[j, c] = s_j P[g_j, c]; out[0] = max |P[mg_j, c] - conj(P[g_j, c])|, out[1] = max |P| (bit patterns of
 // non-negative doubles order like integers -> atomicMax on the 64-bit image)
-__global__ void k_gr_gather_P(int64_t nh, const int* __restrict__ g, const int* __restrict__ mg,
-                              const cd* __restrict__ P, int64_t ldP, cd* __restrict__ Ph, int64_t ldh,
-                              unsigned long long* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_gr_gather_P(int64_t nh, const int* __restrict__ g, const int* __restrict__ mg,
+                                                     const cd* __restrict__ P, int64_t ldP, cd* __restrict__ Ph, int64_t ldh,
+                                                     unsigned long long* __restrict__ out) {
+    __shared__ double sh[2][256];
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nh) return;
-    const cd* pc = P + (int64_t)blockIdx.y * ldP;
-    const cd a = pc[g[j]], b = pc[mg[j]];
-    const double asym = hypot(b.x - a.x, b.y + a.y), mag = hypot(a.x, a.y);
-    atomicMax(out, (unsigned long long)__double_as_longlong(asym));
-    atomicMax(out + 1, (unsigned long long)__double_as_longlong(mag));
-    Ph[j + (int64_t)blockIdx.y * ldh] = j ? make_double2(GR_SQRT2 * a.x, GR_SQRT2 * a.y) : make_double2(a.x, 0.0);
+    double asym = 0.0, mag = 0.0;
+    if (j < nh) {
+        const cd* pc = P + (int64_t)blockIdx.y * ldP;
+        const cd a = pc[g[j]], b = pc[mg[j]];
+        asym = hypot(b.x - a.x, b.y + a.y);
+        mag = hypot(a.x, a.y);
+        Ph[j + (int64_t)blockIdx.y * ldh] = j ? make_double2(GR_SQRT2 * a.x, GR_SQRT2 * a.y) : make_double2(a.x, 0.0);
+    }
+    // one pair of atomics per workgroup (NaNs must not get lost in the max: they compare false, so carry them as +inf)
+    sh[0][threadIdx.x] = asym == asym ? asym : INFINITY;
+    sh[1][threadIdx.x] = mag == mag ? mag : INFINITY;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            sh[0][threadIdx.x] = fmax(sh[0][threadIdx.x], sh[0][threadIdx.x + s]);
+            sh[1][threadIdx.x] = fmax(sh[1][threadIdx.x], sh[1][threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicMax(out, (unsigned long long)__double_as_longlong(sh[0][0]));
+        atomicMax(out + 1, (unsigned long long)__double_as_longlong(sh[1][0]));
+    }
 }
 
 static dim3 gr_grid(int64_t rows, int cols) { return dim3((unsigned)((rows + 255) / 256), (unsigned)cols); }
@@ -273,7 +290,7 @@ static int gr_projectors(dftk_mi_kblock* kb) {
     HIPCHK(hipMalloc((void**)&gr->P_half, (size_t)gr->n_half * kb->n_p * sizeof(cd)));
     double h[2];
     CHK(gamma_gather_P(kb, kb->n_p, kb->P, kb->ldP, gr->P_half, gr->n_half, h));
-    if (!(h[0] <= 1e-10 * (h[1] > 0 ? h[1] : 1.0))) {
+    if (!(std::isfinite(h[1]) && h[0] <= 1e-10 * (h[1] > 0 ? h[1] : 1.0))) {
         dftk_set_error("gamma_real: the projectors are not real-symmetric (max |P(-G) - conj P(G)| = %.3e, max |P| = %.3e)",
                        h[0], h[1]);
         HIPCHK(hipFree(gr->P_half));

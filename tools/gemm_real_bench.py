@@ -49,6 +49,17 @@ if only == "gram":      # (PMC passes: just the two Gram formulations and the tw
     run("update REAL", b"N", nh, M, k3, Y, n_G, Cm, k3, out, n_G, 8, 4.0 * nh * M * k3, reps=1)
     check(lib.dftk_mi_basis_destroy(h))
     sys.exit(0)
+if only == "kscan":       # does the K-major path recover when the columns are close together (few pages)?
+    for kk in (8192, 16384, 32768, 65536, nh):
+        Ys = Y.reshape(-1)[: 3 * M * kk].reshape(3 * M, kk)
+        AYs = AY.reshape(-1)[: 3 * M * kk].reshape(3 * M, kk)
+        for mm in (k3, 2 * M):
+            run(f"Gram REAL m=n={mm} K={kk} (packed: lda=K)", b"C", mm, mm, kk, Ys, kk, AYs, kk, G, mm, 8,
+                4.0 * mm * mm * kk, reps=5)
+            run(f"Gram REAL m=n={mm} K={kk} (lda=n_G)      ", b"C", mm, mm, kk, Y, n_G, AY, n_G, G, mm, 8,
+                4.0 * mm * mm * kk, reps=5)
+    check(lib.dftk_mi_basis_destroy(h))
+    sys.exit(0)
 if only == "upper1006":
     for fl in (0, 1):
         run(f"Gram REAL m=n=1006 flags={fl}", b"C", 2 * M, 2 * M, nh, Y, n_G, AY, n_G, G, 2 * M, fl | 8,

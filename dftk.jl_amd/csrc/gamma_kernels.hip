@@ -67,63 +67,12 @@ int gamma_tables_host(int nx, int ny, int nz, int64_t n_G, const int64_t* mappin
 #define GR_SQRT2 1.4142135623730951
 #define GR_ISQRT2 0.70710678118654752
 
-// u[c] = exp(-i phi_c) with exp(2 i phi_c) = s_c / |s_c|, s_c = sum_G x(G) x(-G): a column that is a real-symmetric
-// vector times a global phase, x = exp(i phi) r, has s = exp(2 i phi) |r|^2, so u x = +-r and nothing is lost when
-// the symmetric part is taken (warm starts from orbitals of a complex iteration; a real-symmetric column gives s > 0,
-// u = 1 exactly).  One workgroup per column.
-__global__ __launch_bounds__(256) void k_gr_phase(int64_t nh, const int* __restrict__ g, const int* __restrict__ mg,
-                                                  const cd* __restrict__ X, int64_t ldx, cd* __restrict__ u) {
-    __shared__ double sh[2][256];
-    const cd* x = X + (int64_t)blockIdx.x * ldx;
-    double sr = 0.0, si = 0.0;
-    for (int64_t j = threadIdx.x; j < nh; j += 256) {
-        const cd a = x[g[j]], b = x[mg[j]];
-        const double w = j ? 2.0 : 1.0;
-        sr += w * (a.x * b.x - a.y * b.y);
-        si += w * (a.x * b.y + a.y * b.x);
-    }
-    sh[0][threadIdx.x] = sr;
-    sh[1][threadIdx.x] = si;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
-            sh[1][threadIdx.x] += sh[1][threadIdx.x + s];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const double re = sh[0][0], im = sh[1][0], mag = hypot(re, im);
-        double c = 1.0, sn = 0.0;                         // cos(phi), sin(phi)
-        if (mag > 0.0 && isfinite(mag) && im != 0.0) {    // (im == 0, re > 0: already aligned; re < 0: phi = pi/2)
-            const double c2 = re / mag, s2 = im / mag;    // cos(2 phi), sin(2 phi)
-            if (c2 >= 0.0) {
-                c = sqrt(0.5 * (1.0 + c2));
-                sn = s2 / (2.0 * c);
-            } else {
-                sn = copysign(sqrt(0.5 * (1.0 - c2)), s2);
-                c = s2 / (2.0 * sn);
-            }
-        } else if (mag > 0.0 && isfinite(mag) && re < 0.0) {
-            c = 0.0;
-            sn = 1.0;
-        }
-        u[blockIdx.x] = make_double2(c, -sn);             // exp(-i phi)
-    }
-}
-
 __global__ void k_gr_compress(int64_t nh, const int* __restrict__ g, const int* __restrict__ mg,
-                              const cd* __restrict__ X, int64_t ldx, cd* __restrict__ H, int64_t ldh,
-                              const cd* __restrict__ u) {
+                              const cd* __restrict__ X, int64_t ldx, cd* __restrict__ H, int64_t ldh) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nh) return;
     const cd* x = X + (int64_t)blockIdx.y * ldx;
-    cd a = x[g[j]], b = x[mg[j]];
-    if (u) {                                             // rotate the column by its phase first
-        const cd w = u[blockIdx.y];
-        a = make_double2(w.x * a.x - w.y * a.y, w.x * a.y + w.y * a.x);
-        b = make_double2(w.x * b.x - w.y * b.y, w.x * b.y + w.y * b.x);
-    }
+    const cd a = x[g[j]], b = x[mg[j]];
     const double s = j ? GR_ISQRT2 : 0.5;            // sqrt(2) * 1/2 (symmetric part), row 0: 1/2 (a == b)
     H[j + (int64_t)blockIdx.y * ldh] = make_double2(s * (a.x + b.x), s * (a.y - b.y));
 }
@@ -295,18 +244,11 @@ int gamma_ensure_buf(dftk_mi_kblock* kb, size_t elems) {
     return 0;
 }
 
-int gamma_compress(dftk_mi_kblock* kb, int m, const cd* X, int64_t ldx, cd* H, int64_t ldh, bool align_phase) {
+int gamma_compress(dftk_mi_kblock* kb, int m, const cd* X, int64_t ldx, cd* H, int64_t ldh) {
     if (m <= 0) return 0;
     GammaReal* gr = kb->gr;
-    dftk_mi_basis* b = kb->basis;
-    cd* u = nullptr;
-    if (align_phase) {   // per-column phases in the general workspace (free between products)
-        CHK(ensure_ws(b, (size_t)m * sizeof(cd)));
-        u = reinterpret_cast<cd*>(b->ws);
-        hipLaunchKernelGGL(k_gr_phase, dim3(m), dim3(256), 0, b->stream, gr->n_half, gr->d_g, gr->d_mg, X, ldx, u);
-    }
-    hipLaunchKernelGGL(k_gr_compress, gr_grid(gr->n_half, m), dim3(256), 0, b->stream, gr->n_half, gr->d_g, gr->d_mg, X,
-                       ldx, H, ldh, (const cd*)u);
+    hipLaunchKernelGGL(k_gr_compress, gr_grid(gr->n_half, m), dim3(256), 0, kb->basis->stream, gr->n_half, gr->d_g,
+                       gr->d_mg, X, ldx, H, ldh);
     HIPCHK(hipGetLastError());
     return 0;
 }

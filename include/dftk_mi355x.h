@@ -272,8 +272,7 @@ int dftk_mi_kblock_set_shard(dftk_mi_kblock* kb, dftk_mi_comm* comm, const int64
  * At k = 0 the Hamiltonian of the reference's models (real local potential, projectors of real functions)
  * commutes with complex conjugation in real space: its eigenvectors can be chosen with psi(-G) = conj(psi(G)).
  * After dftk_mi_kblock_set_gamma_real(kb, 1), dftk_mi_lobpcg on this block projects the caller's X onto that
- * invariant subspace (each column first rotated by the global phase that maximises its real-symmetric part, so that
- * orbitals of a complex iteration -- real fields times arbitrary phases -- are taken over without loss), iterates on its HALF-SPHERE image (row 0 = x(G = 0), real; row j > 0 = sqrt(2) x(G_j) for one
+ * invariant subspace, iterates on its HALF-SPHERE image (row 0 = x(G = 0), real; row j > 0 = sqrt(2) x(G_j) for one
  * representative of every pair {G, -G}; n_half = (n_G + 1) / 2 rows), and hands back full-sphere vectors.
  * Eigenvalues, residual norms, density and energies are those of the general complex iteration (same operator,
  * same spectrum and multiplicities); every n_G-long product runs as a REAL matrix product over half the rows

@@ -246,7 +246,7 @@ def test_scf_gamma_real_equals_complex():
     nconv = r0["n_bands_converge"]
     np.testing.assert_allclose(r1["eigenvalues"][0][:nconv], r0["eigenvalues"][0][:nconv], atol=1e-8)
     assert float(torch.linalg.norm(r1["rho"] - r0["rho"])) * np.sqrt(b0.dvol) < 1e-8
-    assert abs(r1["n_iter"] - r0["n_iter"]) <= 8      # (tol = 1e-10 sits in the round-off tail of the Anderson iteration)
+    assert abs(r1["n_iter"] - r0["n_iter"]) <= 2
     # restart from the converged real-symmetric orbitals: one cheap step
     r2 = dftk.self_consistent_field(b1, rho=r1["rho"], psi=r1["psi"], tol=1e-8)
     assert r2["converged"] and r2["n_iter"] <= 3
@@ -292,23 +292,3 @@ def test_heev_real_symmetric_input(lib, n):
     assert not V.imag.any()
     assert np.linalg.norm(V.T @ V - np.eye(n)) < 1e-12 * n
     assert np.linalg.norm(A @ V.real - V.real * w[None, :]) < 1e-12 * n * np.linalg.norm(A)
-
-
-def test_lobpcg_entry_aligns_global_phases(lib):
-    """Warm start from orbitals of a COMPLEX iteration: real-symmetric vectors times arbitrary global phases (one of
-    them exactly i, whose plain real-symmetric part vanishes) must be taken over without loss -- the entry projection
-    rotates every column by its own phase first.  maxiter = 0: orthonormal input comes back as +-r_n."""
-    obasis, H, bs, kb, g, mg, rng = gamma_block(lib, 10, (21, 21, 21))
-    n, M = kb.n_G, 6
-    _, R = symmetric_block(rng, n, M, g, mg)
-    R = np.linalg.qr(np.vstack([R.real, R.imag]))[0]                # orthonormalise with REAL coefficients
-    R = R[:n] + 1j * R[n:]
-    assert relerr(from_half(to_half(R, g, mg), g, mg, n), R) < 1e-13     # still real-symmetric, orthonormal
-    phases = np.exp(1j * np.array([0.0, np.pi / 2, 1.0, -2.5, np.pi, 0.3]))
-    X0 = R * phases[None, :]
-    lam, res, nit, conv, nmv, X = run_lobpcg(lib, kb, X0, 1e-30, maxiter=0)
-    ov = np.abs(R.conj().T @ X)           # (the result is sorted by Rayleigh quotient: a signed permutation of the r_n)
-    np.testing.assert_allclose(np.sort(ov, axis=0)[-1], 1.0, atol=1e-10)
-    np.testing.assert_allclose(np.sort(ov, axis=1)[:, -1], 1.0, atol=1e-10)
-    assert np.abs(ov).sum() < M + 1e-8
-    assert relerr(from_half(to_half(X, g, mg), g, mg, n), X) < 1e-13      # what comes back is real-symmetric

@@ -1,3 +1,4 @@
 #!/bin/bash
-export HSA_ENABLE_IPC_MODE_LEGACY=0
-timeout 900 python -m pytest tests/test_gpu_gamma_real.py -x -q -k aligns 2>&1 | tail -40
+timeout 900 python -m pytest tests/test_gpu_gamma_real.py tests/test_gpu_kernels.py -x -q -k "zgemm or lobpcg or potrf" 2>&1 | tail -4
+python tools/gemm_real_bench.py 264859 503 gramscan 2>&1 | grep -v amdgpu
+python tools/gemm_real_bench.py 264859 503 2>&1 | grep -v amdgpu

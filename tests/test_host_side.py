@@ -790,3 +790,35 @@ def test_gamma_pair_tables_host(lib):
     full = np.arange(8 ** 3, dtype=np.int64)
     assert lib.dftk_mi_gamma_tables_host(8, 8, 8, len(full), full.ctypes.data, C.byref(cnt), None, None) == -1
     assert b"Nyquist" in lib.dftk_mi_last_error()
+
+
+def test_gamma_half_format_restriction_has_the_oracle_spectrum(lib):
+    """The claim behind the Gamma-real extension, checked against the ORACLE on the CPU: in the half-sphere format
+    (pair tables of the library, row 0 = x(0), rows j > 0 = sqrt(2) x(G_j), 2 n_half - 1 real unknowns) the oracle's
+    Gamma-point Hamiltonian is a REAL SYMMETRIC matrix with exactly the eigenvalues -- and multiplicities -- of the
+    complex Hermitian one, and plain real dot products of half-format vectors are the complex inner products."""
+    Si = oracle.ElementPsp("Si", oracle.load_psp_hgh("Si", "lda"))
+    lat = 10.26 / 2 * np.array([[0, 1, 1.0], [1, 0, 1.0], [1, 1, 0.0]])
+    model = oracle.Model(lat, [Si, Si], [np.ones(3) / 8, -np.ones(3) / 8], terms=("Kinetic", "AtomicLocal", "AtomicNonlocal"))
+    basis = oracle.PlaneWaveBasis(model, 4, oracle.ExplicitKpoints([[0, 0, 0]], [1.0]), fft_size=(15, 15, 15))
+    _, ham = oracle.energy_hamiltonian(basis, None, None)
+    H = ham[0].to_dense()
+    n = H.shape[0]
+    nx, ny, nz = basis.fft_size
+    m = np.ascontiguousarray(basis.kpoints[0].mapping, dtype=np.int64)
+    cnt = C.c_int64()
+    check(lib.dftk_mi_gamma_tables_host(nx, ny, nz, n, m.ctypes.data, C.byref(cnt), None, None))
+    nh = cnt.value
+    g, mg = np.zeros(nh, dtype=np.int32), np.zeros(nh, dtype=np.int32)
+    check(lib.dftk_mi_gamma_tables_host(nx, ny, nz, n, m.ctypes.data, C.byref(cnt), g.ctypes.data, mg.ctypes.data))
+    # E: real unknowns (x0; Re, Im of sqrt(2) x(G_j)) -> full complex vector
+    E = np.zeros((n, 2 * nh - 1), dtype=complex)
+    E[g[0], 0] = 1.0
+    for j in range(1, nh):
+        E[g[j], 2 * j - 1] = E[mg[j], 2 * j - 1] = 1 / np.sqrt(2)
+        E[g[j], 2 * j], E[mg[j], 2 * j] = 1j / np.sqrt(2), -1j / np.sqrt(2)
+    G = E.conj().T @ E
+    assert np.abs(G - np.eye(2 * nh - 1)).max() < 1e-14                  # real dot products = complex inner products
+    Hr = E.conj().T @ H @ E
+    assert np.abs(Hr.imag).max() < 1e-12 * np.abs(Hr).max()              # H maps real fields to real fields
+    np.testing.assert_allclose(np.linalg.eigvalsh(Hr.real), np.linalg.eigvalsh(H), atol=1e-11)

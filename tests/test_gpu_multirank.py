@@ -44,12 +44,36 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-def _spawn(cmds_env):
-    procs = [subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=ROOT)
-             for cmd, env in cmds_env]
-    outs = [p.communicate(timeout=900)[0] for p in procs]
+def _spawn(cmds_env, timeout=600.0, grace=10.0):
+    """Run the rank processes to completion.  A rank that dies leaves its peers waiting in a collective for ever, so
+    the survivors are killed ``grace`` seconds after the first failure (and everybody at ``timeout``): a broken rank
+    fails the test in seconds with its output instead of hanging the suite.  Output goes to temporary files (no pipe
+    that could fill up while nobody reads it)."""
+    import tempfile
+    import time
+    logs = [tempfile.TemporaryFile(mode="w+") for _ in cmds_env]
+    procs = [subprocess.Popen(cmd, env=env, stdout=log, stderr=subprocess.STDOUT, text=True, cwd=ROOT)
+             for (cmd, env), log in zip(cmds_env, logs)]
+    t0 = time.time()
+    first_failure = None
+    while any(p.poll() is None for p in procs):
+        now = time.time()
+        if first_failure is None and any(p.poll() not in (None, 0) for p in procs):
+            first_failure = now
+        if now - t0 > timeout or (first_failure is not None and now - first_failure > grace):
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.1)
+    outs = []
+    for p, log in zip(procs, logs):
+        p.wait()
+        log.seek(0)
+        outs.append(log.read())
+        log.close()
     for r, (p, o) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, f"rank {r} failed:\n{o[-4000:]}"
+        assert p.returncode == 0, f"rank {r} failed (exit {p.returncode}):\n{o[-4000:]}"
     return outs
 
 

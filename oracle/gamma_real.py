@@ -123,3 +123,34 @@ def lobpcg_gamma_real(ham_block, fft_size, X0, tol=1e-8, maxiter=100, n_conv_che
     res["X_real"] = res["X"]
     res["X"] = blk.unpack(np.real(res["X"]))
     return res
+
+
+# ---- two bands per transform (k_gr_pack / k_gr_unpack / k_gr_pack_full of gamma_kernels.hip) ------------------------
+def pack_pair(ha, hb, g, mg, n_G):
+    """Full-sphere image of a + i b for two half-format vectors (b = None: a alone)."""
+    a = from_half(ha, g, mg, n_G)
+    return a if hb is None else a + 1j * from_half(hb, g, mg, n_G)
+
+
+def unpack_pair(w, g, mg):
+    """Inverse on the output of a REAL-linear, conjugation-commuting operator: A = (W(G) + conj W(-G)) / 2 and
+    B = (W(G) - conj W(-G)) / (2i), both back in the half format."""
+    wg, wm = w[g], w[mg]
+    s = np.full(len(g), SQRT2 / 2)
+    s[0] = 0.5
+    a = s * (wg + np.conj(wm))
+    b = s * (wg - np.conj(wm)) / 1j
+    a[0], b[0] = np.real(a[0]), np.real(b[0])
+    return a, b
+
+
+def align_phase(x, g, mg):
+    """Rotate every column by exp(-i phi), exp(2 i phi) = s / |s|, s = sum_G x(G) x(-G): a real-symmetric vector times
+    a global phase becomes +-itself, so that taking the real-symmetric part afterwards loses nothing (planned entry
+    step of the device LOBPCG)."""
+    x = np.asarray(x, dtype=complex)
+    w = np.ones(len(g))
+    w[1:] = 2.0
+    s = np.sum(w[:, None] * x[g] * x[mg], axis=0)
+    phi = np.where(np.abs(s) > 0, np.angle(s) / 2, 0.0)
+    return x * np.exp(-1j * phi)[None, :]

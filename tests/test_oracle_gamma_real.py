@@ -84,3 +84,50 @@ def test_lobpcg_on_the_real_unknowns_equals_the_complex_iteration():
     R = H.mul(X) - X * rr["λ"][None, :]
     assert np.linalg.norm(R[:, :6], axis=0).max() < 1e-9               # eigenvectors of the GENERAL operator
     assert not np.any(np.imag(rr["X_real"]))                           # the iteration never left the real numbers
+
+
+def test_two_bands_share_one_transform():
+    """The packing identities of the device path against the oracle's local operator and density: with a real potential
+    and an even kinetic factor, H_loc (a + i b) = H_loc a + i H_loc b with both parts real-symmetric, and
+    |IFFT(a + i b)|^2 splits into the two real fields."""
+    basis, H = _block(5, (16, 16, 16))
+    blk = gr.RealSymmetricBlock(H, basis.fft_size)
+    g, mg, n = blk.g, blk.mg, H.n_G
+    rng = np.random.default_rng(1)
+    ra, rb = rng.standard_normal(blk.n_real), rng.standard_normal(blk.n_real)
+    ha, hb = gr.real_to_half(ra), gr.real_to_half(rb)
+    z = gr.pack_pair(ha, hb, g, mg, n)
+    w = H.apply_local(z[:, None])[:, 0] + H.kinetic * z
+    a, b = gr.unpack_pair(w, g, mg)
+    xa, xb = gr.from_half(ha, g, mg, n), gr.from_half(hb, g, mg, n)
+    ref_a = gr.to_half((H.apply_local(xa[:, None])[:, 0] + H.kinetic * xa)[:, None], g, mg)[:, 0]
+    ref_b = gr.to_half((H.apply_local(xb[:, None])[:, 0] + H.kinetic * xb)[:, None], g, mg)[:, 0]
+    assert np.allclose(a, ref_a, atol=1e-13) and np.allclose(b, ref_b, atol=1e-13)
+    assert a[0].imag == 0 and b[0].imag == 0
+    # odd band count: b = None
+    a1, b1 = gr.unpack_pair(H.apply_local(gr.pack_pair(ha, None, g, mg, n)[:, None])[:, 0], g, mg)
+    assert np.allclose(b1, 0, atol=1e-13)
+    # density: Re^2 and Im^2 of the packed transform are the two bands' densities
+    kpt = basis.kpoints[0]
+    cz = basis.ifft(kpt, z, normalize=False)
+    ca, cb = basis.ifft(kpt, xa, normalize=False), basis.ifft(kpt, xb, normalize=False)
+    assert np.allclose(cz.real ** 2, np.abs(ca) ** 2, atol=1e-12 * np.abs(ca).max() ** 2)
+    assert np.allclose(cz.imag ** 2, np.abs(cb) ** 2, atol=1e-12 * np.abs(cb).max() ** 2)
+
+
+def test_phase_alignment_takes_over_complex_orbitals_without_loss():
+    """Real-symmetric vectors times arbitrary global phases (one exactly i, whose plain symmetric part vanishes): after
+    align_phase the real-symmetric part is +-the real field itself."""
+    basis, H = _block()
+    blk = gr.RealSymmetricBlock(H, basis.fft_size)
+    rng = np.random.default_rng(2)
+    r = rng.standard_normal((blk.n_real, 6))
+    x = blk.unpack(r)
+    phases = np.exp(1j * np.array([0.0, np.pi / 2, 1.0, -2.5, np.pi, 0.3]))
+    y = x * phases[None, :]
+    lost = blk.unpack(blk.pack(y))                                     # without alignment: column 1 is annihilated
+    assert np.linalg.norm(lost[:, 1]) < 1e-12 * np.linalg.norm(x[:, 1])
+    z = blk.unpack(blk.pack(gr.align_phase(y, blk.g, blk.mg)))
+    sign = np.sign(np.real(np.sum(np.conj(x) * z, axis=0)))
+    assert np.all(np.abs(sign) == 1) and np.allclose(z, x * sign[None, :], atol=1e-13)
+    assert np.allclose(gr.align_phase(x, blk.g, blk.mg), x, atol=0)    # already aligned: untouched, bit for bit

@@ -197,6 +197,15 @@ class PlaneWaveBasis:
             kgrid = MonkhorstPack((1, 1, 1))
         # symmetries that survive the discretisation, irreducible k-points (PlaneWaveBasis.jl:161-173)
         symmetries = list(model.symmetries)
+        # what todict(basis) reports (input_output.jl:184-196): the grid AS GIVEN and the two constructor flags
+        self.symmetries_respect_rgrid = bool(symmetries_respect_rgrid)
+        self.use_symmetries_for_kpoint_reduction = bool(use_symmetries_for_kpoint_reduction)
+        if isinstance(kgrid, MonkhorstPack):                                   # Base.show, bzmesh.jl:31-37 / :120-122
+            shift = [float(x) for x in kgrid.kshift]
+            self.kgrid_description = (f"MonkhorstPack([{', '.join(str(int(n)) for n in kgrid.kgrid_size)}]"
+                                      + (f", [{', '.join(repr(x) for x in shift)}]" if any(shift) else "") + ")")
+        else:
+            self.kgrid_description = f"ExplicitKpoints with {len(kgrid.kcoords)} k-points"
         if symmetries_respect_rgrid:
             symmetries = _sym.symmetries_preserving_rgrid(symmetries, self.fft_size)
         if isinstance(kgrid, MonkhorstPack):

@@ -830,7 +830,70 @@ extern "C" int dftk_mi_local_potential(dftk_mi_kblock* cube_kb, const double* rh
                                        double* energies_h) {
     if (!cube_kb || !rho_d || !energies_h || (xc_functionals & ~7) || cube_kb->sh_comm) return DFTK_MI_EINVAL;
     HIPCHK(hipSetDevice(cube_kb->basis->device));
-    return local_potential_lda(cube_kb, rho_d, V_loc_d, poisson_green_d, xc_functionals, V_out_d, energies_h);
+    return local_potential_lda(cube_kb, nullptr, rho_d, V_loc_d, poisson_green_d, xc_functionals, 0.0, V_out_d,
+                               energies_h);
+}
+
+// Julia's column-major 3x3 (entry (i, j) at i + 3 j) -> the kernels' row-major copy
+static void rowmajor3(const double* colmajor, double* out) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) out[3 * i + j] = colmajor[i + 3 * j];
+}
+
+extern "C" int dftk_mi_local_potential_gga(dftk_mi_kblock* cube_kb, const double* recip_lattice_h, const double* rho_d,
+                                           const double* V_loc_d, const double* poisson_green_d, int xc_functionals,
+                                           double density_threshold, double* V_out_d, double* energies_h) {
+    if (!cube_kb || !rho_d || !energies_h || (xc_functionals & ~31) || cube_kb->sh_comm) return DFTK_MI_EINVAL;
+    if ((xc_functionals & 24) && !recip_lattice_h) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(cube_kb->basis->device));
+    double B[9] = {0};
+    if (recip_lattice_h) rowmajor3(recip_lattice_h, B);
+    return local_potential_lda(cube_kb, B, rho_d, V_loc_d, poisson_green_d, xc_functionals, density_threshold, V_out_d,
+                               energies_h);
+}
+
+extern "C" int dftk_mi_symmetrize_rho(dftk_mi_kblock* cube_kb, int n_sym, const int32_t* S_h, const double* tau_h,
+                                      int do_lowpass, const double* rho_in_d, double* rho_out_d) {
+    if (!cube_kb || n_sym < 1 || !S_h || !tau_h || !rho_in_d || !rho_out_d || cube_kb->sh_comm) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(cube_kb->basis->device));
+    std::vector<int32_t> S((size_t)9 * n_sym);
+    for (int s = 0; s < n_sym; ++s)
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) S[9 * (size_t)s + 3 * i + j] = S_h[9 * (size_t)s + i + 3 * j];
+    return cube_symmetrize(cube_kb, n_sym, S.data(), tau_h, do_lowpass, rho_in_d, rho_out_d);
+}
+
+static int filter_entry(dftk_mi_kblock* cube_kb, int kind, const double* recip_lattice_h, double p0, double p1,
+                        const double* mult_d, const double* f_d, double* out_d) {
+    if (!cube_kb || !f_d || !out_d || cube_kb->sh_comm) return DFTK_MI_EINVAL;
+    if (kind == 3 ? !mult_d : !recip_lattice_h) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(cube_kb->basis->device));
+    double B[9] = {0};
+    if (recip_lattice_h) rowmajor3(recip_lattice_h, B);
+    return cube_fourier_filter(cube_kb, kind, B, p0, p1, mult_d, f_d, out_d);
+}
+
+extern "C" int dftk_mi_mix_kerker(dftk_mi_kblock* cube_kb, const double* recip_lattice_h, double kTF, const double* dF_d,
+                                  double* drho_d) {
+    if (!(kTF >= 0)) return DFTK_MI_EINVAL;
+    return filter_entry(cube_kb, 0, recip_lattice_h, kTF, 0.0, nullptr, dF_d, drho_d);
+}
+
+extern "C" int dftk_mi_mix_dielectric(dftk_mi_kblock* cube_kb, const double* recip_lattice_h, double kTF, double eps_r,
+                                      const double* dF_d, double* drho_d) {
+    if (!(kTF >= 0) || !(eps_r > 0)) return DFTK_MI_EINVAL;
+    return filter_entry(cube_kb, 1, recip_lattice_h, kTF, eps_r, nullptr, dF_d, drho_d);
+}
+
+extern "C" int dftk_mi_chi0_dielectric_apply(dftk_mi_kblock* cube_kb, const double* recip_lattice_h, double kTF,
+                                             double eps_r, const double* dV_d, double* out_d) {
+    if (!(kTF >= 0) || !(eps_r > 0)) return DFTK_MI_EINVAL;
+    return filter_entry(cube_kb, 2, recip_lattice_h, kTF, eps_r, nullptr, dV_d, out_d);
+}
+
+extern "C" int dftk_mi_cube_fourier_filter(dftk_mi_kblock* cube_kb, const double* multiplier_d, const double* f_d,
+                                           double* out_d) {
+    return filter_entry(cube_kb, 3, nullptr, 0.0, 0.0, multiplier_d, f_d, out_d);
 }
 
 extern "C" int dftk_mi_kpoint_sphere_host(int nx, int ny, int nz, const double* recip_lattice_h, const double* kcoord_h,

@@ -231,8 +231,14 @@ int comm_alltoallv(dftk_mi_comm* c, dftk_mi_basis* b, const cd* send, const size
                    cd* recv, const size_t* roff, const size_t* rcnt);
 
 // xc_kernels.hip
-int local_potential_lda(dftk_mi_kblock* cube_kb, const double* rho, const double* vloc, const double* green,
-                        int fun_mask, double* V_out, double* energies_h);
+int local_potential_lda(dftk_mi_kblock* cube_kb, const double* recip_h, const double* rho, const double* vloc,
+                        const double* green, int fun_mask, double threshold, double* V_out, double* energies_h);
+
+// cube_kernels.hip: density-sized operations of the SCF glue (symmetrisation, mixing multipliers) on a full-cube k-block
+int cube_symmetrize(dftk_mi_kblock* cube_kb, int n_sym, const int32_t* S_h, const double* tau_h, int do_lowpass,
+                    const double* rho_in, double* rho_out);
+int cube_fourier_filter(dftk_mi_kblock* cube_kb, int kind, const double* recip_h, double p0, double p1,
+                        const double* mult_d, const double* f, double* out);
 int xc_gga_pointwise(dftk_mi_basis* b, int64_t n, const double* rho, const double* sigma, int fun_mask,
                      double threshold, double* e, double* vrho, double* vsigma);
 

@@ -88,6 +88,7 @@ __device__ __forceinline__ void lda_c_pw(double rho, double& e, double& v) {
 // V = V_loc + V_H + v_xc ; partials: [0] sum e_xc, [1] sum rho V_loc
 __global__ __launch_bounds__(256) void k_xc_sum(int64_t n, const double* __restrict__ rho, const cd* __restrict__ vh_cube,
                                                 double vh_scale, const double* __restrict__ vloc, int fun_mask,
+                                                const double* __restrict__ e_extra, const double* __restrict__ v_extra,
                                                 double* __restrict__ V, double* __restrict__ partial) {
     __shared__ double sh[4];
     double acc_xc = 0.0, acc_loc = 0.0;
@@ -99,6 +100,10 @@ __global__ __launch_bounds__(256) void k_xc_sum(int64_t n, const double* __restr
             if (fun_mask & 1) { lda_x(r, ei, vi); e += ei; v += vi; }
             if (fun_mask & 2) { lda_c_vwn(r, ei, vi); e += ei; v += vi; }
             if (fun_mask & 4) { lda_c_pw(r, ei, vi); e += ei; v += vi; }
+        }
+        if (e_extra) {                       // GGA part: e(rho, sigma) and v_rho - 2 div(v_sigma grad rho), precomputed
+            e += e_extra[i];
+            v += v_extra[i];
         }
         acc_xc += e;
         double tot = v;
@@ -192,9 +197,22 @@ int xc_gga_pointwise(dftk_mi_basis* b, int64_t n, const double* rho, const doubl
     return 0;
 }
 
+// cube_kernels.hip
+int cube_ws_ensure(dftk_mi_basis* b, size_t bytes);
+int cube_forward_real(dftk_mi_kblock* cube_kb, const double* f, const double* g, cd* tmp, cd* c_out);
+int cube_gradient_multiply(dftk_mi_kblock* cube_kb, const double* recip_h, int alpha, const cd* c, cd* out, bool accumulate);
+int cube_backward_real(dftk_mi_kblock* cube_kb, const cd* c, cd* tmp, double scale, double* out);
+int cube_sigma(dftk_mi_basis* b, int64_t N, const double* gx, const double* gy, const double* gz, double* sigma);
+int cube_axpy_real(dftk_mi_basis* b, int64_t N, const double* a, double scale, const cd* c, double* out);
+
 // cube_kb: a k-block whose "sphere" is the whole cube (mapping = 0 .. N-1), i.e. the library's cube FFT.
-int local_potential_lda(dftk_mi_kblock* cube_kb, const double* rho, const double* vloc, const double* green,
-                        int fun_mask, double* V_out, double* energies_h) {
+// fun_mask may carry LDA bits (1, 2, 4: point-wise in the final pass) and GGA bits (8, 16): for the latter
+//   grad rho = irfft(i G_a fft(rho))            (LibxcDensities, xc.jl:356-409)
+//   sigma = |grad rho|^2, (e, v_rho, v_sigma) = point-wise PBE forms (k_gga)
+//   v_xc = v_rho - 2 div(v_sigma grad rho),  div f = irfft(sum_a i G_a fft(f_a))   (xc.jl:140-150, :576-584)
+// with G in cartesian coordinates from recip_h (row-major recip_lattice).  8 cube FFTs in total.
+int local_potential_lda(dftk_mi_kblock* cube_kb, const double* recip_h, const double* rho, const double* vloc,
+                        const double* green, int fun_mask, double threshold, double* V_out, double* energies_h) {
     dftk_mi_basis* b = cube_kb->basis;
     const int64_t N = (int64_t)b->nx * b->ny * b->nz;
     if (cube_kb->n_G != N) {
@@ -202,19 +220,41 @@ int local_potential_lda(dftk_mi_kblock* cube_kb, const double* rho, const double
                        (long long)cube_kb->n_G, (long long)N);
         return DFTK_MI_EINVAL;
     }
-    // two complex cubes + reduction partials in the basis' dense workspace
-    const size_t need = 2 * (size_t)N * sizeof(cd) + 3 * XC_BLOCKS * sizeof(double);
-    if (need > b->dense_ws_bytes) {
-        HIPCHK(hipStreamSynchronize(b->stream));
-        if (b->dense_ws) HIPCHK(hipFree(b->dense_ws));
-        b->dense_ws = nullptr;
-        b->dense_ws_bytes = 0;
-        HIPCHK(dftk_scratch_malloc(&b->dense_ws, need));
-        b->dense_ws_bytes = need;
-    }
+    const int gga_mask = fun_mask & 24;
+    // complex cubes c1, c2 (+ c3 and 7 real cubes for GGA) + reduction partials in the basis' dense workspace
+    const size_t need = (gga_mask ? 3 : 2) * (size_t)N * sizeof(cd) + (gga_mask ? 7 : 0) * (size_t)N * sizeof(double) +
+                        3 * XC_BLOCKS * sizeof(double);
+    CHK(cube_ws_ensure(b, need));
     cd* c1 = reinterpret_cast<cd*>(b->dense_ws);
     cd* c2 = c1 + N;
-    double* partial = reinterpret_cast<double*>(c2 + N);
+    cd* c3 = gga_mask ? c2 + N : nullptr;
+    double* rbase = reinterpret_cast<double*>(c2 + N + (gga_mask ? N : 0));
+    double *e_g = nullptr, *v_g = nullptr;
+    if (gga_mask) {
+        double* grad[3] = {rbase, rbase + N, rbase + 2 * N};
+        double* sigma = rbase + 3 * N;
+        e_g = rbase + 4 * N;
+        double* vrho = rbase + 5 * N;
+        double* vsig = rbase + 6 * N;
+        rbase += 7 * N;
+        CHK(cube_forward_real(cube_kb, rho, nullptr, c1, c2));                         // c2 = F[rho]
+        for (int a = 0; a < 3; ++a) {
+            CHK(cube_gradient_multiply(cube_kb, recip_h, a, c2, c3, false));           // c3 = i G_a F[rho]
+            CHK(cube_backward_real(cube_kb, c3, c1, 1.0 / (double)N, grad[a]));
+        }
+        CHK(cube_sigma(b, N, grad[0], grad[1], grad[2], sigma));
+        hipLaunchKernelGGL(k_gga, dim3(XC_BLOCKS), dim3(256), 0, b->stream, N, rho, sigma, gga_mask, threshold, e_g, vrho,
+                           vsig);
+        HIPCHK(hipGetLastError());
+        for (int a = 0; a < 3; ++a) {
+            CHK(cube_forward_real(cube_kb, vsig, grad[a], c1, c2));                    // c2 = F[v_sigma d_a rho]
+            CHK(cube_gradient_multiply(cube_kb, recip_h, a, c2, c3, a > 0));           // c3 (+)= i G_a c2
+        }
+        CHK(launch_ifft_to_cube(cube_kb, c3, c1));                                     // c1 = N div(...)
+        v_g = sigma;                                                                   // (sigma is dead by now)
+        CHK(cube_axpy_real(b, N, vrho, -2.0 / (double)N, c1, v_g));
+    }
+    double* partial = rbase;
     const cd* vh = nullptr;
     std::vector<double> hp(3 * XC_BLOCKS, 0.0);
     if (green) {
@@ -224,8 +264,8 @@ int local_potential_lda(dftk_mi_kblock* cube_kb, const double* rho, const double
         CHK(launch_ifft_to_cube(cube_kb, c2, c1));                        // c1 = N * V_H(r)
         vh = c1;
     }
-    hipLaunchKernelGGL(k_xc_sum, dim3(XC_BLOCKS), dim3(256), 0, b->stream, N, rho, vh, 1.0 / (double)N, vloc, fun_mask,
-                       V_out, partial);
+    hipLaunchKernelGGL(k_xc_sum, dim3(XC_BLOCKS), dim3(256), 0, b->stream, N, rho, vh, 1.0 / (double)N, vloc,
+                       fun_mask & 7, (const double*)e_g, (const double*)v_g, V_out, partial);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(hp.data(), partial, (green ? 3 : 2) * XC_BLOCKS * sizeof(double), hipMemcpyDeviceToHost,
                           b->stream));

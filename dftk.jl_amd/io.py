@@ -34,6 +34,13 @@ def _tolist(x):
     return x
 
 
+def _symmetries_to_dict(symmetries) -> dict:
+    """``[symop.W for symop in symmetries]`` / ``[symop.w ...]`` (input_output.jl:101-102): each W as Julia writes a
+    matrix -- the list of its COLUMNS."""
+    return {"symmetries_rotations": [np.asarray(s.W, dtype=int).T.tolist() for s in symmetries],
+            "symmetries_translations": [np.asarray(s.w, dtype=float).tolist() for s in symmetries]}
+
+
 def model_to_dict(model) -> dict:
     """``todict(model)`` (input_output.jl:75-110).  Matrices as Julia writes them: list of COLUMNS."""
     lat = np.asarray(model.lattice)
@@ -45,7 +52,7 @@ def model_to_dict(model) -> dict:
         "atomic_positions": [np.asarray(p).tolist() for p in model.positions],
         "atomic_positions_cart": [(lat @ np.asarray(p)).tolist() for p in model.positions],
         "n_electrons": model.n_electrons, "pseudofamily": "hgh",
-        "symmetries_rotations": [np.eye(3, dtype=int).tolist()], "symmetries_translations": [[0.0, 0.0, 0.0]],
+        **_symmetries_to_dict(model.symmetries),
         "terms": list(model.term_types), "functionals": list(model.functionals),
     }
 
@@ -56,11 +63,14 @@ def basis_to_dict(basis) -> dict:
     recip = np.asarray(basis.model.recip_lattice)
     kc = [np.asarray(k).tolist() for k in basis.kcoords_global]
     d.update({
-        "kgrid": "ExplicitKpoints", "kcoords": kc, "kcoords_cart": [(recip @ np.asarray(k)).tolist() for k in kc],
+        "kgrid": getattr(basis, "kgrid_description", f"ExplicitKpoints with {len(kc)} k-points"), "kcoords": kc, "kcoords_cart": [(recip @ np.asarray(k)).tolist() for k in kc],
         "kweights": list(map(float, basis.kweights_global)), "n_kpoints": len(kc), "fft_size": list(basis.fft_size),
-        "dvol": basis.dvol, "Ecut": basis.Ecut, "variational": True, "symmetries_respect_rgrid": True,
-        "use_symmetries_for_kpoint_reduction": False,
+        "dvol": basis.dvol, "Ecut": basis.Ecut, "variational": True,
+        "symmetries_respect_rgrid": bool(getattr(basis, "symmetries_respect_rgrid", True)),
+        "use_symmetries_for_kpoint_reduction": bool(getattr(basis, "use_symmetries_for_kpoint_reduction", False)),
     })
+    # the discretisation may have broken some of the model's symmetries: the basis' own list replaces them (:198-202)
+    d.update(_symmetries_to_dict(basis.symmetries))
     return d
 
 
@@ -156,6 +166,15 @@ def load_scfres(filename: str, basis=None) -> dict:
         if list(basis.fft_size) != out["fft_size"] or abs(basis.Ecut - out["Ecut"]) > 1e-12 \
                 or len(basis.kcoords_global) != out["n_kpoints"]:
             raise ValueError("stored and passed basis are inconsistent (fft_size / Ecut / k-points)")
+        kc = np.asarray([np.asarray(k, dtype=float) for k in basis.kcoords_global]).reshape(-1, 3)
+        if (np.abs(kc - np.asarray(out["kcoords"], dtype=float).reshape(-1, 3)).max(initial=0.0) > 1e-10
+                or np.abs(np.asarray(basis.kweights_global, dtype=float)
+                          - np.asarray(out["kweights"], dtype=float)).max(initial=0.0) > 1e-10):
+            raise ValueError("stored and passed basis are inconsistent (k-point coordinates / weights)")
+        if basis.comm_kpts.size > 1 or basis.comm_pw.size > 1:
+            raise NotImplementedError("npz checkpoints restart single-rank runs")
+        if "kpt_n_G_vectors" in out and [int(k.n_G) for k in basis.kpoints] != list(out["kpt_n_G_vectors"][0]):
+            raise ValueError("stored and passed basis are inconsistent (plane waves per k-point)")
         dev = basis.device
         if "rho" in data:
             out["rho"] = torch.from_numpy(data["rho"]).to(dev)

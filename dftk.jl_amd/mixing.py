@@ -118,6 +118,34 @@ def _G2(basis):
     return (Gc * Gc).sum(dim=-1)
 
 
+def _torch_twin():
+    """``DFTK_MI_TORCH_LOCAL=1``: the torch formulation of the cube multipliers (parity twin of the library calls)."""
+    import os
+    return os.environ.get("DFTK_MI_TORCH_LOCAL") is not None
+
+
+def _filter(basis, entry, x, *params):
+    """One of the library's Fourier-multiplier passes on a real cube (``dftk_mi_mix_kerker`` / ``_mix_dielectric`` /
+    ``_chi0_dielectric_apply``): fft, multiplier evaluated per G in the kernel, irfft."""
+    from . import _lib
+    Bh = np.asfortranarray(basis.model.recip_lattice, dtype=np.float64)
+    xin = x.to(torch.float64).contiguous()
+    out = torch.empty_like(xin)
+    torch.cuda.current_stream(basis.device).synchronize()
+    _lib.check(getattr(basis.lib, entry)(basis._cube_handle, Bh.ctypes.data, *params, xin.data_ptr(), out.data_ptr()))
+    return out
+
+
+def _filter_array(basis, mult, x):
+    """irfft(mult .* fft(x)) with a real multiplier cube (``dftk_mi_cube_fourier_filter``)."""
+    from . import _lib
+    xin, m = x.to(torch.float64).contiguous(), mult.to(torch.float64).contiguous()
+    out = torch.empty_like(xin)
+    torch.cuda.current_stream(basis.device).synchronize()
+    _lib.check(basis.lib.dftk_mi_cube_fourier_filter(basis._cube_handle, m.data_ptr(), xin.data_ptr(), out.data_ptr()))
+    return out
+
+
 class SimpleMixing:
     """mixing.jl:36-39: J^-1 ~ 1."""
 
@@ -132,6 +160,8 @@ class KerkerMixing:
         self.kTF = float(kTF)
 
     def mix_density(self, basis, dF, **info):
+        if not _torch_twin():
+            return _filter(basis, "dftk_mi_mix_kerker", dF, self.kTF)
         G2 = _G2(basis)
         drho_f = basis.fft(dF) * (G2 / (self.kTF ** 2 + G2)) * basis.enforce_real_mask()
         drho = basis.irfft(drho_f)
@@ -166,6 +196,8 @@ class DielectricMixing:
             return dF
         if er > 1 / math.sqrt(EPS):
             return KerkerMixing(kTF).mix_density(basis, dF)
+        if not _torch_twin():
+            return _filter(basis, "dftk_mi_mix_dielectric", dF, kTF, er)
         C0 = 1 - er
         G2 = _G2(basis)
         drho = basis.irfft(basis.fft(dF) * ((kTF ** 2 - C0 * G2) / (er * kTF ** 2 - C0 * G2)))
@@ -206,6 +238,10 @@ class DielectricModel:
         if C0 == 0:
             return None
         kTF = self.kTF
+        if not _torch_twin():
+            def apply(drho, dV, alpha=1.0):
+                return drho + alpha * _filter(basis, "dftk_mi_chi0_dielectric_apply", dV, kTF, self.eps_r)
+            return apply
         G2 = _G2(basis)
         mult = C0 * kTF ** 2 * G2 / (4 * math.pi) / (kTF ** 2 - C0 * G2)
 
@@ -232,7 +268,12 @@ class Chi0Mixing:
 
         def dielectric_adjoint(x):
             count[0] += 1
-            dV = basis.irfft(poisson * basis.fft(x)) if poisson is not None else torch.zeros_like(x)   # apply_kernel, RPA
+            if poisson is None:
+                dV = torch.zeros_like(x)
+            elif _torch_twin():
+                dV = basis.irfft(poisson * basis.fft(x))                                            # apply_kernel, RPA
+            else:
+                dV = _filter_array(basis, poisson, x)
             dV = dV - dV.mean()
             out = x
             for a in applies:

@@ -234,13 +234,45 @@ class AndersonAcceleration:
         return xn.reshape(x.shape)
 
 
-def determine_diagtol(n_iter, history_drho, ratio=0.2, diagtol_max=0.005, diagtol_first=None):
-    """AdaptiveDiagtol (scf_callbacks.jl:191-212)."""
+def determine_diagtol(n_iter, history_drho, ratio=0.2, diagtol_max=0.005, diagtol_first=None, diagtol_min=None):
+    """``determine_diagtol(::AdaptiveDiagtol, info)`` (scf_callbacks.jl:191-212): ``diagtol_first = 6 diagtol_max``
+    unless given, ``min(diagtol_first, 5 diagtol_max)`` while ``n_iter <= 1``, then ``ratio * min(history_drho)``
+    clamped to ``[diagtol_min = 100 eps, diagtol_max]``."""
     if diagtol_first is None:
         diagtol_first = 6 * diagtol_max
     if n_iter <= 1:
         return min(diagtol_first, 5 * diagtol_max)
-    return float(np.clip(min(history_drho) * ratio, 100 * EPS, diagtol_max))
+    diagtol = min(history_drho) * ratio
+    if not math.isfinite(diagtol):
+        raise FloatingPointError("AdaptiveDiagtol: non-finite density change")
+    return float(np.clip(diagtol, 100 * EPS if diagtol_min is None else diagtol_min, diagtol_max))
+
+
+NONLINEAR_TERMS = ("Hartree", "Xc", "LocalNonlinearity")   # <: TermNonlinear (hartree.jl:24, xc.jl:75, local_nonlinearity.jl:7)
+
+
+def has_nonlinear_terms(model):
+    """``any(t -> t isa TermNonlinear, basis.terms)``; an ``Xc`` without functionals instantiates as ``TermNoop``
+    (xc.jl:33) and does not count."""
+    return any(t in NONLINEAR_TERMS and not (t == "Xc" and not model.functionals) for t in model.term_types)
+
+
+def default_diagtolalg(basis, tol):
+    """``default_diagtolalg(basis; tol)`` (scf_callbacks.jl:220-230): exact exchange -> ``ratio_rhodiff = 5e-4``;
+    any nonlinear term (Hartree, Xc: every DFT model) -> plain ``AdaptiveDiagtol()``, i.e. 0.025 on the first two
+    steps; only LINEAR models (one diagonalisation is the answer) take ``diagtol_first = tol / 5``."""
+    terms = basis.model.term_types
+    if "ExactExchange" in terms:
+        kw = dict(ratio=5e-4)
+    elif has_nonlinear_terms(basis.model):
+        kw = dict()
+    else:
+        kw = dict(diagtol_first=tol / 5)
+
+    def determine_tol(n_iter, history_drho):
+        return determine_diagtol(n_iter, history_drho, **kw)
+    determine_tol.params = kw
+    return determine_tol
 
 
 class ScfStepper:
@@ -263,11 +295,8 @@ class ScfStepper:
         self.rho_in = guess_density(basis) if rho is None else rho
         self.nbandsalg = nbandsalg if nbandsalg is not None else AdaptiveBands(basis.model)
         self.is_converged = is_converged or (lambda info: info["history_drho"][-1] < tol)   # ScfConvergenceDensity
-        if determine_tol is determine_diagtol:
-            # default_diagtolalg (scf_callbacks.jl:223-233): AdaptiveDiagtol(; diagtol_first = tol / 5) for models
-            # without nonlinear / exact-exchange terms -- the first two SCF steps diagonalise to tol / 5
-            def determine_tol(n_iter, history_drho, _first=tol / 5):
-                return determine_diagtol(n_iter, history_drho, diagtol_first=_first)
+        if determine_tol is None or determine_tol is determine_diagtol:
+            determine_tol = default_diagtolalg(basis, tol)      # self_consistent_field.jl:179
         self.eigensolver, self.damping, self.determine_tol = eigensolver, damping, determine_tol
         self.accel = AndersonAcceleration(m=anderson_m)
         self.sqrt_dvol = math.sqrt(basis.dvol)

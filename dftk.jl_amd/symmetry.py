@@ -231,11 +231,24 @@ def _tables(basis):
 
 
 def symmetrize_rho(basis, rho, do_lowpass=True):
-    """``symmetrize_rho(basis, rho; do_lowpass)`` (symmetry.jl:346-357) on the device."""
+    """``symmetrize_rho(basis, rho; do_lowpass)`` (symmetry.jl:346-357): ONE library call (``dftk_mi_symmetrize_rho``:
+    cube FFT, all symmetries accumulated per G in one kernel, low-pass, inverse FFT).  ``DFTK_MI_TORCH_LOCAL=1`` keeps
+    the torch formulation (one gather per symmetry), the parity twin of tests/test_gpu_symmetry.py."""
+    import os
     import torch
     syms = basis.symmetries
     if all(s.isone() for s in syms):
         return rho
+    if os.environ.get("DFTK_MI_TORCH_LOCAL") is None:
+        from . import _lib
+        S_h = np.ascontiguousarray(np.stack([np.asfortranarray(s.S).ravel(order="F") for s in syms]), dtype=np.int32)
+        tau_h = np.ascontiguousarray(np.stack([s.tau for s in syms]), dtype=np.float64)
+        rin = rho.to(torch.float64).contiguous()
+        out = torch.empty_like(rin)
+        torch.cuda.current_stream(basis.device).synchronize()
+        _lib.check(basis.lib.dftk_mi_symmetrize_rho(basis._cube_handle, len(syms), S_h.ctypes.data, tau_h.ctypes.data,
+                                                    1 if do_lowpass else 0, rin.data_ptr(), out.data_ptr()))
+        return out
     rf = basis.fft(rho).reshape(-1)
     acc = torch.zeros_like(rf)
     for idx, phase in _tables(basis):                  # accumulate_over_symmetries! (:282-319)

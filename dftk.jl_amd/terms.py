@@ -472,30 +472,39 @@ def _PH_psi(basis, Pt, psik):
 
 
 _LDA_BITS = {"lda_x": 1, "lda_c_vwn": 2, "lda_c_pw": 4}
+_GGA_BITS = {"gga_x_pbe": 8, "gga_c_pbe": 16}
 
 
 def local_potential_fused(basis, rho, want_potential=True):
-    """Hartree + LDA XC + V_loc summed into one potential and their three energies by ONE library call
-    (``dftk_mi_local_potential``: hartree.jl:50-59, xc.jl:84-160, local.jl:15-16, operators.jl:213-222).
-    Returns None when the model needs the torch path (GGA functionals)."""
+    """Hartree + XC (LDA point-wise; PBE with its gradient / divergence Fourier passes) + V_loc summed into one
+    potential and their three energies by ONE library call (``dftk_mi_local_potential`` / ``_gga``: hartree.jl:50-59,
+    xc.jl:84-160,356-409,576-584, local.jl:15-16, operators.jl:213-222).  Returns None for functionals the library does
+    not evaluate."""
     import ctypes as C
     T = basis.terms
     mask = 0
     if "Xc" in T.names:
         for name in basis.model.functionals:
-            if name not in _LDA_BITS:
+            if name in _LDA_BITS:
+                mask |= _LDA_BITS[name]
+            elif name in _GGA_BITS:
+                mask |= _GGA_BITS[name]
+            else:
                 return None
-            mask |= _LDA_BITS[name]
     rho = rho.to(torch.float64).contiguous()
     V = torch.empty_like(rho) if want_potential else None
     vloc = T.V_loc if "AtomicLocal" in T.names else None
     green = T.poisson if "Hartree" in T.names else None
     E3 = (C.c_double * 3)()
     torch.cuda.current_stream(basis.device).synchronize()
-    _lib.check(basis.lib.dftk_mi_local_potential(basis._cube_handle, rho.data_ptr(),
-                                                 vloc.data_ptr() if vloc is not None else None,
-                                                 green.data_ptr() if green is not None else None, mask,
-                                                 V.data_ptr() if V is not None else None, E3))
+    args = (vloc.data_ptr() if vloc is not None else None, green.data_ptr() if green is not None else None)
+    if mask & 24:
+        Bh = np.asfortranarray(basis.model.recip_lattice, dtype=np.float64)
+        _lib.check(basis.lib.dftk_mi_local_potential_gga(basis._cube_handle, Bh.ctypes.data, rho.data_ptr(), *args, mask,
+                                                         _DENSITY_THRESHOLD, V.data_ptr() if V is not None else None, E3))
+    else:
+        _lib.check(basis.lib.dftk_mi_local_potential(basis._cube_handle, rho.data_ptr(), *args, mask,
+                                                     V.data_ptr() if V is not None else None, E3))
     return dict(Hartree=E3[0], Xc=E3[1], AtomicLocal=E3[2], V=V)
 
 
@@ -534,8 +543,8 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, ei
     have_psi = psi is not None and occupation is not None
     reduce_kpts = []       # terms that are sums over this rank's k-points: ONE fused reduction at the end
     ritz_fix = None
-    # local-potential pipeline behind the C ABI (LDA); DFTK_MI_TORCH_LOCAL=1 keeps the torch formulation (the
-    # parity reference of tests/test_gpu_scf.py and the only path for GGA functionals)
+    # local-potential pipeline behind the C ABI (LDA and PBE); DFTK_MI_TORCH_LOCAL=1 keeps the torch formulation
+    # (the parity twin of tests/test_gpu_scf.py)
     fused = None
     if rho is not None and os.environ.get("DFTK_MI_TORCH_LOCAL") is None and \
             any(n in T.names for n in ("AtomicLocal", "Hartree", "Xc")):

@@ -135,6 +135,42 @@ int dftk_mi_atomic_superposition(dftk_mi_kblock* cube_kb, int kind, const double
 int dftk_mi_local_potential(dftk_mi_kblock* cube_kb, const double* rho_d, const double* V_loc_d,
                             const double* poisson_green_d, int xc_functionals, double* V_out_d, double* energies_h);
 
+/* The same pipeline with GGA functionals (PBE() = gga_x_pbe + gga_c_pbe, DFTK_MI_XC_GGA_* bits, may be mixed with the
+ * LDA bits): the density gradient and the divergence term of the potential (LibxcDensities src/terms/xc.jl:356-409,
+ * xc_potential_real :140-150, divergence_real :576-584) are taken with i G multipliers between the library's cube FFTs,
+ *   grad rho = irfft(i G_a fft(rho)),  v_xc = de/drho - 2 div(de/dsigma grad rho),  sigma = |grad rho|^2,
+ * G cartesian from recip_lattice_h (3x3 column-major, Julia's model.recip_lattice; required with a GGA bit).  Points
+ * with rho <= density_threshold contribute nothing to the GGA part.  Everything else as dftk_mi_local_potential. */
+int dftk_mi_local_potential_gga(dftk_mi_kblock* cube_kb, const double* recip_lattice_h, const double* rho_d,
+                                const double* V_loc_d, const double* poisson_green_d, int xc_functionals,
+                                double density_threshold, double* V_out_d, double* energies_h);
+
+/* ---- density-sized operations of the SCF glue ----------------------------------------------
+ * symmetrize_rho(basis, rho; symmetries, do_lowpass) for one spin component (src/symmetry.jl:346-357): fft, then
+ * accumulate_over_symmetries! (:282-319: out(G) = sum_s e^{-2 pi i G.tau_s} in(S_s^-1 G), terms whose S_s^-1 G leaves
+ * the grid dropped) and lowpass_for_symmetry! (:323-343) as ONE kernel over G, / n_sym, irfft.  S_h: n_sym 3x3 integer
+ * matrices, column-major (Julia's symop.S = W'); tau_h: 3 doubles each (symop.tau = -W^-1 w).  rho_out_d may alias
+ * rho_in_d.  With identity-only symmetries the density is copied (all(isone, symmetries), :292-295). */
+int dftk_mi_symmetrize_rho(dftk_mi_kblock* cube_kb, int n_sym, const int32_t* S_h, const double* tau_h, int do_lowpass,
+                           const double* rho_in_d, double* rho_out_d);
+/* mix_density(::KerkerMixing, basis, dF) (src/scf/mixing.jl:61-72, spin-unpolarised):
+ *   d_rho = irfft(enforce_real!(G^2 / (kTF^2 + G^2) fft(dF))),  d_rho .+= mean(dF) - mean(d_rho)
+ * (the last line = the G = 0 coefficient of dF kept as it is).  Multiplier evaluated on the fly from the integer G of
+ * each cube entry and recip_lattice_h (column-major). */
+int dftk_mi_mix_kerker(dftk_mi_kblock* cube_kb, const double* recip_lattice_h, double kTF, const double* dF_d,
+                       double* drho_d);
+/* mix_density(::DielectricMixing, ...) (mixing.jl:161-171): multiplier (kTF^2 - C0 G^2) / (eps_r kTF^2 - C0 G^2),
+ * C0 = 1 - eps_r, DC component kept.  (eps_r = 1 and eps_r > 1/sqrt(eps) are the caller's special cases, :163-164.) */
+int dftk_mi_mix_dielectric(dftk_mi_kblock* cube_kb, const double* recip_lattice_h, double kTF, double eps_r,
+                           const double* dF_d, double* drho_d);
+/* apply!(d_rho, ::DielectricModel, dV) kernel part (src/scf/chi0models.jl:66-77, identity localisation):
+ *   out = irfft(C0 kTF^2 G^2 / (4 pi (kTF^2 - C0 G^2)) fft(dV)) */
+int dftk_mi_chi0_dielectric_apply(dftk_mi_kblock* cube_kb, const double* recip_lattice_h, double kTF, double eps_r,
+                                  const double* dV_d, double* out_d);
+/* out = irfft(multiplier .* fft(f)) with a real multiplier cube on the device, e.g. apply_kernel(::TermHartree, ...)
+ * with the Poisson Green's function (src/terms/hartree.jl:68-81) inside the chi0-mixing GMRES (mixing.jl:255-275). */
+int dftk_mi_cube_fourier_filter(dftk_mi_kblock* cube_kb, const double* multiplier_d, const double* f_d, double* out_d);
+
 /* GGA exchange-correlation point by point (the libxc call of src/terms/xc.jl:111 for PBE(): gga_x_pbe + gga_c_pbe):
  * e_d = energy density per volume, vrho_d = de/drho, vsigma_d = de/dsigma (sigma = |grad rho|^2) for n grid points;
  * derivatives by forward-mode differentiation of the closed forms on the device.  Points with rho <= density_threshold

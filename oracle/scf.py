@@ -217,7 +217,21 @@ def determine_diagtol(n_iter, history_drho, ratio=0.2, diagtol_max=0.005, diagto
     if n_iter <= 1:
         return min(diagtol_first, 5 * diagtol_max)
     diagtol = min(history_drho) * ratio
+    assert math.isfinite(diagtol)
     return float(np.clip(diagtol, 100 * EPS, diagtol_max))
+
+
+def default_diagtol_params(model, tol):
+    """``default_diagtolalg`` (scf_callbacks.jl:220-230) as keyword arguments of ``determine_diagtol``:
+    ``TermExactExchange`` -> ratio 5e-4; any ``TermNonlinear`` (Hartree ``hartree.jl:24``, Xc ``xc.jl:75`` unless it
+    has no functionals, ``xc.jl:33``; LocalNonlinearity) -> the plain ``AdaptiveDiagtol()``; linear models only ->
+    ``diagtol_first = tol / 5``."""
+    terms = tuple(model.terms)
+    if "ExactExchange" in terms:
+        return dict(ratio=5e-4)
+    if "Hartree" in terms or "LocalNonlinearity" in terms or ("Xc" in terms and len(model.functionals) > 0):
+        return dict()
+    return dict(diagtol_first=tol / 5)
 
 
 def self_consistent_field(basis, rho=None, psi=None, tol=1e-6, maxiter=100, damping=0.8,
@@ -243,8 +257,8 @@ def self_consistent_field(basis, rho=None, psi=None, tol=1e-6, maxiter=100, damp
         n_iter = info["n_iter"] + 1
         _, ham = energy_hamiltonian(basis, info["psi"], info["occupation"], rho=rho_in)
         info_for_tol = dict(n_iter=info["n_iter"], history_drho=info["history_drho"])
-        # default_diagtolalg (scf_callbacks.jl:223-233): AdaptiveDiagtol(; diagtol_first = tol / 5)
-        diagtol = determine_diagtol(info_for_tol["n_iter"], info_for_tol["history_drho"], diagtol_first=tol / 5)
+        diagtol = determine_diagtol(info_for_tol["n_iter"], info_for_tol["history_drho"],
+                                    **default_diagtol_params(basis.model, tol))
         nxt = next_density(basis, ham, nbandsalg, psi=info["psi"], eigenvalues=info["eigenvalues"],
                            occupation=info["occupation"], tol=diagtol, rng=rng)
         energies, _ = energy_hamiltonian(basis, nxt["psi"], nxt["occupation"], rho=nxt["rho"],

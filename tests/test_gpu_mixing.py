@@ -100,3 +100,31 @@ def test_metal_scf_default_ldos_mixing_matches_oracle_and_simple():
     assert abs(r_ldos["eF"] - o_ldos["eF"]) < 1e-7
     assert abs(r_ldos["n_iter"] - o_ldos["n_iter"]) <= 3
     assert r_ldos["n_iter"] <= r_simple["n_iter"] + 2
+
+
+@pytest.mark.parametrize("fft_size", [(16, 18, 20), (15, 16, 25)])
+def test_fourier_multiplier_kernels_match_torch_twin(fft_size, monkeypatch):
+    """The library's on-the-fly Fourier multipliers (``dftk_mi_mix_kerker``, ``dftk_mi_mix_dielectric``,
+    ``dftk_mi_chi0_dielectric_apply``, ``dftk_mi_cube_fourier_filter``; src/scf/mixing.jl:61-72,161-171,
+    chi0models.jl:66-77, hartree.jl:68-81) against the torch formulation with stored |G|^2 cubes, on even / odd /
+    anisotropic cubes of a non-orthogonal cell (the multiplier needs the cartesian |B G|^2)."""
+    dm, _ = _al_models(supercell=(2, 1, 1))
+    db = dftk.PlaneWaveBasis(dm, 6, dftk.MonkhorstPack((1, 1, 1)), fft_size=fft_size)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    dF = torch.randn(fft_size[::-1], dtype=torch.float64, device="cuda", generator=gen) + 0.3
+    mixes = [dftk.KerkerMixing(0.8), dftk.KerkerMixing(0.05), dftk.DielectricMixing(0.8, 10.0),
+             dftk.DielectricMixing(1.3, 2.5)]
+    chi0 = dftk.mixing.DielectricModel(7.0, 0.9)
+    from dftk_jl_amd.mixing import _filter_array
+    got = [m.mix_density(db, dF.clone()) for m in mixes]
+    got.append(chi0(db)(torch.zeros_like(dF), dF, -1.0))
+    got.append(_filter_array(db, db.terms.poisson, dF))
+    monkeypatch.setenv("DFTK_MI_TORCH_LOCAL", "1")
+    ref = [m.mix_density(db, dF.clone()) for m in mixes]
+    ref.append(chi0(db)(torch.zeros_like(dF), dF, -1.0))
+    ref.append(db.irfft(db.terms.poisson * db.fft(dF)))
+    monkeypatch.delenv("DFTK_MI_TORCH_LOCAL")
+    for g, r in zip(got, ref):
+        assert float((g - r).norm()) < 1e-13 * float(r.norm())
+    # the DC component of dF survives Kerker / dielectric mixing (mixing.jl:70-71)
+    assert abs(float(got[0].mean()) - float(dF.mean())) < 1e-14 and abs(float(got[2].mean()) - float(dF.mean())) < 1e-14

@@ -413,6 +413,38 @@ def test_pbe_pointwise_kernel_matches_autograd(monkeypatch):
     assert float((v1 - v2).abs().max()) < 1e-11 * float(v2.abs().max())
 
 
+@pytest.mark.parametrize("fft_size", [(24, 24, 24), (20, 27, 25)])
+def test_pbe_local_potential_pipeline_behind_abi(fft_size, monkeypatch):
+    """``dftk_mi_local_potential_gga``: the whole PBE branch of ``energy_hamiltonian`` in one library call -- grad rho
+    and div(v_sigma grad rho) as i G multipliers between the cube FFTs (xc.jl:356-409, :576-584), point-wise PBE,
+    Hartree, V = V_loc + V_H + v_xc and the three energies -- against the torch formulation and the oracle."""
+    model, omodel = _pbe_models("Si", LATTICE, POSITIONS)
+    basis = dftk.PlaneWaveBasis(model, 12, dftk.MonkhorstPack((1, 1, 1)), fft_size=fft_size)
+    ob = oracle.PlaneWaveBasis(omodel, 12, oracle.MonkhorstPack((1, 1, 1)), fft_size=fft_size)
+    rho = dftk.guess_density(basis)
+    rho = rho * (1 + 0.25 * torch.cos(torch.arange(fft_size[1], device="cuda", dtype=torch.float64) * 0.9))[None, :, None]
+    rho[1, 2, :4] = torch.tensor([0.0, 1e-13, -1e-6, 5e-12], device="cuda", dtype=torch.float64)   # below the threshold
+    E1, ham1 = dftk.energy_hamiltonian(basis, None, None, rho=rho)
+    monkeypatch.setenv("DFTK_MI_TORCH_LOCAL", "1")
+    E2, ham2 = dftk.energy_hamiltonian(basis, None, None, rho=rho)
+    monkeypatch.delenv("DFTK_MI_TORCH_LOCAL")
+    for name in ("AtomicLocal", "Hartree", "Xc"):
+        assert abs(E1[name] - E2[name]) < 1e-12 * max(1.0, abs(E2[name])), name
+    V1, V2 = ham1[0].potential, ham2[0].potential
+    assert float((V1 - V2).abs().max()) < 1e-11 * float(V2.abs().max())
+    oE, oham = oracle.energy_hamiltonian(ob, None, None, rho=rho.cpu().numpy())
+    for name in ("AtomicLocal", "Hartree", "Xc"):
+        assert abs(E1[name] - oE[name]) < 1e-10 * max(1.0, abs(oE[name])), name
+    assert np.abs(V1.cpu().numpy() - oham[0].potential).max() < 1e-9
+    Eo, _ = dftk.energy_hamiltonian(basis, None, None, rho=rho, only_energies=True)
+    assert Eo["Xc"] == E1["Xc"] and Eo["Hartree"] == E1["Hartree"]
+    # a GGA bit without the reciprocal lattice is an argument error
+    import ctypes as C
+    E3 = (C.c_double * 3)()
+    assert basis.lib.dftk_mi_local_potential_gga(basis._cube_handle, None, rho.data_ptr(), None, None, 24, 1e-12, None,
+                                                 E3) != 0
+
+
 def test_setup_behind_abi_matches_torch_construction(monkeypatch):
     """the k-point sphere (dftk_mi_kpoint_sphere_host) and the projector matrix
     (dftk_mi_build_projectors_hgh, one device kernel) against the torch construction of the same objects and the

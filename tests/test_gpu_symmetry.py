@@ -90,3 +90,44 @@ def test_cfg1_with_symmetries_as_the_reference_runs_it():
     for kpt, lam in zip(basis.kpoints, res["eigenvalues"]):
         ik = [i for i, k in enumerate(g["kcoords"]) if np.allclose(k, kpt.coordinate)][0]
         np.testing.assert_allclose(lam[:4], np.array(g["eigenvalues"][ik])[:4], atol=1e-7)
+
+
+@pytest.mark.parametrize("fft_size", [(20, 20, 20), (18, 20, 24), (15, 15, 15)])
+def test_symmetrize_rho_kernel_matches_torch_twin_and_oracle(fft_size, monkeypatch):
+    """``dftk_mi_symmetrize_rho`` (ONE kernel over G for all symmetries, src/symmetry.jl:282-357) against the torch
+    formulation (one gather per symmetry) and the oracle, on cubes where the low-pass matters (even sizes: the Nyquist
+    planes leave the grid under rotations; anisotropic sizes lose most rotations on the r-grid unless the cube is
+    given) -- explicit ``fft_size`` keeps all 48 operations, so S G regularly leaves the cube."""
+    dm, om = _models(True)
+    db = dftk.PlaneWaveBasis(dm, 7, dftk.MonkhorstPack((2, 2, 2)), fft_size=fft_size)
+    ob = oracle.PlaneWaveBasis(om, 7, oracle.MonkhorstPack((2, 2, 2)), fft_size=fft_size)
+    assert len(db.symmetries) == len(ob.symmetries) == 48
+    rng = np.random.default_rng(3)
+    rho = rng.standard_normal(fft_size[::-1])
+    from oracle.symmetry import symmetrize_rho as osym
+    for lowpass in (True, False):
+        got = dftk.symmetrize_rho(db, torch.from_numpy(rho).cuda(), do_lowpass=lowpass)
+        monkeypatch.setenv("DFTK_MI_TORCH_LOCAL", "1")
+        twin = dftk.symmetrize_rho(db, torch.from_numpy(rho).cuda(), do_lowpass=lowpass)
+        monkeypatch.delenv("DFTK_MI_TORCH_LOCAL")
+        ref = osym(ob, rho, do_lowpass=lowpass)
+        assert float((got - twin).norm()) < 1e-13 * float(twin.norm())
+        assert np.linalg.norm(got.cpu().numpy() - ref) < 1e-12 * np.linalg.norm(ref)
+    # in place (rho_out aliases rho_in at the ABI) and the identity-only shortcut
+    import ctypes as C
+    from dftk_jl_amd._lib import check
+    S_h = np.ascontiguousarray(np.stack([np.asfortranarray(s.S).ravel(order="F") for s in db.symmetries]), dtype=np.int32)
+    tau_h = np.ascontiguousarray(np.stack([s.tau for s in db.symmetries]))
+    buf = torch.from_numpy(rho).cuda()
+    check(db.lib.dftk_mi_symmetrize_rho(db._cube_handle, 48, S_h.ctypes.data, tau_h.ctypes.data, 1, buf.data_ptr(),
+                                        buf.data_ptr()))
+    assert float((buf - got.new_tensor(osym(ob, rho, do_lowpass=True))).norm()) < 1e-12 * float(buf.norm())
+    one = torch.from_numpy(rho).cuda()
+    out = torch.empty_like(one)
+    check(db.lib.dftk_mi_symmetrize_rho(db._cube_handle, 1, S_h[:1].ctypes.data, tau_h[:1].ctypes.data, 1,
+                                        one.data_ptr(), out.data_ptr()))
+    assert db.symmetries[0].isone() and torch.equal(out, one)
+    bad = S_h[:1].copy()
+    bad[0, 0] = 2                                                # det = 2: not a lattice symmetry
+    assert db.lib.dftk_mi_symmetrize_rho(db._cube_handle, 1, bad.ctypes.data, tau_h[:1].ctypes.data, 1,
+                                         one.data_ptr(), out.data_ptr()) != 0

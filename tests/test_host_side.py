@@ -615,6 +615,33 @@ def test_scfres_dict_layout_on_host():
     assert d["norm_Δρ"] == 1e-7 and d["εF"] == 0.3 and d["diagonalization"]["n_iter"] == [[3, 4]]
     import json
     json.dumps(d)
+    assert d["kgrid"] == "MonkhorstPack([2, 1, 1])" and d["symmetries_rotations"] == [np.eye(3, dtype=int).tolist()]
+    assert d["use_symmetries_for_kpoint_reduction"] is True and d["symmetries_respect_rgrid"] is True
+
+
+def test_basis_dict_reports_the_symmetries_it_used():
+    """``todict(basis)`` (input_output.jl:181-204): the k-points written are the IRREDUCIBLE ones, so the symmetry
+    operations (W as its list of columns, w), the two constructor flags and the grid as given must travel with them --
+    DFTK-side post-processing unfolds k-points / densities from exactly these keys."""
+    from dftk_jl_amd.io import basis_to_dict
+    lat, atoms, pos = dftk.silicon_cell()
+    m = dftk.model_DFT(lat, atoms, pos, symmetries=True)
+    b = dftk.PlaneWaveBasis(m, 5, dftk.MonkhorstPack((4, 4, 4)), device="cpu", build_terms=False)
+    d = basis_to_dict(b)
+    assert d["kgrid"] == "MonkhorstPack([4, 4, 4])" and d["n_kpoints"] == len(d["kcoords"]) < 64
+    assert d["use_symmetries_for_kpoint_reduction"] is True and d["symmetries_respect_rgrid"] is True
+    assert len(d["symmetries_rotations"]) == len(b.symmetries) == 48 == len(d["symmetries_translations"])
+    for s, Wl, wl in zip(b.symmetries, d["symmetries_rotations"], d["symmetries_translations"]):
+        assert np.array_equal(np.array(Wl).T, s.W) and np.allclose(wl, s.w)      # Julia nesting: list of columns
+    # unfolding the irreducible points with S = W' reproduces the full mesh with the stored weights
+    full = {tuple(np.round(np.mod(np.array(Wl) @ np.array(k) + 0.5, 1.0) - 0.5, 9) % 1.0)
+            for k in d["kcoords"] for Wl in d["symmetries_rotations"]}
+    assert len(full) == 64 and abs(sum(d["kweights"]) - 1.0) < 1e-14
+    sh = dftk.PlaneWaveBasis(m, 5, dftk.MonkhorstPack((2, 2, 2), kshift=(0.5, 0.5, 0.5)), device="cpu", build_terms=False,
+                             use_symmetries_for_kpoint_reduction=False, fft_size=(20, 20, 20))
+    ds = basis_to_dict(sh)
+    assert ds["kgrid"] == "MonkhorstPack([2, 2, 2], [0.5, 0.5, 0.5])" and ds["n_kpoints"] == 8
+    assert ds["use_symmetries_for_kpoint_reduction"] is False and ds["symmetries_respect_rgrid"] is False
 
 
 def test_kpoint_sphere_host_matches_oracle_and_torch():
@@ -822,3 +849,42 @@ def test_gamma_half_format_restriction_has_the_oracle_spectrum(lib):
     Hr = E.conj().T @ H @ E
     assert np.abs(Hr.imag).max() < 1e-12 * np.abs(Hr).max()              # H maps real fields to real fields
     np.testing.assert_allclose(np.linalg.eigvalsh(Hr.real), np.linalg.eigvalsh(H), atol=1e-11)
+
+
+def test_default_diagtolalg_per_model_class():
+    """``default_diagtolalg`` (scf_callbacks.jl:220-230) + ``determine_diagtol`` (:196-212), mirror and oracle:
+    models with a nonlinear term (Hartree / Xc -- every DFT model) diagonalise the first TWO steps (``n_iter <= 1``)
+    to ``min(6 * 0.005, 5 * 0.005) = 0.025``; only linear models (core Hamiltonian) take ``tol / 5`` there; an ``Xc``
+    term without functionals is a ``TermNoop`` (xc.jl:33) and does not make the model nonlinear."""
+    from types import SimpleNamespace
+    from dftk_jl_amd.scf import default_diagtolalg, determine_diagtol
+    from oracle.scf import default_diagtol_params, determine_diagtol as oracle_determine
+    lat, atoms, pos = dftk.silicon_cell()
+    olat, oatoms, opos = oracle.basis.silicon_primitive(a=10.26, functional="lda")
+    tol = 1e-6
+    cases = [
+        ("dft", dftk.model_DFT(lat, atoms, pos), oracle.model_DFT(olat, oatoms, opos), 0.025),
+        ("dft_T", dftk.model_DFT(lat, atoms, pos, temperature=1e-3, smearing="gaussian"),
+         oracle.model_DFT(olat, oatoms, opos, temperature=1e-3, smearing="gaussian"), 0.025),
+        ("hartree_only", dftk.model_atomic(lat, atoms, pos, extra_terms=("Hartree",)),
+         oracle.model_atomic(olat, oatoms, opos, extra_terms=("Hartree",)), 0.025),
+        ("core", dftk.model_atomic(lat, atoms, pos), oracle.model_atomic(olat, oatoms, opos), tol / 5),
+        ("noop_xc", dftk.model_atomic(lat, atoms, pos, extra_terms=("Xc",), functionals=()),
+         oracle.model_atomic(olat, oatoms, opos, extra_terms=("Xc",), functionals=()), tol / 5),
+    ]
+    hist = [3e-2, 4e-3, 7e-3]
+    for name, m, om, first in cases:
+        f = default_diagtolalg(SimpleNamespace(model=m), tol)
+        okw = default_diagtol_params(om, tol)
+        for n_iter in (0, 1):
+            assert f(n_iter, hist[:n_iter]) == pytest.approx(first, rel=0, abs=0), name
+            assert oracle_determine(n_iter, hist[:n_iter], **okw) == f(n_iter, hist[:n_iter]), name
+        # afterwards: ratio_rhodiff * min(history), clamped to [100 eps, diagtol_max]; never grows again
+        assert f(2, hist[:2]) == pytest.approx(0.2 * 4e-3) == oracle_determine(2, hist[:2], **okw)
+        assert f(3, hist) == pytest.approx(0.2 * 4e-3)
+        assert f(2, [1.0, 1.0]) == 0.005 and f(2, [1e-20, 1.0]) == 100 * np.finfo(float).eps
+    assert determine_diagtol(0, [], diagtol_first=1.0) == 0.025          # min(diagtol_first, 5 diagtol_max)
+    fx = default_diagtolalg(SimpleNamespace(model=SimpleNamespace(term_types=("Kinetic", "ExactExchange"),
+                                                                  functionals=())), tol)
+    assert fx(0, []) == 0.025 and fx(2, [1e-2, 1e-2]) == pytest.approx(5e-4 * 1e-2)
+    assert default_diagtol_params(SimpleNamespace(terms=("Kinetic", "ExactExchange"), functionals=()), tol) == dict(ratio=5e-4)

@@ -8,6 +8,8 @@ fixtures together with this script (task statement, section 3).  Run:  python to
 
 cfg2  -- SURVEY appendix B identity: the Si 4x4x4 supercell at Gamma with a 160^3 cube == the primitive cell
          (a = 10.26, LDA = lda_x + lda_c_pw, Ecut 30) on the unshifted 4x4x4 Monkhorst-Pack mesh with a 40^3 cube.
+cfg5  -- the same identity for the headline cell: Si 5x5x5 supercell at Gamma with a 200^3 cube == the primitive cell on
+         the unshifted 5x5x5 mesh with a 40^3 cube.
 cfg1  -- Si primitive, LDA, Ecut 15, unreduced 4x4x4 mesh, cube from compute_fft_size (27^3; the reference's
          symmetry-adapted 30^3 is run as a second fixture "cfg1_fft30").
 cfg3  -- Al fcc (a = 7.6324708938577865), HGH PBE, Ecut 40, 36^3, Gaussian smearing T = 1e-3, unreduced 3x3x3 mesh
@@ -68,6 +70,10 @@ def main(which):
     if "cfg2" in which:
         run("cfg2_prim_4x4x4_ecut30_fft40", si_model(), 30, oracle.MonkhorstPack((4, 4, 4)), (40, 40, 40),
             note="== Si 4x4x4 supercell at Gamma with fft 160^3 (E_total x 64; union spectrum)")
+    if "cfg5" in which:
+        run("cfg5_prim_5x5x5_ecut30_fft40", si_model(), 30, oracle.MonkhorstPack((5, 5, 5)), (40, 40, 40),
+            note="== Si 5x5x5 supercell (250 atoms, 1000 electrons: the headline cell) at Gamma with fft 200^3 "
+                 "(E_total x 125; union spectrum)")
     if "cfg1" in which:
         run("cfg1_si_ecut15_k4_fft27", si_model(), 15, oracle.MonkhorstPack((4, 4, 4)), None)
         run("cfg1_si_ecut15_k4_fft30", si_model(), 15, oracle.MonkhorstPack((4, 4, 4)), (30, 30, 30))
@@ -112,4 +118,4 @@ def main_full(which):
 
 if __name__ == "__main__":
     main_full(sys.argv[1:])
-    main(sys.argv[1:] or ["cfg2", "cfg1", "cfg3", "cfg4"])
+    main(sys.argv[1:] or ["cfg2", "cfg5", "cfg1", "cfg3", "cfg4"])

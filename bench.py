@@ -66,6 +66,10 @@ def parse():
                     help="Gamma-only modes: iterate general complex orbitals exactly as the reference does, instead of the "
                          "real-symmetric ones (psi(-G) = conj psi(G)) the library uses at k = 0 by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-complex-leg", action="store_true",
+                    help="skip the second timed SCF with general complex orbitals (config.complex_iteration)")
+    ap.add_argument("--cpu-step-budget", type=float, default=150.0,
+                    help="run the REAL timed CPU step only if the sampled model predicts fewer seconds than this")
     ap.add_argument("--prof-all", action="store_true",
                     help="count kernel-family launches from the warm-up on (lines the counts up with a whole-process "
                          "rocprofv3 --pmc pass; tools/pmc_traffic_bench.sh)")
@@ -179,7 +183,7 @@ def cpu_baseline_gamma(basis, info, n_sample, per_step):
         t_dens = (time.time() - t0) / n_sample
     bsz = threads
     # dense algebra rate: Gram matrix and rotation of a panel (threaded OpenBLAS zgemm)
-    mcols = min(128, M)
+    mcols = M                      # panels of the true width (LOBPCG's are M .. 3M wide)
     Xs = rng.standard_normal((n_G, mcols)) + 1j * rng.standard_normal((n_G, mcols))
     G = Xs.conj().T @ Xs
     t0 = time.time()
@@ -189,8 +193,11 @@ def cpu_baseline_gamma(basis, info, n_sample, per_step):
     rate = 2 * 8.0 * n_G * mcols * mcols / t_blas                  # flop/s of zgemm on this host
     n_occ = basis.model.n_electrons // 2
     t_step = (per_step["n_matvec"] * t_hpsi + per_step["zgemm_flops"] / rate + n_occ * t_dens)
+    late_flops = 80.0 * n_G * M * M         # one 1-iteration LOBPCG call: Gram / update products of a late step
     return {"value": 1.0 / t_step, "unit": "SCF iterations/s", "cores": cores, "kind": "port",
             "hpsi_applies_per_s": 1.0 / t_hpsi,
+            "model_terms": {"hpsi_s_per_band": t_hpsi, "density_s_per_band": t_dens, "zgemm_gflops": rate / 1e9,
+                            "late_step_zgemm_s": late_flops / rate},
             "sample": (f"NumPy/SciPy oracle arithmetic (not DFTK: no Julia here), band-parallel as the reference: "
                        f"{bsz} threads x one band each (pocketfft workers=1) + threaded OpenBLAS: {n_sample} bands of H psi "
                        f"({t_hpsi * 1e3:.2f} ms/band; checked against oracle.HamiltonianBlock.mul to {err:.1e}), "
@@ -226,6 +233,256 @@ def cfg1_scf_3steps(device):
             "note": "64 tiny k-blocks (n_G ~ 725, 7 bands): launch-latency bound on the device"}
 
 
+# ------------------------------------------------------------------------------------------ CPU leg: a timed step
+def cpu_timed_late_step(basis, info, diagtol, budget_s):
+    """kind = "port, timed step": ONE real SCF step of the reference's algorithm on the host cores, with wall seconds,
+    beside the device's time for the same step.  Input = the converged state of the device run (psi, rho): from there
+    a step is what every late SCF step of this workload is -- H[rho] is rebuilt, LOBPCG (general complex orbitals,
+    the oracle's restatement of lobpcg_hyper_impl.jl) starts from the previous orbitals and needs ONE iteration at
+    the step's ``diagtol`` (2 M H psi applies, a 2M x 2M Rayleigh-Ritz, block updates of the true width), then
+    ``compute_density`` over the occupied bands.  H psi and the density are band-parallel over all cores exactly like
+    the sampled leg above (one band per thread, pocketfft workers = 1); the dense algebra is NumPy's threaded OpenBLAS.
+    Returns None when the host lacks the memory (13 blocks of n_G x M complex) or the sampled model predicts more than
+    ``budget_s`` seconds."""
+    import scipy.fft as sfft
+    import oracle
+    from oracle.lobpcg import PreconditionerTPA, lobpcg_hyper
+    from concurrent.futures import ThreadPoolExecutor
+    cores = os.cpu_count()
+    kpt = basis.kpoints[0]
+    T = basis.terms
+    nx, ny, nz = basis.fft_size
+    N = basis.N
+    n_G, M = kpt.n_G, info["psi"][0].shape[0]
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+    except Exception:
+        avail = 64 << 30
+    need = 16 * n_G * M * 16 + 16 * n_G * (T.D.shape[0] if T.D is not None else 0) * 2
+    if avail < need + (8 << 30):
+        return None
+    try:
+        from threadpoolctl import threadpool_info
+        blas_threads = max((p_.get("num_threads", 0) for p_ in threadpool_info() if p_.get("user_api") == "blas"),
+                           default=0)
+    except Exception:
+        blas_threads = 0
+    P = T.P[0].cpu().numpy().T.copy() if T.P is not None else None       # (n_G, n_p)
+    D = T.D
+    V = info["ham"][0].potential.cpu().numpy()
+    kin = kpt.kinetic.cpu().numpy()
+    pot = V.reshape(-1) * (basis.fft_normalization * basis.ifft_normalization)
+    X0 = info["psi"][0].cpu().numpy().T.copy()                            # (n_G, M) general complex orbitals
+    mapping = kpt.mapping
+    threads = int(max(1, min(cores, M, avail // (8 * 16 * N))))
+    pool = ThreadPoolExecutor(max_workers=threads)
+    n_hpsi = [0]
+
+    def local_one(col):
+        cube = np.zeros(N, dtype=complex)
+        cube[mapping] = col
+        cube = sfft.ifftn(cube.reshape(nz, ny, nx), workers=1, norm="forward", overwrite_x=True).reshape(N)
+        cube *= pot
+        cube = sfft.fftn(cube.reshape(nz, ny, nx), workers=1, norm="backward", overwrite_x=True).reshape(N)
+        return cube[mapping]
+
+    def A(block):                       # mul!(H psi, H, psi) (Hamiltonian.jl:137-192), band-parallel
+        n_hpsi[0] += block.shape[1]
+        out = np.empty_like(block)
+        for j, col in enumerate(pool.map(local_one, (block[:, j] for j in range(block.shape[1])))):
+            out[:, j] = col
+        out += kin[:, None] * block
+        if P is not None:
+            out += P @ (D @ (P.conj().T @ block))
+        return out
+
+    def dens_one(col):
+        cube = np.zeros(N, dtype=complex)
+        cube[mapping] = col
+        cube = sfft.ifftn(cube.reshape(nz, ny, nx), workers=1, norm="forward", overwrite_x=True)
+        return cube.real ** 2 + cube.imag ** 2
+
+    # check the band-parallel operator against the oracle's own (2 bands)
+    class OB:
+        pass
+    ob = OB()
+    ob.fft_size, ob.N = basis.fft_size, basis.N
+    ob.fft_normalization, ob.ifft_normalization = basis.fft_normalization, basis.ifft_normalization
+    ob.ifft = oracle.PlaneWaveBasis.ifft.__get__(ob)
+    ob.fft = oracle.PlaneWaveBasis.fft.__get__(ob)
+    okpt = oracle.Kpoint(1, kpt.coordinate, kpt.G_vectors.cpu().numpy(), kpt.mapping)
+    ref = oracle.terms.HamiltonianBlock(ob, okpt, kin, V, P, D).mul(X0[:, :2])
+    err = float(np.linalg.norm(A(X0[:, :2]) - ref) / np.linalg.norm(ref))
+    assert err < 1e-12, f"band-parallel CPU H psi deviates from the oracle: {err}"
+    n_hpsi[0] = 0
+    n_conv = int(info["n_bands_converge"])
+    t0 = time.time()
+    res = lobpcg_hyper(A, X0, prec=PreconditionerTPA(kin), tol=diagtol, n_conv_check=n_conv, maxiter=100)
+    t_lobpcg = time.time() - t0
+    occ = np.asarray(info["occupation"][0], dtype=float)
+    t0 = time.time()
+    rho = np.zeros((nz, ny, nx))
+    live = [j for j in range(M) if abs(occ[j]) > 1e-8]
+    for j, d in zip(live, pool.map(dens_one, (res["X"][:, j] for j in live))):
+        rho += occ[j] * d
+    rho *= basis.kweights[0] / basis.model.unit_cell_volume
+    t_dens = time.time() - t0
+    pool.shutdown()
+    drho = float(np.linalg.norm(rho - info["rho"].cpu().numpy()) * np.sqrt(basis.dvol))
+    dlam = float(np.max(np.abs(res["λ"][:n_conv] - np.asarray(info["eigenvalues"][0])[:n_conv])))
+    return {"cpu_step_s": round(t_lobpcg + t_dens, 2), "cpu_lobpcg_s": round(t_lobpcg, 2), "cpu_density_s": round(t_dens, 2),
+            "lobpcg_iterations": int(res["n_iter"]), "n_matvec": int(res["n_matvec"]), "converged": bool(res["converged"]),
+            "diagtol": diagtol, "fft_threads": threads, "blas_threads": blas_threads,
+            "hpsi_check_vs_oracle": err, "drho_vs_device": drho, "max_eigenvalue_diff_vs_device": dlam}
+
+
+def device_late_step(dftk, basis, info, tol):
+    """The device's wall time for the same step as ``cpu_timed_late_step``: one more SCF step from the converged state."""
+    st = dftk.ScfStepper(basis, rho=info["rho"], psi=info["psi"], tol=tol)
+    st.info.update(eigenvalues=info["eigenvalues"], occupation=info["occupation"], eF=info["eF"], n_iter=2,
+                   history_drho=list(info["history_drho"]))
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.time()
+    out = st.step()
+    torch.cuda.synchronize()
+    return time.time() - t0, out
+
+
+# ------------------------------------------------------------------------------------------ the timed SCF
+def run_scf(dftk, lib, basis, args, barrier, world, dist, torch):
+    """--warmup steps on a throw-away stepper, then ONE whole self_consistent_field capped at --steps, HIP-event
+    family timings switched on for the timed part.  Returns the numbers of the JSON line."""
+    from dftk_jl_amd._lib import check
+    if args.prof_all:
+        check(lib.dftk_mi_prof_enable(basis.handle, 1))
+    if args.warmup > 0:
+        warm = dftk.ScfStepper(basis, tol=args.tol)
+        for _ in range(args.warmup):
+            if warm.step()["converged"]:
+                break
+        del warm
+    barrier()
+    if not args.prof_all:
+        check(lib.dftk_mi_prof_enable(basis.handle, 1))
+    iters, diagtols, step_s, nmv_steps = [], [], [], []
+    host_timers = {}
+    t0 = time.time()
+    stepper = dftk.ScfStepper(basis, tol=args.tol)          # guess_density is part of self_consistent_field
+    info = None
+    for _ in range(max(args.steps, 1)):
+        ts = time.time()
+        info = stepper.step()
+        step_s.append(time.time() - ts)
+        iters.append(float(np.mean(info["diagonalization"]["n_iter"])))
+        diagtols.append(info["diagtol"])
+        nmv_steps.append(int(info["n_matvec_step"]))
+        for k_, v_ in info["timers"].items():
+            host_timers[k_] = host_timers.get(k_, 0.0) + v_
+        if info["converged"]:
+            break
+    info = stepper.finalize()                                # energies + Hamiltonian of the final state, as the reference
+    barrier()
+    elapsed = time.time() - t0
+    check(lib.dftk_mi_prof_enable(basis.handle, 0))
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    fam = {f: prof_get(lib, basis, f) for f in list(FAMILIES) + [10, 12, 14]}
+    return dict(info=info, elapsed=elapsed, iters=iters, diagtols=diagtols, step_s=step_s, nmv_steps=nmv_steps,
+                host_timers=host_timers, fam=fam)
+
+
+def roofline_of(fam, n_gpus, workload):
+    """``roofline`` object of the JSON line from the HIP-event family timings of one timed SCF."""
+    zg_ms = fam[0][0] + fam[11][0]
+    zg_useful = fam[0][1] + fam[11][1]
+    zg_launch = fam[0][2] + fam[11][2]
+    fam_ms = {f: (zg_ms if f == 0 else fam[f][0]) for f in KERNEL_FAMS}
+    dom = max((f for f in KERNEL_FAMS if fam_ms[f] > 0), key=lambda f: fam_ms[f])
+    if dom == 0:
+        ms, work, launches = zg_ms, zg_useful, zg_launch
+        roof = {"bound": "mfma", "achieved": work / (ms * 1e-3) / 1e12, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s"}
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["achieved_unstructured"] = (fam[0][1] / (fam[0][0] * 1e-3) / 1e12) if fam[0][0] > 0 else None
+        roof["mfma_executed_tflops"] = fam[12][1] / (ms * 1e-3) / 1e12
+        roof["mfma_busy_frac"] = roof["mfma_executed_tflops"] / F64_MFMA_PEAK_TF
+        roof["note"] = ("achieved = USEFUL flops / time over all zgemm launches: 8mnk for an unstructured complex "
+                        "call, 4mnk for a REAL call (real-symmetric Gamma orbitals: the product IS a real GEMM of "
+                        "that many flops, nothing is saved by a trick); for UPPER (Gram, only i <= j needed) and "
+                        "B_UPPER (X inv(R), k <= j) only the mathematically needed part.  achieved_unstructured = "
+                        "the same for the unstructured calls alone.  mfma_executed_tflops = real flops the launched "
+                        "tiles run on the matrix pipe (3M complex product: 6 per complex multiply-add, REAL: 4; "
+                        "whole tiles incl. shifted / border recompute) / time; mfma_busy_frac = that / dense f64 "
+                        "MFMA peak")
+    else:
+        ms, work, launches = fam[dom]
+        roof = {"bound": "hbm", "achieved": work / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        roof["frac"] = roof["achieved"] / roof["peak"]
+    # HBM bytes per launch of the dominant family from PMC passes over THIS command and THIS build
+    # (tools/pmc_traffic_bench.sh writes profiles/<round>_pmc_traffic.json with the library's source hash)
+    roof["traffic"] = None
+    for pmc_file in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", pmc_file)) as fh:
+                pmc = json.load(fh)
+            key = FAMILIES[dom]
+            if (n_gpus == 1 and pmc.get("lib_hash") == library_source_hash() and pmc.get("workload") == workload
+                    and key in pmc["families"]):       # (collected on one GPU: says nothing about a sharded launch mix)
+                roof["traffic"] = pmc["families"][key]["bytes_per_launch"]
+                roof["traffic_unit"] = "B/launch"
+                roof["traffic_source"] = f"profiles/{pmc_file} (" + pmc["collected"] + ")"
+                break
+        except (OSError, KeyError, ValueError):
+            pass
+    roof["algorithmic_bytes_per_launch"] = (fam[10][1] / max(launches, 1)) if dom == 0 else work / max(launches, 1)
+    roof["kernel"] = FAMILIES[dom]
+    roof["launches"] = launches
+    roof["avg_launch_ms"] = ms / max(launches, 1)
+    roof["families_ms"] = {FAMILIES[f]: round(fam[f][0], 3) for f in FAMILIES}
+    roof["families_launches"] = {FAMILIES[f]: int(fam[f][2]) for f in FAMILIES}
+    roof["families_work"] = {FAMILIES[f]: fam[f][1] for f in FAMILIES}   # flops (zgemm) / algorithmic bytes (FFT)
+    roof["families_work"]["zgemm_executed_real_flops"] = fam[12][1]
+    roof["families_work"]["zgemm_operand_bytes"] = fam[10][1]
+    roof["families_rate"] = {
+        FAMILIES[f]: (round(fam[f][1] / (fam[f][0] * 1e-3) / (1e12 if f in (0, 11) else 1e9), 2)
+                      if fam[f][0] > 0 and (f < 7 or f == 11) else None) for f in FAMILIES}
+    return roof
+
+
+def sharded_self_check(dftk, basis, comm_size):
+    """--mode gamma, N > 1, before the SCF: one sharded H psi and one Gram matrix of a seeded random block against the
+    UNSHARDED result computed from the gathered block on every rank -- a broken slab <-> band all-to-all plan or
+    all-reduce shows up here, in seconds, instead of as a non-converging SCF.  Returns the relative deviations."""
+    import torch
+    kpt = basis.kpoints[0]
+    nb = 8
+    gen = torch.Generator(device="cpu").manual_seed(1234)
+    full = torch.randn((nb, kpt.n_G, 2), dtype=torch.float64, generator=gen)
+    full = torch.view_as_complex(full).to(basis.device)
+    _, ham = dftk.energy_hamiltonian(basis, None, None, rho=dftk.guess_density(basis))
+    H = ham[0]
+    loc = full[:, kpt.row0:kpt.row1].contiguous()
+    got = H @ loc                                         # sharded apply (this rank's rows of H psi)
+    # reference: gather the rows of H psi over the ranks, and compare norms / Gram with a replicated evaluation
+    parts = basis.comm_pw.gather_lists(torch.view_as_real(got).cpu().numpy().tolist()) if comm_size > 1 else None
+    gram_loc = loc.conj() @ got.T                         # partial Gram psi' H psi from this rank's rows
+    g = torch.view_as_real(gram_loc.contiguous()).reshape(-1).clone()
+    basis.comm_pw.sum_(g, basis.stream_ptr)
+    basis.sync()
+    gram = torch.view_as_complex(g.reshape(nb, nb, 2))
+    herm = float((gram - gram.conj().T).abs().max() / gram.abs().max())
+    out = {"gram_hermiticity": herm}
+    if parts is not None:
+        Hfull = torch.cat([torch.view_as_complex(torch.tensor(p_, dtype=torch.float64).reshape(nb, -1, 2).contiguous())
+                           for p_ in parts], dim=1).to(basis.device)
+        ref = full.conj() @ Hfull.T
+        out["gram_vs_gathered"] = float((gram - ref).abs().max() / ref.abs().max())
+    return out
+
+
 # ------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
@@ -257,6 +514,7 @@ def main():
 
     lib = dftk.load_library()
     t0 = time.time()
+    model = None
     if args.mode == "kpoints":
         a = 7.6324708938577865                                       # test/testcases.jl:74
         lat = a / 2 * np.array([[0, 1, 1.0], [1, 0, 1.0], [1, 1, 0.0]])
@@ -297,104 +555,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    from dftk_jl_amd._lib import check
-    # ---- warm-up on a throw-away stepper (same seed: the timed run repeats these steps from the same guess)
-    if args.prof_all:
-        check(lib.dftk_mi_prof_enable(basis.handle, 1))
-    if args.warmup > 0:
-        warm = dftk.ScfStepper(basis, tol=args.tol)
-        for _ in range(args.warmup):
-            if warm.step()["converged"]:
-                break
-        del warm
-    barrier()
-    if not args.prof_all:
-        check(lib.dftk_mi_prof_enable(basis.handle, 1))
-    iters, diagtols, step_s, nmv_steps = [], [], [], []
-    host_timers = {}
-    t0 = time.time()
-    stepper = dftk.ScfStepper(basis, tol=args.tol)          # guess_density is part of self_consistent_field
-    info = None
-    for _ in range(max(args.steps, 1)):
-        ts = time.time()
-        info = stepper.step()
-        step_s.append(time.time() - ts)
-        iters.append(float(np.mean(info["diagonalization"]["n_iter"])))
-        diagtols.append(info["diagtol"])
-        nmv_steps.append(int(info["n_matvec_step"]))
-        for k_, v_ in info["timers"].items():
-            host_timers[k_] = host_timers.get(k_, 0.0) + v_
-        if info["converged"]:
-            break
-    info = stepper.finalize()                                # energies + Hamiltonian of the final state, as the reference
-    barrier()
-    elapsed = time.time() - t0
-    check(lib.dftk_mi_prof_enable(basis.handle, 0))
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    # what the library's communicator (the data path of every collective) really is: proves N ranks met over RCCL
+    comm_info = comm.describe() if hasattr(comm, "describe") else {"n_ranks": comm.size}
+    self_check = None
+    if world > 1 and args.mode == "gamma":
+        self_check = sharded_self_check(dftk, basis, world)
+        bad = [k_ for k_, v_ in self_check.items() if not (v_ < 1e-10)]
+        if bad:
+            raise SystemExit(f"sharded self-check failed on rank {rank}: {self_check}")
+
+    run = run_scf(dftk, lib, basis, args, barrier, world, dist, torch)
+    info, elapsed, fam = run["info"], run["elapsed"], run["fam"]
     steps_run = info["n_iter"]
     n_matvec = info["n_matvec"]                  # already summed over the k-point ranks
     kblocks = n_gpus if (args.mode == "weak" and n_gpus > 1) else 1
     value = kblocks * steps_run / elapsed
 
     if rank == 0:
-        fam = {f: prof_get(lib, basis, f) for f in list(FAMILIES) + [10, 12, 14]}
         gamma_real = bool(getattr(basis.kpoints[0], "gamma_real", False))
-        zg_ms = fam[0][0] + fam[11][0]
-        zg_useful = fam[0][1] + fam[11][1]
-        zg_launch = fam[0][2] + fam[11][2]
-        fam_ms = {f: (zg_ms if f == 0 else fam[f][0]) for f in KERNEL_FAMS}
-        dom = max((f for f in KERNEL_FAMS if fam_ms[f] > 0), key=lambda f: fam_ms[f])
-        if dom == 0:
-            ms, work, launches = zg_ms, zg_useful, zg_launch
-            roof = {"bound": "mfma", "achieved": work / (ms * 1e-3) / 1e12, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s"}
-            roof["frac"] = roof["achieved"] / roof["peak"]
-            roof["achieved_unstructured"] = (fam[0][1] / (fam[0][0] * 1e-3) / 1e12) if fam[0][0] > 0 else None
-            roof["mfma_executed_tflops"] = fam[12][1] / (ms * 1e-3) / 1e12
-            roof["mfma_busy_frac"] = roof["mfma_executed_tflops"] / F64_MFMA_PEAK_TF
-            roof["note"] = ("achieved = USEFUL flops / time over all zgemm launches: 8mnk for an unstructured complex "
-                            "call, 4mnk for a REAL call (real-symmetric Gamma orbitals: the product IS a real GEMM of "
-                            "that many flops, nothing is saved by a trick); for UPPER (Gram, only i <= j needed) and "
-                            "B_UPPER (X inv(R), k <= j) only the mathematically needed part.  achieved_unstructured = "
-                            "the same for the unstructured calls alone.  mfma_executed_tflops = real flops the launched "
-                            "tiles run on the matrix pipe (3M complex product: 6 per complex multiply-add, REAL: 4; "
-                            "whole tiles incl. shifted / border recompute) / time; mfma_busy_frac = that / dense f64 "
-                            "MFMA peak.  complex_equivalent_tflops = what the same calls would cost the general "
-                            "complex iteration (REAL calls counted twice) / time")
-            roof["complex_equivalent_tflops"] = fam[14][1] / (ms * 1e-3) / 1e12
-            roof["frac_complex_equivalent"] = roof["complex_equivalent_tflops"] / F64_MFMA_PEAK_TF
-        else:
-            ms, work, launches = fam[dom]
-            roof = {"bound": "hbm", "achieved": work / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
-            roof["frac"] = roof["achieved"] / roof["peak"]
-        # HBM bytes per launch of the dominant family from PMC passes over THIS command and THIS build
-        # (tools/pmc_traffic_bench.sh writes profiles/r02_pmc_traffic.json with the library's source hash)
-        roof["traffic"] = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
-                pmc = json.load(fh)
-            key = FAMILIES[dom]
-            if (n_gpus == 1 and pmc.get("lib_hash") == library_source_hash() and pmc.get("workload") == workload
-                    and key in pmc["families"]):       # (collected on one GPU: says nothing about a sharded launch mix)
-                roof["traffic"] = pmc["families"][key]["bytes_per_launch"]
-                roof["traffic_unit"] = "B/launch"
-                roof["traffic_source"] = "profiles/r02_pmc_traffic.json (" + pmc["collected"] + ")"
-        except (OSError, KeyError, ValueError):
-            pass
-        roof["algorithmic_bytes_per_launch"] = (fam[10][1] / max(launches, 1)) if dom == 0 else work / max(launches, 1)
-        roof["kernel"] = FAMILIES[dom]
-        roof["launches"] = launches
-        roof["avg_launch_ms"] = ms / max(launches, 1)
-        roof["families_ms"] = {FAMILIES[f]: round(fam[f][0], 3) for f in FAMILIES}
-        roof["families_launches"] = {FAMILIES[f]: int(fam[f][2]) for f in FAMILIES}
-        roof["families_work"] = {FAMILIES[f]: fam[f][1] for f in FAMILIES}   # flops (zgemm) / algorithmic bytes (FFT)
-        roof["families_work"]["zgemm_executed_real_flops"] = fam[12][1]
-        roof["families_work"]["zgemm_operand_bytes"] = fam[10][1]
-        roof["families_rate"] = {
-            FAMILIES[f]: (round(fam[f][1] / (fam[f][0] * 1e-3) / (1e12 if f in (0, 11) else 1e9), 2)
-                          if fam[f][0] > 0 and (f < 7 or f == 11) else None) for f in FAMILIES}
+        roof = roofline_of(fam, n_gpus, workload)
         booked = sum(fam[f][0] for f in (0, 11, 1, 2, 3, 4, 5, 6, 7, 8, 13))
         kp0 = basis.kpoints[0]
         out = {
@@ -406,30 +585,87 @@ def main():
             "config": {"workload": workload, "timed": "whole self_consistent_field (scf_full): guess_density -> "
                                                       f"tol={args.tol:g}, capped at --steps={args.steps}",
                        "converged": bool(info["converged"]), "scf_wall_s": round(elapsed, 3),
+                       "scf_wall_s_to_convergence": round(elapsed, 3) if info["converged"] else None,
                        "n_G": kp0.n_G, "n_bands": int(info["psi"][0].shape[0]),
                        "n_proj": int(basis.terms.D.shape[0]) if basis.terms.D is not None else 0,
-                       "parallelism": parallelism, "setup_s": round(t_setup, 2),
+                       "parallelism": parallelism, "rccl": comm_info, "sharded_self_check": self_check,
+                       "setup_s": round(t_setup, 2),
                        "orbitals": ("real-symmetric at Gamma (psi(-G) = conj psi(G)): half-sphere real GEMMs, two bands "
                                     "per FFT pass; same eigenvalues / density / energies as the reference's complex "
-                                    "iteration (--no-gamma-real runs that one)") if gamma_real else "general complex",
-                       "n_matvec": int(n_matvec), "lobpcg_iters_per_step": iters, "n_matvec_per_step": nmv_steps,
-                       "diagtol_per_step": [float(f"{d:.3g}") for d in diagtols],
-                       "step_wall_s": [round(s_, 3) for s_ in step_s],
-                       "host_timers_ms_per_step": {k_: round(1e3 * v_ / steps_run, 2) for k_, v_ in host_timers.items()},
+                                    "iteration, which is timed in the same run: config.complex_iteration")
+                       if gamma_real else "general complex",
+                       "n_matvec": int(n_matvec), "lobpcg_iters_per_step": run["iters"],
+                       "n_matvec_per_step": run["nmv_steps"],
+                       "diagtol_per_step": [float(f"{d:.3g}") for d in run["diagtols"]],
+                       "step_wall_s": [round(s_, 3) for s_ in run["step_s"]],
+                       "host_timers_ms_per_step": {k_: round(1e3 * v_ / steps_run, 2)
+                                                   for k_, v_ in run["host_timers"].items()},
                        "library_booked_ms": round(booked, 1), "lib_hash": library_source_hash(),
                        "E_total": info["energies"].total, "drho": info["history_drho"][-1]},
             "roofline": roof,
         }
+    # ---- the reference's own iteration (general complex orbitals) on the same cell, same run, same box
+    if (world == 1 and args.mode == "gamma" and not args.no_gamma_real and not args.no_complex_leg
+            and bool(getattr(basis.kpoints[0], "gamma_real", False))):
+        cbasis = dftk.PlaneWaveBasis(model, ecut, dftk.MonkhorstPack((1, 1, 1)), device=device, gamma_real=False)
+        crun = run_scf(dftk, lib, cbasis, args, barrier, world, dist, torch)
+        ci = crun["info"]
+        croof = roofline_of(crun["fam"], 1, workload)
+        out["config"]["complex_iteration"] = {
+            "what": "the same self_consistent_field with gamma_real=False: LOBPCG on general complex orbitals exactly as "
+                    "the reference iterates them (3M complex zgemm, one band per FFT pass)",
+            "value": ci["n_iter"] / crun["elapsed"], "unit": "SCF iterations/s", "steps": ci["n_iter"],
+            "converged": bool(ci["converged"]), "scf_wall_s": round(crun["elapsed"], 3),
+            "scf_wall_s_to_convergence": round(crun["elapsed"], 3) if ci["converged"] else None,
+            "hpsi_applies_per_s": ci["n_matvec"] / crun["elapsed"], "n_matvec": int(ci["n_matvec"]),
+            "E_total": ci["energies"].total, "dE_total_vs_real": ci["energies"].total - info["energies"].total,
+            "lobpcg_iters_per_step": crun["iters"], "step_wall_s": [round(s_, 3) for s_ in crun["step_s"]],
+            "roofline": {k_: croof[k_] for k_ in ("bound", "achieved", "peak", "unit", "frac", "achieved_unstructured",
+                                                  "mfma_busy_frac", "kernel", "launches", "avg_launch_ms", "families_ms",
+                                                  "families_rate") if k_ in croof}}
+        del crun, ci, cbasis
+        torch.cuda.empty_cache()
+
+    if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:
                 if args.mode == "kpoints":
                     out["cpu_baseline"] = {"value": None, "unit": "SCF iterations/s", "cores": os.cpu_count(),
                                            "kind": "port", "sample": "see cfg1_scf_3steps"}
                 else:
-                    # the CPU leg models the REFERENCE's iteration: general complex orbitals, complex zgemm flops
+                    # the CPU leg is the REFERENCE's iteration: general complex orbitals, complex zgemm flops
                     per_step = {"n_matvec": n_matvec / steps_run, "zgemm_flops": fam[14][1] / steps_run}
                     n_smp = args.cpu_sample_bands or min(os.cpu_count(), 256)
-                    out["cpu_baseline"] = cpu_baseline_gamma(basis, info, n_smp, per_step)
+                    model_leg = cpu_baseline_gamma(basis, info, n_smp, per_step)
+                    out["cpu_baseline"] = model_leg
+                    # a REAL timed step when the sampled model says it fits the budget
+                    t_dev, dinfo = device_late_step(dftk, basis, info, args.tol)
+                    late_model = (2 * info["psi"][0].shape[0] / model_leg["hpsi_applies_per_s"]
+                                  + model_leg["model_terms"]["density_s_per_band"] * (basis.model.n_electrons // 2)
+                                  + model_leg["model_terms"]["late_step_zgemm_s"])
+                    timed = None
+                    if late_model < args.cpu_step_budget:
+                        timed = cpu_timed_late_step(basis, info, float(dinfo["diagtol"]), args.cpu_step_budget)
+                    if timed is not None:
+                        timed["device_step_s"] = round(t_dev, 4)
+                        timed["device_lobpcg_iterations"] = float(np.mean(dinfo["diagonalization"]["n_iter"]))
+                        timed["speedup_same_step"] = round(timed["cpu_step_s"] / t_dev, 1)
+                        out["cpu_baseline"] = {
+                            "value": 1.0 / timed["cpu_step_s"], "unit": "SCF iterations/s", "cores": os.cpu_count(),
+                            "kind": "port, timed step",
+                            "sample": (f"ONE real late SCF step of this workload on the host, wall-clocked: the oracle's LOBPCG "
+                                       f"(general complex orbitals, restatement of lobpcg_hyper_impl.jl) from the converged "
+                                       f"orbitals at diagtol={timed['diagtol']:.2g} -> {timed['lobpcg_iterations']} iteration(s), "
+                                       f"{timed['n_matvec']} H psi applies ({timed['cpu_lobpcg_s']} s) + compute_density "
+                                       f"({timed['cpu_density_s']} s); H psi / density band-parallel on {timed['fft_threads']} "
+                                       f"threads (pocketfft workers=1 each), dense algebra = NumPy OpenBLAS "
+                                       f"({timed['blas_threads']} threads) on panels of the true width; the device ran the "
+                                       f"same step in {t_dev:.3f} s.  Not DFTK (no Julia in the image)"),
+                            "timed_step": timed, "sampled_model": model_leg}
+                    else:
+                        out["cpu_baseline"]["timed_step"] = (f"skipped: the sampled model predicts {late_model:.0f} s "
+                                                             f"(budget {args.cpu_step_budget:.0f} s) or host memory is short")
+                        out["cpu_baseline"]["device_late_step_s"] = round(t_dev, 4)
                 out["cpu_baseline"]["cfg1_scf_3steps"] = cfg1_scf_3steps(device)
             except Exception as e:  # the baseline is reporting only; never lose the measurement
                 out["cpu_baseline"] = {"value": None, "unit": "SCF iterations/s", "cores": os.cpu_count(),

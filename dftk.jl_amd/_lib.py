@@ -98,6 +98,7 @@ _SIGNATURES = {
     "dftk_mi_comm_create_host": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.POINTER(C.c_void_p)]),
     "dftk_mi_comm_destroy": (C.c_int, [C.c_void_p]),
+    "dftk_mi_comm_describe": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dftk_mi_comm_rank": (C.c_int, [C.c_void_p]),
     "dftk_mi_comm_size": (C.c_int, [C.c_void_p]),
     "dftk_mi_allreduce_sum_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -50,16 +50,43 @@ class KptComm:
         return KptComm()
 
     @staticmethod
-    def from_torch(group=None):
+    def from_torch(group=None, host_group=None):
+        """Communicator over a ``torch.distributed`` group (default: the world).  For an nccl group a gloo twin carries
+        the small host-side collectives; ``dist.new_group`` is COLLECTIVE OVER THE WHOLE WORLD, so for a sub-group
+        either every world rank calls ``from_torch(group=...)`` (non-members pass the group too and get a single-rank
+        communicator back) or the caller creates the gloo twin itself, collectively, and passes it as ``host_group``."""
         import torch.distributed as dist
         if not dist.is_initialized():
             return KptComm()
-        comm = KptComm(dist.get_rank(group), dist.get_world_size(group), group if group is not None else True)
-        if comm.size > 1 and dist.get_backend(group) == "nccl":
+        member = group is None or dist.get_rank(group) >= 0
+        need_twin = dist.get_backend(group if member else None) == "nccl" and host_group is None
+        twin = None
+        if need_twin and dist.get_world_size(group if member else None) > 1:
             # small host-side collectives (eigenvalue / energy gathers) stay off the GPU and off RCCL
-            ranks = [dist.get_global_rank(group, i) for i in range(comm.size)] if group is not None else None
-            comm.host_group = dist.new_group(ranks=ranks, backend="gloo")
+            ranks = dist.get_process_group_ranks(group) if group is not None else None
+            twin = dist.new_group(ranks=ranks, backend="gloo")            # entered by every world rank
+        if not member:
+            return KptComm()
+        comm = KptComm(dist.get_rank(group), dist.get_world_size(group), group if group is not None else True)
+        if comm.size > 1:
+            comm.host_group = host_group if host_group is not None else twin
         return comm
+
+    def describe(self, device_index=None):
+        """What the data path of this communicator is, as the library itself reports it
+        (``dftk_mi_comm_describe``): backend, the rank count RCCL saw (``ncclCommCount``), the RCCL version."""
+        if self.size == 1:
+            return {"backend": "none", "n_ranks": 1}
+        import torch
+        from ._lib import check, load
+        if device_index is None:
+            device_index = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        h = self.abi_handle(device_index)
+        be, n, ver = C.c_int(), C.c_int(), C.c_int()
+        check(load().dftk_mi_comm_describe(h, C.byref(be), C.byref(n), C.byref(ver)))
+        v = ver.value
+        return {"backend": "rccl" if be.value == 0 else "host-staged callbacks", "n_ranks": n.value,
+                "version": f"{v // 10000}.{(v // 100) % 100}.{v % 100}" if v else None, "version_code": v}
 
     def _group(self):
         return None if self.group is True else self.group

@@ -29,6 +29,8 @@ typedef int (*fn_Send)(const void*, size_t, int, int, ncclComm_t_, hipStream_t);
 typedef int (*fn_Recv)(void*, size_t, int, int, ncclComm_t_, hipStream_t);
 typedef int (*fn_Group)(void);
 typedef const char* (*fn_GetErrorString)(int);
+typedef int (*fn_GetVersion)(int*);
+typedef int (*fn_CommCount)(ncclComm_t_, int*);
 
 struct Rccl {
     void* h = nullptr;
@@ -40,6 +42,8 @@ struct Rccl {
     fn_Recv Recv = nullptr;
     fn_Group GroupStart = nullptr, GroupEnd = nullptr;
     fn_GetErrorString GetErrorString = nullptr;
+    fn_GetVersion GetVersion = nullptr;
+    fn_CommCount CommCount = nullptr;
 };
 Rccl g_rccl;
 
@@ -63,6 +67,8 @@ int load_rccl() {
     g_rccl.GroupStart = (fn_Group)dlsym(g_rccl.h, "ncclGroupStart");
     g_rccl.GroupEnd = (fn_Group)dlsym(g_rccl.h, "ncclGroupEnd");
     g_rccl.GetErrorString = (fn_GetErrorString)dlsym(g_rccl.h, "ncclGetErrorString");
+    g_rccl.GetVersion = (fn_GetVersion)dlsym(g_rccl.h, "ncclGetVersion");
+    g_rccl.CommCount = (fn_CommCount)dlsym(g_rccl.h, "ncclCommCount");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce || !g_rccl.Send ||
         !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd) {
         dftk_set_error("RCCL symbols missing");
@@ -156,6 +162,24 @@ extern "C" int dftk_mi_comm_destroy(dftk_mi_comm* c) {
     return 0;
 }
 
+extern "C" int dftk_mi_comm_describe(const dftk_mi_comm* c, int* backend, int* n_ranks, int* version) {
+    if (!c) return DFTK_MI_EINVAL;
+    if (backend) *backend = c->backend;
+    if (n_ranks) {
+        *n_ranks = c->n_ranks;
+        // ask RCCL itself how many ranks met in this communicator (not what the caller told us)
+        if (c->backend == 0 && g_rccl.CommCount) {
+            int cnt = -1;
+            if (g_rccl.CommCount(c->comm, &cnt) == 0) *n_ranks = cnt;
+        }
+    }
+    if (version) {
+        *version = 0;
+        if (c->backend == 0 && g_rccl.GetVersion) g_rccl.GetVersion(version);
+    }
+    return 0;
+}
+
 extern "C" int dftk_mi_comm_rank(const dftk_mi_comm* c) { return c ? c->rank : -1; }
 extern "C" int dftk_mi_comm_size(const dftk_mi_comm* c) { return c ? c->n_ranks : -1; }
 
@@ -228,18 +252,22 @@ int comm_alltoallv(dftk_mi_comm* c, dftk_mi_basis* b, const cd* send, const size
         if (p == 1) return 0;
         int rc = g_rccl.GroupStart();
         if (rc != 0) return rccl_fail("ncclGroupStart", rc);
-        for (int i = 0; i < p; ++i) {
+        // an error inside the group must still close it (an open group poisons every later RCCL call of the process)
+        int bad = 0;
+        const char* what = nullptr;
+        for (int i = 0; i < p && !bad; ++i) {
             if (i == me) continue;
             if (scnt[i]) {
-                rc = g_rccl.Send(send + soff[i], 2 * scnt[i], NCCL_F64, i, c->comm, b->stream);
-                if (rc != 0) return rccl_fail("ncclSend", rc);
+                bad = g_rccl.Send(send + soff[i], 2 * scnt[i], NCCL_F64, i, c->comm, b->stream);
+                if (bad) what = "ncclSend";
             }
-            if (rcnt[i]) {
-                rc = g_rccl.Recv(recv + roff[i], 2 * rcnt[i], NCCL_F64, i, c->comm, b->stream);
-                if (rc != 0) return rccl_fail("ncclRecv", rc);
+            if (!bad && rcnt[i]) {
+                bad = g_rccl.Recv(recv + roff[i], 2 * rcnt[i], NCCL_F64, i, c->comm, b->stream);
+                if (bad) what = "ncclRecv";
             }
         }
         rc = g_rccl.GroupEnd();
+        if (bad) return rccl_fail(what, bad);
         if (rc != 0) return rccl_fail("ncclGroupEnd", rc);
         return 0;
     }

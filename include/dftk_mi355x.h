@@ -287,6 +287,9 @@ typedef int (*dftk_mi_alltoallv_fn)(void* user, const double* send_h, const size
 int dftk_mi_comm_create_host(int n_ranks, int rank, int device, dftk_mi_allreduce_fn allreduce,
                              dftk_mi_alltoallv_fn alltoallv, void* user, dftk_mi_comm** comm_out);
 int dftk_mi_comm_destroy(dftk_mi_comm* comm);
+/* What the communicator is: *backend = 0 RCCL / 1 host callbacks; *n_ranks as RCCL itself reports it
+ * (ncclCommCount) for an RCCL communicator; *version = ncclGetVersion code (0 for the host back end). */
+int dftk_mi_comm_describe(const dftk_mi_comm* comm, int* backend, int* n_ranks, int* version);
 int dftk_mi_comm_rank(const dftk_mi_comm* comm);
 int dftk_mi_comm_size(const dftk_mi_comm* comm);
 /* In-place sum all-reduce of n doubles on `stream` (hipStream_t as void*, NULL = default). */

@@ -151,6 +151,11 @@ def test_bench_two_ranks_one_gpu_gamma_sharded_equals_single_rank():
     assert out["config"]["parallelism"].startswith("pw2") and out["steps"] < 40
     assert out["config"]["orbitals"].startswith("real-symmetric")
     assert out["roofline"]["families_launches"]["collectives"] > 0
+    # the library's own communicator saw both ranks; the start-up self-check (one sharded H psi + Gram against the
+    # gathered block) ran and passed before the SCF
+    assert out["config"]["rccl"]["n_ranks"] == 2 and out["config"]["rccl"]["backend"].startswith("host-staged")
+    chk = out["config"]["sharded_self_check"]
+    assert chk["gram_hermiticity"] < 1e-10 and chk["gram_vs_gathered"] < 1e-10
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + args
     one = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900)
     assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]

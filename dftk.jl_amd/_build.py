@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libdftk_mi355x.so")
-SOURCES = ["api.cpp", "comm.cpp", "lobpcg.cpp", "fft_kernels.hip", "gemm_kernels.hip", "dense_kernels.hip", "xc_kernels.hip", "setup_kernels.hip", "gamma_kernels.hip", "cube_kernels.hip"]
+SOURCES = ["api.cpp", "comm.cpp", "lobpcg.cpp", "batch.cpp", "batch_kernels.hip", "fft_kernels.hip", "gemm_kernels.hip", "dense_kernels.hip", "xc_kernels.hip", "setup_kernels.hip", "gamma_kernels.hip", "cube_kernels.hip"]
 
 
 HASHPATH = LIBPATH + ".srchash"
@@ -21,7 +21,7 @@ def source_hash() -> str:
     -- the .so is git-ignored but ships to the GPU box -- is never used silently, whatever its mtime says."""
     import hashlib
     h = hashlib.sha256()
-    deps = [os.path.join(CSRC, f) for f in sorted(SOURCES + ["common.h"])]
+    deps = [os.path.join(CSRC, f) for f in sorted(SOURCES + ["common.h", "batch.h"])]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "dftk_mi355x.h"))
     for d in deps:
         with open(d, "rb") as fh:

@@ -226,6 +226,13 @@ class PlaneWaveBasis:
         # reference loops over them sequentially (diag.jl:24).  Here the local k-points are dealt round-robin onto
         # n_lanes library handles = HIP streams with their own scratch; host threads drive the lanes concurrently
         # (diagonalize_all_kblocks, compute_density), so the small kernels of different k-points overlap on the GPU.
+        # kbatch: many small k-blocks iterate in lock-step inside ONE library call (dftk_mi_lobpcg_multi) -- batched
+        # launches over all k-points instead of per-k launches overlapped by host threads; needs one handle (lane).
+        # DFTK_MI_KBATCH=0 (or an explicit n_lanes) keeps the lane pool.
+        self.kbatch = (n_lanes is None and os.environ.get("DFTK_MI_KBATCH", "1") != "0" and "DFTK_MI_LANES" not in os.environ
+                       and len(kc) > 1 and self.comm_pw.size == 1)
+        if self.kbatch:
+            n_lanes = 1
         if n_lanes is None:
             n_lanes = int(os.environ.get("DFTK_MI_LANES", "16"))
         n_lanes = max(1, min(n_lanes, len(kc))) if (self.handle is not None and self.comm_pw.size == 1) else 1

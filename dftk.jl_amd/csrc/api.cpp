@@ -1,5 +1,6 @@
 // api.cpp -- the extern "C" boundary (include/dftk_mi355x.h), handles and host-side planning.
 #include "common.h"
+#include "batch.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -787,6 +788,13 @@ extern "C" int dftk_mi_apply_H_parts(dftk_mi_kblock* kb, int which, int n_bands,
     const int64_t rows = local_rows(kb);
     if (ld_psi < rows || ld_Hpsi < rows) return DFTK_MI_EINVAL;
     if (n_bands == 0) return 0;   // "Nothing to do if psi empty" (Hamiltonian.jl:141)
+    if (batching() && !kb->sh_comm) {   // fiber of a batched multi-k call: all k-blocks' bands go through ONE pipeline later
+        BOp o;
+        o.b = kb->basis;
+        o.kb = kb;
+        o.type = BOP_APPLYH; o.flags = which; o.m = n_bands; o.A = psi_d; o.lda = ld_psi; o.C = Hpsi_d; o.ldc = ld_Hpsi;
+        return batch_record(std::move(o));
+    }
     HIPCHK(hipSetDevice(kb->basis->device));
     const cd* psi = reinterpret_cast<const cd*>(psi_d);
     cd* H = reinterpret_cast<cd*>(Hpsi_d);
@@ -1046,6 +1054,21 @@ extern "C" int dftk_mi_lobpcg(dftk_mi_kblock* kb, int M, dftk_mi_cplx* X_d, int6
     HIPCHK(hipSetDevice(kb->basis->device));
     return lobpcg_run(kb, M, reinterpret_cast<cd*>(X_d), ldX, tol, miniter, maxiter, n_conv_check, use_tpa, seed,
                       lambda_h, resid_h, n_iter, converged, n_matvec);
+}
+
+extern "C" int dftk_mi_lobpcg_multi(int n_kblocks, dftk_mi_kblock* const* kbs, int M, dftk_mi_cplx* const* X_d,
+                                    const int64_t* ldX, double tol, int miniter, int maxiter, int n_conv_check, int use_tpa,
+                                    const uint64_t* seeds, double* lambda_h, double* resid_h, int* n_iter, int* converged,
+                                    int64_t* n_matvec, int* status) {
+    if (n_kblocks < 0 || (n_kblocks > 0 && (!kbs || !X_d || !ldX || !lambda_h || !resid_h || !n_iter || !converged ||
+                                            !n_matvec || !status)) || M < 1 || maxiter < 0)
+        return DFTK_MI_EINVAL;
+    if (n_kblocks == 0) return 0;
+    for (int i = 0; i < n_kblocks; ++i)
+        if (!kbs[i] || !X_d[i] || ldX[i] < local_rows(kbs[i])) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(kbs[0]->basis->device));
+    return lobpcg_run_multi(n_kblocks, kbs, M, reinterpret_cast<cd* const*>(X_d), ldX, tol, miniter, maxiter, n_conv_check,
+                            use_tpa, seeds, lambda_h, resid_h, n_iter, converged, n_matvec, status);
 }
 
 extern "C" const dftk_mi_cplx* dftk_mi_lobpcg_last_AX(dftk_mi_kblock* kb) {

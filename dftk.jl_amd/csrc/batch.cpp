@@ -1,0 +1,320 @@
+// batch.cpp -- fibers, recording and merged execution for many small k-blocks (see batch.h).
+#include "batch.h"
+#include <ucontext.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace {
+struct Fiber {
+    ucontext_t ctx;
+    std::vector<char> stack;
+    std::vector<BOp> fifo;
+    size_t head = 0;
+    bool done = false;
+    int ret = 0;
+    std::function<int()> body;
+};
+}  // namespace
+
+// staging for batched launches: argument tables travel host -> device through one pinned ring, small results come
+// back through another; both are reset after the stream synchronisation that ends a round
+struct BatchCtx {
+    hipStream_t stream = nullptr;
+    char *h_ring = nullptr, *d_ring = nullptr;
+    size_t cap = 0, off = 0;
+    char *h_res = nullptr, *d_res = nullptr;
+    size_t res_cap = 0, res_off = 0;
+    void* d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+    std::vector<std::function<void()>> fixups;   // run after the round's stream synchronisation
+    bool failed = false;
+    int64_t n_rounds = 0, n_ops = 0, n_launch_groups = 0, n_sequential = 0;   // dftk_mi_batch_stats
+};
+
+const void* batch_stage(BatchCtx* c, const void* src, size_t bytes) {
+    const size_t al = (bytes + 255) & ~(size_t)255;
+    if (c->off + al > c->cap) {
+        // ring exhausted inside a round: drain the stream (the tables already queued are consumed) and start over
+        if (hipStreamSynchronize(c->stream) != hipSuccess) c->failed = true;
+        c->off = 0;
+        if (al > c->cap) {
+            c->failed = true;
+            return nullptr;
+        }
+    }
+    memcpy(c->h_ring + c->off, src, bytes);
+    if (hipMemcpyAsync(c->d_ring + c->off, c->h_ring + c->off, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        c->failed = true;
+    const void* d = c->d_ring + c->off;
+    c->off += al;
+    return d;
+}
+void* batch_result_slot(BatchCtx* c, size_t bytes, void** host_twin) {
+    const size_t al = (bytes + 255) & ~(size_t)255;
+    if (c->res_off + al > c->res_cap) {
+        c->failed = true;
+        return nullptr;
+    }
+    void* d = c->d_res + c->res_off;
+    *host_twin = c->h_res + c->res_off;
+    c->res_off += al;
+    return d;
+}
+int batch_results_fetch(BatchCtx* c) {
+    if (c->res_off == 0) return 0;
+    HIPCHK(hipMemcpyAsync(c->h_res, c->d_res, c->res_off, hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+void batch_add_fixup(BatchCtx* c, std::function<void()> f) { c->fixups.push_back(std::move(f)); }
+void* batch_scratch(BatchCtx* c, size_t bytes) {
+    if (bytes > c->scratch_bytes) {
+        hipStreamSynchronize(c->stream);
+        if (c->d_scratch) hipFree(c->d_scratch);
+        c->d_scratch = nullptr;
+        c->scratch_bytes = 0;
+        if (dftk_scratch_malloc(&c->d_scratch, bytes + bytes / 4) != hipSuccess) {
+            c->failed = true;
+            return nullptr;
+        }
+        c->scratch_bytes = bytes + bytes / 4;
+    }
+    return c->d_scratch;
+}
+
+namespace {
+struct Recorder {
+    std::vector<Fiber> fibers;
+    int cur = -1;
+    ucontext_t main_ctx;
+    BatchCtx ctx;
+};
+thread_local Recorder* g_rec = nullptr;
+thread_local bool g_suspended = false;   // executors call the original entry points: recording is off meanwhile
+
+void fiber_entry(unsigned lo, unsigned hi) {
+    Fiber* f = reinterpret_cast<Fiber*>(((uintptr_t)hi << 32) | (uintptr_t)lo);
+    f->ret = f->body();
+    f->done = true;   // falls back to the scheduler through uc_link
+}
+
+// the original entry point of a recorded operation (recording suspended by the caller)
+int exec_one(BOp& o) {
+    cd* Cc = reinterpret_cast<cd*>(o.C);
+    switch (o.type) {
+        case BOP_ZGEMM:
+            return zgemm(o.b, o.trans, o.gm, o.gn, o.gk, o.alpha, (const cd*)o.A, o.lda, (const cd*)o.B, o.ldb, o.beta, Cc,
+                         o.ldc, o.flags);
+        case BOP_COLRED:
+            switch (o.mode) {
+                case 0: return ew_colnorms(o.b, o.n, o.m, (const cd*)o.A, o.lda, (double*)o.C);
+                case 1: return ew_coldots(o.b, o.n, o.m, (const cd*)o.A, o.lda, (const cd*)o.B, o.ldb, (double*)o.C);
+                case 2: return ew_weighted_colsums(o.b, o.n, o.m, (const cd*)o.A, o.lda, (const double*)o.W, (double*)o.C);
+                case 3: return ew_frob2(o.b, o.n, o.m, (const cd*)o.A, o.lda, (double*)o.C);
+                default: return ew_coldots_im(o.b, o.n, o.m, (const cd*)o.A, o.lda, (const cd*)o.B, o.ldb, (double*)o.C);
+            }
+        case BOP_RESIDUAL:
+            return ew_residual(o.b, o.n, o.m, (const cd*)o.A, o.lda, (const cd*)o.B, o.ldb, (const double*)o.W, Cc, o.ldc,
+                               (double*)o.D, (const double*)o.W2, (double*)o.E, (double*)o.F);
+        case BOP_TPA:
+            return ew_tpa(o.b, o.n, o.m, (const cd*)o.A, o.lda, Cc, o.ldc, (const double*)o.W, (const double*)o.W2,
+                          (double*)o.D, o.s0);
+        case BOP_SCALE: return ew_scale_cols(o.b, o.n, o.m, Cc, o.ldc, (const double*)o.W, o.flags != 0);
+        case BOP_COPY: return ew_copy(o.b, o.n, o.m, (const cd*)o.A, o.lda, Cc, o.ldc);
+        case BOP_FILL0: return ew_fill_zero(o.b, Cc, o.bytes / sizeof(cd));
+        case BOP_SUBID: return ew_sub_identity_shifted(o.b, (int)o.n, o.m, Cc, o.ldc, o.i0);
+        case BOP_GATHER: return ew_gather_cols(o.b, o.n, o.m, (const cd*)o.A, o.lda, (const int*)o.W, Cc, o.ldc);
+        case BOP_ADDDIAG: return ew_add_diag(o.b, o.m, Cc, o.ldc, o.s0);
+        case BOP_HERMIT: return ew_hermitize_upper(o.b, o.m, Cc, o.ldc);
+        case BOP_CTRANS: return ew_conj_transpose(o.b, o.m, (const cd*)o.A, o.lda, Cc, o.ldc);
+        case BOP_H2D:
+            // (pageable source: staged by the runtime before the call returns; the payload outlives the round anyway)
+            HIPCHK(hipMemcpyAsync(o.C, o.payload.data(), o.payload.size(), hipMemcpyHostToDevice, o.b->stream));
+            return 0;
+        case BOP_D2H:
+            HIPCHK(hipMemcpyAsync(o.host, o.A, o.bytes, hipMemcpyDeviceToHost, o.b->stream));
+            return 0;
+        case BOP_POTRF: {
+            double* out = reinterpret_cast<double*>(o.host);
+            o.status = dense_potrf_trtri(o.b, o.m, Cc, o.ldc, (cd*)o.D, o.ldb, out, out + 1);
+            return (o.status < 0) ? o.status : 0;   // numerical (> 0) results travel to the fiber in o.status
+        }
+        case BOP_HEEV:
+            o.status = dense_heev(o.b, o.m, Cc, o.ldc, (double*)o.host, (cd*)o.D, o.ldb);
+            return (o.status < 0) ? o.status : 0;
+        case BOP_APPLYH:
+            return dftk_mi_apply_H_parts(o.kb, o.flags, o.m, (const dftk_mi_cplx*)o.A, o.lda, (dftk_mi_cplx*)o.C, o.ldc);
+        case BOP_DENSITY: {
+            const double* w = reinterpret_cast<const double*>(o.payload.data());
+            return launch_density(o.kb, o.m, (const cd*)o.A, o.lda, w, (double*)o.C, o.flags ? w + o.m : nullptr);
+        }
+        default: return DFTK_MI_EINVAL;
+    }
+}
+
+// Merge the queues position by position and execute; ONE stream synchronisation at the end of the round.
+int flush(Recorder* r) {
+    BatchCtx* c = &r->ctx;
+    const bool no_merge = getenv("DFTK_MI_KBATCH_SEQUENTIAL") != nullptr;   // debugging: every op as recorded
+    int status = 0;
+    g_suspended = true;
+    std::vector<BOp*> groups[BOP_NTYPES];
+    std::vector<BOp*> all;
+    for (;;) {
+        bool any = false;
+        for (auto& g : groups) g.clear();
+        for (auto& f : r->fibers)
+            if (f.head < f.fifo.size()) {
+                BOp* op = &f.fifo[f.head++];
+                groups[op->type].push_back(op);
+                all.push_back(op);
+                any = true;
+            }
+        if (!any) break;
+        for (int t = 0; t < BOP_NTYPES && status == 0; ++t) {
+            auto& g = groups[t];
+            if (g.empty()) continue;
+            c->n_ops += (int64_t)g.size();
+            int st = 1;
+            if (!no_merge) st = batch_exec_group(c, c->stream, t, g);
+            if (st < 0) status = st;
+            if (st == 0) c->n_launch_groups += 1;
+            if (st == 1) {
+                c->n_sequential += (int64_t)g.size();
+                for (BOp* op : g) {
+                    const int s1 = exec_one(*op);
+                    if (s1 != 0) {
+                        status = s1;
+                        break;
+                    }
+                }
+            }
+        }
+        if (status != 0) break;
+    }
+    if (status == 0 && batch_results_fetch(c) != 0) status = DFTK_MI_EHIP;
+    g_suspended = false;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) {
+        dftk_set_error("batched round: stream synchronisation failed: %s", hipGetErrorString(hipGetLastError()));
+        status = status ? status : DFTK_MI_EHIP;
+    }
+    if (c->failed && status == 0) {
+        dftk_set_error("batched round: staging buffers exhausted or a copy failed");
+        status = DFTK_MI_EHIP;
+    }
+    if (status == 0) {
+        for (auto& fx : c->fixups) fx();
+        for (BOp* op : all)
+            if (op->status_out) *op->status_out = op->status;
+    }
+    c->fixups.clear();
+    c->off = 0;
+    c->res_off = 0;
+    c->n_rounds += 1;
+    for (auto& f : r->fibers) {
+        f.fifo.clear();
+        f.head = 0;
+    }
+    return status;
+}
+
+void yield_to_main() {
+    Recorder* r = g_rec;
+    Fiber& f = r->fibers[r->cur];
+    swapcontext(&f.ctx, &r->main_ctx);
+}
+}  // namespace
+
+bool batching() { return g_rec != nullptr && !g_suspended && g_rec->cur >= 0; }
+
+int batch_record(BOp&& op) {
+    Recorder* r = g_rec;
+    r->fibers[r->cur].fifo.push_back(std::move(op));
+    return 0;
+}
+
+int batch_record_sync(BOp&& op) {
+    int st = 0;   // lives on the fiber's stack; the scheduler writes it after the round
+    op.status_out = &st;
+    Recorder* r = g_rec;
+    r->fibers[r->cur].fifo.push_back(std::move(op));
+    yield_to_main();
+    return st;
+}
+
+int batch_sync() {
+    yield_to_main();
+    return 0;
+}
+
+static thread_local int64_t g_last_stats[4] = {0, 0, 0, 0};
+extern "C" int dftk_mi_batch_stats(int64_t* rounds, int64_t* ops, int64_t* merged_launches, int64_t* sequential_ops) {
+    if (rounds) *rounds = g_last_stats[0];
+    if (ops) *ops = g_last_stats[1];
+    if (merged_launches) *merged_launches = g_last_stats[2];
+    if (sequential_ops) *sequential_ops = g_last_stats[3];
+    return 0;
+}
+
+int batch_run(dftk_mi_basis* b, std::vector<std::function<int()>>& bodies, std::vector<int>& rets) {
+    if (g_rec) {
+        dftk_set_error("batched calls do not nest");
+        return DFTK_MI_EINVAL;
+    }
+    Recorder rec;
+    BatchCtx* c = &rec.ctx;
+    c->stream = b->stream;
+    c->cap = 16u << 20;
+    c->res_cap = 8u << 20;
+    HIPCHK(hipHostMalloc((void**)&c->h_ring, c->cap));
+    HIPCHK(hipMalloc((void**)&c->d_ring, c->cap));
+    HIPCHK(hipHostMalloc((void**)&c->h_res, c->res_cap));
+    HIPCHK(hipMalloc((void**)&c->d_res, c->res_cap));
+    const size_t n = bodies.size();
+    rec.fibers.resize(n);
+    const size_t stack_bytes = 1u << 20;
+    for (size_t i = 0; i < n; ++i) {
+        Fiber& f = rec.fibers[i];
+        f.body = bodies[i];
+        f.stack.resize(stack_bytes);
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack.data();
+        f.ctx.uc_stack.ss_size = stack_bytes;
+        f.ctx.uc_link = &rec.main_ctx;
+        const uintptr_t p = reinterpret_cast<uintptr_t>(&f);
+        makecontext(&f.ctx, (void (*)())fiber_entry, 2, (unsigned)(p & 0xFFFFFFFFu), (unsigned)(p >> 32));
+    }
+    g_rec = &rec;
+    int status = 0;
+    for (;;) {
+        bool alive = false;
+        for (size_t i = 0; i < n; ++i) {
+            Fiber& f = rec.fibers[i];
+            if (f.done) continue;
+            alive = true;
+            rec.cur = (int)i;
+            swapcontext(&rec.main_ctx, &f.ctx);   // runs until the fiber yields or finishes
+        }
+        rec.cur = -1;
+        bool queued = false;
+        for (auto& f : rec.fibers) queued = queued || !f.fifo.empty();
+        if (!alive && !queued) break;
+        status = flush(&rec);
+        if (status != 0) break;   // (fibers still suspended are abandoned with their stacks)
+    }
+    g_rec = nullptr;
+    g_last_stats[0] = c->n_rounds;
+    g_last_stats[1] = c->n_ops;
+    g_last_stats[2] = c->n_launch_groups;
+    g_last_stats[3] = c->n_sequential;
+    hipStreamSynchronize(c->stream);
+    hipHostFree(c->h_ring);
+    hipFree(c->d_ring);
+    hipHostFree(c->h_res);
+    hipFree(c->d_res);
+    if (c->d_scratch) hipFree(c->d_scratch);
+    rets.resize(n);
+    for (size_t i = 0; i < n; ++i) rets[i] = rec.fibers[i].done ? rec.fibers[i].ret : DFTK_MI_EHIP;
+    return status;
+}

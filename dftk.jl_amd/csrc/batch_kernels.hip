@@ -1,0 +1,832 @@
+// batch_kernels.hip -- batched forms of the small device operations of LOBPCG for many small k-blocks (batch.h):
+// one launch over all k-blocks of a scheduling round instead of one launch per k-block.  Every kernel takes a table
+// of per-item arguments (staged through the round's pinned ring) and a grid whose z dimension is the item index; x / y
+// are sized for the largest item, smaller items let their surplus workgroups exit at once.
+//
+//   element-wise / column kernels   the arithmetic of dense_kernels.hip's k_col_reduce, k_residual, k_tpa, ... per item
+//   small products                  C = alpha A^H B + beta C  (m, n <= 96; the long dimension is reduced inside ONE
+//                                   workgroup per 16 x 16 tile: deterministic) and C = alpha A B + beta C (inner
+//                                   dimension <= 128), honouring zgemm()'s UPPER / B_UPPER flags
+//   Cholesky + inverse + normest    n <= 64, one workgroup per matrix, everything in LDS
+//                                   (safe_cholesky, src/eigen/lobpcg_hyper_impl.jl:190-212)
+//   Hermitian eigensolver           n <= 64, one workgroup per matrix: cyclic Jacobi with round-robin ordering in LDS
+//                                   (rayleigh_ritz, :141-171), eigenvalues ascending
+// These are latency problems (n_G ~ 1e3, 6-8 bands, matrices of order <= 3 M): no roofline applies; what counts is
+// launches and host synchronisations per LOBPCG iteration.
+#include "batch.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+__device__ __forceinline__ double b_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+// block-wide sum for 256 threads; result valid in thread 0
+__device__ __forceinline__ double b_block_sum(double v, double* sh) {
+    v = b_wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 4; ++i) r += sh[i];
+    __syncthreads();
+    return r;
+}
+
+struct EwItem {
+    int64_t n, lda, ldb, ldc;
+    int m, mode, flags, i0;
+    const void *A, *B, *W, *W2;
+    void *C, *D, *E, *F;
+    double s0;
+    size_t bytes;
+};
+
+// ---- column reductions / residual / TPA: one workgroup per (column, item), same trees as the per-block kernels ----
+__global__ __launch_bounds__(256) void k_b_colred(const EwItem* __restrict__ items) {
+    const EwItem it = items[blockIdx.z];
+    const int c = blockIdx.x;
+    if (c >= it.m) return;
+    __shared__ double sh[4];
+    const cd* x = reinterpret_cast<const cd*>(it.A) + (int64_t)c * it.lda;
+    const cd* y = it.B ? reinterpret_cast<const cd*>(it.B) + (int64_t)c * it.ldb : nullptr;
+    const double* w = reinterpret_cast<const double*>(it.W);
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < it.n; i += 256) {
+        const cd a = x[i];
+        if (it.mode == 1) {
+            const cd bb = y[i];
+            acc += a.x * bb.x + a.y * bb.y;
+        } else if (it.mode == 4) {
+            const cd bb = y[i];
+            acc += a.x * bb.y - a.y * bb.x;
+        } else if (it.mode == 2) {
+            acc += w[i] * (a.x * a.x + a.y * a.y);
+        } else {
+            acc += a.x * a.x + a.y * a.y;
+        }
+    }
+    const double r = b_block_sum(acc, sh);
+    if (threadIdx.x == 0) reinterpret_cast<double*>(it.C)[c] = (it.mode == 0) ? sqrt(r) : r;
+}
+
+__global__ __launch_bounds__(256) void k_b_residual(const EwItem* __restrict__ items) {
+    const EwItem it = items[blockIdx.z];
+    const int c = blockIdx.x;
+    if (c >= it.m) return;
+    __shared__ double sh[4];
+    const cd* AX = reinterpret_cast<const cd*>(it.A);
+    const cd* X = reinterpret_cast<const cd*>(it.B);
+    cd* R = reinterpret_cast<cd*>(it.C);
+    const double* kin = reinterpret_cast<const double*>(it.W2);
+    const double l = reinterpret_cast<const double*>(it.W)[c];
+    double acc = 0.0, acck = 0.0, accx = 0.0;
+    for (int64_t i = threadIdx.x; i < it.n; i += 256) {
+        const cd a = AX[(int64_t)c * it.lda + i];
+        const cd x = X[(int64_t)c * it.ldb + i];
+        const cd r = make_double2(a.x - l * x.x, a.y - l * x.y);
+        R[(int64_t)c * it.ldc + i] = r;
+        acc += r.x * r.x + r.y * r.y;
+        const double x2 = x.x * x.x + x.y * x.y;
+        accx += x2;
+        if (kin) acck += kin[i] * x2;
+    }
+    const double s = b_block_sum(acc, sh);
+    const double sk = b_block_sum(acck, sh);
+    const double sx = b_block_sum(accx, sh);
+    if (threadIdx.x == 0) {
+        reinterpret_cast<double*>(it.D)[c] = sqrt(s);
+        if (kin) reinterpret_cast<double*>(it.E)[c] = sk;
+        if (it.F) reinterpret_cast<double*>(it.F)[c] = sx;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_b_tpa(const EwItem* __restrict__ items) {
+    const EwItem it = items[blockIdx.z];
+    const int c = blockIdx.x;
+    if (c >= it.m) return;
+    __shared__ double sh[4];
+    const cd* src = reinterpret_cast<const cd*>(it.A);
+    cd* dst = reinterpret_cast<cd*>(it.C);
+    const double* kin = reinterpret_cast<const double*>(it.W);
+    const double* mean_kin = reinterpret_cast<const double*>(it.W2);
+    const double mk = (kin && mean_kin) ? mean_kin[c] : 0.0;
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < it.n; i += 256) {
+        cd r = src[(int64_t)c * it.lda + i];
+        if (kin) {
+            const double f = mean_kin ? mk / (mk + kin[i]) : 1.0 / (kin[i] + it.s0);
+            r.x *= f;
+            r.y *= f;
+        }
+        dst[(int64_t)c * it.ldc + i] = r;
+        acc += r.x * r.x + r.y * r.y;
+    }
+    const double s = b_block_sum(acc, sh);
+    if (threadIdx.x == 0) reinterpret_cast<double*>(it.D)[c] = sqrt(s);
+}
+
+// ---- element-wise: grid (row blocks of the largest item, columns of the widest item, items) ----
+// kind 0: scale columns (s or 1/s), 1: copy, 2: gather columns through perm, 3: zero fill of `bytes`
+__global__ __launch_bounds__(256) void k_b_rows(const EwItem* __restrict__ items, int kind) {
+    const EwItem it = items[blockIdx.z];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    if (kind == 3) {
+        double* p = reinterpret_cast<double*>(it.C);
+        const int64_t nd = (int64_t)(it.bytes / sizeof(double));
+        for (int64_t t = i; t < nd; t += (int64_t)gridDim.x * 256) p[t] = 0.0;
+        return;
+    }
+    if (c >= it.m || i >= it.n) return;
+    cd* C = reinterpret_cast<cd*>(it.C);
+    if (kind == 0) {
+        const double s = reinterpret_cast<const double*>(it.W)[c];
+        const double f = it.flags ? 1.0 / s : s;
+        cd v = C[(int64_t)c * it.ldc + i];
+        v.x *= f;
+        v.y *= f;
+        C[(int64_t)c * it.ldc + i] = v;
+    } else {
+        const cd* A = reinterpret_cast<const cd*>(it.A);
+        const int sc = kind == 2 ? reinterpret_cast<const int*>(it.W)[c] : c;
+        C[(int64_t)c * it.ldc + i] = A[(int64_t)sc * it.lda + i];
+    }
+}
+
+// kind 0: C[i0 + a, a] -= 1 (a < m, i0 + a < n); 1: C[i, i] += s0 (i < m); 2: hermitise from the upper triangle (m x m);
+// 3: C = A^H (m x m)
+__global__ __launch_bounds__(256) void k_b_small(const EwItem* __restrict__ items, int kind) {
+    const EwItem it = items[blockIdx.z];
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    cd* C = reinterpret_cast<cd*>(it.C);
+    if (kind == 0) {
+        if (idx < it.m && it.i0 + idx < it.n) C[(it.i0 + idx) + idx * it.ldc].x -= 1.0;
+    } else if (kind == 1) {
+        if (idx < it.m) C[idx + idx * it.ldc].x += it.s0;
+    } else {
+        const int n = it.m;
+        if (idx >= (int64_t)n * n) return;
+        const int j = (int)(idx / n), i = (int)(idx - (int64_t)j * n);
+        if (kind == 2) {
+            if (i == j) C[i + (int64_t)j * it.ldc].y = 0.0;
+            if (i < j) {
+                const cd v = C[i + (int64_t)j * it.ldc];
+                C[j + (int64_t)i * it.ldc] = make_double2(v.x, -v.y);
+            }
+        } else {
+            const cd v = reinterpret_cast<const cd*>(it.A)[j + (int64_t)i * it.lda];
+            C[i + (int64_t)j * it.ldc] = make_double2(v.x, -v.y);
+        }
+    }
+}
+
+// ---- host <-> device traffic of a round: many tiny copies as ONE copy + a scatter / gather kernel ----
+struct CopyItem {
+    const void* src;
+    void* dst;
+    int64_t words;   // 4-byte words
+};
+__global__ __launch_bounds__(256) void k_b_copy_words(const CopyItem* __restrict__ items) {
+    const CopyItem it = items[blockIdx.y];
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(it.src);
+    uint32_t* d = reinterpret_cast<uint32_t*>(it.dst);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < it.words; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+}
+
+// ---- small products ----
+struct GemmItem {
+    int m, n, k, flags;
+    int64_t lda, ldb, ldc;
+    const cd *A, *B;
+    cd* C;
+    cd alpha, beta;
+};
+#define BG_T 16
+#define BG_KC 64
+// C (m x n) = alpha A^H B + beta C, A: k x m, B: k x n (k = the long dimension).  One workgroup per 16 x 16 tile of C,
+// the whole k range inside it (fixed order: bitwise reproducible).  flags & 1 (UPPER): tiles strictly below the
+// diagonal are skipped and left untouched, as zgemm() does.
+__global__ __launch_bounds__(256) void k_b_gemm_c(const GemmItem* __restrict__ items, int tiles_n) {
+    const GemmItem it = items[blockIdx.z];
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int i0 = tm * BG_T, j0 = tn * BG_T;
+    if (i0 >= it.m || j0 >= it.n) return;
+    if ((it.flags & 1) && i0 > j0 + BG_T - 1) return;
+    __shared__ cd As[BG_KC][BG_T + 1];
+    __shared__ cd Bs[BG_KC][BG_T + 1];
+    const int tid = threadIdx.x;
+    const int ti = tid & 15, tj = tid >> 4;
+    const int lr = tid & 63, lc = tid >> 6;   // loader: row lr of the chunk, columns lc, lc + 4, ...
+    double ar = 0.0, ai = 0.0;
+    for (int k0 = 0; k0 < it.k; k0 += BG_KC) {
+        const int kr = k0 + lr;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = lc + 4 * q;
+            cd va = make_double2(0.0, 0.0), vb = make_double2(0.0, 0.0);
+            if (kr < it.k) {
+                if (i0 + c < it.m) va = it.A[kr + (int64_t)(i0 + c) * it.lda];
+                if (j0 + c < it.n) vb = it.B[kr + (int64_t)(j0 + c) * it.ldb];
+            }
+            As[lr][c] = va;
+            Bs[lr][c] = vb;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int r = 0; r < BG_KC; ++r) {
+            const cd a = As[r][ti], bb = Bs[r][tj];
+            ar += a.x * bb.x + a.y * bb.y;     // conj(a) * b
+            ai += a.x * bb.y - a.y * bb.x;
+        }
+        __syncthreads();
+    }
+    const int i = i0 + ti, j = j0 + tj;
+    if (i < it.m && j < it.n) {
+        cd* cp = it.C + i + (int64_t)j * it.ldc;
+        cd out = make_double2(it.alpha.x * ar - it.alpha.y * ai, it.alpha.x * ai + it.alpha.y * ar);
+        if (it.beta.x != 0.0 || it.beta.y != 0.0) {
+            const cd o = *cp;
+            out.x += it.beta.x * o.x - it.beta.y * o.y;
+            out.y += it.beta.x * o.y + it.beta.y * o.x;
+        }
+        *cp = out;
+    }
+}
+
+#define BN_C 8
+#define BN_KMAX 128
+// C (m x n) = alpha A B + beta C, A: m x k (m = the long dimension, k <= 128), B: k x n.  One thread per row, 8
+// columns per workgroup column block; flags & 2 (B_UPPER): B[kk][j] = 0 for kk > j (never read, as zgemm()).
+__global__ __launch_bounds__(256) void k_b_gemm_n(const GemmItem* __restrict__ items) {
+    const GemmItem it = items[blockIdx.z];
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int j0 = blockIdx.y * BN_C;
+    if (j0 >= it.n || (int64_t)blockIdx.x * 256 >= it.m) return;
+    __shared__ cd Bs[BN_KMAX][BN_C];
+    for (int t = threadIdx.x; t < it.k * BN_C; t += 256) {
+        const int kk = t / BN_C, jj = t - kk * BN_C;
+        const int j = j0 + jj;
+        cd v = make_double2(0.0, 0.0);
+        if (j < it.n && !((it.flags & 2) && kk > j)) v = it.B[kk + (int64_t)j * it.ldb];
+        Bs[kk][jj] = v;
+    }
+    __syncthreads();
+    if (r >= it.m) return;
+    double accr[BN_C], acci[BN_C];
+#pragma unroll
+    for (int jj = 0; jj < BN_C; ++jj) accr[jj] = acci[jj] = 0.0;
+    // triangular B: column block j0 needs kk <= j0 + 7 only
+    const int kend = (it.flags & 2) ? min(it.k, j0 + BN_C) : it.k;
+    for (int kk = 0; kk < kend; ++kk) {
+        const cd a = it.A[r + (int64_t)kk * it.lda];
+#pragma unroll
+        for (int jj = 0; jj < BN_C; ++jj) {
+            const cd bb = Bs[kk][jj];
+            accr[jj] += a.x * bb.x - a.y * bb.y;
+            acci[jj] += a.x * bb.y + a.y * bb.x;
+        }
+    }
+#pragma unroll
+    for (int jj = 0; jj < BN_C; ++jj) {
+        const int j = j0 + jj;
+        if (j >= it.n) break;
+        cd* cp = it.C + r + (int64_t)j * it.ldc;
+        cd out = make_double2(it.alpha.x * accr[jj] - it.alpha.y * acci[jj], it.alpha.x * acci[jj] + it.alpha.y * accr[jj]);
+        if (it.beta.x != 0.0 || it.beta.y != 0.0) {
+            const cd o = *cp;
+            out.x += it.beta.x * o.x - it.beta.y * o.y;
+            out.y += it.beta.x * o.y + it.beta.y * o.x;
+        }
+        *cp = out;
+    }
+}
+
+// ---- Cholesky + inverse + normest, one workgroup per matrix (n <= 64), everything in LDS ----
+struct DenseItem {
+    int n;
+    int64_t lda, ldb;
+    cd *A, *B;        // POTRF: A in / R out (upper), B = inv(R) out;  HEEV: A in (destroyed), B = eigenvectors out
+    double* res;      // POTRF: 8 doubles {info, max|diag R|, sum|offdiag R|^2, bad R, same three for inv R, 0}
+                      // HEEV : n eigenvalues ascending + {converged, non-finite}
+};
+extern __shared__ __attribute__((aligned(16))) char b_smem[];
+
+__global__ __launch_bounds__(256) void k_b_potrf(const DenseItem* __restrict__ items, int pitch) {
+    const DenseItem it = items[blockIdx.x];
+    const int n = it.n, tid = threadIdx.x;
+    cd* S = reinterpret_cast<cd*>(b_smem);            // S[i * pitch + j]: row i, column j (upper part used)
+    cd* Iv = S + (size_t)pitch * pitch;
+    __shared__ double sh[4];
+    __shared__ int s_info;
+    __shared__ double s_piv;
+    if (tid == 0) s_info = 0;
+    for (int t = tid; t < n * n; t += 256) {
+        const int j = t / n, i = t - j * n;
+        S[i * pitch + j] = it.A[i + (int64_t)j * it.lda];
+        Iv[i * pitch + j] = make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        if (tid == 0) {
+            const cd d = S[j * pitch + j];
+            if (!(d.x > 0.0) || !isfinite(d.x) || !isfinite(d.y)) {
+                if (s_info == 0) s_info = j + 1;
+                s_piv = 1.0;
+            } else {
+                s_piv = sqrt(d.x);
+                S[j * pitch + j] = make_double2(s_piv, 0.0);
+            }
+        }
+        __syncthreads();
+        if (s_info != 0) break;
+        const double inv = 1.0 / s_piv;
+        for (int c = j + 1 + tid; c < n; c += 256) {
+            cd v = S[j * pitch + c];
+            v.x *= inv;
+            v.y *= inv;
+            S[j * pitch + c] = v;
+        }
+        __syncthreads();
+        // trailing update of the upper triangle: S[i][c] -= conj(S[j][i]) S[j][c],  j < i <= c < n
+        const int rem = n - j - 1;
+        for (int t = tid; t < rem * rem; t += 256) {
+            const int a = t / rem, bq = t - a * rem;
+            const int i = j + 1 + a, c = j + 1 + bq;
+            if (i <= c) {
+                const cd u = S[j * pitch + i], v = S[j * pitch + c];
+                cd w = S[i * pitch + c];
+                w.x -= u.x * v.x + u.y * v.y;
+                w.y -= u.x * v.y - u.y * v.x;
+                S[i * pitch + c] = w;
+            }
+        }
+        __syncthreads();
+    }
+    const int info = s_info;
+    if (info == 0) {
+        // inverse of the upper triangular factor, one thread per column: x_j = 1 / R_jj, x_i = -(sum_{k>i} R_ik x_k) / R_ii
+        if (tid < n) {
+            const int j = tid;
+            Iv[j * pitch + j] = make_double2(1.0 / S[j * pitch + j].x, 0.0);
+            for (int i = j - 1; i >= 0; --i) {
+                double sr = 0.0, si = 0.0;
+                for (int k = i + 1; k <= j; ++k) {
+                    const cd rr = S[i * pitch + k], x = Iv[k * pitch + j];
+                    sr += rr.x * x.x - rr.y * x.y;
+                    si += rr.x * x.y + rr.y * x.x;
+                }
+                const double d = S[i * pitch + i].x;
+                Iv[i * pitch + j] = make_double2(-sr / d, -si / d);
+            }
+        }
+        __syncthreads();
+    }
+    // write back R (upper triangle of A) and inv(R) (upper, zeros below); normest pieces of both
+    double mx[2] = {0.0, 0.0}, off[2] = {0.0, 0.0}, bad[2] = {0.0, 0.0};
+    for (int t = tid; t < n * n; t += 256) {
+        const int j = t / n, i = t - j * n;
+        if (i <= j) {
+            const cd r = S[i * pitch + j], x = Iv[i * pitch + j];
+            it.A[i + (int64_t)j * it.lda] = r;
+            it.B[i + (int64_t)j * it.ldb] = x;
+            const cd v2[2] = {r, x};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (!(isfinite(v2[q].x) && isfinite(v2[q].y))) bad[q] = 1.0;
+                const double a2 = v2[q].x * v2[q].x + v2[q].y * v2[q].y;
+                if (i == j)
+                    mx[q] = fmax(mx[q], sqrt(a2));
+                else
+                    off[q] += a2;
+            }
+        } else {
+            it.B[i + (int64_t)j * it.ldb] = make_double2(0.0, 0.0);
+        }
+    }
+    __shared__ double smax[2][256];
+    smax[0][tid] = mx[0];
+    smax[1][tid] = mx[1];
+    __syncthreads();
+    const double o0 = b_block_sum(off[0], sh), o1 = b_block_sum(off[1], sh);
+    const double b0 = b_block_sum(bad[0], sh), b1 = b_block_sum(bad[1], sh);
+    if (tid == 0) {
+        double m0 = 0.0, m1 = 0.0;
+        for (int i = 0; i < 256; ++i) {
+            m0 = fmax(m0, smax[0][i]);
+            m1 = fmax(m1, smax[1][i]);
+        }
+        it.res[0] = (double)info;
+        it.res[1] = m0;
+        it.res[2] = o0;
+        it.res[3] = b0;
+        it.res[4] = m1;
+        it.res[5] = o1;
+        it.res[6] = b1;
+        it.res[7] = 0.0;
+    }
+}
+
+// ---- Hermitian eigensolver, one workgroup per matrix (n <= 64): cyclic Jacobi, round-robin ordering, in LDS ----
+// Rotation of the pair (p, q) as in dense_kernels.hip (k_jacobi_round): with a = S_pp, g = S_qq, b = S_pq,
+// d = (g - a) / 2: t = sgn(d) / (|d| + sqrt(d^2 + |b|^2)), c = 1 / sqrt(1 + t^2 |b|^2), s = t c b;
+// rows (p, q) <- (c row_p - s row_q, conj(s) row_p + c row_q), columns (p, q) <- (c col_p - conj(s) col_q, s col_p + c col_q).
+__device__ __forceinline__ void rr_pair(int np, int round, int k, int& p, int& q) {
+    // round-robin: player np - 1 stays, the others rotate
+    if (k == 0) {
+        p = np - 1;
+        q = round;
+    } else {
+        p = (round + k) % (np - 1);
+        q = (round - k + (np - 1)) % (np - 1);
+    }
+    if (p > q) {
+        const int t = p;
+        p = q;
+        q = t;
+    }
+}
+__global__ __launch_bounds__(256) void k_b_heev(const DenseItem* __restrict__ items, int pitch) {
+    const DenseItem it = items[blockIdx.x];
+    const int n = it.n, tid = threadIdx.x;
+    const int np = n + (n & 1);                     // padded to even; the pad is a decoupled large diagonal entry
+    cd* S = reinterpret_cast<cd*>(b_smem);          // S[i * pitch + j]
+    cd* V = S + (size_t)pitch * pitch;
+    __shared__ double sh[4];
+    __shared__ double s_c[32];
+    __shared__ cd s_s[32];
+    __shared__ int s_p[32], s_q[32];
+    __shared__ double s_red[2];
+    double dg = 0.0, of = 0.0;
+    for (int t = tid; t < np * np; t += 256) {
+        const int j = t / np, i = t - j * np;
+        cd v = make_double2(0.0, 0.0);
+        if (i < n && j < n) v = it.A[i + (int64_t)j * it.lda];
+        S[i * pitch + j] = v;
+        V[i * pitch + j] = make_double2(i == j ? 1.0 : 0.0, 0.0);
+        const double a2 = v.x * v.x + v.y * v.y;
+        if (i == j)
+            dg += a2;
+        else
+            of += a2;
+    }
+    const double dg2 = b_block_sum(dg, sh), of2 = b_block_sum(of, sh);
+    if (tid == 0) {
+        s_red[0] = dg2 + of2;
+        s_red[1] = of2;
+    }
+    __syncthreads();
+    const double fro2 = s_red[0];
+    const bool finite_in = isfinite(fro2);
+    const double fro = sqrt(fro2);
+    if (np > n && tid == 0) S[n * pitch + n] = make_double2(2.0 * fro + 1.0, 0.0);
+    __syncthreads();
+    const double tol = 1e-14;
+    bool done = !finite_in || s_red[1] == 0.0;
+    double prev_off = -1.0;
+    const int npairs = np / 2;
+    for (int sweep = 0; sweep < 40 && !done; ++sweep) {
+        for (int round = 0; round < np - 1; ++round) {
+            if (tid < npairs) {
+                int p, q;
+                rr_pair(np, round, tid, p, q);
+                const cd beta = S[p * pitch + q];
+                const double al = S[p * pitch + p].x, ga = S[q * pitch + q].x;
+                const double b2 = beta.x * beta.x + beta.y * beta.y;
+                double c = 1.0;
+                cd s = make_double2(0.0, 0.0);
+                if (b2 > 1e-300 && b2 > 1e-36 * (fabs(al * ga) + 1e-300)) {
+                    const double d = 0.5 * (ga - al);
+                    const double den = fabs(d) + sqrt(d * d + b2);
+                    const double u = 1.0 / den;
+                    c = 1.0 / sqrt(1.0 + b2 * u * u);
+                    const double f = (d >= 0.0 ? c : -c) * u;
+                    s = make_double2(f * beta.x, f * beta.y);
+                }
+                s_c[tid] = c;
+                s_s[tid] = s;
+                s_p[tid] = p;
+                s_q[tid] = q;
+            }
+            __syncthreads();
+            for (int t = tid; t < npairs * np; t += 256) {     // rows
+                const int k = t / np, j = t - k * np;
+                const int p = s_p[k], q = s_q[k];
+                const double c = s_c[k];
+                const cd s = s_s[k];
+                const cd a = S[p * pitch + j], b = S[q * pitch + j];
+                S[p * pitch + j] = make_double2(c * a.x - (s.x * b.x - s.y * b.y), c * a.y - (s.x * b.y + s.y * b.x));
+                S[q * pitch + j] = make_double2(s.x * a.x + s.y * a.y + c * b.x, s.x * a.y - s.y * a.x + c * b.y);
+            }
+            __syncthreads();
+            for (int t = tid; t < npairs * np; t += 256) {     // columns of S and of V
+                const int k = t / np, i = t - k * np;
+                const int p = s_p[k], q = s_q[k];
+                const double c = s_c[k];
+                const cd s = s_s[k];
+                {
+                    const cd xp = S[i * pitch + p], xq = S[i * pitch + q];
+                    S[i * pitch + p] = make_double2(c * xp.x - (s.x * xq.x + s.y * xq.y), c * xp.y - (s.x * xq.y - s.y * xq.x));
+                    S[i * pitch + q] = make_double2(s.x * xp.x - s.y * xp.y + c * xq.x, s.x * xp.y + s.y * xp.x + c * xq.y);
+                }
+                {
+                    const cd xp = V[i * pitch + p], xq = V[i * pitch + q];
+                    V[i * pitch + p] = make_double2(c * xp.x - (s.x * xq.x + s.y * xq.y), c * xp.y - (s.x * xq.y - s.y * xq.x));
+                    V[i * pitch + q] = make_double2(s.x * xp.x - s.y * xp.y + c * xq.x, s.x * xp.y + s.y * xp.x + c * xq.y);
+                }
+            }
+            __syncthreads();
+        }
+        double o = 0.0;
+        for (int t = tid; t < np * np; t += 256) {
+            const int j = t / np, i = t - j * np;
+            if (i != j) {
+                const cd v = S[i * pitch + j];
+                o += v.x * v.x + v.y * v.y;
+            }
+        }
+        const double o2 = b_block_sum(o, sh);
+        if (tid == 0) s_red[1] = o2;
+        __syncthreads();
+        const double off = sqrt(s_red[1]);
+        if (!isfinite(off)) break;
+        if (off <= tol * fro) done = true;
+        if (!done && prev_off >= 0.0 && off > 0.5 * prev_off && off <= 1e-12 * fro) done = true;
+        prev_off = off;
+        __syncthreads();
+    }
+    // eigenvalues ascending (stable rank sort), eigenvector columns in that order; the pad sorts last and is dropped
+    double* res = it.res;
+    if (tid < np) {
+        const double di = S[tid * pitch + tid].x;
+        int rank = 0;
+        for (int j = 0; j < np; ++j) {
+            const double dj = S[j * pitch + j].x;
+            if (dj < di || (dj == di && j < tid)) rank += 1;
+        }
+        if (rank < n) {
+            res[rank] = di;
+            for (int i = 0; i < n; ++i) it.B[i + (int64_t)rank * it.ldb] = V[i * pitch + tid];
+        }
+    }
+    if (tid == 0) {
+        res[n] = (done && finite_in) ? 1.0 : 0.0;
+        res[n + 1] = finite_in ? 0.0 : 1.0;
+    }
+}
+
+EwItem ew_item(const BOp& o) {
+    EwItem e;
+    e.n = o.n;
+    e.lda = o.lda;
+    e.ldb = o.ldb;
+    e.ldc = o.ldc;
+    e.m = o.m;
+    e.mode = o.mode;
+    e.flags = o.flags;
+    e.i0 = o.i0;
+    e.A = o.A;
+    e.B = o.B;
+    e.W = o.W;
+    e.W2 = o.W2;
+    e.C = o.C;
+    e.D = o.D;
+    e.E = o.E;
+    e.F = o.F;
+    e.s0 = o.s0;
+    e.bytes = o.bytes;
+    return e;
+}
+
+int set_big_lds(const void* kernel, size_t bytes) {
+    if (bytes > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+}  // namespace
+
+int batch_exec_group(BatchCtx* ctx, hipStream_t stream, int type, std::vector<BOp*>& ops) {
+    const int n_items = (int)ops.size();
+    if (n_items == 0) return 0;
+    if (n_items > 65535) return 1;
+    if (type == BOP_APPLYH) return batch_exec_apply_H(ctx, stream, ops);
+    if (type == BOP_DENSITY) return batch_exec_density(ctx, stream, ops);
+
+    // ------------------------------------------------------------------ element-wise / column kernels
+    if (type == BOP_COLRED || type == BOP_RESIDUAL || type == BOP_TPA || type == BOP_SCALE || type == BOP_COPY ||
+        type == BOP_GATHER || type == BOP_FILL0 || type == BOP_SUBID || type == BOP_ADDDIAG || type == BOP_HERMIT ||
+        type == BOP_CTRANS) {
+        std::vector<EwItem> items(n_items);
+        int64_t maxn = 1;
+        int maxm = 1;
+        size_t maxbytes = 0;
+        for (int i = 0; i < n_items; ++i) {
+            items[i] = ew_item(*ops[i]);
+            maxn = std::max<int64_t>(maxn, ops[i]->n);
+            maxm = std::max(maxm, ops[i]->m);
+            maxbytes = std::max(maxbytes, ops[i]->bytes);
+            if (type == BOP_FILL0 && (ops[i]->bytes % sizeof(double))) return 1;
+        }
+        const EwItem* d = reinterpret_cast<const EwItem*>(batch_stage(ctx, items.data(), items.size() * sizeof(EwItem)));
+        if (!d) return DFTK_MI_EHIP;
+        const unsigned rows = (unsigned)((maxn + 255) / 256);
+        switch (type) {
+            case BOP_COLRED: hipLaunchKernelGGL(k_b_colred, dim3(maxm, 1, n_items), dim3(256), 0, stream, d); break;
+            case BOP_RESIDUAL: hipLaunchKernelGGL(k_b_residual, dim3(maxm, 1, n_items), dim3(256), 0, stream, d); break;
+            case BOP_TPA: hipLaunchKernelGGL(k_b_tpa, dim3(maxm, 1, n_items), dim3(256), 0, stream, d); break;
+            case BOP_SCALE: hipLaunchKernelGGL(k_b_rows, dim3(rows, maxm, n_items), dim3(256), 0, stream, d, 0); break;
+            case BOP_COPY: hipLaunchKernelGGL(k_b_rows, dim3(rows, maxm, n_items), dim3(256), 0, stream, d, 1); break;
+            case BOP_GATHER: hipLaunchKernelGGL(k_b_rows, dim3(rows, maxm, n_items), dim3(256), 0, stream, d, 2); break;
+            case BOP_FILL0: {
+                const unsigned g = (unsigned)std::min<size_t>(64, (maxbytes / sizeof(double) + 255) / 256 + 1);
+                hipLaunchKernelGGL(k_b_rows, dim3(g, 1, n_items), dim3(256), 0, stream, d, 3);
+                break;
+            }
+            case BOP_SUBID:
+                hipLaunchKernelGGL(k_b_small, dim3((maxm + 255) / 256, 1, n_items), dim3(256), 0, stream, d, 0);
+                break;
+            case BOP_ADDDIAG:
+                hipLaunchKernelGGL(k_b_small, dim3((maxm + 255) / 256, 1, n_items), dim3(256), 0, stream, d, 1);
+                break;
+            case BOP_HERMIT:
+                hipLaunchKernelGGL(k_b_small, dim3((unsigned)(((size_t)maxm * maxm + 255) / 256), 1, n_items), dim3(256), 0,
+                                   stream, d, 2);
+                break;
+            default:
+                hipLaunchKernelGGL(k_b_small, dim3((unsigned)(((size_t)maxm * maxm + 255) / 256), 1, n_items), dim3(256), 0,
+                                   stream, d, 3);
+                break;
+        }
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+
+    // ------------------------------------------------------------------ small products
+    if (type == BOP_ZGEMM) {
+        std::vector<GemmItem> cn, nn;
+        int max_m_c = 1, max_n_c = 1, max_n_n = 1;
+        int64_t max_m_n = 1;
+        for (BOp* o : ops) {
+            if (o->flags & DFTK_MI_GEMM_REAL) return 1;
+            if (o->gk <= 0) return 1;
+            GemmItem g;
+            g.m = (int)o->gm;
+            g.n = (int)o->gn;
+            g.k = (int)o->gk;
+            g.flags = o->flags & 3;
+            g.lda = o->lda;
+            g.ldb = o->ldb;
+            g.ldc = o->ldc;
+            g.A = reinterpret_cast<const cd*>(o->A);
+            g.B = reinterpret_cast<const cd*>(o->B);
+            g.C = reinterpret_cast<cd*>(o->C);
+            g.alpha = o->alpha;
+            g.beta = o->beta;
+            if (o->trans == 'C') {
+                if (o->gm > 96 || o->gn > 96) return 1;
+                cn.push_back(g);
+                max_m_c = std::max(max_m_c, g.m);
+                max_n_c = std::max(max_n_c, g.n);
+            } else {
+                if (o->gk > BN_KMAX || o->gn > 512) return 1;
+                nn.push_back(g);
+                max_m_n = std::max<int64_t>(max_m_n, g.m);
+                max_n_n = std::max(max_n_n, g.n);
+            }
+        }
+        if (!cn.empty()) {
+            const GemmItem* d = reinterpret_cast<const GemmItem*>(batch_stage(ctx, cn.data(), cn.size() * sizeof(GemmItem)));
+            if (!d) return DFTK_MI_EHIP;
+            const int tm = (max_m_c + BG_T - 1) / BG_T, tn = (max_n_c + BG_T - 1) / BG_T;
+            hipLaunchKernelGGL(k_b_gemm_c, dim3(tm * tn, 1, (unsigned)cn.size()), dim3(256), 0, stream, d, tn);
+        }
+        if (!nn.empty()) {
+            const GemmItem* d = reinterpret_cast<const GemmItem*>(batch_stage(ctx, nn.data(), nn.size() * sizeof(GemmItem)));
+            if (!d) return DFTK_MI_EHIP;
+            hipLaunchKernelGGL(k_b_gemm_n, dim3((unsigned)((max_m_n + 255) / 256), (max_n_n + BN_C - 1) / BN_C, (unsigned)nn.size()),
+                               dim3(256), 0, stream, d);
+        }
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+
+    // ------------------------------------------------------------------ host <-> device copies
+    if (type == BOP_H2D) {
+        // all payloads packed behind one another in the ring (ONE copy), then scattered to their destinations
+        size_t total = 0;
+        for (BOp* o : ops) {
+            if (o->payload.size() % 4) return 1;
+            total += (o->payload.size() + 15) & ~(size_t)15;
+        }
+        std::vector<char> pack(total);
+        std::vector<CopyItem> items(n_items);
+        size_t off = 0;
+        for (int i = 0; i < n_items; ++i) {
+            memcpy(pack.data() + off, ops[i]->payload.data(), ops[i]->payload.size());
+            items[i].src = reinterpret_cast<const void*>(off);   // patched below with the device base
+            items[i].dst = ops[i]->C;
+            items[i].words = (int64_t)(ops[i]->payload.size() / 4);
+            off += (ops[i]->payload.size() + 15) & ~(size_t)15;
+        }
+        const char* dbase = reinterpret_cast<const char*>(batch_stage(ctx, pack.data(), pack.size()));
+        if (!dbase) return DFTK_MI_EHIP;
+        for (auto& it : items) it.src = dbase + reinterpret_cast<size_t>(it.src);
+        const CopyItem* d = reinterpret_cast<const CopyItem*>(batch_stage(ctx, items.data(), items.size() * sizeof(CopyItem)));
+        if (!d) return DFTK_MI_EHIP;
+        hipLaunchKernelGGL(k_b_copy_words, dim3(4, n_items), dim3(256), 0, stream, d);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    if (type == BOP_D2H) {
+        std::vector<CopyItem> items(n_items);
+        for (int i = 0; i < n_items; ++i) {
+            if (ops[i]->bytes % 4) return 1;
+            void* htwin = nullptr;
+            void* dslot = batch_result_slot(ctx, ops[i]->bytes, &htwin);
+            if (!dslot) return DFTK_MI_EHIP;
+            items[i].src = ops[i]->A;
+            items[i].dst = dslot;
+            items[i].words = (int64_t)(ops[i]->bytes / 4);
+            void* dst_h = ops[i]->host;
+            const size_t nb = ops[i]->bytes;
+            batch_add_fixup(ctx, [=]() { memcpy(dst_h, htwin, nb); });
+        }
+        const CopyItem* d = reinterpret_cast<const CopyItem*>(batch_stage(ctx, items.data(), items.size() * sizeof(CopyItem)));
+        if (!d) return DFTK_MI_EHIP;
+        hipLaunchKernelGGL(k_b_copy_words, dim3(4, n_items), dim3(256), 0, stream, d);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+
+    // ------------------------------------------------------------------ small factorizations
+    if (type == BOP_POTRF || type == BOP_HEEV) {
+        int nmax = 1;
+        for (BOp* o : ops) {
+            if (o->m > 64 || o->m < 1) return 1;
+            nmax = std::max(nmax, o->m);
+        }
+        std::vector<DenseItem> items(n_items);
+        for (int i = 0; i < n_items; ++i) {
+            BOp* o = ops[i];
+            const size_t rb = (type == BOP_POTRF ? 8 : (size_t)o->m + 2) * sizeof(double);
+            void* htwin = nullptr;
+            double* dres = reinterpret_cast<double*>(batch_result_slot(ctx, rb, &htwin));
+            if (!dres) return DFTK_MI_EHIP;
+            items[i].n = o->m;
+            items[i].lda = o->ldc;
+            items[i].ldb = o->ldb;
+            items[i].A = reinterpret_cast<cd*>(o->C);
+            items[i].B = reinterpret_cast<cd*>(o->D);
+            items[i].res = dres;
+            const double* h = reinterpret_cast<const double*>(htwin);
+            if (type == BOP_POTRF) {
+                batch_add_fixup(ctx, [o, h]() {
+                    double* out = reinterpret_cast<double*>(o->host);
+                    if (h[0] != 0.0 || h[3] != 0.0 || h[6] != 0.0) {
+                        o->status = DFTK_MI_NUM_CHOLESKY;
+                    } else {
+                        o->status = 0;
+                        out[0] = h[1] + sqrt(h[2]);
+                        out[1] = h[4] + sqrt(h[5]);
+                    }
+                });
+            } else {
+                batch_add_fixup(ctx, [o, h]() {
+                    const int n = o->m;
+                    if (h[n + 1] != 0.0) {
+                        o->status = DFTK_MI_NUM_NONFINITE;
+                    } else if (h[n] == 0.0) {
+                        dftk_set_error("dense_heev (batched): Jacobi did not converge (n=%d)", n);
+                        o->status = DFTK_MI_NUM_EIGEN;
+                    } else {
+                        o->status = 0;
+                        memcpy(o->host, h, (size_t)n * sizeof(double));
+                    }
+                });
+            }
+        }
+        const DenseItem* d = reinterpret_cast<const DenseItem*>(batch_stage(ctx, items.data(), items.size() * sizeof(DenseItem)));
+        if (!d) return DFTK_MI_EHIP;
+        const int pitch = nmax + 1 + (nmax & 1);
+        const size_t lds = 2 * (size_t)pitch * pitch * sizeof(cd);
+        if (type == BOP_POTRF) {
+            CHK(set_big_lds(reinterpret_cast<const void*>(k_b_potrf), lds));
+            hipLaunchKernelGGL(k_b_potrf, dim3(n_items), dim3(256), lds, stream, d, pitch);
+        } else {
+            CHK(set_big_lds(reinterpret_cast<const void*>(k_b_heev), lds));
+            hipLaunchKernelGGL(k_b_heev, dim3(n_items), dim3(256), lds, stream, d, pitch);
+        }
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    return 1;
+}
+
+int batch_exec_apply_H(BatchCtx*, hipStream_t, std::vector<BOp*>&) { return 1; }
+int batch_exec_density(BatchCtx*, hipStream_t, std::vector<BOp*>&) { return 1; }

@@ -286,6 +286,9 @@ int apply_nonlocal_rows(dftk_mi_kblock* kb, int nb, const cd* P, int64_t ldP, in
 // ortho!(X) (Cholesky-QR with the reference's shift-and-retry and SVD fallback) on a stand-alone block;
 // force_svd = 1 takes the SVD branch directly (tests)
 int lobpcg_ortho(dftk_mi_basis* b, int64_t n, int m, cd* X, int64_t ldx, int force_svd, int* n_chol, int* used_svd);
+int lobpcg_run_multi(int n_kb, dftk_mi_kblock* const* kbs, int M, cd* const* X, const int64_t* ldX, double tol, int miniter,
+                     int maxiter, int n_conv_check, int use_tpa, const uint64_t* seeds, double* lambda_h, double* resid_h,
+                     int* n_iter, int* converged, int64_t* n_matvec, int* status);
 int lobpcg_run(dftk_mi_kblock* kb, int M, cd* X, int64_t ldX, double tol, int miniter, int maxiter,
                int n_conv_check, int use_tpa, uint64_t seed, double* lambda_h, double* resid_h,
                int* n_iter, int* converged, int64_t* n_matvec);

@@ -8,6 +8,7 @@
 //                                             src/gpu/linalg.jl:25-36                  (K16-K19)
 //   D * (P' psi)                              src/terms/operators.jl:127               (K8)
 #include "common.h"
+#include "batch.h"
 #include <algorithm>
 #include <cmath>
 #include <numeric>
@@ -951,6 +952,16 @@ static int fetch_scalars(dftk_mi_basis* b, int count) {
 
 int dense_potrf_trtri(dftk_mi_basis* b, int n, cd* A, int64_t lda, cd* invR, int64_t ldi, double* normest_R,
                       double* normest_invR) {
+    if (batching()) {
+        double out[2] = {0.0, 0.0};      // on the fiber's stack: filled by the round's executor
+        BOp o;
+        o.b = b;
+        o.type = BOP_POTRF; o.m = n; o.C = A; o.ldc = lda; o.D = invR; o.ldb = ldi; o.host = out;
+        const int st = batch_record_sync(std::move(o));
+        if (normest_R) *normest_R = out[0];
+        if (normest_invR) *normest_invR = out[1];
+        return st;
+    }
     const int ps = prof_begin(b, PROF_CHOL, (double)n);
     int* d_info = reinterpret_cast<int*>(b->d_scalars + 200);
     HIPCHK(hipMemsetAsync(d_info, 0, sizeof(int), b->stream));
@@ -1128,6 +1139,12 @@ static int heev_impl(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, c
 
 int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, int64_t ldv) {
     if (n <= 0) return 0;
+    if (batching()) {
+        BOp o;
+        o.b = b;
+        o.type = BOP_HEEV; o.m = n; o.C = A; o.ldc = lda; o.D = V; o.ldb = ldv; o.host = W_h;
+        return batch_record_sync(std::move(o));
+    }
     const int pslot = prof_begin(b, PROF_HEEV, (double)n);
     struct ProfGuard {
         dftk_mi_basis* b;
@@ -1169,6 +1186,12 @@ int apply_D(dftk_mi_kblock* kb, int n_bands, const cd* X, cd* Y) {
 // ---- thin launch wrappers -------------------------------------------------------------------
 int ew_colnorms(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, double* out_d) {
     if (m <= 0) return 0;
+    if (batching()) {
+        BOp o;
+        o.b = b;
+        o.type = BOP_COLRED; o.mode = 0; o.n = n; o.m = m; o.A = X; o.lda = ldx; o.C = out_d;
+        return batch_record(std::move(o));
+    }
     hipLaunchKernelGGL(k_col_reduce, dim3(m), dim3(256), 0, b->stream, 0, n, X, ldx, (const cd*)nullptr, (int64_t)0,
                        (const double*)nullptr, out_d);
     HIPCHK(hipGetLastError());
@@ -1177,6 +1200,12 @@ int ew_colnorms(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, do
 int ew_coldots(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, const cd* Y, int64_t ldy,
                double* out_re_d) {
     if (m <= 0) return 0;
+    if (batching()) {
+        BOp o;
+        o.b = b;
+        o.type = BOP_COLRED; o.mode = 1; o.n = n; o.m = m; o.A = X; o.lda = ldx; o.B = Y; o.ldb = ldy; o.C = out_re_d;
+        return batch_record(std::move(o));
+    }
     hipLaunchKernelGGL(k_col_reduce, dim3(m), dim3(256), 0, b->stream, 1, n, X, ldx, Y, ldy, (const double*)nullptr,
                        out_re_d);
     HIPCHK(hipGetLastError());
@@ -1185,6 +1214,12 @@ int ew_coldots(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, con
 int ew_coldots_im(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, const cd* Y, int64_t ldy,
                   double* out_im_d) {
     if (m <= 0) return 0;
+    if (batching()) {
+        BOp o;
+        o.b = b;
+        o.type = BOP_COLRED; o.mode = 4; o.n = n; o.m = m; o.A = X; o.lda = ldx; o.B = Y; o.ldb = ldy; o.C = out_im_d;
+        return batch_record(std::move(o));
+    }
     hipLaunchKernelGGL(k_col_reduce, dim3(m), dim3(256), 0, b->stream, 4, n, X, ldx, Y, ldy, (const double*)nullptr,
                        out_im_d);
     HIPCHK(hipGetLastError());
@@ -1193,6 +1228,12 @@ int ew_coldots_im(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, 
 int ew_weighted_colsums(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, const double* w_d,
                         double* out_d) {
     if (m <= 0) return 0;
+    if (batching()) {
+        BOp o;
+        o.b = b;
+        o.type = BOP_COLRED; o.mode = 2; o.n = n; o.m = m; o.A = X; o.lda = ldx; o.W = w_d; o.C = out_d;
+        return batch_record(std::move(o));
+    }
     hipLaunchKernelGGL(k_col_reduce, dim3(m), dim3(256), 0, b->stream, 2, n, X, ldx, (const cd*)nullptr, (int64_t)0,
                        w_d, out_d);
     HIPCHK(hipGetLastError());
@@ -1200,6 +1241,12 @@ int ew_weighted_colsums(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t
 }
 int ew_conj_transpose(dftk_mi_basis* b, int n, const cd* A, int64_t lda, cd* B, int64_t ldb) {
     if (n <= 0) return 0;
+    if (batching()) {
+        BOp o;
+        o.b = b;
+        o.type = BOP_CTRANS; o.m = n; o.A = A; o.lda = lda; o.C = B; o.ldc = ldb;
+        return batch_record(std::move(o));
+    }
     hipLaunchKernelGGL(k_conj_transpose, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, b->stream, n, A,
                        lda, B, ldb);
     HIPCHK(hipGetLastError());
@@ -1219,6 +1266,12 @@ int ew_sqrt(dftk_mi_basis* b, double* d, size_t n) {
 }
 int ew_frob2(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, double* out_d) {
     if (m <= 0) return 0;
+    if (batching()) {
+        BOp o;
+        o.b = b;
+        o.type = BOP_COLRED; o.mode = 3; o.n = n; o.m = m; o.A = X; o.lda = ldx; o.C = out_d;
+        return batch_record(std::move(o));
+    }
     hipLaunchKernelGGL(k_col_reduce, dim3(m), dim3(256), 0, b->stream, 3, n, X, ldx, (const cd*)nullptr, (int64_t)0,
                        (const double*)nullptr, out_d);
     HIPCHK(hipGetLastError());
@@ -1228,6 +1281,13 @@ int ew_residual(dftk_mi_basis* b, int64_t n, int m, const cd* AX, int64_t lda, c
                 const double* lam_d, cd* R, int64_t ldr, double* norms_d, const double* kin, double* mean_kin_d,
                 double* xx_d) {
     if (m <= 0) return 0;
+    if (batching()) {
+        BOp o;
+        o.b = b;
+        o.type = BOP_RESIDUAL; o.n = n; o.m = m; o.A = AX; o.lda = lda; o.B = X; o.ldb = ldx; o.W = lam_d; o.C = R; o.ldc = ldr;
+        o.D = norms_d; o.W2 = kin; o.E = mean_kin_d; o.F = xx_d;
+        return batch_record(std::move(o));
+    }
     hipLaunchKernelGGL(k_residual, dim3(m), dim3(256), 0, b->stream, n, AX, lda, X, ldx, lam_d, R, ldr, norms_d, kin,
                        mean_kin_d, xx_d);
     HIPCHK(hipGetLastError());
@@ -1236,6 +1296,13 @@ int ew_residual(dftk_mi_basis* b, int64_t n, int m, const cd* AX, int64_t lda, c
 int ew_tpa(dftk_mi_basis* b, int64_t n, int m, const cd* src, int64_t lds, cd* dst, int64_t ldd, const double* kin,
            const double* mean_kin_d, double* norms_d, double default_shift) {
     if (m <= 0) return 0;
+    if (batching()) {
+        BOp o;
+        o.b = b;
+        o.type = BOP_TPA; o.n = n; o.m = m; o.A = src; o.lda = lds; o.C = dst; o.ldc = ldd; o.W = kin; o.W2 = mean_kin_d;
+        o.D = norms_d; o.s0 = default_shift;
+        return batch_record(std::move(o));
+    }
     hipLaunchKernelGGL(k_tpa, dim3(m), dim3(256), 0, b->stream, n, src, lds, dst, ldd, kin, mean_kin_d, norms_d,
                        default_shift);
     HIPCHK(hipGetLastError());
@@ -1243,6 +1310,12 @@ int ew_tpa(dftk_mi_basis* b, int64_t n, int m, const cd* src, int64_t lds, cd* d
 }
 int ew_scale_cols(dftk_mi_basis* b, int64_t n, int m, cd* X, int64_t ldx, const double* s_d, bool invert) {
     if (m <= 0) return 0;
+    if (batching()) {
+        BOp o;
+        o.b = b;
+        o.type = BOP_SCALE; o.n = n; o.m = m; o.C = X; o.ldc = ldx; o.W = s_d; o.flags = invert ? 1 : 0;
+        return batch_record(std::move(o));
+    }
     hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, n, m, X, ldx, s_d,
                        invert ? 1 : 0);
     HIPCHK(hipGetLastError());
@@ -1250,16 +1323,34 @@ int ew_scale_cols(dftk_mi_basis* b, int64_t n, int m, cd* X, int64_t ldx, const 
 }
 int ew_copy(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, cd* Y, int64_t ldy) {
     if (m <= 0 || n <= 0) return 0;
+    if (batching()) {
+        BOp o;
+        o.b = b;
+        o.type = BOP_COPY; o.n = n; o.m = m; o.A = X; o.lda = ldx; o.C = Y; o.ldc = ldy;
+        return batch_record(std::move(o));
+    }
     hipLaunchKernelGGL(k_copy, dim3((unsigned)((n + 255) / 256), m), dim3(256), 0, b->stream, n, m, X, ldx, Y, ldy);
     HIPCHK(hipGetLastError());
     return 0;
 }
 int ew_fill_zero(dftk_mi_basis* b, cd* X, size_t count) {
+    if (batching()) {
+        BOp o;
+        o.b = b;
+        o.type = BOP_FILL0; o.C = X; o.bytes = count * sizeof(cd);
+        return batch_record(std::move(o));
+    }
     HIPCHK(hipMemsetAsync(X, 0, count * sizeof(cd), b->stream));
     return 0;
 }
 int ew_sub_identity_shifted(dftk_mi_basis* b, int rows, int cols, cd* C, int64_t ldc, int row0) {
     if (cols <= 0) return 0;
+    if (batching()) {
+        BOp o;
+        o.b = b;
+        o.type = BOP_SUBID; o.n = rows; o.m = cols; o.C = C; o.ldc = ldc; o.i0 = row0;
+        return batch_record(std::move(o));
+    }
     hipLaunchKernelGGL(k_sub_identity_shifted, dim3((cols + 255) / 256), dim3(256), 0, b->stream, rows, cols, C, ldc,
                        row0);
     HIPCHK(hipGetLastError());
@@ -1268,17 +1359,35 @@ int ew_sub_identity_shifted(dftk_mi_basis* b, int rows, int cols, cd* C, int64_t
 int ew_gather_cols(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, const int* perm_d, cd* Y,
                    int64_t ldy) {
     if (m <= 0) return 0;
+    if (batching()) {
+        BOp o;
+        o.b = b;
+        o.type = BOP_GATHER; o.n = n; o.m = m; o.A = X; o.lda = ldx; o.W = perm_d; o.C = Y; o.ldc = ldy;
+        return batch_record(std::move(o));
+    }
     hipLaunchKernelGGL(k_gather_cols, dim3((unsigned)((n + 255) / 256), m), dim3(256), 0, b->stream, n, X, ldx,
                        perm_d, Y, ldy);
     HIPCHK(hipGetLastError());
     return 0;
 }
 int ew_add_diag(dftk_mi_basis* b, int n, cd* A, int64_t lda, double shift) {
+    if (batching()) {
+        BOp o;
+        o.b = b;
+        o.type = BOP_ADDDIAG; o.m = n; o.C = A; o.ldc = lda; o.s0 = shift;
+        return batch_record(std::move(o));
+    }
     hipLaunchKernelGGL(k_add_diag, dim3((n + 255) / 256), dim3(256), 0, b->stream, n, A, lda, shift);
     HIPCHK(hipGetLastError());
     return 0;
 }
 int ew_hermitize_upper(dftk_mi_basis* b, int n, cd* A, int64_t lda) {
+    if (batching()) {
+        BOp o;
+        o.b = b;
+        o.type = BOP_HERMIT; o.m = n; o.C = A; o.ldc = lda;
+        return batch_record(std::move(o));
+    }
     hipLaunchKernelGGL(k_hermitize_upper, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, b->stream, n,
                        A, lda);
     HIPCHK(hipGetLastError());

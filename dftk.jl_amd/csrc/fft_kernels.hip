@@ -309,9 +309,10 @@ __device__ __forceinline__ bool fft_tile(cd* buf, const cd* tw, const FftAxis& a
 }
 
 template <int FFT_LS>
-__device__ __forceinline__ void tile_prologue(cd* buf, cd* tw, const FftAxis& ax, bool zero) {
+__device__ __forceinline__ void tile_prologue(cd* buf, cd* tw, const FftAxis& ax, bool zero, bool copy_tw = true) {
     const int n = ax.n;
-    for (int t = threadIdx.x; t < n; t += FFT_THREADS) tw[t] = ax.tw[t];
+    if (copy_tw)
+        for (int t = threadIdx.x; t < n; t += FFT_THREADS) tw[t] = ax.tw[t];
     if (zero) {
         const cd z = make_double2(0.0, 0.0);
         for (int t = threadIdx.x; t < n * FFT_LS; t += FFT_THREADS) buf[t] = z;
@@ -396,7 +397,10 @@ __global__ __launch_bounds__(FFT_THREADS) void k_ybwd(FftAxis ay, int nxp, int n
 // MODE 0: backward z, multiply by Vs, forward z (fused local apply), T2 -> T2 in place
 // MODE 1: backward z only, natural-order output to an (nx,ny,nz) cube
 // MODE 2: forward z only from an (nx,ny,nz) cube, sphere planes -> T2
-template <int MODE, bool GEN>
+// TWG: the twiddle table is read from global memory (3 KB, L1-resident) instead of an LDS copy: a third of the
+// butterflies' LDS reads moves to the otherwise idle vector-memory pipe, and without the table a 192-long tile
+// (24 KiB) fits six times into a CU's 160 KiB instead of five.
+template <int MODE, bool GEN, bool TWG = false>
 __global__ __launch_bounds__(FFT_THREADS, ZPASS_MIN_BLOCKS) void k_zpass(FftAxis az, int nx, int nxp, int ny, int nzx,
                                                        int nbands, const int* __restrict__ zpos,
                                                        const double* __restrict__ Vs,
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(FFT_THREADS, ZPASS_MIN_BLOCKS) void k_zpass(FftAxis
                                                        cd* __restrict__ cube) {
     constexpr int FFT_LS = FFT_LS_YZ;
     cd* buf = reinterpret_cast<cd*>(dftk_smem);
-    cd* tw = buf + az.n * FFT_LS;
+    cd* tw = TWG ? const_cast<cd*>(az.tw) : buf + az.n * FFT_LS;
     const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
     // 1-D XCD-aware grid: workgroup id -> (xcd = id % 8, slot = id / 8); the bands of one (x tile, y) column
     // are consecutive slots of the SAME XCD, so the potential tile they all multiply with is fetched into
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(FFT_THREADS, ZPASS_MIN_BLOCKS) void k_zpass(FftAxis
         if (j + FFT_TPL < nzx) e1 = t2[(int64_t)(j + FFT_TPL) * plane];
         if (j + 2 * FFT_TPL < nzx) e2 = t2[(int64_t)(j + 2 * FFT_TPL) * plane];
     }
-    tile_prologue<FFT_LS>(buf, tw, az, MODE != 2);
+    tile_prologue<FFT_LS>(buf, tw, az, MODE != 2, !TWG);
     __syncthreads();
     bool fused_v = false;
     if (MODE != 2) {
@@ -759,6 +763,13 @@ int launch_local_apply(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi,
         // stage C: T2 read + written per band, the potential once per launch
         const int pc = prof_begin(b, PROF_FFT_C, 2.0 * 16.0 * (double)kb->nzx * b->ny * b->nxp * nbb +
                                                      8.0 * (double)b->nz * b->ny * b->nxp);
+        static const bool twg = getenv("DFTK_MI_FFT_TWG") != nullptr;
+        if (twg && !axis_generic(b->ax[2])) {
+            const size_t lds = (size_t)b->nz * FFT_LS_YZ * sizeof(cd);
+            CHK(set_lds_attr(k_zpass<0, false, true>, lds));
+            hipLaunchKernelGGL((k_zpass<0, false, true>), zpass_grid(b, nbb), dim3(FFT_THREADS), lds, b->stream, b->ax[2],
+                               b->nx, b->nxp, b->ny, kb->nzx, nbb, kb->d_zpos, kb->d_Vs, b->T2, st.s2, (cd*)nullptr);
+        } else
         LAUNCH_ZPASS(0, b->ax[2], zpass_grid(b, nbb), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, nbb, kb->d_zpos, kb->d_Vs, b->T2, st.s2,
                            (cd*)nullptr);
         prof_end(b, pc);

@@ -16,6 +16,7 @@
 // Host side: tiling into full tiles + ragged border, a cost-model K split that fills the resident
 // workgroup slots once, XCD-aware 1-D grids (zgemm(), gemm_tiling(), gemm_plan_split()).
 #include "common.h"
+#include "batch.h"
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -1054,6 +1055,13 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
         return DFTK_MI_EINVAL;
     }
     if (m > INT32_MAX || n > INT32_MAX || k > INT32_MAX) return DFTK_MI_EINVAL;
+    if (batching()) {   // a fiber of a batched multi-k call: recorded, merged with its siblings' products later
+        BOp o;
+        o.b = b;
+        o.type = BOP_ZGEMM; o.trans = conja ? 'C' : 'N'; o.gm = m; o.gn = n; o.gk = k; o.alpha = alpha; o.A = A; o.lda = lda;
+        o.B = B; o.ldb = ldb; o.beta = beta; o.C = C; o.ldc = ldc; o.flags = upper_in;
+        return batch_record(std::move(o));
+    }
     if (k <= 0) {   // C = beta * C : run the reduce kernel over zero slabs
         hipLaunchKernelGGL(k_zgemm_reduce, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, b->stream, (int)m,
                            (int)n, (int)m, (int)n, 0, (const cd*)nullptr, 0, (const cd*)nullptr, C, ldc, alpha, beta, 0);

@@ -8,6 +8,7 @@
 // orthogonalisation loops) runs on the host from a handful of reduced scalars per iteration;
 // every n_G-sized operation is a kernel on the basis' stream.
 #include "common.h"
+#include "batch.h"
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -67,11 +68,40 @@ struct Ctx {
     dftk_mi_basis* c_b() { return b; }
 };
 
+// host <-> device traffic of the driver.  Inside a fiber of a batched multi-k call (batch.h) these are recorded like
+// every other device operation: the copies of all k-blocks of a round travel together, and "wait for the result" is
+// the point where the fiber yields to its siblings.
+int h2d(dftk_mi_basis* b, void* dst_d, const void* src_h, size_t bytes) {
+    if (batching()) {
+        BOp o;
+        o.b = b;
+        o.type = BOP_H2D; o.C = dst_d;
+        o.payload.assign(reinterpret_cast<const char*>(src_h), reinterpret_cast<const char*>(src_h) + bytes);
+        return batch_record(std::move(o));
+    }
+    HIPCHK(hipMemcpyAsync(dst_d, src_h, bytes, hipMemcpyHostToDevice, b->stream));
+    return 0;
+}
+int stream_sync(dftk_mi_basis* b) {
+    if (batching()) return batch_sync();
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+int d2h_sync(dftk_mi_basis* b, void* dst_h, const void* src_d, size_t bytes) {
+    if (batching()) {
+        BOp o;
+        o.b = b;
+        o.type = BOP_D2H; o.A = src_d; o.host = dst_h; o.bytes = bytes;
+        return batch_record_sync(std::move(o));
+    }
+    HIPCHK(hipMemcpyAsync(dst_h, src_d, bytes, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
 int d2h(Ctx& c, const double* d, int n) {
     if ((int)c.h.size() < n) c.h.resize(n);
-    HIPCHK(hipMemcpyAsync(c.h.data(), d, n * sizeof(double), hipMemcpyDeviceToHost, c.b->stream));
-    HIPCHK(hipStreamSynchronize(c.b->stream));
-    return 0;
+    return d2h_sync(c.b, c.h.data(), d, n * sizeof(double));
 }
 
 // Frobenius norm^2 of a matrix (sum over columns)
@@ -225,10 +255,8 @@ int randomize_column(Ctx& c, Mat X, int col) {
         else if (c.holds_g0)
             v[1] = 0.0;
     }
-    HIPCHK(hipMemcpyAsync(X.p + (int64_t)col * X.ld, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice,
-                          c.b->stream));
-    HIPCHK(hipStreamSynchronize(c.b->stream));
-    return 0;
+    CHK(h2d(c.b, X.p + (int64_t)col * X.ld, v.data(), v.size() * sizeof(double)));
+    return stream_sync(c.b);
 }
 
 // true when the blocks are adjacent column ranges of one array (same leading dimension)
@@ -588,7 +616,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
         }
 
         // residuals
-        HIPCHK(hipMemcpyAsync(d_lam, full_lam.data() + lo, nact * sizeof(double), hipMemcpyHostToDevice, b->stream));
+        CHK(h2d(b, d_lam, full_lam.data() + lo, nact * sizeof(double)));
         // residuals; the same pass over the new X yields precondprep!'s mean kinetic energies and <x,x>
         CHK(ew_residual(b, N, nact, nAX.p, nAX.ld, nX.p, nX.ld, d_lam, nR.p, nR.ld, d_norms, kin, d_mk, d_xx));
         if (comm) {   // norms hold sqrt(local sums); mean_kin and <x,x> are plain sums (adjacent slots)
@@ -670,8 +698,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
             CHK(c.mm('C', nc, nc, N, ONE, Yb[cur].p, N, Yb[cur].p, N, ZERO, G, nc));
             CHK(c.reduce_c(G, (size_t)nc * nc));
             std::vector<double> hg(2 * (size_t)nc * nc);
-            HIPCHK(hipMemcpyAsync(hg.data(), G, hg.size() * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-            HIPCHK(hipStreamSynchronize(b->stream));
+            CHK(d2h_sync(b, hg.data(), G, hg.size() * sizeof(double)));
             double worst[3][3] = {{0}};
             auto blk_of = [&](int j) { return j < M ? 0 : (niter > 0 && j < M + lenXn ? 1 : 2); };
             for (int j = 0; j < nc; ++j)
@@ -702,12 +729,12 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     if (!sorted) {
         std::stable_sort(perm.begin(), perm.end(), [&](int a, int d) { return full_lam[a] < full_lam[d]; });
         int* d_perm = reinterpret_cast<int*>(dd + 7 * (M + 8));
-        HIPCHK(hipMemcpyAsync(d_perm, perm.data(), M * sizeof(int), hipMemcpyHostToDevice, b->stream));
+        CHK(h2d(b, d_perm, perm.data(), M * sizeof(int)));
         CHK(ew_gather_cols(b, N, M, X.p, X.ld, d_perm, tmp, N));
         CHK(ew_copy(b, N, M, tmp, N, X.p, X.ld));
         CHK(ew_gather_cols(b, N, M, AX.p, AX.ld, d_perm, tmp, N));
         CHK(ew_copy(b, N, M, tmp, N, AX.p, AX.ld));
-        HIPCHK(hipStreamSynchronize(b->stream));
+        CHK(stream_sync(b));
     }
     // hand the eigenvectors back to the caller's array
     if (real_mode)
@@ -731,6 +758,41 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     *converged_out = (maxres < tol) ? 1 : 0;
     *n_iter_out = final_iter;
     *n_matvec_out = n_matvec;
-    HIPCHK(hipStreamSynchronize(b->stream));
-    return 0;
+    return stream_sync(b);
+}
+
+// diagonalize_all_kblocks' loop over k-points (src/eigen/diag.jl:24-48) as ONE call: every k-block runs lobpcg_run as a
+// fiber whose device operations are recorded and merged with its siblings' (batch.h)
+int lobpcg_run_multi(int n_kb, dftk_mi_kblock* const* kbs, int M, cd* const* X, const int64_t* ldX, double tol, int miniter,
+                     int maxiter, int n_conv_check, int use_tpa, const uint64_t* seeds, double* lambda_h, double* resid_h,
+                     int* n_iter, int* converged, int64_t* n_matvec, int* status) {
+    if (n_kb <= 0) return 0;
+    dftk_mi_basis* b = kbs[0]->basis;
+    for (int i = 0; i < n_kb; ++i) {
+        if (kbs[i]->basis != b) {
+            dftk_set_error("lobpcg_multi: all k-blocks must belong to ONE basis handle (one stream, one scratch pool)");
+            return DFTK_MI_EINVAL;
+        }
+        if (kbs[i]->sh_comm || (kbs[i]->gr && kbs[i]->gr->on)) {
+            dftk_set_error("lobpcg_multi: plane-wave sharded / Gamma-real k-blocks take dftk_mi_lobpcg");
+            return DFTK_MI_EINVAL;
+        }
+        // the LOBPCG workspace of a k-block is (re)allocated with real synchronisations: do it before the fibers start
+        for (int j = 0; j < i; ++j)
+            if (kbs[j] == kbs[i]) {
+                dftk_set_error("lobpcg_multi: k-block %d appears twice", i);
+                return DFTK_MI_EINVAL;
+            }
+    }
+    std::vector<std::function<int()>> bodies;
+    for (int i = 0; i < n_kb; ++i)
+        bodies.push_back([=]() {
+            return lobpcg_run(kbs[i], M, X[i], ldX[i], tol, miniter, maxiter, n_conv_check, use_tpa,
+                              seeds ? seeds[i] : 0, lambda_h + (size_t)i * M, resid_h + (size_t)i * M, n_iter + i,
+                              converged + i, n_matvec + i);
+        });
+    std::vector<int> rets;
+    const int st = batch_run(b, bodies, rets);
+    for (int i = 0; i < n_kb; ++i) status[i] = rets[i];
+    return st;
 }

@@ -117,6 +117,50 @@ def lobpcg_hyper(A: DftHamiltonianBlock, X0: torch.Tensor, maxiter: int = 100, p
                      real_symmetric=bool(getattr(A.kpoint, "gamma_real", False)))
 
 
+def lobpcg_hyper_multi(As, X0s, maxiter: int = 100, prec=True, tol: float | None = None, n_conv_check: int | None = None,
+                       miniter: int = 1, seeds=None):
+    """``[lobpcg_hyper(A, X0; ...) for (A, X0) in zip(As, X0s)]`` -- the k loop of ``diagonalize_all_kblocks``
+    (diag.jl:24-48) -- as ONE library call (``dftk_mi_lobpcg_multi``): the k-blocks iterate in lock-step, their device
+    operations merged into batched launches.  All blocks need the same number of bands and one basis handle (lane)."""
+    if not As:
+        return []
+    basis = As[0].basis
+    n, M = len(As), X0s[0].shape[0]
+    for A, X0 in zip(As, X0s):
+        if not (X0.is_cuda and X0.dtype == torch.complex128):
+            raise TypeError("lobpcg_hyper_multi: complex128 CUDA blocks required (no CPU fallback)")
+        if X0.shape != (M, A.n_loc):
+            raise ValueError(f"Mismatch in dimension between guess {tuple(X0.shape)} and Hamiltonian ({M}, {A.n_loc})")
+        A.bind()
+    if tol is None:
+        tol = 20 * max(A.n_G for A in As) * EPS
+    Xs = [X0.clone().contiguous() for X0 in X0s]
+    kbs = (C.c_void_p * n)(*[A.kpoint.handle.value for A in As])
+    Xp = (C.c_void_p * n)(*[X.data_ptr() for X in Xs])
+    ld = (C.c_int64 * n)(*[X.stride(0) for X in Xs])
+    sd = (C.c_uint64 * n)(*[(int(s_) & (2 ** 64 - 1)) for s_ in (seeds if seeds is not None else range(n))])
+    lam, res = np.zeros((n, M)), np.zeros((n, M))
+    nit, conv, status = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+    nmv = np.zeros(n, dtype=np.int64)
+    torch.cuda.current_stream(basis.device).synchronize()
+    _lib.check(basis.lib.dftk_mi_lobpcg_multi(n, kbs, M, Xp, ld, float(tol), int(miniter), int(maxiter),
+                                              int(n_conv_check or 0), 1 if prec else 0, sd, lam.ctypes.data,
+                                              res.ctypes.data, nit.ctypes.data, conv.ctypes.data, nmv.ctypes.data,
+                                              status.ctypes.data))
+    for i, st in enumerate(status):
+        if st != 0:
+            raise _lib.DftkMiError(int(st), f"k-block {i} of a batched LOBPCG call: "
+                                            + basis.lib.dftk_mi_last_error().decode(errors="replace"))
+    return [EigResult(lam[i].copy(), Xs[i], res[i].copy(), int(nit[i]), bool(conv[i]), int(nmv[i])) for i in range(n)]
+
+
+def batch_stats(basis):
+    """(rounds, recorded operations, merged launches, one-by-one operations) of this thread's last batched call."""
+    r, o, m_, q = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    _lib.check(basis.lib.dftk_mi_batch_stats(C.byref(r), C.byref(o), C.byref(m_), C.byref(q)))
+    return dict(rounds=r.value, ops=o.value, merged_launches=m_.value, sequential_ops=q.value)
+
+
 def lobpcg_residual_history(A: DftHamiltonianBlock):
     """``resid_history`` of the last ``lobpcg_hyper`` call on this block (lobpcg_hyper_impl.jl:368,443-446):
     array (M, n_iter + 1), rows ordered like the returned eigenpairs; second value = number of SVD fallbacks."""
@@ -214,6 +258,28 @@ def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None
         guesses.append(g)
     if guesses:
         torch.cuda.synchronize(ham[0].basis.device)
+
+    basis0 = ham[0].basis if ham else None
+    if (ham and eigensolver is lobpcg_hyper and getattr(basis0, "kbatch", False) and basis0.n_lanes == 1
+            and all(g is not None for g in guesses)):
+        # many small k-blocks: ONE library call iterates them in lock-step (dftk_mi_lobpcg_multi); the Gamma point, if
+        # it runs the real-symmetric iteration, keeps its own call
+        multi = [ik for ik, Hk in enumerate(ham) if not getattr(Hk.kpoint, "gamma_real", False)]
+        results = [None] * len(ham)
+        if len(multi) > 1:
+            out = lobpcg_hyper_multi([ham[ik] for ik in multi], [guesses[ik] for ik in multi], maxiter=maxiter,
+                                     prec=prec_type is not None, tol=tol, n_conv_check=n_conv_check, miniter=miniter,
+                                     seeds=[seed + ik for ik in multi])
+            for ik, r_ in zip(multi, out):
+                results[ik] = r_
+        for ik, Hk in enumerate(ham):
+            if results[ik] is None:
+                results[ik] = eigensolver(Hk, guesses[ik], prec=prec_type(Hk) if prec_type is not None else None, tol=tol,
+                                          miniter=miniter, maxiter=maxiter, n_conv_check=n_conv_check, seed=seed + ik)
+        return dict(λ=[r.λ for r in results], X=[r.X for r in results],
+                    residual_norms=[r.residual_norms for r in results], n_iter=[r.n_iter for r in results],
+                    converged=all(r.converged for r in results), n_matvec=sum(r.n_matvec for r in results),
+                    real_symmetric=[bool(getattr(r, "real_symmetric", False)) for r in results])
 
     done = {}
 

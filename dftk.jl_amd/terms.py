@@ -559,6 +559,16 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, ei
             if have_psi:
                 e = 0.0
                 for ik, psik in enumerate(psi):
+                    kpt = basis.kpoints[ik]
+                    if basis.comm_pw.size == 1 and psik.stride(1) == 1 and os.environ.get("DFTK_MI_TORCH_LOCAL") is None:
+                        # sum_G kin_G |psi_Gn|^2 per band: the library's one-pass column reduction (the kernel of
+                        # precondprep!, preconditioners.jl:75-77) instead of three cube-sized torch temporaries
+                        mk = np.zeros(psik.shape[0])
+                        torch.cuda.current_stream(basis.device).synchronize()
+                        _lib.check(basis.lib.dftk_mi_tpa_precondprep(kpt.handle, psik.shape[0], psik.data_ptr(),
+                                                                     psik.stride(0), mk.ctypes.data))
+                        e += basis.kweights[ik] * float(np.dot(np.asarray(occupation[ik], dtype=float), mk))
+                        continue
                     dots = ((psik.real ** 2 + psik.imag ** 2) * T.kinetic[ik][None, :]).sum(dim=1)   # (n_bands,)
                     occ = torch.as_tensor(occupation[ik], dtype=torch.float64, device=basis.device)
                     e += basis.kweights[ik] * float((occ * dots).sum().item())

@@ -208,6 +208,20 @@ int dftk_mi_lobpcg(dftk_mi_kblock* kb, int M, dftk_mi_cplx* X_d, int64_t ldX, do
  * lobpcg_hyper_impl.jl:368,443-446, rows ordered like the returned eigenpairs): hist_h[i + M * it] for
  * it = 0 .. n_iter; cap = capacity of hist_h in doubles (hist_h may be NULL to query the sizes).
  * *n_svd = how many times ortho! took its SVD fallback (:226-231, :307-314) during the call. */
+/* The loop over k-points of diagonalize_all_kblocks (src/eigen/diag.jl:24-48) in ONE call, for workloads of many small
+ * k-blocks (k-point meshes of small cells: n_G ~ 1e3, a handful of bands -- launch-latency bound one at a time).  Every
+ * k-block runs exactly the iteration of dftk_mi_lobpcg, but in lock-step with its siblings: device operations of the
+ * same kind are merged into one launch over all k-blocks (batched small GEMMs / Cholesky / Jacobi kernels, one FFT
+ * pipeline over the bands of all k-points), and the host waits once per round instead of once per k-block and
+ * operation.  All k-blocks must belong to ONE basis handle.  Arrays of n_kblocks entries; lambda_h / resid_h hold M
+ * values per k-block; status[i] = what dftk_mi_lobpcg would have returned for k-block i.  Same eigenpairs as n_kblocks
+ * separate calls up to the round-off of the different summation orders. */
+int dftk_mi_lobpcg_multi(int n_kblocks, dftk_mi_kblock* const* kbs, int M, dftk_mi_cplx* const* X_d, const int64_t* ldX,
+                         double tol, int miniter, int maxiter, int n_conv_check, int use_tpa, const uint64_t* seeds,
+                         double* lambda_h, double* resid_h, int* n_iter, int* converged, int64_t* n_matvec, int* status);
+/* Counters of the calling thread's last batched call: scheduling rounds (= host synchronisations), recorded
+ * operations, merged launches, operations that ran one by one (no batched form). */
+int dftk_mi_batch_stats(int64_t* rounds, int64_t* ops, int64_t* merged_launches, int64_t* sequential_ops);
 int dftk_mi_lobpcg_history(dftk_mi_kblock* kb, int* M, int* n_iter, double* hist_h, size_t cap, int* n_svd);
 /* Optional: device pointer to H*X of the last dftk_mi_lobpcg call on this block (n_G x M,
  * leading dimension n_G; valid until the next lobpcg call on the block). */

@@ -1,0 +1,94 @@
+"""Lock-step batching of many small k-blocks (``dftk_mi_lobpcg_multi``, dftk.jl_amd/csrc/batch.{h,cpp}): the k loop of
+``diagonalize_all_kblocks`` (src/eigen/diag.jl:24-48) as ONE library call.  Every k-block runs the same LOBPCG driver
+as ``dftk_mi_lobpcg`` (as a fiber whose device operations are merged with its siblings'), so the results must agree
+with the one-by-one calls to round-off, with the oracle, and the SCF on top of it with the lane-pool path."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import dftk_jl_amd as dftk  # noqa: E402
+import oracle  # noqa: E402
+from dftk_jl_amd.eigen import batch_stats, lobpcg_hyper_multi  # noqa: E402
+
+A_AL = 7.6324708938577865
+
+
+@pytest.fixture(autouse=True)
+def _gpu():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    torch.manual_seed(3)
+
+
+def _si_basis(kgrid=(3, 3, 3), Ecut=12, **kw):
+    lat, atoms, pos = dftk.silicon_cell()
+    model = dftk.model_DFT(lat, atoms, pos, functionals=("lda_x", "lda_c_pw"))
+    return dftk.PlaneWaveBasis(model, Ecut, dftk.MonkhorstPack(kgrid), gamma_real=False, **kw)
+
+
+@pytest.mark.parametrize("sequential", [True, False])
+def test_lobpcg_multi_equals_one_by_one_calls(sequential, monkeypatch):
+    """27 k-blocks (n_G ~ 500, 7 bands) from the same random start vectors: ``dftk_mi_lobpcg_multi`` against 27 calls of
+    ``dftk_mi_lobpcg``.  ``DFTK_MI_KBATCH_SEQUENTIAL=1`` executes every recorded operation through its original entry
+    point (only the fibers + recording are exercised: results identical to the last bit); with the merged launches the
+    summation orders differ, so eigenvalues agree to 1e-10 and the iteration counts match."""
+    if sequential:
+        monkeypatch.setenv("DFTK_MI_KBATCH_SEQUENTIAL", "1")
+    basis = _si_basis()
+    assert basis.kbatch and basis.n_lanes == 1 and len(basis.kpoints) == 27
+    _, ham = dftk.energy_hamiltonian(basis, None, None, rho=dftk.guess_density(basis))
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    X0 = [dftk.random_orbitals(basis, H.kpoint, 7, gen) for H in ham]
+    kw = dict(tol=1e-7, n_conv_check=4, maxiter=60)
+    one = [dftk.lobpcg_hyper(H, x, prec=dftk.PreconditionerTPA(H), seed=11 + i, **kw) for i, (H, x) in enumerate(zip(ham, X0))]
+    many = lobpcg_hyper_multi(ham, X0, prec=True, seeds=[11 + i for i in range(len(ham))], **kw)
+    st = batch_stats(basis)
+    assert st["rounds"] > 3 and st["ops"] > 100 * len(ham)
+    if sequential:
+        assert st["merged_launches"] == 0 and st["sequential_ops"] == st["ops"]
+    for a, b in zip(one, many):
+        assert a.converged and b.converged
+        if sequential:
+            assert np.array_equal(a.λ, b.λ) and a.n_iter == b.n_iter and a.n_matvec == b.n_matvec
+            assert torch.equal(a.X, b.X)
+        else:
+            np.testing.assert_allclose(b.λ[:4], a.λ[:4], atol=1e-10)
+            assert abs(a.n_iter - b.n_iter) <= 1
+            # same invariant subspace of the converged bands: | X_a' X_b | is unitary on it
+            S = (a.X[:4].conj() @ b.X[:4].T).cpu().numpy()
+            assert np.allclose(np.linalg.svd(S, compute_uv=False), 1.0, atol=1e-5)
+    if not sequential:
+        assert st["merged_launches"] > 0 and st["sequential_ops"] < 0.2 * st["ops"]
+    # the first eigenpairs against the oracle's dense diagonalisation of one k-block
+    H = ham[5]
+    olat, oatoms, opos = oracle.basis.silicon_primitive(a=10.26, functional="lda")
+    ob = oracle.PlaneWaveBasis(oracle.model_DFT(olat, oatoms, opos), 12, oracle.MonkhorstPack((3, 3, 3)))
+    _, oham = oracle.energy_hamiltonian(ob, None, None, rho=oracle.guess_density(ob))
+    ik = [i for i, k in enumerate(ob.kpoints) if np.allclose(k.coordinate, H.kpoint.coordinate)][0]
+    dense = np.linalg.eigvalsh(oham[ik].to_dense())[:4]
+    np.testing.assert_allclose(many[5].λ[:4], dense, atol=1e-8)
+
+
+def test_scf_with_kbatch_equals_lane_pool(monkeypatch):
+    """``self_consistent_field`` on a k-point mesh with the batched k loop (default) and with the lane pool
+    (``DFTK_MI_KBATCH=0``): same energy, eigenvalues and density; Al (metal, PBE, smearing) so that the Gamma point
+    (real-symmetric iteration, its own call) and LDOS mixing take part."""
+    lat = A_AL / 2 * np.array([[0, 1, 1.0], [1, 0, 1.0], [1, 1, 0.0]])
+    Al = dftk.ElementPsp("Al", dftk.load_psp("Al", "pbe"))
+    model = dftk.model_DFT(lat, [Al], [np.zeros(3)], functionals=("gga_x_pbe", "gga_c_pbe"), temperature=1e-3,
+                           smearing="gaussian", symmetries=True)
+    b1 = dftk.PlaneWaveBasis(model, 20, dftk.MonkhorstPack((6, 6, 6)))
+    assert b1.kbatch and b1.n_lanes == 1 and len(b1.kpoints) > 10
+    r1 = dftk.self_consistent_field(b1, tol=1e-9)
+    monkeypatch.setenv("DFTK_MI_KBATCH", "0")
+    b0 = dftk.PlaneWaveBasis(model, 20, dftk.MonkhorstPack((6, 6, 6)))
+    assert not b0.kbatch and b0.n_lanes > 1
+    r0 = dftk.self_consistent_field(b0, tol=1e-9)
+    assert r0["converged"] and r1["converged"]
+    assert abs(r0["energies"].total - r1["energies"].total) < 1e-8
+    assert abs(r0["eF"] - r1["eF"]) < 1e-7
+    for l0, l1 in zip(r0["eigenvalues"], r1["eigenvalues"]):
+        np.testing.assert_allclose(l1[:3], l0[:3], atol=1e-7)
+    assert float((r0["rho"] - r1["rho"]).norm()) * np.sqrt(b0.dvol) < 1e-7

@@ -66,6 +66,23 @@ if only == "upper1006":
             4.0 * (2 * M * (2 * M + 1) / 2 if fl else 4 * M * M) * nh, reps=3)
     check(lib.dftk_mi_basis_destroy(h))
     sys.exit(0)
+if only == "struct":      # the structured launches of a late SCF step (UPPER Gram, triangular X inv(R)) and their plans
+    def plan(trans, m, n, k, fl):
+        out = (C.c_int * 12)()
+        check(lib.dftk_mi_zgemm_plan_host(trans, m, n, k, fl, out))
+        v = list(out)
+        return f"BN={v[0]} full tiles {v[1]}x{v[2]} nsplit={v[5]} kchunk={v[6]} zmajor={v[7]} shift={v[11]}"
+    for mm in (M, 2 * M, 3 * M):
+        for fl in (0, 1):
+            print("   plan:", plan(b"C", mm, mm, nh, fl | 8))
+            run(f"Gram REAL m=n={mm} flags={fl}", b"C", mm, mm, nh, Y, n_G, AY, n_G, G, mm, fl | 8,
+                4.0 * (mm * (mm + 1) / 2 if fl else mm * mm) * nh, reps=5)
+    for fl in (0, 2):
+        print("   plan:", plan(b"N", nh, M, M, fl | 8))
+        run(f"X inv(R) REAL {nh}x{M}x{M} flags={fl}", b"N", nh, M, M, Y, n_G, Cm, k3, out, n_G, fl | 8,
+            4.0 * nh * M * ((M + 1) / 2 if fl else M), reps=5)
+    check(lib.dftk_mi_basis_destroy(h))
+    sys.exit(0)
 if only == "gramscan":
     for mm in (k3, 2 * M, M):
         for fl in (0, 1):

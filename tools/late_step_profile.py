@@ -18,13 +18,14 @@ lat, atoms, pos = dftk.silicon_cell((n, n, n))
 model = dftk.model_DFT(lat, atoms, pos, functionals=("lda_x", "lda_c_pw"))
 basis = dftk.PlaneWaveBasis(model, 30.0, dftk.MonkhorstPack((1, 1, 1)))
 st = dftk.ScfStepper(basis, tol=1e-6)
-for _ in range(3):
+skip = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+for _ in range(skip):
     st.step()
 torch.cuda.synchronize()
 check(lib.dftk_mi_prof_enable(basis.handle, 1))
 t0 = time.time()
 timers = {}
-nst = 5
+nst = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 for _ in range(nst):
     info = st.step()
     for k, v in info["timers"].items():
@@ -42,3 +43,4 @@ for f, nm in names.items():
         tot += ms.value
 print(f"booked {tot / nst:.1f} ms/step of wall {1e3 * wall / nst:.1f} ms/step; host timers/step:",
       {k: round(1e3 * v / nst, 1) for k, v in timers.items()}, "iters", info["diagonalization"]["n_iter"])
+# (DFTK_MI_GEMM_SHAPES=1: the per-shape zgemm table of these steps is printed to stderr by dftk_mi_prof_enable(0) above)

@@ -1071,6 +1071,35 @@ extern "C" int dftk_mi_lobpcg_multi(int n_kblocks, dftk_mi_kblock* const* kbs, i
                             use_tpa, seeds, lambda_h, resid_h, n_iter, converged, n_matvec, status);
 }
 
+extern "C" int dftk_mi_density_accumulate_multi(int n_kblocks, dftk_mi_kblock* const* kbs, const int* n_bands,
+                                                const dftk_mi_cplx* const* psi_d, const int64_t* ld_psi,
+                                                const double* weights_h, double* rho_d) {
+    if (n_kblocks < 0 || (n_kblocks > 0 && (!kbs || !n_bands || !psi_d || !ld_psi || !weights_h)) || !rho_d)
+        return DFTK_MI_EINVAL;
+    if (n_kblocks == 0) return 0;
+    dftk_mi_basis* b = kbs[0] ? kbs[0]->basis : nullptr;
+    if (!b) return DFTK_MI_EINVAL;
+    for (int i = 0; i < n_kblocks; ++i)
+        if (!kbs[i] || kbs[i]->basis != b || kbs[i]->sh_comm || !psi_d[i] || n_bands[i] < 0 || ld_psi[i] < kbs[i]->n_G)
+            return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(b->device));
+    // every k-block records its accumulation; the queue is merged into ONE pipeline over all bands (batch.h)
+    std::vector<std::function<int()>> bodies;
+    size_t off = 0;
+    for (int i = 0; i < n_kblocks; ++i) {
+        const double* w = weights_h + off;
+        off += (size_t)n_bands[i];
+        bodies.push_back([=]() {
+            return launch_density(kbs[i], n_bands[i], reinterpret_cast<const cd*>(psi_d[i]), ld_psi[i], w, rho_d, nullptr);
+        });
+    }
+    std::vector<int> rets;
+    CHK(batch_run(b, bodies, rets));
+    for (int r : rets)
+        if (r != 0) return r;
+    return 0;
+}
+
 extern "C" const dftk_mi_cplx* dftk_mi_lobpcg_last_AX(dftk_mi_kblock* kb) {
     return kb ? reinterpret_cast<const dftk_mi_cplx*>(kb->last_AX) : nullptr;
 }

@@ -145,6 +145,7 @@ int exec_one(BOp& o) {
             return (o.status < 0) ? o.status : 0;
         case BOP_APPLYH:
             return dftk_mi_apply_H_parts(o.kb, o.flags, o.m, (const dftk_mi_cplx*)o.A, o.lda, (dftk_mi_cplx*)o.C, o.ldc);
+        case BOP_APPLYD: return apply_D(o.kb, o.m, (const cd*)o.A, Cc);
         case BOP_DENSITY: {
             const double* w = reinterpret_cast<const double*>(o.payload.data());
             return launch_density(o.kb, o.m, (const cd*)o.A, o.lda, w, (double*)o.C, o.flags ? w + o.m : nullptr);
@@ -265,12 +266,39 @@ int batch_run(dftk_mi_basis* b, std::vector<std::function<int()>>& bodies, std::
     Recorder rec;
     BatchCtx* c = &rec.ctx;
     c->stream = b->stream;
-    c->cap = 16u << 20;
-    c->res_cap = 8u << 20;
-    HIPCHK(hipHostMalloc((void**)&c->h_ring, c->cap));
-    HIPCHK(hipMalloc((void**)&c->d_ring, c->cap));
-    HIPCHK(hipHostMalloc((void**)&c->h_res, c->res_cap));
-    HIPCHK(hipMalloc((void**)&c->d_res, c->res_cap));
+    // staging rings and scratch are kept per (thread, device) across calls: pinned allocations cost milliseconds, a
+    // batched call of a k-point workload a few
+    struct Pool {
+        int device = -1;
+        char *h_ring = nullptr, *d_ring = nullptr, *h_res = nullptr, *d_res = nullptr;
+        void* d_scratch = nullptr;
+        size_t scratch_bytes = 0;
+    };
+    static thread_local Pool pool;
+    const size_t cap = 16u << 20, res_cap = 8u << 20;
+    if (pool.device != b->device) {
+        if (pool.h_ring) {
+            hipHostFree(pool.h_ring);
+            hipFree(pool.d_ring);
+            hipHostFree(pool.h_res);
+            hipFree(pool.d_res);
+            if (pool.d_scratch) hipFree(pool.d_scratch);
+            pool = Pool();
+        }
+        HIPCHK(hipHostMalloc((void**)&pool.h_ring, cap));
+        HIPCHK(hipMalloc((void**)&pool.d_ring, cap));
+        HIPCHK(hipHostMalloc((void**)&pool.h_res, res_cap));
+        HIPCHK(hipMalloc((void**)&pool.d_res, res_cap));
+        pool.device = b->device;
+    }
+    c->cap = cap;
+    c->res_cap = res_cap;
+    c->h_ring = pool.h_ring;
+    c->d_ring = pool.d_ring;
+    c->h_res = pool.h_res;
+    c->d_res = pool.d_res;
+    c->d_scratch = pool.d_scratch;
+    c->scratch_bytes = pool.scratch_bytes;
     const size_t n = bodies.size();
     rec.fibers.resize(n);
     const size_t stack_bytes = 1u << 20;
@@ -309,11 +337,11 @@ int batch_run(dftk_mi_basis* b, std::vector<std::function<int()>>& bodies, std::
     g_last_stats[2] = c->n_launch_groups;
     g_last_stats[3] = c->n_sequential;
     hipStreamSynchronize(c->stream);
-    hipHostFree(c->h_ring);
-    hipFree(c->d_ring);
-    hipHostFree(c->h_res);
-    hipFree(c->d_res);
-    if (c->d_scratch) hipFree(c->d_scratch);
+    if (getenv("DFTK_MI_KBATCH_TRACE"))
+        fprintf(stderr, "[kbatch] %zu fibers: %lld rounds, %lld ops, %lld merged launches, %lld one-by-one ops\n", n,
+                (long long)c->n_rounds, (long long)c->n_ops, (long long)c->n_launch_groups, (long long)c->n_sequential);
+    pool.d_scratch = c->d_scratch;          // (may have grown during the call)
+    pool.scratch_bytes = c->scratch_bytes;
     rets.resize(n);
     for (size_t i = 0; i < n; ++i) rets[i] = rec.fibers[i].done ? rec.fibers[i].ret : DFTK_MI_EHIP;
     return status;

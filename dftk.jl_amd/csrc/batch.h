@@ -31,6 +31,7 @@ enum BOpType {
     BOP_HEEV,        // dense_heev (eigenvalues on the host)
     BOP_APPLYH,      // dftk_mi_apply_H_parts
     BOP_DENSITY,     // launch_density
+    BOP_APPLYD,      // apply_D: Y = D X with the banded real D of a k-block (internal to the batched apply_H)
     BOP_NTYPES
 };
 
@@ -46,6 +47,7 @@ enum BOpType {
 //   POTRF    m = n, C = A, ldc, D = invR, ldb = ldi, host = double[2] {normest R, normest inv R}
 //   HEEV     m = n, C = A, ldc, D = V, ldb = ldv, host = eigenvalues (n doubles)
 //   APPLYH   kb, flags = which, m = bands, A = psi, lda, C = H psi, ldc
+//   APPLYD   kb, m = bands, A = X (n_p x m), C = Y
 //   DENSITY  kb, m = bands, A = psi, lda, C = rho, payload = m weights (+ m weights of the imaginary parts, flags = 1)
 struct BOp {
     int type = 0;

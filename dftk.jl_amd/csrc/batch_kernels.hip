@@ -580,6 +580,29 @@ __global__ __launch_bounds__(256) void k_b_heev(const DenseItem* __restrict__ it
     }
 }
 
+// Y = D X per item: banded real D (n_p x n_p, half bandwidth bw), X and Y n_p x nb complex (k_apply_D of dense_kernels.hip)
+struct ApplyDItem {
+    int n_p, nb, bw;
+    const double* D;
+    const cd* X;
+    cd* Y;
+};
+__global__ __launch_bounds__(256) void k_b_apply_D(const ApplyDItem* __restrict__ items) {
+    const ApplyDItem it = items[blockIdx.y];
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)it.n_p * it.nb) return;
+    const int c = (int)(idx / it.n_p), i = (int)(idx - (int64_t)c * it.n_p);
+    const int j0 = max(0, i - it.bw), j1 = min(it.n_p - 1, i + it.bw);
+    double sr = 0.0, si = 0.0;
+    for (int j = j0; j <= j1; ++j) {
+        const double d = it.D[i + (int64_t)j * it.n_p];
+        const cd x = it.X[j + (int64_t)c * it.n_p];
+        sr += d * x.x;
+        si += d * x.y;
+    }
+    it.Y[idx] = make_double2(sr, si);
+}
+
 EwItem ew_item(const BOp& o) {
     EwItem e;
     e.n = o.n;
@@ -617,6 +640,22 @@ int batch_exec_group(BatchCtx* ctx, hipStream_t stream, int type, std::vector<BO
     if (n_items > 65535) return 1;
     if (type == BOP_APPLYH) return batch_exec_apply_H(ctx, stream, ops);
     if (type == BOP_DENSITY) return batch_exec_density(ctx, stream, ops);
+
+    if (type == BOP_APPLYD) {
+        std::vector<ApplyDItem> items(n_items);
+        int64_t mx = 1;
+        for (int i = 0; i < n_items; ++i) {
+            const dftk_mi_kblock* kb = ops[i]->kb;
+            items[i] = ApplyDItem{kb->n_p, ops[i]->m, kb->D_bw, kb->d_D, reinterpret_cast<const cd*>(ops[i]->A),
+                                  reinterpret_cast<cd*>(ops[i]->C)};
+            mx = std::max<int64_t>(mx, (int64_t)kb->n_p * ops[i]->m);
+        }
+        const ApplyDItem* d = reinterpret_cast<const ApplyDItem*>(batch_stage(ctx, items.data(), items.size() * sizeof(ApplyDItem)));
+        if (!d) return DFTK_MI_EHIP;
+        hipLaunchKernelGGL(k_b_apply_D, dim3((unsigned)((mx + 255) / 256), n_items), dim3(256), 0, stream, d);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
 
     // ------------------------------------------------------------------ element-wise / column kernels
     if (type == BOP_COLRED || type == BOP_RESIDUAL || type == BOP_TPA || type == BOP_SCALE || type == BOP_COPY ||
@@ -828,5 +867,3 @@ int batch_exec_group(BatchCtx* ctx, hipStream_t stream, int type, std::vector<BO
     return 1;
 }
 
-int batch_exec_apply_H(BatchCtx*, hipStream_t, std::vector<BOp*>&) { return 1; }
-int batch_exec_density(BatchCtx*, hipStream_t, std::vector<BOp*>&) { return 1; }

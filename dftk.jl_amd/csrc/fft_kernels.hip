@@ -17,6 +17,9 @@
 // (input placed at the permuted position `pos`, natural output) for backward transforms and
 // decimation in frequency (natural input, output read back through `pos`) for forward ones.
 #include "common.h"
+#include "batch.h"
+#include <algorithm>
+#include <cstring>
 
 #define FFT_L 8
 #ifndef ZPASS_MIN_BLOCKS
@@ -321,25 +324,47 @@ __device__ __forceinline__ void tile_prologue(cd* buf, cd* tw, const FftAxis& ax
 
 extern __shared__ __attribute__((aligned(16))) char dftk_smem[];
 
+// Multi-k launches (batch.h): the bands of MANY k-blocks go through one launch of each stage.  `jobs` (nullable) holds
+// one entry per band: the sphere tables of its k-block and its own pointers replace the scalar kernel arguments; the
+// grid is sized for the largest k-block and surplus workgroups of smaller ones leave at once.
+struct FftJob {
+    const int *line_start, *cpos, *line_ypos, *zls, *zpos;
+    const double* kin;    // stage E: kinetic multiplier (or null)
+    const double* Vs;     // stage C: this k-block's padded potential / N
+    const cd* psi;        // the band's sphere coefficients (stage A input, stage E kinetic term)
+    cd* out;              // stage E output
+    int n_lines, nzx;
+    double w, wim;        // density weights of the band
+};
+
 // ---------------------------------------------------------------------------------------- stage A
 template <bool GEN>
 __global__ __launch_bounds__(FFT_THREADS) void k_xbwd_scatter(FftAxis ax, int nxp, int n_lines,
                                                               const int* __restrict__ line_start,
                                                               const int* __restrict__ cpos,
                                                               const cd* __restrict__ psi, int64_t ldpsi,
-                                                              cd* __restrict__ T1, int64_t T1_stride) {
+                                                              cd* __restrict__ T1, int64_t T1_stride,
+                                                              const FftJob* __restrict__ jobs) {
     constexpr int FFT_LS = FFT_LS_X;
     cd* buf = reinterpret_cast<cd*>(dftk_smem);
     cd* tw = buf + ax.n * FFT_LS;
     const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
     const int band = blockIdx.y;
     const int l0 = blockIdx.x * FFT_L;
+    const cd* p = psi + (int64_t)band * ldpsi;
+    if (jobs) {
+        const FftJob jb = jobs[band];
+        n_lines = jb.n_lines;
+        line_start = jb.line_start;
+        cpos = jb.cpos;
+        p = jb.psi;
+        if (l0 >= n_lines) return;   // whole workgroup, before any barrier
+    }
     tile_prologue<FFT_LS>(buf, tw, ax, true);
     __syncthreads();
     const int line = l0 + l;
     if (line < n_lines) {
         const int c0 = line_start[line], c1 = line_start[line + 1];
-        const cd* p = psi + (int64_t)band * ldpsi;
         for (int c = c0 + j; c < c1; c += FFT_TPL) buf[cpos[c] * FFT_LS + l] = p[c];
     }
     __syncthreads();
@@ -360,13 +385,20 @@ __global__ __launch_bounds__(FFT_THREADS) void k_ybwd(FftAxis ay, int nxp, int n
                                                       const int* __restrict__ zls,
                                                       const int* __restrict__ line_ypos,
                                                       const cd* __restrict__ T1, int64_t T1_stride,
-                                                      cd* __restrict__ T2, int64_t T2_stride) {
+                                                      cd* __restrict__ T2, int64_t T2_stride,
+                                                      const FftJob* __restrict__ jobs) {
     constexpr int FFT_LS = FFT_LS_YZ;
     cd* buf = reinterpret_cast<cd*>(dftk_smem);
     cd* tw = buf + ay.n * FFT_LS;
     const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
     const int x = blockIdx.x * FFT_L + l;
     const int zi = blockIdx.y, band = blockIdx.z;
+    if (jobs) {
+        const FftJob jb = jobs[band];
+        if (zi >= jb.nzx) return;   // whole workgroup
+        zls = jb.zls;
+        line_ypos = jb.line_ypos;
+    }
     const cd* t1 = T1 + (int64_t)band * T1_stride;
     const int ln0 = zls[zi] + j, ln1 = zls[zi + 1];
     // lines of this plane to registers before the prologue (HBM latency overlaps twiddles + zero fill);
@@ -405,7 +437,7 @@ __global__ __launch_bounds__(FFT_THREADS, ZPASS_MIN_BLOCKS) void k_zpass(FftAxis
                                                        int nbands, const int* __restrict__ zpos,
                                                        const double* __restrict__ Vs,
                                                        cd* __restrict__ T2, int64_t T2_stride,
-                                                       cd* __restrict__ cube) {
+                                                       cd* __restrict__ cube, const FftJob* __restrict__ jobs = nullptr) {
     constexpr int FFT_LS = FFT_LS_YZ;
     cd* buf = reinterpret_cast<cd*>(dftk_smem);
     cd* tw = TWG ? const_cast<cd*>(az.tw) : buf + az.n * FFT_LS;
@@ -419,6 +451,12 @@ __global__ __launch_bounds__(FFT_THREADS, ZPASS_MIN_BLOCKS) void k_zpass(FftAxis
     const int grp = (slot / nbands) * 8 + xcd;
     const int nxt = nxp / FFT_L;
     if (grp >= nxt * ny) return;   // whole workgroup, before any barrier
+    if (jobs) {
+        const FftJob jb = jobs[band];
+        zpos = jb.zpos;
+        nzx = jb.nzx;
+        Vs = jb.Vs;
+    }
     const int y = grp / nxt;
     const int x = (grp - y * nxt) * FFT_L + l;
     const int nz = az.n;
@@ -479,13 +517,20 @@ __global__ __launch_bounds__(FFT_THREADS, YFWD_MIN_BLOCKS) void k_yfwd(FftAxis a
                                                       const int* __restrict__ zls,
                                                       const int* __restrict__ line_ypos,
                                                       const cd* __restrict__ T2, int64_t T2_stride,
-                                                      cd* __restrict__ T1, int64_t T1_stride) {
+                                                      cd* __restrict__ T1, int64_t T1_stride,
+                                                      const FftJob* __restrict__ jobs) {
     constexpr int FFT_LS = FFT_LS_YZ;
     cd* buf = reinterpret_cast<cd*>(dftk_smem);
     cd* tw = buf + ay.n * FFT_LS;
     const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
     const int x = blockIdx.x * FFT_L + l;
     const int zi = blockIdx.y, band = blockIdx.z;
+    if (jobs) {
+        const FftJob jb = jobs[band];
+        if (zi >= jb.nzx) return;   // whole workgroup
+        zls = jb.zls;
+        line_ypos = jb.line_ypos;
+    }
     tile_prologue<FFT_LS>(buf, tw, ay, false);
     const cd* t2 = T2 + (int64_t)band * T2_stride + (int64_t)zi * ny * nxp + x;
     for (int y = j; y < ny; y += FFT_TPL) buf[y * FFT_LS + l] = t2[(int64_t)y * nxp];
@@ -506,7 +551,8 @@ __global__ __launch_bounds__(FFT_THREADS, YFWD_MIN_BLOCKS) void k_xfwd_gather(Ff
                                                              const cd* __restrict__ T1, int64_t T1_stride,
                                                              const double* __restrict__ kin,
                                                              const cd* __restrict__ psi, int64_t ldpsi,
-                                                             cd* __restrict__ out, int64_t ldout) {
+                                                             cd* __restrict__ out, int64_t ldout,
+                                                             const FftJob* __restrict__ jobs) {
     constexpr int FFT_LS = FFT_LS_X;
     cd* buf = reinterpret_cast<cd*>(dftk_smem);
     cd* tw = buf + ax.n * FFT_LS;
@@ -514,6 +560,18 @@ __global__ __launch_bounds__(FFT_THREADS, YFWD_MIN_BLOCKS) void k_xfwd_gather(Ff
     const int band = blockIdx.y;
     const int l0 = blockIdx.x * FFT_L;
     const int n = ax.n;
+    cd* o = out + (int64_t)band * ldout;
+    const cd* p = psi + (int64_t)band * ldpsi;
+    if (jobs) {
+        const FftJob jb = jobs[band];
+        n_lines = jb.n_lines;
+        line_start = jb.line_start;
+        cpos = jb.cpos;
+        kin = jb.kin;
+        p = jb.psi;
+        o = jb.out;
+        if (l0 >= n_lines) return;   // whole workgroup, before any barrier
+    }
     tile_prologue<FFT_LS>(buf, tw, ax, false);
     const cd* in = T1 + (int64_t)band * T1_stride + (int64_t)l0 * nxp;
     const int nlv = min(FFT_L, n_lines - l0);
@@ -527,8 +585,6 @@ __global__ __launch_bounds__(FFT_THREADS, YFWD_MIN_BLOCKS) void k_xfwd_gather(Ff
     const int line = l0 + l;
     if (line < n_lines) {
         const int c0 = line_start[line], c1 = line_start[line + 1];
-        cd* o = out + (int64_t)band * ldout;
-        const cd* p = psi + (int64_t)band * ldpsi;
         for (int c = c0 + j; c < c1; c += FFT_TPL) {
             cd v = buf[cpos[c] * FFT_LS + l];
             if (kin != nullptr) {
@@ -552,7 +608,7 @@ __global__ __launch_bounds__(FFT_THREADS, DENS_MIN_BLOCKS) void k_zdensity(FftAx
                                                           const double* __restrict__ w,
                                                           const double* __restrict__ wim,
                                                           const cd* __restrict__ T2, int64_t T2_stride,
-                                                          double* __restrict__ rho) {
+                                                          double* __restrict__ rho, const FftJob* __restrict__ jobs) {
     constexpr int FFT_LS = FFT_LS_YZ;
     cd* buf = reinterpret_cast<cd*>(dftk_smem);
     cd* tw = buf + az.n * FFT_LS;
@@ -566,8 +622,17 @@ __global__ __launch_bounds__(FFT_THREADS, DENS_MIN_BLOCKS) void k_zdensity(FftAx
     for (int k = 0; k < DENS_MAXACC; ++k) acc[k] = 0.0;
     for (int t = tid; t < nz; t += FFT_THREADS) tw[t] = az.tw[t];
     for (int ib = 0; ib < nb; ++ib) {
-        const double wb = w[ib];
-        const double wi = wim ? wim[ib] : wb;
+        double wb, wi;
+        if (jobs) {               // multi-k launch: the band's k-block decides the z planes, its entry the weights
+            const FftJob jb = jobs[ib];
+            wb = jb.w;
+            wi = jb.wim;
+            zpos = jb.zpos;
+            nzx = jb.nzx;
+        } else {
+            wb = w[ib];
+            wi = wim ? wim[ib] : wb;
+        }
         if (wb == 0.0 && wi == 0.0) continue;   // uniform across the block
         const cd z0 = make_double2(0.0, 0.0);
         for (int t = tid; t < nz * FFT_LS; t += FFT_THREADS) buf[t] = z0;
@@ -714,11 +779,11 @@ static int run_AB(dftk_mi_kblock* kb, int nbb, const cd* psi, int64_t ldpsi) {
     (void)Ncube;
     int ps = prof_begin(b, PROF_FFT_A, (16.0 * kb->n_G + t1b) * nbb);
     LAUNCH_FFT(k_xbwd_scatter, b->ax[0], dim3(gl, nbb), lds_bytes(b->nx, FFT_LS_X), b->stream, b->ax[0],
-                       b->nxp, (int)kb->n_lines, kb->d_line_start, kb->d_cpos, psi, ldpsi, b->T1, st.s1);
+                       b->nxp, (int)kb->n_lines, kb->d_line_start, kb->d_cpos, psi, ldpsi, b->T1, st.s1, (const FftJob*)nullptr);
     prof_end(b, ps);
     ps = prof_begin(b, PROF_FFT_B, (t1b + t2b) * nbb);
     LAUNCH_FFT(k_ybwd, b->ax[1], dim3(nxt, kb->nzx, nbb), lds_bytes(b->ny), b->stream, b->ax[1],
-                       b->nxp, b->ny, kb->d_zls, kb->d_line_ypos, b->T1, st.s1, b->T2, st.s2);
+                       b->nxp, b->ny, kb->d_zls, kb->d_line_ypos, b->T1, st.s1, b->T2, st.s2, (const FftJob*)nullptr);
     prof_end(b, ps);
     return 0;
 }
@@ -734,12 +799,12 @@ static int run_DE(dftk_mi_kblock* kb, int nbb, const double* kin, const cd* psi,
     (void)Ncube;
     int ps = prof_begin(b, PROF_FFT_D, (t1b + t2b) * nbb);
     LAUNCH_FFT(k_yfwd, b->ax[1], dim3(nxt, kb->nzx, nbb), lds_bytes(b->ny), b->stream, b->ax[1],
-                       b->nxp, b->ny, kb->d_zls, kb->d_line_ypos, b->T2, st.s2, b->T1, st.s1);
+                       b->nxp, b->ny, kb->d_zls, kb->d_line_ypos, b->T2, st.s2, b->T1, st.s1, (const FftJob*)nullptr);
     prof_end(b, ps);
     ps = prof_begin(b, PROF_FFT_E, (t1b + (kin ? 40.0 : 16.0) * kb->n_G) * nbb);
     LAUNCH_FFT(k_xfwd_gather, b->ax[0], dim3(gl, nbb), lds_bytes(b->nx, FFT_LS_X), b->stream, b->ax[0],
                        b->nxp, (int)kb->n_lines, kb->d_line_start, kb->d_cpos, b->T1, st.s1, kin, psi, ldpsi, out,
-                       ldout);
+                       ldout, (const FftJob*)nullptr);
     prof_end(b, ps);
     return 0;
 }
@@ -768,10 +833,10 @@ int launch_local_apply(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi,
             const size_t lds = (size_t)b->nz * FFT_LS_YZ * sizeof(cd);
             CHK(set_lds_attr(k_zpass<0, false, true>, lds));
             hipLaunchKernelGGL((k_zpass<0, false, true>), zpass_grid(b, nbb), dim3(FFT_THREADS), lds, b->stream, b->ax[2],
-                               b->nx, b->nxp, b->ny, kb->nzx, nbb, kb->d_zpos, kb->d_Vs, b->T2, st.s2, (cd*)nullptr);
+                               b->nx, b->nxp, b->ny, kb->nzx, nbb, kb->d_zpos, kb->d_Vs, b->T2, st.s2, (cd*)nullptr, (const FftJob*)nullptr);
         } else
         LAUNCH_ZPASS(0, b->ax[2], zpass_grid(b, nbb), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, nbb, kb->d_zpos, kb->d_Vs, b->T2, st.s2,
-                           (cd*)nullptr);
+                           (cd*)nullptr, (const FftJob*)nullptr);
         prof_end(b, pc);
         CHK(run_DE(kb, nbb, add_kinetic ? kb->d_kin : nullptr, p, ldpsi, out + (int64_t)b0 * ldout, ldout));
     }
@@ -797,7 +862,7 @@ int launch_ifft_to_cube(dftk_mi_kblock* kb, const cd* c, cd* cube) {
     const Strides st = strides(kb);
     CHK(run_AB(kb, 1, c, kb->n_G));
     LAUNCH_ZPASS(1, b->ax[2], zpass_grid(b, 1), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, 1, kb->d_zpos, (const double*)nullptr, b->T2, st.s2,
-                       cube);
+                       cube, (const FftJob*)nullptr);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -808,7 +873,7 @@ int launch_fft_from_cube(dftk_mi_kblock* kb, const cd* cube, cd* c) {
     CHK(fft_ensure_scratch(b, kb, 1));
     const Strides st = strides(kb);
     LAUNCH_ZPASS(2, b->ax[2], zpass_grid(b, 1), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, 1, kb->d_zpos, (const double*)nullptr, b->T2, st.s2,
-                       const_cast<cd*>(cube));
+                       const_cast<cd*>(cube), (const FftJob*)nullptr);
     CHK(run_DE(kb, 1, nullptr, c, kb->n_G, c, kb->n_G));
     HIPCHK(hipGetLastError());
     return 0;
@@ -817,6 +882,16 @@ int launch_fft_from_cube(dftk_mi_kblock* kb, const cd* cube, cd* c) {
 int launch_density(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, const double* w_h, double* rho,
                    const double* w_im_h) {
     dftk_mi_basis* b = kb->basis;
+    if (batching() && nb > 0) {   // part of a batched multi-k call: the bands of all k-blocks share one pipeline later
+        BOp o;
+        o.b = b;
+        o.kb = kb;
+        o.type = BOP_DENSITY; o.m = nb; o.A = psi; o.lda = ldpsi; o.C = rho; o.flags = w_im_h ? 1 : 0;
+        o.payload.resize((size_t)(w_im_h ? 2 : 1) * nb * sizeof(double));
+        memcpy(o.payload.data(), w_h, (size_t)nb * sizeof(double));
+        if (w_im_h) memcpy(o.payload.data() + (size_t)nb * sizeof(double), w_im_h, (size_t)nb * sizeof(double));
+        return batch_record(std::move(o));
+    }
     CHK(check_lds(b));
     if (b->nz > DENS_MAXACC * FFT_TPL) {
         dftk_set_error("density kernel supports nz <= %d", DENS_MAXACC * FFT_TPL);
@@ -841,7 +916,7 @@ int launch_density(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, con
         const int pz = prof_begin(b, PROF_DENS_Z, 16.0 * (double)kb->nzx * b->ny * b->nxp * nbb +
                                                       16.0 * (double)b->nx * b->ny * b->nz);   // T2 per band + rho read-modify-write
         LAUNCH_FFT(k_zdensity, b->ax[2], dim3(b->nxp / FFT_L, b->ny), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, kb->d_zpos, nbb, w_d + b0,
-                           wim_d ? wim_d + b0 : (const double*)nullptr, b->T2, st.s2, rho);
+                           wim_d ? wim_d + b0 : (const double*)nullptr, b->T2, st.s2, rho, (const FftJob*)nullptr);
         prof_end(b, pz);
     }
     HIPCHK(hipGetLastError());
@@ -855,6 +930,178 @@ int launch_pad_potential(dftk_mi_kblock* kb, const double* V) {
     const double scale = 1.0 / ((double)b->nx * b->ny * b->nz);
     hipLaunchKernelGGL(k_pad_potential, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, b->stream, b->nx,
                        b->nxp, rows, scale, V, kb->d_Vs);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------- multi-k executors (batch.h)
+// One pipeline for the bands of MANY k-blocks: job table (one entry per band), scratch for all of them, the five
+// stages launched once with grids sized for the largest k-block.  Bands are processed in chunks so that the scratch
+// stays below ~2 GiB.
+namespace {
+struct MultiPlan {
+    std::vector<FftJob> jobs;
+    int max_lines = 1, max_nzx = 1;
+};
+void add_jobs(MultiPlan& mp, const dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, cd* out, int64_t ldout,
+              bool kinetic, const double* w, const double* wim) {
+    for (int i = 0; i < nb; ++i) {
+        FftJob j;
+        j.line_start = kb->d_line_start;
+        j.cpos = kb->d_cpos;
+        j.line_ypos = kb->d_line_ypos;
+        j.zls = kb->d_zls;
+        j.zpos = kb->d_zpos;
+        j.kin = kinetic ? kb->d_kin : nullptr;
+        j.Vs = kb->d_Vs;
+        j.psi = psi + (int64_t)i * ldpsi;
+        j.out = out ? out + (int64_t)i * ldout : nullptr;
+        j.n_lines = (int)kb->n_lines;
+        j.nzx = kb->nzx;
+        j.w = w ? w[i] : 0.0;
+        j.wim = wim ? wim[i] : j.w;
+        mp.jobs.push_back(j);
+    }
+    mp.max_lines = std::max(mp.max_lines, (int)kb->n_lines);
+    mp.max_nzx = std::max(mp.max_nzx, kb->nzx);
+}
+}  // namespace
+
+int batch_exec_apply_H(BatchCtx* ctx, hipStream_t stream, std::vector<BOp*>& ops) {
+    dftk_mi_basis* b = ops[0]->kb->basis;
+    for (BOp* o : ops) {
+        const dftk_mi_kblock* kb = o->kb;
+        // the merged pipeline covers the full H psi of unsharded blocks with a local potential; anything else one by one
+        if (o->flags != 7 || kb->basis != b || kb->sh_comm || kb->d_Vs == nullptr) return 1;
+    }
+    if (axis_generic(b->ax[0]) || axis_generic(b->ax[1]) || axis_generic(b->ax[2])) return 1;
+    CHK(check_lds(b));
+    MultiPlan mp;
+    for (BOp* o : ops)
+        add_jobs(mp, o->kb, o->m, reinterpret_cast<const cd*>(o->A), o->lda, reinterpret_cast<cd*>(o->C), o->ldc, true, nullptr,
+                 nullptr);
+    const int nxt = b->nxp / FFT_L;
+    const int64_t s1 = (int64_t)mp.max_lines * b->nxp, s2 = (int64_t)mp.max_nzx * b->ny * b->nxp;
+    const size_t per_band = (size_t)(s1 + s2) * sizeof(cd);
+    int chunk = (int)std::max<size_t>(1, std::min<size_t>(mp.jobs.size(), ((size_t)2 << 30) / per_band));
+    if (chunk > 4096) chunk = 4096;
+    // one scratch request for the whole call: T1 / T2 of a chunk of bands, then the two projection panels of all k-blocks
+    size_t np_total = 0;
+    for (BOp* o : ops) np_total += (size_t)o->kb->n_p * o->m;
+    cd* T1 = reinterpret_cast<cd*>(batch_scratch(ctx, per_band * chunk + 2 * np_total * sizeof(cd)));
+    if (!T1) return DFTK_MI_EHIP;
+    cd* T2 = T1 + (size_t)s1 * chunk;
+    cd* Pbuf = reinterpret_cast<cd*>(reinterpret_cast<char*>(T1) + per_band * chunk);
+    const int gl = (mp.max_lines + FFT_L - 1) / FFT_L;
+    for (size_t j0 = 0; j0 < mp.jobs.size(); j0 += chunk) {
+        const int nb = (int)std::min<size_t>(chunk, mp.jobs.size() - j0);
+        const FftJob* dj = reinterpret_cast<const FftJob*>(batch_stage(ctx, mp.jobs.data() + j0, nb * sizeof(FftJob)));
+        if (!dj) return DFTK_MI_EHIP;
+        CHK(set_lds_attr(k_xbwd_scatter<false>, lds_bytes(b->nx, FFT_LS_X)));
+        CHK(set_lds_attr(k_ybwd<false>, lds_bytes(b->ny)));
+        CHK(set_lds_attr(k_yfwd<false>, lds_bytes(b->ny)));
+        CHK(set_lds_attr(k_xfwd_gather<false>, lds_bytes(b->nx, FFT_LS_X)));
+        hipLaunchKernelGGL((k_xbwd_scatter<false>), dim3(gl, nb), dim3(FFT_THREADS), lds_bytes(b->nx, FFT_LS_X), stream, b->ax[0],
+                           b->nxp, 0, (const int*)nullptr, (const int*)nullptr, (const cd*)nullptr, (int64_t)0, T1, s1, dj);
+        hipLaunchKernelGGL((k_ybwd<false>), dim3(nxt, mp.max_nzx, nb), dim3(FFT_THREADS), lds_bytes(b->ny), stream, b->ax[1],
+                           b->nxp, b->ny, (const int*)nullptr, (const int*)nullptr, (const cd*)T1, s1, T2, s2, dj);
+        {
+            const int64_t groups = (int64_t)nxt * b->ny;
+            const dim3 grid((unsigned)(((groups + 7) / 8) * 8 * nb));
+            CHK(set_lds_attr(k_zpass<0, false>, lds_bytes(b->nz)));
+            hipLaunchKernelGGL((k_zpass<0, false>), grid, dim3(FFT_THREADS), lds_bytes(b->nz), stream, b->ax[2], b->nx, b->nxp,
+                               b->ny, 0, nb, (const int*)nullptr, (const double*)nullptr, T2, s2, (cd*)nullptr, dj);
+        }
+        hipLaunchKernelGGL((k_yfwd<false>), dim3(nxt, mp.max_nzx, nb), dim3(FFT_THREADS), lds_bytes(b->ny), stream, b->ax[1],
+                           b->nxp, b->ny, (const int*)nullptr, (const int*)nullptr, (const cd*)T2, s2, T1, s1, dj);
+        hipLaunchKernelGGL((k_xfwd_gather<false>), dim3(gl, nb), dim3(FFT_THREADS), lds_bytes(b->nx, FFT_LS_X), stream, b->ax[0],
+                           b->nxp, 0, (const int*)nullptr, (const int*)nullptr, (const cd*)T1, s1, (const double*)nullptr,
+                           (const cd*)nullptr, (int64_t)0, (cd*)nullptr, (int64_t)0, dj);
+    }
+    HIPCHK(hipGetLastError());
+    // nonlocal part: H psi += P (D (P' psi)) per k-block through the batched small products
+    if (np_total == 0) return 0;
+    std::vector<BOp> g1, g2, g3;
+    size_t off = 0;
+    for (BOp* o : ops) {
+        const dftk_mi_kblock* kb = o->kb;
+        if (kb->n_p == 0) continue;
+        cd* Ppsi = Pbuf + off;
+        cd* DPpsi = Pbuf + np_total + off;
+        off += (size_t)kb->n_p * o->m;
+        BOp a;
+        a.type = BOP_ZGEMM; a.b = b; a.trans = 'C'; a.gm = kb->n_p; a.gn = o->m; a.gk = kb->n_G; a.alpha = make_double2(1.0, 0.0);
+        a.A = kb->P; a.lda = kb->ldP; a.B = o->A; a.ldb = o->lda; a.beta = make_double2(0.0, 0.0); a.C = Ppsi; a.ldc = kb->n_p;
+        g1.push_back(a);
+        BOp d;
+        d.type = BOP_APPLYD; d.b = b; d.kb = o->kb; d.m = o->m; d.A = Ppsi; d.C = DPpsi;
+        g2.push_back(d);
+        BOp c;
+        c.type = BOP_ZGEMM; c.b = b; c.trans = 'N'; c.gm = kb->n_G; c.gn = o->m; c.gk = kb->n_p; c.alpha = make_double2(1.0, 0.0);
+        c.A = kb->P; c.lda = kb->ldP; c.B = DPpsi; c.ldb = kb->n_p; c.beta = make_double2(1.0, 0.0); c.C = o->C; c.ldc = o->ldc;
+        g3.push_back(c);
+    }
+    for (auto* g : {&g1, &g2, &g3}) {
+        std::vector<BOp*> ptrs;
+        for (auto& o : *g) ptrs.push_back(&o);
+        if (ptrs.empty()) continue;
+        const int st = batch_exec_group(ctx, stream, (*g)[0].type, ptrs);
+        if (st < 0) return st;
+        if (st == 1) {   // shapes outside the batched kernels: the recorded entry points (same stream, same order)
+            for (auto& o : *g) {
+                const int s1_ = o.type == BOP_APPLYD
+                                    ? apply_D(o.kb, o.m, (const cd*)o.A, (cd*)o.C)
+                                    : zgemm(b, o.trans, o.gm, o.gn, o.gk, o.alpha, (const cd*)o.A, o.lda, (const cd*)o.B, o.ldb, o.beta,
+                                            (cd*)o.C, o.ldc, 0);
+                if (s1_ != 0) return s1_;
+            }
+        }
+    }
+    return 0;
+}
+
+int batch_exec_density(BatchCtx* ctx, hipStream_t stream, std::vector<BOp*>& ops) {
+    dftk_mi_basis* b = ops[0]->kb->basis;
+    double* rho = reinterpret_cast<double*>(ops[0]->C);
+    for (BOp* o : ops)
+        if (o->kb->basis != b || o->kb->sh_comm || o->C != rho) return 1;
+    if (axis_generic(b->ax[0]) || axis_generic(b->ax[1]) || axis_generic(b->ax[2])) return 1;
+    if (b->nz > DENS_MAXACC * FFT_TPL) return 1;
+    CHK(check_lds(b));
+    MultiPlan mp;
+    for (BOp* o : ops) {
+        const double* w = reinterpret_cast<const double*>(o->payload.data());
+        // bands without weight never enter the pipeline (compute_density's occupation threshold, densities.jl:25-33)
+        for (int i = 0; i < o->m; ++i) {
+            const double wi = o->flags ? w[o->m + i] : w[i];
+            if (w[i] == 0.0 && wi == 0.0) continue;
+            add_jobs(mp, o->kb, 1, reinterpret_cast<const cd*>(o->A) + (int64_t)i * o->lda, o->lda, nullptr, 0, false, w + i,
+                     o->flags ? w + o->m + i : nullptr);
+        }
+    }
+    if (mp.jobs.empty()) return 0;
+    const int nxt = b->nxp / FFT_L;
+    const int64_t s1 = (int64_t)mp.max_lines * b->nxp, s2 = (int64_t)mp.max_nzx * b->ny * b->nxp;
+    const size_t per_band = (size_t)(s1 + s2) * sizeof(cd);
+    int chunk = (int)std::max<size_t>(1, std::min<size_t>(mp.jobs.size(), ((size_t)2 << 30) / per_band));
+    if (chunk > 4096) chunk = 4096;
+    cd* T1 = reinterpret_cast<cd*>(batch_scratch(ctx, per_band * chunk));
+    if (!T1) return DFTK_MI_EHIP;
+    cd* T2 = T1 + (size_t)s1 * chunk;
+    const int gl = (mp.max_lines + FFT_L - 1) / FFT_L;
+    for (size_t j0 = 0; j0 < mp.jobs.size(); j0 += chunk) {
+        const int nb = (int)std::min<size_t>(chunk, mp.jobs.size() - j0);
+        const FftJob* dj = reinterpret_cast<const FftJob*>(batch_stage(ctx, mp.jobs.data() + j0, nb * sizeof(FftJob)));
+        if (!dj) return DFTK_MI_EHIP;
+        hipLaunchKernelGGL((k_xbwd_scatter<false>), dim3(gl, nb), dim3(FFT_THREADS), lds_bytes(b->nx, FFT_LS_X), stream, b->ax[0],
+                           b->nxp, 0, (const int*)nullptr, (const int*)nullptr, (const cd*)nullptr, (int64_t)0, T1, s1, dj);
+        hipLaunchKernelGGL((k_ybwd<false>), dim3(nxt, mp.max_nzx, nb), dim3(FFT_THREADS), lds_bytes(b->ny), stream, b->ax[1],
+                           b->nxp, b->ny, (const int*)nullptr, (const int*)nullptr, (const cd*)T1, s1, T2, s2, dj);
+        CHK(set_lds_attr(k_zdensity<false>, lds_bytes(b->nz)));
+        hipLaunchKernelGGL((k_zdensity<false>), dim3(nxt, b->ny), dim3(FFT_THREADS), lds_bytes(b->nz), stream, b->ax[2], b->nx,
+                           b->nxp, b->ny, 0, (const int*)nullptr, nb, (const double*)nullptr, (const double*)nullptr,
+                           (const cd*)T2, s2, rho, dj);
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }

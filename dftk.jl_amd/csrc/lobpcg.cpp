@@ -41,7 +41,8 @@ struct Ctx {
     // small scratch (device)
     cd *O, *Rw, *invR, *BYX, *tmpS;
     cd* Vh;                   // m x m: V^H of the SVD fallback (survives the Cholesky-QR polish)
-    double *d_a, *d_b;        // M-sized double scratch
+    double *d_a, *d_b;        // M-sized double scratch; d_b == d_a + dstride (adjacent: one fetch serves both)
+    int dstride = 0;
     std::vector<double> h;    // host scratch
     std::mt19937_64 rng;      // re-randomised columns of n_G-sized blocks (per-rank stream: each rank draws its slab)
     std::mt19937_64 rng_rep;  // ... of REPLICATED small matrices of a sharded run: must be identical on all ranks
@@ -305,10 +306,20 @@ int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol, con
             CHK(c.mm('N', X.rows, X.cols, Y.cols, MONE, Y.p, Y.ld, c.BYX + off, ny, ONE, X.p, X.ld));
             off += Y.cols;
         }
-        // drop_small!
+        // drop_small!  (the column sums of |BYX|^2 for the convergence test below ride on the same fetch: every host
+        // synchronisation of this loop is a round of latency, in the batched multi-k driver a whole scheduling round)
         CHK(ew_colnorms(c.b, X.rows, X.cols, X.p, X.ld, c.d_a));
         CHK(c.reduce_norms(c.d_a, X.cols));
-        CHK(d2h(c, c.d_a, X.cols));
+        const bool one_fetch = c.dstride > 0 && c.d_b == c.d_a + c.dstride && X.cols <= c.dstride;
+        if (one_fetch) {
+            CHK(ew_frob2(c.b, ny, X.cols, c.BYX, ny, c.d_b));
+            CHK(d2h(c, c.d_a, c.dstride + X.cols));
+        } else {
+            CHK(d2h(c, c.d_a, X.cols));
+        }
+        double byx2 = 0.0;
+        if (one_fetch)
+            for (int j = 0; j < X.cols; ++j) byx2 += c.h[c.dstride + j];
         std::vector<int> dropped;
         for (int j = 0; j < X.cols; ++j) {
             if (!std::isfinite(c.h[j])) return DFTK_MI_NUM_NONFINITE;
@@ -333,8 +344,7 @@ int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol, con
                 o2 += Y.cols;
             }
         }
-        double byx2;
-        CHK(frob2(c, Mat{c.BYX, ny, ny, X.cols}, &byx2));
+        if (!one_fetch) CHK(frob2(c, Mat{c.BYX, ny, ny, X.cols}, &byx2));
         if (std::sqrt(byx2) < tol && niter > 1) break;
         int ninner;
         double growth;
@@ -407,6 +417,7 @@ int lobpcg_ortho(dftk_mi_basis* b, int64_t n, int m, cd* X, int64_t ldx, int for
     c.BYX = c.tmpS = nullptr;
     c.d_a = reinterpret_cast<double*>(c.Vh + (size_t)m * m);
     c.d_b = c.d_a + (m + 8);
+    c.dstride = m + 8;
     c.rng.seed(0x9E3779B97F4A7C15ull);
     int nch = 0;
     double gr = 1.0;
@@ -507,6 +518,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     double* dd = reinterpret_cast<double*>(w);
     c.d_a = dd;
     c.d_b = dd + (M + 8);
+    c.dstride = M + 8;
     double* d_lam = dd + 2 * (M + 8);
     double* d_norms = dd + 3 * (M + 8);
     double* d_mk = dd + 4 * (M + 8);
@@ -623,7 +635,9 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
             CHK(c.reduce_norms(d_norms, nact));
             CHK(c.reduce_d(d_mk, (size_t)(M + 8) + nact));
         }
-        CHK(d2h(c, d_norms, nact));
+        // norms, mean kinetic energies and <x,x> sit (M + 8) apart: ONE fetch; <x,x> is checked further down
+        CHK(d2h(c, d_norms, 2 * (M + 8) + nact));
+        std::vector<double> h_xx(c.h.begin() + 2 * (M + 8), c.h.begin() + 2 * (M + 8) + nact);
         for (int i = 0; i < nact; ++i) {
             if (!std::isfinite(c.h[i])) {
                 dftk_set_error("non-finite residual norm in LOBPCG iteration %d", niter);
@@ -668,11 +682,10 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
             CHK(hcat_mul(c, AYs, cP, nY, lenXn, nAP));
         }
         // sanity: |<x,x> - 1| < sqrt(eps)
-        CHK(d2h(c, d_xx, nact));
         for (int i = 0; i < nact; ++i)
-            if (!(std::fabs(c.h[i] - 1.0) < std::sqrt(EPS))) {
+            if (!(std::fabs(h_xx[i] - 1.0) < std::sqrt(EPS))) {
                 dftk_set_error("LOBPCG is badly failing to keep the vectors normalized (column %d: %g; iteration %d, "
-                               "%d locked, %d active, %d ranks)", lo + i, c.h[i], niter, nlocked, nact, comm_size(comm));
+                               "%d locked, %d active, %d ranks)", lo + i, h_xx[i], niter, nlocked, nact, comm_size(comm));
                 return DFTK_MI_NUM_NORMALIZATION;
             }
         // newly locked columns never change again: keep them identical in both pairs

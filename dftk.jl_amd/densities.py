@@ -18,7 +18,37 @@ def compute_density(basis, psi, occupation, occupation_threshold: float = 0.0, r
     rhos = [torch.zeros((nz, ny, nx), dtype=torch.float64, device=basis.device) for _ in range(basis.n_lanes)]
     torch.cuda.current_stream(basis.device).synchronize()
 
+    if getattr(basis, "kbatch", False) and basis.n_lanes == 1 and len(basis.kpoints) > 1:
+        # many small k-blocks: the bands of all of them go through ONE pipeline (dftk_mi_density_accumulate_multi);
+        # k-points whose orbitals are real-symmetric keep their paired call
+        import ctypes as C
+        multi = [ik for ik in range(len(basis.kpoints)) if not (real_symmetric is not None and real_symmetric[ik])]
+        if len(multi) > 1:
+            ws, keep = [], []
+            for ik in multi:
+                occ = np.asarray(occupation[ik], dtype=np.float64)
+                ws.append(np.where(np.abs(occ) >= occupation_threshold, occ, 0.0) * basis.kweights[ik]
+                          * basis.ifft_normalization ** 2)
+                psik = psi[ik]
+                if not (psik.is_cuda and psik.dtype == torch.complex128 and psik.stride(1) == 1):
+                    raise TypeError("compute_density: complex128 CUDA band-major blocks required")
+                keep.append(psik)
+            n = len(multi)
+            w_all = np.ascontiguousarray(np.concatenate(ws))
+            kbs = (C.c_void_p * n)(*[basis.kpoints[ik].handle.value for ik in multi])
+            nbs = (C.c_int * n)(*[len(w_) for w_ in ws])
+            pp = (C.c_void_p * n)(*[p_.data_ptr() for p_ in keep])
+            ld = (C.c_int64 * n)(*[p_.stride(0) for p_ in keep])
+            _lib.check(basis.lib.dftk_mi_density_accumulate_multi(n, kbs, nbs, pp, ld, w_all.ctypes.data, rhos[0].data_ptr()))
+            done_multi = set(multi)
+        else:
+            done_multi = set()
+    else:
+        done_multi = set()
+
     def accumulate(ik, kpt):
+        if ik in done_multi:
+            return
         occ = np.asarray(occupation[ik], dtype=np.float64)          # occupations live on the host (:16)
         w = np.where(np.abs(occ) >= occupation_threshold, occ, 0.0) * basis.kweights[ik] * basis.ifft_normalization ** 2
         w = np.ascontiguousarray(w)

@@ -9,6 +9,7 @@ runs inside the library (``dftk_mi_lobpcg``).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -228,6 +229,15 @@ def interpolate_kpoint(data_in: torch.Tensor, kpoint_in, kpoint_out) -> torch.Te
     return out
 
 
+def _chain_width(basis) -> int:
+    """How many k-points start from random orbitals when no guess is given; k-point ik > width interpolates the solution
+    of k-point ik - width (the reference: width 1, diag.jl:39-42; here the number of concurrent lanes, or the same 16
+    when the k loop is one batched library call)."""
+    if getattr(basis, "kbatch", False) and basis.n_lanes == 1:
+        return max(1, int(os.environ.get("DFTK_MI_KBATCH_CHAIN", "16")))
+    return basis.n_lanes
+
+
 def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None, prec_type=PreconditionerTPA,
                             tol: float = 1e-6, miniter: int = 1, maxiter: int = 100, n_conv_check=None,
                             generator: torch.Generator | None = None, seed: int = 0, interpolate_kpoints: bool = True):
@@ -251,7 +261,7 @@ def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None
             elif g.shape[0] < nev_per_kpoint:
                 extra = random_orbitals(basis, kpt, nev_per_kpoint - g.shape[0], generator)
                 g = torch.cat([g, extra * np.sqrt(2 * kpt.n_G)], dim=0)
-        elif interpolate_kpoints and ik >= basis.n_lanes and basis.comm_pw.size == 1:
+        elif interpolate_kpoints and ik >= _chain_width(basis) and basis.comm_pw.size == 1:
             g = None                                   # filled in by the lane from its previous k-point
         else:
             g = random_orbitals(basis, kpt, nev_per_kpoint, generator)
@@ -260,22 +270,31 @@ def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None
         torch.cuda.synchronize(ham[0].basis.device)
 
     basis0 = ham[0].basis if ham else None
-    if (ham and eigensolver is lobpcg_hyper and getattr(basis0, "kbatch", False) and basis0.n_lanes == 1
-            and all(g is not None for g in guesses)):
-        # many small k-blocks: ONE library call iterates them in lock-step (dftk_mi_lobpcg_multi); the Gamma point, if
-        # it runs the real-symmetric iteration, keeps its own call
-        multi = [ik for ik, Hk in enumerate(ham) if not getattr(Hk.kpoint, "gamma_real", False)]
+    if ham and eigensolver is lobpcg_hyper and getattr(basis0, "kbatch", False) and basis0.n_lanes == 1:
+        # many small k-blocks: ONE library call iterates a whole wave of them in lock-step (dftk_mi_lobpcg_multi); the
+        # Gamma point, if it runs the real-symmetric iteration, keeps its own call.  With guesses for everybody (every
+        # SCF step but the first) there is one wave; without, k-point ik starts from the interpolated solution of
+        # k-point ik - W like the lanes of the non-batched path (W = _chain_width), i.e. waves of W k-points.
+        W = _chain_width(basis0)
         results = [None] * len(ham)
-        if len(multi) > 1:
-            out = lobpcg_hyper_multi([ham[ik] for ik in multi], [guesses[ik] for ik in multi], maxiter=maxiter,
-                                     prec=prec_type is not None, tol=tol, n_conv_check=n_conv_check, miniter=miniter,
-                                     seeds=[seed + ik for ik in multi])
-            for ik, r_ in zip(multi, out):
-                results[ik] = r_
-        for ik, Hk in enumerate(ham):
-            if results[ik] is None:
-                results[ik] = eigensolver(Hk, guesses[ik], prec=prec_type(Hk) if prec_type is not None else None, tol=tol,
-                                          miniter=miniter, maxiter=maxiter, n_conv_check=n_conv_check, seed=seed + ik)
+        for w0 in range(0, len(ham), W if any(g is None for g in guesses) else len(ham)):
+            wave = list(range(w0, min(len(ham), w0 + (W if any(g is None for g in guesses) else len(ham)))))
+            for ik in wave:
+                if guesses[ik] is None:
+                    guesses[ik] = interpolate_kpoint(results[ik - W].X, ham[ik - W].kpoint, ham[ik].kpoint)
+            multi = [ik for ik in wave if not getattr(ham[ik].kpoint, "gamma_real", False)]
+            if len(multi) > 1:
+                out = lobpcg_hyper_multi([ham[ik] for ik in multi], [guesses[ik] for ik in multi], maxiter=maxiter,
+                                         prec=prec_type is not None, tol=tol, n_conv_check=n_conv_check, miniter=miniter,
+                                         seeds=[seed + ik for ik in multi])
+                for ik, r_ in zip(multi, out):
+                    results[ik] = r_
+            for ik in wave:
+                if results[ik] is None:
+                    Hk = ham[ik]
+                    results[ik] = eigensolver(Hk, guesses[ik], prec=prec_type(Hk) if prec_type is not None else None,
+                                              tol=tol, miniter=miniter, maxiter=maxiter, n_conv_check=n_conv_check,
+                                              seed=seed + ik)
         return dict(λ=[r.λ for r in results], X=[r.X for r in results],
                     residual_norms=[r.residual_norms for r in results], n_iter=[r.n_iter for r in results],
                     converged=all(r.converged for r in results), n_matvec=sum(r.n_matvec for r in results),

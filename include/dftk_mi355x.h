@@ -219,6 +219,13 @@ int dftk_mi_lobpcg(dftk_mi_kblock* kb, int M, dftk_mi_cplx* X_d, int64_t ldX, do
 int dftk_mi_lobpcg_multi(int n_kblocks, dftk_mi_kblock* const* kbs, int M, dftk_mi_cplx* const* X_d, const int64_t* ldX,
                          double tol, int miniter, int maxiter, int n_conv_check, int use_tpa, const uint64_t* seeds,
                          double* lambda_h, double* resid_h, int* n_iter, int* converged, int64_t* n_matvec, int* status);
+/* compute_density's loop over k-points (src/densities.jl:35-43) in ONE call: rho_d += sum_k sum_n weight[k][n]
+ * |ifft(psi_k[:, n])|^2 with all bands of all k-blocks in one pipeline (bands of zero weight never enter it).
+ * weights_h: the per-band weights (occupation * kweight * ifft_normalization^2) of k-block 0, then of k-block 1, ...
+ * One basis handle, unsharded k-blocks.  Asynchronous like dftk_mi_density_accumulate up to the final round. */
+int dftk_mi_density_accumulate_multi(int n_kblocks, dftk_mi_kblock* const* kbs, const int* n_bands,
+                                     const dftk_mi_cplx* const* psi_d, const int64_t* ld_psi, const double* weights_h,
+                                     double* rho_d);
 /* Counters of the calling thread's last batched call: scheduling rounds (= host synchronisations), recorded
  * operations, merged launches, operations that ran one by one (no batched form). */
 int dftk_mi_batch_stats(int64_t* rounds, int64_t* ops, int64_t* merged_launches, int64_t* sequential_ops);

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 
 namespace {
 struct Fiber {
@@ -31,6 +32,7 @@ struct BatchCtx {
     std::vector<std::function<void()>> fixups;   // run after the round's stream synchronisation
     bool failed = false;
     int64_t n_rounds = 0, n_ops = 0, n_launch_groups = 0, n_sequential = 0;   // dftk_mi_batch_stats
+    double t_fibers = 0, t_exec = 0, t_sync = 0, t_fix = 0;                     // DFTK_MI_KBATCH_TRACE: seconds per phase
 };
 
 const void* batch_stage(BatchCtx* c, const void* src, size_t bytes) {
@@ -45,9 +47,17 @@ const void* batch_stage(BatchCtx* c, const void* src, size_t bytes) {
         }
     }
     memcpy(c->h_ring + c->off, src, bytes);
-    if (hipMemcpyAsync(c->d_ring + c->off, c->h_ring + c->off, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess)
-        c->failed = true;
-    const void* d = c->d_ring + c->off;
+    // small tables are read by the kernels straight from the pinned ring (host memory mapped into the device's address
+    // space): no copy to enqueue in front of every launch; large ones (job tables of thousands of bands) are copied
+    static const bool zero_copy = getenv("DFTK_MI_KBATCH_NO_ZEROCOPY") == nullptr;
+    const void* d;
+    if (zero_copy && bytes <= 16384) {
+        d = c->h_ring + c->off;
+    } else {
+        if (hipMemcpyAsync(c->d_ring + c->off, c->h_ring + c->off, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+            c->failed = true;
+        d = c->d_ring + c->off;
+    }
     c->off += al;
     return d;
 }
@@ -160,6 +170,7 @@ int flush(Recorder* r) {
     const bool no_merge = getenv("DFTK_MI_KBATCH_SEQUENTIAL") != nullptr;   // debugging: every op as recorded
     int status = 0;
     g_suspended = true;
+    const auto tp0 = std::chrono::steady_clock::now();
     std::vector<BOp*> groups[BOP_NTYPES];
     std::vector<BOp*> all;
     for (;;) {
@@ -196,6 +207,8 @@ int flush(Recorder* r) {
     }
     if (status == 0 && batch_results_fetch(c) != 0) status = DFTK_MI_EHIP;
     g_suspended = false;
+    const auto tp1 = std::chrono::steady_clock::now();
+    c->t_exec += std::chrono::duration<double>(tp1 - tp0).count();
     if (hipStreamSynchronize(c->stream) != hipSuccess) {
         dftk_set_error("batched round: stream synchronisation failed: %s", hipGetErrorString(hipGetLastError()));
         status = status ? status : DFTK_MI_EHIP;
@@ -204,11 +217,14 @@ int flush(Recorder* r) {
         dftk_set_error("batched round: staging buffers exhausted or a copy failed");
         status = DFTK_MI_EHIP;
     }
+    const auto tp2 = std::chrono::steady_clock::now();
+    c->t_sync += std::chrono::duration<double>(tp2 - tp1).count();
     if (status == 0) {
         for (auto& fx : c->fixups) fx();
         for (BOp* op : all)
             if (op->status_out) *op->status_out = op->status;
     }
+    c->t_fix += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp2).count();
     c->fixups.clear();
     c->off = 0;
     c->res_off = 0;
@@ -317,6 +333,7 @@ int batch_run(dftk_mi_basis* b, std::vector<std::function<int()>>& bodies, std::
     int status = 0;
     for (;;) {
         bool alive = false;
+        const auto tf0 = std::chrono::steady_clock::now();
         for (size_t i = 0; i < n; ++i) {
             Fiber& f = rec.fibers[i];
             if (f.done) continue;
@@ -325,6 +342,7 @@ int batch_run(dftk_mi_basis* b, std::vector<std::function<int()>>& bodies, std::
             swapcontext(&rec.main_ctx, &f.ctx);   // runs until the fiber yields or finishes
         }
         rec.cur = -1;
+        c->t_fibers += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count();
         bool queued = false;
         for (auto& f : rec.fibers) queued = queued || !f.fifo.empty();
         if (!alive && !queued) break;
@@ -338,8 +356,10 @@ int batch_run(dftk_mi_basis* b, std::vector<std::function<int()>>& bodies, std::
     g_last_stats[3] = c->n_sequential;
     hipStreamSynchronize(c->stream);
     if (getenv("DFTK_MI_KBATCH_TRACE"))
-        fprintf(stderr, "[kbatch] %zu fibers: %lld rounds, %lld ops, %lld merged launches, %lld one-by-one ops\n", n,
-                (long long)c->n_rounds, (long long)c->n_ops, (long long)c->n_launch_groups, (long long)c->n_sequential);
+        fprintf(stderr, "[kbatch] %zu fibers: %lld rounds, %lld ops, %lld merged launches, %lld one-by-one ops; ms: fibers %.2f, "
+                "launching %.2f, waiting %.2f, fix-ups %.2f\n", n, (long long)c->n_rounds, (long long)c->n_ops,
+                (long long)c->n_launch_groups, (long long)c->n_sequential, 1e3 * c->t_fibers, 1e3 * c->t_exec, 1e3 * c->t_sync,
+                1e3 * c->t_fix);
     pool.d_scratch = c->d_scratch;          // (may have grown during the call)
     pool.scratch_bytes = c->scratch_bytes;
     rets.resize(n);

@@ -446,6 +446,13 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm
         if (R >= gm * nsplit) return;   // whole workgroup
         z = R / gm;
         row_t = R - z * gm;
+        // upper & 8: rotate the row panels by floor(z gcd(8, gm) / 8).  An XCD sees the groups R = xcd + 8 t, i.e. only
+        // gm / gcd(8, gm) different row panels; with UPPER the panels hold different numbers of live tiles (8, 6, 4, 2
+        // for a 503^2 Gram matrix), so without the rotation XCDs 0 and 4 do four times the work of XCDs 3 and 7
+        if (upper & 8) {
+            const int g = (gm % 8 == 0) ? 8 : (gm % 4 == 0) ? 4 : (gm % 2 == 0) ? 2 : 1;
+            row_t = (row_t + (z * g) / 8) % gm;
+        }
     }
 
     const int tid = threadIdx.x;
@@ -913,6 +920,12 @@ struct Split {
     bool zmajor;
     cd* slab;
 };
+// UPPER launches of the 3M / REAL kernels rotate the row panels over the XCDs (k_zgemm_3m, `upper & 8`);
+// DFTK_MI_GEMM_NO_ROT=1 keeps the plain mapping (measurements)
+static bool gemm_rotate_rows() {
+    static const bool on = getenv("DFTK_MI_GEMM_NO_ROT") == nullptr;
+    return on;
+}
 static int64_t gemm_slots2() {
     const char* senv = getenv("DFTK_MI_GEMM_BLOCKS");
     return senv ? atoll(senv) : 512;   // resident workgroups of the 2-per-CU kernels
@@ -924,12 +937,16 @@ static Split gemm_plan_split(int64_t m, int64_t n, int64_t k, int upper, const s
     static std::map<std::vector<int64_t>, std::pair<int, int>> plan_cache;   // key -> (nsplit, zmajor)
     static std::mutex plan_mutex;   // host-only cache shared by every basis / thread of the process
     std::lock_guard<std::mutex> plan_lock(plan_mutex);
+    // (measured, REAL Gram products of the 1000-electron cell: 503^2 UPPER 2.29 -> 1.90 ms with the rotation; at 1006^2 /
+    //  1509^2 -- 8 / 12 row panels -- the k-major mapping with whole chunks per XCD stays as fast or faster, so the rotated
+    //  mapping only competes where an XCD would otherwise see at most 4 different row panels)
+    const bool rot_rows = (upper & 1) && kind >= 3 && gemm_rotate_rows() && (int)live_rows.size() <= 4;
     int64_t total = 0;
     for (int v : live_rows) total += v;
     const int gm_s = (int)live_rows.size();
     int best_ns = 1, best_zm = 0;
     if (k >= 128 && total > 0 && total < slots) {
-        const std::vector<int64_t> key = {m, n, k, (int64_t)(upper & 1), (int64_t)kind, slots};
+        const std::vector<int64_t> key = {m, n, k, (int64_t)(upper & 1), (int64_t)kind, slots, (int64_t)rot_rows};
         auto it = plan_cache.find(key);
         if (it != plan_cache.end()) {
             best_ns = it->second.first;
@@ -955,7 +972,12 @@ static Split gemm_plan_split(int64_t m, int64_t n, int64_t k, int upper, const s
                         for (int z = 0; z < ns; ++z) load[z & 7] += total;
                     } else {
                         const int64_t R = (int64_t)gm_s * ns;
-                        for (int64_t r = 0; r < R; ++r) load[r & 7] += live_rows[r % gm_s];
+                        const int g8 = (gm_s % 8 == 0) ? 8 : (gm_s % 4 == 0) ? 4 : (gm_s % 2 == 0) ? 2 : 1;
+                        for (int64_t r = 0; r < R; ++r) {
+                            const int64_t z = r / gm_s;
+                            const int64_t row = rot_rows ? (r % gm_s + (z * g8) / 8) % gm_s : r % gm_s;
+                            load[r & 7] += live_rows[row];
+                        }
                     }
                     int64_t mx = 0;
                     for (int x = 0; x < 8; ++x) mx = load[x] > mx ? load[x] : mx;
@@ -1167,7 +1189,8 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
         const int64_t nblk = zmajor ? (int64_t)((sp.nsplit + 7) / 8) * 8 * gm_s * gn_s : grid_for(gm_s, gn_s, sp.nsplit);
         if (nblk > INT32_MAX) return DFTK_MI_EINVAL;
         dim3 grid((unsigned)nblk);
-        const int upper = (upper_in & 3) | (zmajor ? 4 : 0);
+        const int upper = (upper_in & 3) | (zmajor ? 4 : 0) |
+                          ((!zmajor && (upper_in & 1) && use3m && gemm_rotate_rows() && gm_s <= 4) ? 8 : 0);
 #define DFTK_LAUNCH_LDS(CJ, FL)                                                                                        \
     hipLaunchKernelGGL((k_zgemm_lds<CJ, FL>), grid, dim3(GEMM_WAVES * 64), pad_lds, b->stream, (int)m, (int)n, (int)k, \
                        sp.kchunk, gm_s, gn_s, rt0, ct0, lsplit, upper, sp.nsplit, A, lda, B, ldb, C, ldc, alpha, beta, sp.slab)

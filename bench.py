@@ -234,7 +234,7 @@ def cfg1_scf_3steps(device):
 
 
 # ------------------------------------------------------------------------------------------ CPU leg: a timed step
-def cpu_timed_late_step(basis, info, diagtol, budget_s):
+def cpu_timed_late_step(basis, info, diagtol, budget_s, dinfo=None):
     """kind = "port, timed step": ONE real SCF step of the reference's algorithm on the host cores, with wall seconds,
     beside the device's time for the same step.  Input = the converged state of the device run (psi, rho): from there
     a step is what every late SCF step of this workload is -- H[rho] is rebuilt, LOBPCG (general complex orbitals,
@@ -329,8 +329,11 @@ def cpu_timed_late_step(basis, info, diagtol, budget_s):
     rho *= basis.kweights[0] / basis.model.unit_cell_volume
     t_dens = time.time() - t0
     pool.shutdown()
-    drho = float(np.linalg.norm(rho - info["rho"].cpu().numpy()) * np.sqrt(basis.dvol))
-    dlam = float(np.max(np.abs(res["λ"][:n_conv] - np.asarray(info["eigenvalues"][0])[:n_conv])))
+    # the device ran the SAME step (device_late_step: same potential, same start orbitals, same tolerance): its
+    # density and eigenvalues are what the host's must agree with, to the step's diagonalisation tolerance
+    cmp_ = dinfo if dinfo is not None else info
+    drho = float(np.linalg.norm(rho - cmp_["rho"].cpu().numpy()) * np.sqrt(basis.dvol))
+    dlam = float(np.max(np.abs(res["λ"][:n_conv] - np.asarray(cmp_["eigenvalues"][0])[:n_conv])))
     return {"cpu_step_s": round(t_lobpcg + t_dens, 2), "cpu_lobpcg_s": round(t_lobpcg, 2), "cpu_density_s": round(t_dens, 2),
             "lobpcg_iterations": int(res["n_iter"]), "n_matvec": int(res["n_matvec"]), "converged": bool(res["converged"]),
             "diagtol": diagtol, "fft_threads": threads, "blas_threads": blas_threads,
@@ -619,7 +622,10 @@ def main():
             "converged": bool(ci["converged"]), "scf_wall_s": round(crun["elapsed"], 3),
             "scf_wall_s_to_convergence": round(crun["elapsed"], 3) if ci["converged"] else None,
             "hpsi_applies_per_s": ci["n_matvec"] / crun["elapsed"], "n_matvec": int(ci["n_matvec"]),
-            "E_total": ci["energies"].total, "dE_total_vs_real": ci["energies"].total - info["energies"].total,
+            "E_total": ci["energies"].total,
+            # (meaningful when both runs converged; capped runs stop at different points of their trajectories)
+            "dE_total_vs_real": (ci["energies"].total - info["energies"].total)
+            if (ci["converged"] and info["converged"]) else None,
             "lobpcg_iters_per_step": crun["iters"], "step_wall_s": [round(s_, 3) for s_ in crun["step_s"]],
             "roofline": {k_: croof[k_] for k_ in ("bound", "achieved", "peak", "unit", "frac", "achieved_unstructured",
                                                   "mfma_busy_frac", "kernel", "launches", "avg_launch_ms", "families_ms",
@@ -649,7 +655,7 @@ def main():
                                   + model_leg["model_terms"]["late_step_zgemm_s"])
                     timed = None
                     if late_model < args.cpu_step_budget:
-                        timed = cpu_timed_late_step(basis, info, float(dinfo["diagtol"]), args.cpu_step_budget)
+                        timed = cpu_timed_late_step(basis, info, float(dinfo["diagtol"]), args.cpu_step_budget, dinfo)
                     if timed is not None:
                         timed["device_step_s"] = round(t_dev, 4)
                         timed["device_lobpcg_iterations"] = float(np.mean(dinfo["diagonalization"]["n_iter"]))

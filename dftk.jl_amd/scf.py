@@ -333,7 +333,8 @@ class ScfStepper:
         t = time.time()
         energies, _ = energy_hamiltonian(basis, nxt["psi"], nxt["occupation"], rho=nxt["rho"], only_energies=True,
                                          eigenvalues=nxt["eigenvalues"], eF=nxt["eF"],
-                                         ritz_potential=ham[0].potential if self.ritz_energies else None)
+                                         ritz_potential=ham[0].potential if self.ritz_energies else None,
+                                         ritz_occupation_threshold=self.nbandsalg.occupation_threshold)
         t = lap("energies", t)
         drho = nxt["rho"] - self.rho_in
         n_matvec_total = info["n_matvec"] + nxt["n_matvec"]

@@ -62,6 +62,7 @@ def symmetry_operations(lattice, atom_groups, positions, tol=SYMMETRY_TOLERANCE)
     ops = []
     smallest = min(atom_groups, key=len)
     a0 = positions[smallest[0]]
+    group_pos = [np.array([positions[i] for i in group]) for group in atom_groups]
     for c0 in cols[0]:
         for c1 in cols[1]:
             if abs(c0 @ metric @ c1 - metric[0, 1]) > tol * scale:
@@ -75,20 +76,27 @@ def symmetry_operations(lattice, atom_groups, positions, tol=SYMMETRY_TOLERANCE)
                 for j in smallest:
                     w = positions[j] - W @ a0
                     ok = True
-                    for group in atom_groups:
-                        gp = [positions[i] for i in group]
-                        for a in gp:
-                            img = W @ a + w
-                            if not any(_approx_integer(img - b, tol) for b in gp):
-                                ok = False
-                                break
-                        if not ok:
+                    for gp in group_pos:            # every image W a + w must be an atom of the same group (mod lattice)
+                        d = (gp @ W.T + w)[:, None, :] - gp[None, :, :]
+                        if not np.all(np.any(np.all(np.abs(d - np.round(d)) <= tol, axis=2), axis=1)):
+                            ok = False
                             break
                     if ok:
                         op = SymOp.make(W, w)
                         if not any(np.array_equal(op.W, o.W) and _approx_integer(op.w - o.w, tol) for o in ops):
                             ops.append(op)
     ops.sort(key=lambda o: (not o.isone(),))
+    # candidate columns are searched among integer vectors with entries in [-2, 2] (enough for reduced cells); on a badly
+    # skewed, non-reduced lattice that search can miss operations, and a set that is not a GROUP would silently give wrong
+    # irreducible weights -- so the closure is verified (SymOp.jl check_group) and anything else falls back to the identity
+    if 1 < len(ops) <= 192:
+        try:
+            check_group(ops, tol)
+        except AssertionError:
+            import warnings
+            warnings.warn("symmetry_operations: the detected operations do not form a group (non-reduced lattice?); "
+                          "using the identity only")
+            return [identity()]
     return ops
 
 
@@ -224,8 +232,9 @@ def _tables(basis):
         idx = _index_of(G @ invS.T, basis.fft_size).reshape(-1)
         phase = np.exp(-2j * np.pi * (G @ s.tau)).reshape(-1) if s.tau.any() else np.ones(idx.size, dtype=complex)
         phase = np.where(idx >= 0, phase, 0.0)
-        tabs.append((torch.from_numpy(np.maximum(idx, 0)).to(basis.device),
-                     torch.from_numpy(phase).to(basis.device)))
+        tabs.append((torch.from_numpy(np.maximum(idx, 0).astype(np.int32)).to(basis.device),
+                     torch.from_numpy(phase).to(basis.device) if (s.tau.any() or np.any(idx < 0))
+                     else None))
     basis._symm_tables = tabs
     return tabs
 
@@ -252,7 +261,7 @@ def symmetrize_rho(basis, rho, do_lowpass=True):
     rf = basis.fft(rho).reshape(-1)
     acc = torch.zeros_like(rf)
     for idx, phase in _tables(basis):                  # accumulate_over_symmetries! (:282-319)
-        acc += rf[idx] * phase
+        acc += rf[idx.long()] * phase if phase is not None else rf[idx.long()]
     if do_lowpass:                                      # lowpass_for_symmetry! (:323-343)
         G = _G_cube(basis.fft_size)
         keep = np.ones(G.shape[:-1], dtype=bool)

@@ -532,7 +532,7 @@ def smearing_entropy(kind, x):
 
 
 def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, eigenvalues=None, eF=None,
-                       ritz_potential=None):
+                       ritz_potential=None, ritz_occupation_threshold=0.0):
     """``energy_hamiltonian(basis, psi, occupation; rho, eigenvalues, eF)`` (Hamiltonian.jl:200-227); with
     ``only_energies`` it is ``energy(...)`` (:232-236).  Returns (Energies, [DftHamiltonianBlock]).  The entropy
     term -TS (terms/entropy.jl:11-42) needs this rank's eigenvalues and the Fermi level, else it is Inf."""
@@ -543,6 +543,7 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, ei
     have_psi = psi is not None and occupation is not None
     reduce_kpts = []       # terms that are sums over this rank's k-points: ONE fused reduction at the end
     ritz_fix = None
+    kin_bands = []          # per k-point: kinetic energy of every band (library reduction), or None
     # local-potential pipeline behind the C ABI (LDA and PBE); DFTK_MI_TORCH_LOCAL=1 keeps the torch formulation
     # (the parity twin of tests/test_gpu_scf.py)
     fused = None
@@ -568,7 +569,9 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, ei
                         _lib.check(basis.lib.dftk_mi_tpa_precondprep(kpt.handle, psik.shape[0], psik.data_ptr(),
                                                                      psik.stride(0), mk.ctypes.data))
                         e += basis.kweights[ik] * float(np.dot(np.asarray(occupation[ik], dtype=float), mk))
+                        kin_bands.append(mk)
                         continue
+                    kin_bands.append(None)
                     dots = ((psik.real ** 2 + psik.imag ** 2) * T.kinetic[ik][None, :]).sum(dim=1)   # (n_bands,)
                     occ = torch.as_tensor(occupation[ik], dtype=torch.float64, device=basis.device)
                     e += basis.kweights[ik] * float((occ * dots).sum().item())
@@ -583,18 +586,31 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, ei
         elif name == "AtomicNonlocal":
             if T.P is None:
                 E[name] = 0.0
-            elif have_psi and ritz_potential is not None and eigenvalues is not None and "Kinetic" in E:
+            elif (have_psi and ritz_potential is not None and eigenvalues is not None and "Kinetic" in E
+                  and (basis.model.temperature == 0 or (kin_bands and all(kb_ is not None for kb_ in kin_bands)))):
                 # psi are the Ritz vectors of H[V_in] with Ritz values eps_n = <psi_n|H|psi_n> (kinetic + local +
-                # nonlocal): sum_n f_n <psi_n|V_nl|psi_n> = sum f eps - E_kin - int V_in rho[psi].  Exact up to the
+                # nonlocal): sum_n f_n <psi_n|V_nl|psi_n> = sum f eps - sum f kin_n - int V_in rho[psi].  Exact up to the
                 # round-off LOBPCG carries in A X (~1e-13 relative); saves the n_p x n_bands x n_G projection GEMM of
                 # nonlocal.jl:38-44 on every SCF step.  (finalize() and callers without Ritz data take the GEMM.)
+                # rho[psi] was built by compute_density, which DROPS bands with |f| < occupation_threshold
+                # (densities.jl:25-33): the two band sums use the same mask, so that the identity holds term by term;
+                # what is left out is the nonlocal energy of the dropped bands, < threshold * n_dropped * |<V_nl>| --
+                # nothing at T = 0, where occupations are exactly 0 or 2.  With symmetries rho is the SYMMETRISED density of
+                # the irreducible k-points: int V_in rho_sym = int V_in rho_irr needs V_in invariant under basis.symmetries,
+                # which holds by construction (rho_in is the symmetric guess or a mix of symmetrised outputs, the atomic
+                # potentials carry the crystal symmetry; both SCF drivers only ever pass that V_in as ritz_potential).
                 e = 0.0
                 for ik, psik in enumerate(psi):
                     occ = np.asarray(occupation[ik], dtype=float)
-                    e += basis.kweights[ik] * float(np.dot(occ, np.asarray(eigenvalues[ik], dtype=float)[:len(occ)]))
+                    occ = np.where(np.abs(occ) >= ritz_occupation_threshold, occ, 0.0)
+                    e_k = float(np.dot(occ, np.asarray(eigenvalues[ik], dtype=float)[:len(occ)]))
+                    if kin_bands and kin_bands[ik] is not None:
+                        e_k -= float(np.dot(occ, kin_bands[ik]))
+                    e += basis.kweights[ik] * e_k
                 E[name] = e
                 reduce_kpts.append(name)
-                ritz_fix = float((rho * ritz_potential).sum().item() * basis.dvol)
+                ritz_fix = (float((rho * ritz_potential).sum().item() * basis.dvol),
+                            bool(kin_bands) and all(kb_ is not None for kb_ in kin_bands))
             elif have_psi:
                 e = 0.0
                 for ik, psik in enumerate(psi):
@@ -642,7 +658,8 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, ei
         for name, v in zip(reduce_kpts, basis.comm_kpts.sum_scalars([E[n] for n in reduce_kpts])):
             E[name] = v
     if ritz_fix is not None:
-        E["AtomicNonlocal"] = E["AtomicNonlocal"] - E["Kinetic"] - ritz_fix
+        # (band-wise kinetic energies already subtracted with the occupation mask, else the total E_kin: T = 0 only)
+        E["AtomicNonlocal"] = E["AtomicNonlocal"] - (0.0 if ritz_fix[1] else E["Kinetic"]) - ritz_fix[0]
     if only_energies:
         return E, None
     ham = [DftHamiltonianBlock(basis, kpt, pot) for kpt in basis.kpoints]

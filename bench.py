@@ -59,7 +59,10 @@ def parse():
     ap.add_argument("--mode", choices=("gamma", "kpoints", "weak"), default="gamma")
     ap.add_argument("--supercell", type=int, default=5, help="n for the n x n x n Si supercell (5 = 1000 e-, 4 = configs[1])")
     ap.add_argument("--ecut", type=float, default=None)
-    ap.add_argument("--kgrid", type=int, default=12, help="--mode kpoints: n of the n x n x n Monkhorst-Pack mesh")
+    ap.add_argument("--kgrid", type=int, default=None, help="--mode kpoints: n of the n x n x n (graphene: n x n x 1) mesh")
+    ap.add_argument("--system", choices=("al", "si", "graphene"), default="al",
+                    help="--mode kpoints: BASELINE configs[2] (fcc Al PBE, Ecut 40, 12^3 mesh, default), configs[0] (Si primitive "
+                         "LDA, Ecut 15, 4^3 mesh) or configs[3] (graphene slab PBE, Ecut 40, 9x9x1 mesh)")
     ap.add_argument("--no-symmetries", action="store_true", help="--mode kpoints: unreduced mesh")
     ap.add_argument("--tol", type=float, default=1e-6)
     ap.add_argument("--no-gamma-real", action="store_true",
@@ -520,19 +523,34 @@ def main():
     t0 = time.time()
     model = None
     if args.mode == "kpoints":
-        a = 7.6324708938577865                                       # test/testcases.jl:74
-        lat = a / 2 * np.array([[0, 1, 1.0], [1, 0, 1.0], [1, 1, 0.0]])
-        Al = dftk.ElementPsp("Al", dftk.load_psp("Al", "pbe"))
-        model = dftk.model_DFT(lat, [Al], [np.zeros(3)], functionals=("gga_x_pbe", "gga_c_pbe"), temperature=1e-3,
-                               smearing="gaussian", symmetries=not args.no_symmetries)
-        ecut = args.ecut or 40.0
-        kg = dftk.MonkhorstPack((args.kgrid,) * 3)
+        sym = not args.no_symmetries
+        if args.system == "al":
+            a = 7.6324708938577865                                       # test/testcases.jl:74
+            lat = a / 2 * np.array([[0, 1, 1.0], [1, 0, 1.0], [1, 1, 0.0]])
+            Al = dftk.ElementPsp("Al", dftk.load_psp("Al", "pbe"))
+            model = dftk.model_DFT(lat, [Al], [np.zeros(3)], functionals=("gga_x_pbe", "gga_c_pbe"), temperature=1e-3,
+                                   smearing="gaussian", symmetries=sym)
+            ecut, kg_n, what = args.ecut or 40.0, (args.kgrid or 12,) * 3, "Al fcc (1 atom, 3 e-) PBE HGH, Gaussian smearing T=1e-3"
+        elif args.system == "si":
+            lat, atoms, pos = dftk.silicon_cell()
+            model = dftk.model_DFT(lat, atoms, pos, functionals=("lda_x", "lda_c_pw"), symmetries=sym)
+            ecut, kg_n, what = args.ecut or 15.0, (args.kgrid or 4,) * 3, "Si primitive (2 atoms, 8 e-) LDA HGH"
+        else:                                                            # examples/graphene.jl:15-30
+            a, L = 4.66, 20.0
+            lat = np.array([[a / 2, a / 2, 0.0], [-a * np.sqrt(3) / 2, a * np.sqrt(3) / 2, 0.0], [0.0, 0.0, L]])
+            Cc = dftk.ElementPsp("C", dftk.load_psp("C", "pbe"))
+            pos = [np.array([1 / 3, -1 / 3, 0.0]), np.array([-1 / 3, 1 / 3, 0.0])]
+            model = dftk.model_DFT(lat, [Cc, Cc], pos, functionals=("gga_x_pbe", "gga_c_pbe"), temperature=1e-3,
+                                   smearing="fermi_dirac", symmetries=sym)
+            n_ = args.kgrid or 9
+            ecut, kg_n, what = args.ecut or 40.0, (n_, n_, 1), "graphene slab (2 atoms, 8 e-) PBE HGH, Fermi-Dirac T=1e-3"
+        kg = dftk.MonkhorstPack(kg_n)
         basis = dftk.PlaneWaveBasis(model, ecut, kg, device=device, comm_kpts=comm)
         n_kblocks_total = len(basis.kcoords_global)
-        workload = (f"Al fcc (1 atom, 3 e-) PBE HGH, Ecut={ecut:g} Ha, fft={'x'.join(map(str, basis.fft_size))}, "
-                    f"{args.kgrid}x{args.kgrid}x{args.kgrid} k-mesh, {len(basis.symmetries)} symmetries -> "
-                    f"{n_kblocks_total} k-points ({len(basis.kpoints)} on rank 0, {basis.n_lanes} stream lanes), "
-                    f"Gaussian smearing T=1e-3")
+        workload = (f"{what}, Ecut={ecut:g} Ha, fft={'x'.join(map(str, basis.fft_size))}, "
+                    f"{'x'.join(map(str, kg_n))} k-mesh, {len(basis.symmetries)} symmetries -> "
+                    f"{n_kblocks_total} k-points ({len(basis.kpoints)} on rank 0, "
+                    f"{'lock-step batched (dftk_mi_lobpcg_multi)' if basis.kbatch else str(basis.n_lanes) + ' stream lanes'})")
         parallelism, scaling = f"kpt{n_gpus}", "strong"
     else:
         n = args.supercell

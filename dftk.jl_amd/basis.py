@@ -229,8 +229,13 @@ class PlaneWaveBasis:
         # kbatch: many small k-blocks iterate in lock-step inside ONE library call (dftk_mi_lobpcg_multi) -- batched
         # launches over all k-points instead of per-k launches overlapped by host threads; needs one handle (lane).
         # DFTK_MI_KBATCH=0 (or an explicit n_lanes) keeps the lane pool.
-        self.kbatch = (n_lanes is None and os.environ.get("DFTK_MI_KBATCH", "1") != "0" and "DFTK_MI_LANES" not in os.environ
-                       and len(kc) > 1 and self.comm_pw.size == 1)
+        # Measured (one MI355X, whole SCF): Al 72 k-points 17 vs 11 SCF it/s batched vs lanes, but Si 8 k-points 65 vs 80 and
+        # graphene 12 k-points 20 vs 33 -- a scheduling round costs ~150 us whatever the number of k-blocks in it, so a
+        # handful of k-points is better served by as many concurrent streams; DFTK_MI_KBATCH=1 forces the batched loop.
+        env_kb = os.environ.get("DFTK_MI_KBATCH")
+        kb_min = int(os.environ.get("DFTK_MI_KBATCH_MIN", "32"))
+        self.kbatch = (n_lanes is None and env_kb != "0" and "DFTK_MI_LANES" not in os.environ and len(kc) > 1
+                       and self.comm_pw.size == 1 and (env_kb == "1" or len(kc) >= kb_min))
         if self.kbatch:
             n_lanes = 1
         if n_lanes is None:

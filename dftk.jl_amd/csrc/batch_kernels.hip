@@ -212,19 +212,29 @@ struct GemmItem {
 // C (m x n) = alpha A^H B + beta C, A: k x m, B: k x n (k = the long dimension).  One workgroup per 16 x 16 tile of C,
 // the whole k range inside it (fixed order: bitwise reproducible).  flags & 1 (UPPER): tiles strictly below the
 // diagonal are skipped and left untouched, as zgemm() does.
-__global__ __launch_bounds__(256) void k_b_gemm_c(const GemmItem* __restrict__ items, int tiles_n) {
-    const GemmItem it = items[blockIdx.z];
+// nsplit > 1: the k range is cut into nsplit equal chunks (blockIdx.y), every chunk writes its partial 16 x 16 tile to
+// part[(item * nsplit + chunk) * pm * pn + ...]; k_b_gemm_c_reduce adds them in chunk order (deterministic) and applies
+// alpha / beta.  One chunk of a 4 653-row product (graphene) is 5 LDS tiles instead of 73 in a row.
+__global__ __launch_bounds__(256) void k_b_gemm_c(const GemmItem* __restrict__ items, int tiles_n, int nsplit,
+                                                  cd* __restrict__ part, int pm, int pn) {
+    GemmItem it = items[blockIdx.z];
     const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
     const int i0 = tm * BG_T, j0 = tn * BG_T;
     if (i0 >= it.m || j0 >= it.n) return;
     if ((it.flags & 1) && i0 > j0 + BG_T - 1) return;
+    int kbeg = 0;
+    if (nsplit > 1) {
+        const int kc = ((it.k + nsplit - 1) / nsplit + BG_KC - 1) / BG_KC * BG_KC;
+        kbeg = blockIdx.y * kc;
+        it.k = min(it.k, kbeg + kc);      // (an empty chunk writes zeros)
+    }
     __shared__ cd As[BG_KC][BG_T + 1];
     __shared__ cd Bs[BG_KC][BG_T + 1];
     const int tid = threadIdx.x;
     const int ti = tid & 15, tj = tid >> 4;
     const int lr = tid & 63, lc = tid >> 6;   // loader: row lr of the chunk, columns lc, lc + 4, ...
     double ar = 0.0, ai = 0.0;
-    for (int k0 = 0; k0 < it.k; k0 += BG_KC) {
+    for (int k0 = kbeg; k0 < it.k; k0 += BG_KC) {
         const int kr = k0 + lr;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -247,6 +257,11 @@ __global__ __launch_bounds__(256) void k_b_gemm_c(const GemmItem* __restrict__ i
         __syncthreads();
     }
     const int i = i0 + ti, j = j0 + tj;
+    if (nsplit > 1) {
+        if (i < it.m && j < it.n)
+            part[((size_t)blockIdx.z * nsplit + blockIdx.y) * pm * pn + i + (size_t)j * pm] = make_double2(ar, ai);
+        return;
+    }
     if (i < it.m && j < it.n) {
         cd* cp = it.C + i + (int64_t)j * it.ldc;
         cd out = make_double2(it.alpha.x * ar - it.alpha.y * ai, it.alpha.x * ai + it.alpha.y * ar);
@@ -257,6 +272,29 @@ __global__ __launch_bounds__(256) void k_b_gemm_c(const GemmItem* __restrict__ i
         }
         *cp = out;
     }
+}
+
+__global__ __launch_bounds__(256) void k_b_gemm_c_reduce(const GemmItem* __restrict__ items, int nsplit,
+                                                         const cd* __restrict__ part, int pm, int pn) {
+    const GemmItem it = items[blockIdx.y];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= it.m * it.n) return;
+    const int j = idx / it.m, i = idx - j * it.m;
+    if ((it.flags & 1) && (i / BG_T) * BG_T > (j / BG_T) * BG_T + BG_T - 1) return;   // tile skipped by UPPER: untouched
+    double ar = 0.0, ai = 0.0;
+    for (int z = 0; z < nsplit; ++z) {
+        const cd v = part[((size_t)blockIdx.y * nsplit + z) * pm * pn + i + (size_t)j * pm];
+        ar += v.x;
+        ai += v.y;
+    }
+    cd* cp = it.C + i + (int64_t)j * it.ldc;
+    cd out = make_double2(it.alpha.x * ar - it.alpha.y * ai, it.alpha.x * ai + it.alpha.y * ar);
+    if (it.beta.x != 0.0 || it.beta.y != 0.0) {
+        const cd o = *cp;
+        out.x += it.beta.x * o.x - it.beta.y * o.y;
+        out.y += it.beta.x * o.y + it.beta.y * o.x;
+    }
+    *cp = out;
 }
 
 #define BN_C 8
@@ -709,7 +747,7 @@ int batch_exec_group(BatchCtx* ctx, hipStream_t stream, int type, std::vector<BO
     // ------------------------------------------------------------------ small products
     if (type == BOP_ZGEMM) {
         std::vector<GemmItem> cn, nn;
-        int max_m_c = 1, max_n_c = 1, max_n_n = 1;
+        int max_m_c = 1, max_n_c = 1, max_n_n = 1, max_k_c = 1;
         int64_t max_m_n = 1;
         for (BOp* o : ops) {
             if (o->flags & DFTK_MI_GEMM_REAL) return 1;
@@ -732,6 +770,7 @@ int batch_exec_group(BatchCtx* ctx, hipStream_t stream, int type, std::vector<BO
                 cn.push_back(g);
                 max_m_c = std::max(max_m_c, g.m);
                 max_n_c = std::max(max_n_c, g.n);
+                max_k_c = std::max(max_k_c, g.k);
             } else {
                 if (o->gk > BN_KMAX || o->gn > 512) return 1;
                 nn.push_back(g);
@@ -743,7 +782,21 @@ int batch_exec_group(BatchCtx* ctx, hipStream_t stream, int type, std::vector<BO
             const GemmItem* d = reinterpret_cast<const GemmItem*>(batch_stage(ctx, cn.data(), cn.size() * sizeof(GemmItem)));
             if (!d) return DFTK_MI_EHIP;
             const int tm = (max_m_c + BG_T - 1) / BG_T, tn = (max_n_c + BG_T - 1) / BG_T;
-            hipLaunchKernelGGL(k_b_gemm_c, dim3(tm * tn, 1, (unsigned)cn.size()), dim3(256), 0, stream, d, tn);
+            // long reductions are cut into chunks of ~4 LDS tiles (256 rows) so that a product is a few microseconds
+            // of latency instead of tens; the partial tiles are summed in chunk order by a second small kernel
+            int nsplit = std::min(32, (max_k_c + 4 * BG_KC - 1) / (4 * BG_KC));
+            if (nsplit <= 1) {
+                hipLaunchKernelGGL(k_b_gemm_c, dim3(tm * tn, 1, (unsigned)cn.size()), dim3(256), 0, stream, d, tn, 1, (cd*)nullptr,
+                                   0, 0);
+            } else {
+                const int pm = tm * BG_T, pn = tn * BG_T;
+                cd* part = reinterpret_cast<cd*>(batch_scratch(ctx, cn.size() * (size_t)nsplit * pm * pn * sizeof(cd)));
+                if (!part) return DFTK_MI_EHIP;
+                hipLaunchKernelGGL(k_b_gemm_c, dim3(tm * tn, nsplit, (unsigned)cn.size()), dim3(256), 0, stream, d, tn, nsplit,
+                                   part, pm, pn);
+                hipLaunchKernelGGL(k_b_gemm_c_reduce, dim3((max_m_c * max_n_c + 255) / 256, (unsigned)cn.size()), dim3(256), 0,
+                                   stream, d, nsplit, (const cd*)part, pm, pn);
+            }
         }
         if (!nn.empty()) {
             const GemmItem* d = reinterpret_cast<const GemmItem*>(batch_stage(ctx, nn.data(), nn.size() * sizeof(GemmItem)));

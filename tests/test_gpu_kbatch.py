@@ -17,9 +17,11 @@ A_AL = 7.6324708938577865
 
 
 @pytest.fixture(autouse=True)
-def _gpu():
+def _gpu(monkeypatch):
     assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
     torch.manual_seed(3)
+    # the batched k loop is the default from 32 local k-points on (below that the stream lanes win); force it here
+    monkeypatch.setenv("DFTK_MI_KBATCH", "1")
 
 
 def _si_basis(kgrid=(3, 3, 3), Ecut=12, **kw):
@@ -72,7 +74,7 @@ def test_lobpcg_multi_equals_one_by_one_calls(sequential, monkeypatch):
 
 
 def test_scf_with_kbatch_equals_lane_pool(monkeypatch):
-    """``self_consistent_field`` on a k-point mesh with the batched k loop (default) and with the lane pool
+    """``self_consistent_field`` on a k-point mesh with the batched k loop and with the lane pool
     (``DFTK_MI_KBATCH=0``): same energy, eigenvalues and density; Al (metal, PBE, smearing) so that the Gamma point
     (real-symmetric iteration, its own call) and LDOS mixing take part."""
     lat = A_AL / 2 * np.array([[0, 1, 1.0], [1, 0, 1.0], [1, 1, 0.0]])
@@ -126,3 +128,13 @@ def test_density_and_apply_H_multi_equal_per_kblock_calls(monkeypatch):
     rho0 = dftk.compute_density(b0, psi, occ, occupation_threshold=1e-6)
     assert float((rho1 - rho0).norm()) < 1e-13 * float(rho0.norm())
     assert abs(float(rho1.sum()) * basis.dvol - 5.5) < 1e-10
+
+
+def test_kbatch_default_threshold(monkeypatch):
+    """Default choice between the two k loops: batched from 32 local k-points on (BASELINE configs[2]: 72), stream lanes
+    below (configs[0]: 8, configs[3]: 12), where a ~150 us scheduling round per synchronisation costs more than it saves."""
+    monkeypatch.delenv("DFTK_MI_KBATCH")
+    few = _si_basis(kgrid=(3, 3, 3))
+    assert len(few.kpoints) == 27 and not few.kbatch and few.n_lanes > 1
+    many = _si_basis(kgrid=(4, 4, 4), Ecut=8)
+    assert len(many.kpoints) == 64 and many.kbatch and many.n_lanes == 1

@@ -18,7 +18,7 @@
 #include <cmath>
 #include <cstring>
 
-namespace {
+namespace dftk_batch {   // (a NAMED namespace: kernels of an anonymous one show up without names in rocprofv3 traces)
 
 __device__ __forceinline__ double b_wave_sum(double v) {
 #pragma unroll
@@ -33,7 +33,7 @@ __device__ __forceinline__ double b_block_sum(double v, double* sh) {
     __syncthreads();
     double r = 0.0;
     if (threadIdx.x == 0)
-        for (int i = 0; i < 4; ++i) r += sh[i];
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
     __syncthreads();
     return r;
 }
@@ -357,14 +357,14 @@ extern __shared__ __attribute__((aligned(16))) char b_smem[];
 
 __global__ __launch_bounds__(256) void k_b_potrf(const DenseItem* __restrict__ items, int pitch) {
     const DenseItem it = items[blockIdx.x];
-    const int n = it.n, tid = threadIdx.x;
+    const int n = it.n, tid = threadIdx.x, nthr = blockDim.x;   // 256 threads, or ONE wave for n <= 32 (cheap barriers)
     cd* S = reinterpret_cast<cd*>(b_smem);            // S[i * pitch + j]: row i, column j (upper part used)
     cd* Iv = S + (size_t)pitch * pitch;
     __shared__ double sh[4];
     __shared__ int s_info;
     __shared__ double s_piv;
     if (tid == 0) s_info = 0;
-    for (int t = tid; t < n * n; t += 256) {
+    for (int t = tid; t < n * n; t += nthr) {
         const int j = t / n, i = t - j * n;
         S[i * pitch + j] = it.A[i + (int64_t)j * it.lda];
         Iv[i * pitch + j] = make_double2(0.0, 0.0);
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void k_b_potrf(const DenseItem* __restrict__ i
         __syncthreads();
         if (s_info != 0) break;
         const double inv = 1.0 / s_piv;
-        for (int c = j + 1 + tid; c < n; c += 256) {
+        for (int c = j + 1 + tid; c < n; c += nthr) {
             cd v = S[j * pitch + c];
             v.x *= inv;
             v.y *= inv;
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void k_b_potrf(const DenseItem* __restrict__ i
         __syncthreads();
         // trailing update of the upper triangle: S[i][c] -= conj(S[j][i]) S[j][c],  j < i <= c < n
         const int rem = n - j - 1;
-        for (int t = tid; t < rem * rem; t += 256) {
+        for (int t = tid; t < rem * rem; t += nthr) {
             const int a = t / rem, bq = t - a * rem;
             const int i = j + 1 + a, c = j + 1 + bq;
             if (i <= c) {
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void k_b_potrf(const DenseItem* __restrict__ i
     }
     // write back R (upper triangle of A) and inv(R) (upper, zeros below); normest pieces of both
     double mx[2] = {0.0, 0.0}, off[2] = {0.0, 0.0}, bad[2] = {0.0, 0.0};
-    for (int t = tid; t < n * n; t += 256) {
+    for (int t = tid; t < n * n; t += nthr) {
         const int j = t / n, i = t - j * n;
         if (i <= j) {
             const cd r = S[i * pitch + j], x = Iv[i * pitch + j];
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void k_b_potrf(const DenseItem* __restrict__ i
     const double b0 = b_block_sum(bad[0], sh), b1 = b_block_sum(bad[1], sh);
     if (tid == 0) {
         double m0 = 0.0, m1 = 0.0;
-        for (int i = 0; i < 256; ++i) {
+        for (int i = 0; i < nthr; ++i) {
             m0 = fmax(m0, smax[0][i]);
             m1 = fmax(m1, smax[1][i]);
         }
@@ -491,7 +491,7 @@ __device__ __forceinline__ void rr_pair(int np, int round, int k, int& p, int& q
 }
 __global__ __launch_bounds__(256) void k_b_heev(const DenseItem* __restrict__ items, int pitch) {
     const DenseItem it = items[blockIdx.x];
-    const int n = it.n, tid = threadIdx.x;
+    const int n = it.n, tid = threadIdx.x, nthr = blockDim.x;   // 256 threads, or ONE wave for n <= 32 (cheap barriers)
     const int np = n + (n & 1);                     // padded to even; the pad is a decoupled large diagonal entry
     cd* S = reinterpret_cast<cd*>(b_smem);          // S[i * pitch + j]
     cd* V = S + (size_t)pitch * pitch;
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void k_b_heev(const DenseItem* __restrict__ it
     __shared__ int s_p[32], s_q[32];
     __shared__ double s_red[2];
     double dg = 0.0, of = 0.0;
-    for (int t = tid; t < np * np; t += 256) {
+    for (int t = tid; t < np * np; t += nthr) {
         const int j = t / np, i = t - j * np;
         cd v = make_double2(0.0, 0.0);
         if (i < n && j < n) v = it.A[i + (int64_t)j * it.lda];
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256) void k_b_heev(const DenseItem* __restrict__ it
                 s_q[tid] = q;
             }
             __syncthreads();
-            for (int t = tid; t < npairs * np; t += 256) {     // rows
+            for (int t = tid; t < npairs * np; t += nthr) {     // rows
                 const int k = t / np, j = t - k * np;
                 const int p = s_p[k], q = s_q[k];
                 const double c = s_c[k];
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void k_b_heev(const DenseItem* __restrict__ it
                 S[q * pitch + j] = make_double2(s.x * a.x + s.y * a.y + c * b.x, s.x * a.y - s.y * a.x + c * b.y);
             }
             __syncthreads();
-            for (int t = tid; t < npairs * np; t += 256) {     // columns of S and of V
+            for (int t = tid; t < npairs * np; t += nthr) {     // columns of S and of V
                 const int k = t / np, i = t - k * np;
                 const int p = s_p[k], q = s_q[k];
                 const double c = s_c[k];
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void k_b_heev(const DenseItem* __restrict__ it
             __syncthreads();
         }
         double o = 0.0;
-        for (int t = tid; t < np * np; t += 256) {
+        for (int t = tid; t < np * np; t += nthr) {
             const int j = t / np, i = t - j * np;
             if (i != j) {
                 const cd v = S[i * pitch + j];
@@ -670,7 +670,8 @@ int set_big_lds(const void* kernel, size_t bytes) {
     return 0;
 }
 
-}  // namespace
+}  // namespace dftk_batch
+using namespace dftk_batch;
 
 int batch_exec_group(BatchCtx* ctx, hipStream_t stream, int type, std::vector<BOp*>& ops) {
     const int n_items = (int)ops.size();
@@ -907,12 +908,15 @@ int batch_exec_group(BatchCtx* ctx, hipStream_t stream, int type, std::vector<BO
         if (!d) return DFTK_MI_EHIP;
         const int pitch = nmax + 1 + (nmax & 1);
         const size_t lds = 2 * (size_t)pitch * pitch * sizeof(cd);
+        // small matrices (the k-point configs: M = 6 .. 8, 3M <= 24) get ONE wave per matrix: the dozens of barriers per
+        // Jacobi sweep / Cholesky column are then free, and these kernels are pure dependent-latency chains
+        const int threads = nmax <= 32 ? 64 : 256;
         if (type == BOP_POTRF) {
             CHK(set_big_lds(reinterpret_cast<const void*>(k_b_potrf), lds));
-            hipLaunchKernelGGL(k_b_potrf, dim3(n_items), dim3(256), lds, stream, d, pitch);
+            hipLaunchKernelGGL(k_b_potrf, dim3(n_items), dim3(threads), lds, stream, d, pitch);
         } else {
             CHK(set_big_lds(reinterpret_cast<const void*>(k_b_heev), lds));
-            hipLaunchKernelGGL(k_b_heev, dim3(n_items), dim3(256), lds, stream, d, pitch);
+            hipLaunchKernelGGL(k_b_heev, dim3(n_items), dim3(threads), lds, stream, d, pitch);
         }
         HIPCHK(hipGetLastError());
         return 0;

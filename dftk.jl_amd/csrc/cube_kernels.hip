@@ -13,7 +13,7 @@
 #include <cmath>
 #include <vector>
 
-namespace {
+namespace dftk_cube {   // (named: kernels of an anonymous namespace lose their names in rocprofv3 traces)
 const int CUBE_BLOCKS = 2048;
 const int MAX_SYMM = 192;     // 48 point operations x up to 4 centring translations
 
@@ -163,7 +163,8 @@ Lat9 make_lat(const double* recip_h) {
     for (int i = 0; i < 9; ++i) L.B[i] = recip_h ? recip_h[i] : 0.0;
     return L;
 }
-}  // namespace
+}  // namespace dftk_cube
+using namespace dftk_cube;
 
 int cube_ws_ensure(dftk_mi_basis* b, size_t bytes) {
     if (bytes <= b->dense_ws_bytes) return 0;

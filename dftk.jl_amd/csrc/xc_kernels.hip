@@ -11,7 +11,7 @@
 #include <cmath>
 #include <vector>
 
-namespace {
+namespace dftk_xc {   // (named: kernels of an anonymous namespace lose their names in rocprofv3 traces)
 const int XC_BLOCKS = 1024;
 
 __device__ __forceinline__ double wave_sum_d(double v) {
@@ -186,7 +186,8 @@ __global__ __launch_bounds__(256) void k_gga(int64_t n, const double* __restrict
         vsigma[i] = acc.ds;
     }
 }
-}  // namespace
+}  // namespace dftk_xc
+using namespace dftk_xc;
 
 int xc_gga_pointwise(dftk_mi_basis* b, int64_t n, const double* rho, const double* sigma, int fun_mask,
                      double threshold, double* e, double* vrho, double* vsigma) {

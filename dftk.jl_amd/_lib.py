@@ -64,11 +64,13 @@ _SIGNATURES = {
     "dftk_mi_mix_dielectric": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "dftk_mi_chi0_dielectric_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "dftk_mi_cube_fourier_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dftk_mi_kblocks_set_potential": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "dftk_mi_lobpcg_multi": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     "dftk_mi_density_accumulate_multi": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                    C.c_void_p]),
+    "dftk_mi_band_kinetic_multi": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dftk_mi_batch_stats": (C.c_int, [C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "dftk_mi_lobpcg_last_AX": (C.c_void_p, [C.c_void_p]),
     "dftk_mi_lobpcg_history": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t,

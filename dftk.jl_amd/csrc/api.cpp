@@ -745,6 +745,17 @@ extern "C" int dftk_mi_kblock_set_potential(dftk_mi_kblock* kb, const double* V_
     return launch_pad_potential(kb, V_d);
 }
 
+// The SAME summed local potential for many k-blocks (every k-point of a basis applies one V): one call instead of a
+// host round trip per k-block; each block keeps its own padded copy (blocks of different bases / lanes stay independent).
+extern "C" int dftk_mi_kblocks_set_potential(int n_kblocks, dftk_mi_kblock* const* kbs, const double* V_d) {
+    if (n_kblocks < 0 || (n_kblocks > 0 && !kbs) || !V_d) return DFTK_MI_EINVAL;
+    for (int i = 0; i < n_kblocks; ++i) {
+        if (!kbs[i]) return DFTK_MI_EINVAL;
+        CHK(dftk_mi_kblock_set_potential(kbs[i], V_d));     // asynchronous on the block's stream once its buffer exists
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------ H psi
 int apply_nonlocal_rows(dftk_mi_kblock* kb, int nb, const cd* P, int64_t ldP, int64_t rows, const cd* psi,
                         int64_t ldpsi, cd* Hpsi, int64_t ldH, bool accumulate, int gemm_flags, dftk_mi_comm* comm) {
@@ -1069,6 +1080,42 @@ extern "C" int dftk_mi_lobpcg_multi(int n_kblocks, dftk_mi_kblock* const* kbs, i
     HIPCHK(hipSetDevice(kbs[0]->basis->device));
     return lobpcg_run_multi(n_kblocks, kbs, M, reinterpret_cast<cd* const*>(X_d), ldX, tol, miniter, maxiter, n_conv_check,
                             use_tpa, seeds, lambda_h, resid_h, n_iter, converged, n_matvec, status);
+}
+
+// kinetic energy of every band of n k-blocks: out_h = [sum_G kin_G |psi_Gn|^2 for the bands of k-block 0, then 1, ...]
+// (the per-band terms of ene_ops(::KineticOperator), src/terms/kinetic.jl:49-54; the reduction of precondprep!)
+extern "C" int dftk_mi_band_kinetic_multi(int n_kblocks, dftk_mi_kblock* const* kbs, const int* n_bands,
+                                          const dftk_mi_cplx* const* psi_d, const int64_t* ld_psi, double* out_h) {
+    if (n_kblocks < 0 || (n_kblocks > 0 && (!kbs || !n_bands || !psi_d || !ld_psi || !out_h))) return DFTK_MI_EINVAL;
+    if (n_kblocks == 0) return 0;
+    dftk_mi_basis* b = kbs[0] ? kbs[0]->basis : nullptr;
+    if (!b) return DFTK_MI_EINVAL;
+    size_t total = 0;
+    for (int i = 0; i < n_kblocks; ++i) {
+        if (!kbs[i] || kbs[i]->basis != b || kbs[i]->sh_comm || !psi_d[i] || n_bands[i] < 0 || ld_psi[i] < kbs[i]->n_G)
+            return DFTK_MI_EINVAL;
+        total += (size_t)n_bands[i];
+    }
+    HIPCHK(hipSetDevice(b->device));
+    CHK(ensure_ws(b, total * sizeof(double)));
+    double* d = reinterpret_cast<double*>(b->ws);
+    std::vector<std::function<int()>> bodies;
+    size_t off = 0;
+    for (int i = 0; i < n_kblocks; ++i) {
+        const size_t o = off;
+        off += (size_t)n_bands[i];
+        bodies.push_back([=]() {
+            if (n_bands[i] == 0) return 0;
+            CHK(ew_weighted_colsums(b, kbs[i]->n_G, n_bands[i], reinterpret_cast<const cd*>(psi_d[i]), ld_psi[i], kbs[i]->d_kin,
+                                    d + o));
+            return dev_d2h_sync(b, out_h + o, d + o, (size_t)n_bands[i] * sizeof(double));
+        });
+    }
+    std::vector<int> rets;
+    CHK(batch_run(b, bodies, rets));
+    for (int r : rets)
+        if (r != 0) return r;
+    return 0;
 }
 
 extern "C" int dftk_mi_density_accumulate_multi(int n_kblocks, dftk_mi_kblock* const* kbs, const int* n_bands,

@@ -265,6 +265,38 @@ int batch_sync() {
     return 0;
 }
 
+int dev_h2d(dftk_mi_basis* b, void* dst_d, const void* src_h, size_t bytes) {
+    if (batching()) {
+        BOp o;
+        o.b = b;
+        o.type = BOP_H2D;
+        o.C = dst_d;
+        o.payload.assign(reinterpret_cast<const char*>(src_h), reinterpret_cast<const char*>(src_h) + bytes);
+        return batch_record(std::move(o));
+    }
+    HIPCHK(hipMemcpyAsync(dst_d, src_h, bytes, hipMemcpyHostToDevice, b->stream));
+    return 0;
+}
+int dev_stream_sync(dftk_mi_basis* b) {
+    if (batching()) return batch_sync();
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+int dev_d2h_sync(dftk_mi_basis* b, void* dst_h, const void* src_d, size_t bytes) {
+    if (batching()) {
+        BOp o;
+        o.b = b;
+        o.type = BOP_D2H;
+        o.A = src_d;
+        o.host = dst_h;
+        o.bytes = bytes;
+        return batch_record_sync(std::move(o));
+    }
+    HIPCHK(hipMemcpyAsync(dst_h, src_d, bytes, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
 static thread_local int64_t g_last_stats[4] = {0, 0, 0, 0};
 extern "C" int dftk_mi_batch_stats(int64_t* rounds, int64_t* ops, int64_t* merged_launches, int64_t* sequential_ops) {
     if (rounds) *rounds = g_last_stats[0];

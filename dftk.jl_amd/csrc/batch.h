@@ -77,6 +77,10 @@ int batch_record(BOp&& op);
 int batch_record_sync(BOp&& op);
 // plain "wait for everything I have issued": yields (all queued work of the fiber is complete on return)
 int batch_sync();
+// host <-> device traffic of host-driven drivers: recorded inside a fiber of a batched call, plain HIP calls otherwise
+int dev_h2d(dftk_mi_basis* b, void* dst_d, const void* src_h, size_t bytes);
+int dev_d2h_sync(dftk_mi_basis* b, void* dst_h, const void* src_d, size_t bytes);
+int dev_stream_sync(dftk_mi_basis* b);
 
 // batched executors (batch_kernels.hip / fft_kernels.hip); return 0 if the whole group was launched, 1 if the group
 // has no batched form (the caller then runs the ops one by one), < 0 on errors

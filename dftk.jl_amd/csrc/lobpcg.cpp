@@ -72,33 +72,9 @@ struct Ctx {
 // host <-> device traffic of the driver.  Inside a fiber of a batched multi-k call (batch.h) these are recorded like
 // every other device operation: the copies of all k-blocks of a round travel together, and "wait for the result" is
 // the point where the fiber yields to its siblings.
-int h2d(dftk_mi_basis* b, void* dst_d, const void* src_h, size_t bytes) {
-    if (batching()) {
-        BOp o;
-        o.b = b;
-        o.type = BOP_H2D; o.C = dst_d;
-        o.payload.assign(reinterpret_cast<const char*>(src_h), reinterpret_cast<const char*>(src_h) + bytes);
-        return batch_record(std::move(o));
-    }
-    HIPCHK(hipMemcpyAsync(dst_d, src_h, bytes, hipMemcpyHostToDevice, b->stream));
-    return 0;
-}
-int stream_sync(dftk_mi_basis* b) {
-    if (batching()) return batch_sync();
-    HIPCHK(hipStreamSynchronize(b->stream));
-    return 0;
-}
-int d2h_sync(dftk_mi_basis* b, void* dst_h, const void* src_d, size_t bytes) {
-    if (batching()) {
-        BOp o;
-        o.b = b;
-        o.type = BOP_D2H; o.A = src_d; o.host = dst_h; o.bytes = bytes;
-        return batch_record_sync(std::move(o));
-    }
-    HIPCHK(hipMemcpyAsync(dst_h, src_d, bytes, hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
-    return 0;
-}
+int h2d(dftk_mi_basis* b, void* dst_d, const void* src_h, size_t bytes) { return dev_h2d(b, dst_d, src_h, bytes); }
+int stream_sync(dftk_mi_basis* b) { return dev_stream_sync(b); }
+int d2h_sync(dftk_mi_basis* b, void* dst_h, const void* src_d, size_t bytes) { return dev_d2h_sync(b, dst_h, src_d, bytes); }
 
 int d2h(Ctx& c, const double* d, int n) {
     if ((int)c.h.size() < n) c.h.resize(n);

@@ -14,11 +14,31 @@ from . import _lib
 
 
 class DftHamiltonianBlock:
-    def __init__(self, basis, kpoint, potential):
+    def __init__(self, basis, kpoint, potential, bind: bool = True):
         basis._require_gpu()
         self.basis, self.kpoint = basis, kpoint
         self.potential = potential.to(torch.float64).contiguous() if potential is not None else None
-        self.bind(force=True)
+        if bind:
+            self.bind(force=True)
+
+    @staticmethod
+    def for_all_kpoints(basis, potential):
+        """The blocks of every local k-point for ONE summed potential (Hamiltonian.jl:36-57), bound with a single library
+        call (``dftk_mi_kblocks_set_potential``) instead of one host round trip per k-point."""
+        import ctypes as C
+        pot = potential.to(torch.float64).contiguous() if potential is not None else None
+        blocks = [DftHamiltonianBlock(basis, kpt, pot, bind=False) for kpt in basis.kpoints]
+        if pot is None or len(blocks) < 2:
+            for b_ in blocks:
+                b_.bind(force=True)
+            return blocks
+        n = len(blocks)
+        kbs = (C.c_void_p * n)(*[b_.kpoint.handle.value for b_ in blocks])
+        torch.cuda.current_stream(basis.device).synchronize()
+        _lib.check(basis.lib.dftk_mi_kblocks_set_potential(n, kbs, pot.data_ptr()))
+        for b_ in blocks:
+            b_.kpoint._pot_owner = b_
+        return blocks
 
     def bind(self, force: bool = False):
         """Make the device handle of the k-point apply THIS block's potential."""

@@ -559,7 +559,26 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, ei
         if name == "Kinetic":
             if have_psi:
                 e = 0.0
+                kin_multi = None
+                if (getattr(basis, "kbatch", False) and basis.n_lanes == 1 and len(psi) > 1 and basis.comm_pw.size == 1
+                        and os.environ.get("DFTK_MI_TORCH_LOCAL") is None and all(p_.stride(1) == 1 for p_ in psi)):
+                    # many small k-blocks: the band-wise kinetic energies of all of them in ONE library call
+                    import ctypes as C
+                    n = len(psi)
+                    nbs = [int(p_.shape[0]) for p_ in psi]
+                    out = np.zeros(sum(nbs))
+                    kbs = (C.c_void_p * n)(*[k_.handle.value for k_ in basis.kpoints])
+                    torch.cuda.current_stream(basis.device).synchronize()
+                    _lib.check(basis.lib.dftk_mi_band_kinetic_multi(
+                        n, kbs, (C.c_int * n)(*nbs), (C.c_void_p * n)(*[p_.data_ptr() for p_ in psi]),
+                        (C.c_int64 * n)(*[p_.stride(0) for p_ in psi]), out.ctypes.data))
+                    kin_multi = np.split(out, np.cumsum(nbs)[:-1])
                 for ik, psik in enumerate(psi):
+                    if kin_multi is not None:
+                        mk = kin_multi[ik]
+                        e += basis.kweights[ik] * float(np.dot(np.asarray(occupation[ik], dtype=float), mk))
+                        kin_bands.append(mk)
+                        continue
                     kpt = basis.kpoints[ik]
                     if basis.comm_pw.size == 1 and psik.stride(1) == 1 and os.environ.get("DFTK_MI_TORCH_LOCAL") is None:
                         # sum_G kin_G |psi_Gn|^2 per band: the library's one-pass column reduction (the kernel of
@@ -662,5 +681,5 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, ei
         E["AtomicNonlocal"] = E["AtomicNonlocal"] - (0.0 if ritz_fix[1] else E["Kinetic"]) - ritz_fix[0]
     if only_energies:
         return E, None
-    ham = [DftHamiltonianBlock(basis, kpt, pot) for kpt in basis.kpoints]
+    ham = DftHamiltonianBlock.for_all_kpoints(basis, pot)
     return E, ham

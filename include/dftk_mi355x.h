@@ -81,6 +81,9 @@ int dftk_mi_kblock_set_projectors(dftk_mi_kblock* kb, int n_p, const dftk_mi_cpl
 /* local_op.potential (operators.jl:71-78, :213-222): the SUM of all local terms on the cube,
  * un-normalised (the 1/N of Hamiltonian.jl:152-153 is applied inside).  Copied. NULL clears. */
 int dftk_mi_kblock_set_potential(dftk_mi_kblock* kb, const double* V_d);
+/* The same potential for n k-blocks (all k-points of a basis apply ONE summed local potential, Hamiltonian.jl:36-57):
+ * one call instead of one host round trip per k-block.  V_d must stay unchanged until the blocks' streams have run. */
+int dftk_mi_kblocks_set_potential(int n_kblocks, dftk_mi_kblock* const* kbs, const double* V_d);
 
 /* ---- mul!(Hpsi, H::DftHamiltonianBlock, psi)  (src/terms/Hamiltonian.jl:137-192) ------------- */
 int dftk_mi_apply_H(dftk_mi_kblock* kb, int n_bands, const dftk_mi_cplx* psi_d, int64_t ld_psi,
@@ -226,6 +229,10 @@ int dftk_mi_lobpcg_multi(int n_kblocks, dftk_mi_kblock* const* kbs, int M, dftk_
 int dftk_mi_density_accumulate_multi(int n_kblocks, dftk_mi_kblock* const* kbs, const int* n_bands,
                                      const dftk_mi_cplx* const* psi_d, const int64_t* ld_psi, const double* weights_h,
                                      double* rho_d);
+/* Kinetic energy of every band of n k-blocks in one call: out_h = sum_G kin_G |psi_Gn|^2 for the bands of k-block 0,
+ * then of k-block 1, ... (the band terms of the Kinetic energy, src/terms/kinetic.jl:49-54).  One basis handle. */
+int dftk_mi_band_kinetic_multi(int n_kblocks, dftk_mi_kblock* const* kbs, const int* n_bands,
+                               const dftk_mi_cplx* const* psi_d, const int64_t* ld_psi, double* out_h);
 /* Counters of the calling thread's last batched call: scheduling rounds (= host synchronisations), recorded
  * operations, merged launches, operations that ran one by one (no batched form). */
 int dftk_mi_batch_stats(int64_t* rounds, int64_t* ops, int64_t* merged_launches, int64_t* sequential_ops);

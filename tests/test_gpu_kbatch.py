@@ -121,6 +121,17 @@ def test_density_and_apply_H_multi_equal_per_kblock_calls(monkeypatch):
         np.testing.assert_allclose(lam.cpu().numpy()[:4], r.λ[:4], atol=1e-10)
     occ = [np.array([2.0, 2.0, 0.0, 1.5, 1e-9, 0.0]) for _ in ham]
     psi = [r.X for r in res]
+    # band-wise kinetic energies of all k-blocks in one call (dftk_mi_band_kinetic_multi) == per-block reductions
+    import ctypes as C
+    from dftk_jl_amd._lib import check
+    n = len(psi)
+    out = np.zeros(6 * n)
+    check(basis.lib.dftk_mi_band_kinetic_multi(n, (C.c_void_p * n)(*[k.handle.value for k in basis.kpoints]),
+                                               (C.c_int * n)(*[6] * n), (C.c_void_p * n)(*[p.data_ptr() for p in psi]),
+                                               (C.c_int64 * n)(*[p.stride(0) for p in psi]), out.ctypes.data))
+    for ik, (kpt, p) in enumerate(zip(basis.kpoints, psi)):
+        ref = ((p.real ** 2 + p.imag ** 2) * kpt.kinetic[None, :]).sum(dim=1).cpu().numpy()
+        np.testing.assert_allclose(out[6 * ik:6 * ik + 6], ref, rtol=1e-13)
     rho1 = dftk.compute_density(basis, psi, occ, occupation_threshold=1e-6)
     monkeypatch.setenv("DFTK_MI_KBATCH", "0")
     b0 = _si_basis(kgrid=(3, 2, 2), Ecut=14)

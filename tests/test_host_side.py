@@ -888,3 +888,22 @@ def test_default_diagtolalg_per_model_class():
                                                                   functionals=())), tol)
     assert fx(0, []) == 0.025 and fx(2, [1e-2, 1e-2]) == pytest.approx(5e-4 * 1e-2)
     assert default_diagtol_params(SimpleNamespace(terms=("Kinetic", "ExactExchange"), functionals=()), tol) == dict(ratio=5e-4)
+
+
+def test_multi_k_entries_argument_checks_without_gpu(lib):
+    """The multi-k entries (``dftk_mi_lobpcg_multi``, ``dftk_mi_density_accumulate_multi``, ``dftk_mi_band_kinetic_multi``,
+    ``dftk_mi_kblocks_set_potential``): empty batches are no-ops, missing tables are argument errors -- decided on the
+    host before any device call; the counters of the last batched call are readable at any time."""
+    i64 = C.c_int64
+    assert lib.dftk_mi_lobpcg_multi(0, None, 4, None, None, 1e-6, 1, 10, 0, 1, None, None, None, None, None, None, None) == 0
+    assert lib.dftk_mi_lobpcg_multi(2, None, 4, None, None, 1e-6, 1, 10, 0, 1, None, None, None, None, None, None, None) != 0
+    assert lib.dftk_mi_lobpcg_multi(-1, None, 4, None, None, 1e-6, 1, 10, 0, 1, None, None, None, None, None, None, None) != 0
+    rho = (C.c_double * 8)()
+    assert lib.dftk_mi_density_accumulate_multi(0, None, None, None, None, None, rho) == 0
+    assert lib.dftk_mi_density_accumulate_multi(1, None, None, None, None, None, rho) != 0
+    assert lib.dftk_mi_band_kinetic_multi(0, None, None, None, None, None) == 0
+    assert lib.dftk_mi_band_kinetic_multi(3, None, None, None, None, None) != 0
+    assert lib.dftk_mi_kblocks_set_potential(0, None, rho) == 0 and lib.dftk_mi_kblocks_set_potential(1, None, rho) != 0
+    r, o, m, q = i64(-1), i64(-1), i64(-1), i64(-1)
+    assert lib.dftk_mi_batch_stats(C.byref(r), C.byref(o), C.byref(m), C.byref(q)) == 0
+    assert min(r.value, o.value, m.value, q.value) >= 0

@@ -88,6 +88,7 @@ _SIGNATURES = {
     "dftk_mi_gamma_tables_host": (C.c_int, [C.c_int, C.c_int, C.c_int, _i64, C.c_void_p, C.POINTER(_i64), C.c_void_p,
                                             C.c_void_p]),
     "dftk_mi_gamma_compress": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, _i64]),
+    "dftk_mi_gamma_compress_aligned": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, _i64]),
     "dftk_mi_gamma_expand": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, _i64]),
     "dftk_mi_gamma_apply_H": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, _i64, C.c_void_p, _i64]),
     "dftk_mi_density_accumulate_real": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, C.c_void_p]),

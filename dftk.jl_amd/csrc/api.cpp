@@ -672,8 +672,9 @@ int gamma_density_sharded(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldp
 }
 
 // caller's full-sphere block (row slab of it on a sharded block) -> half-format block of dftk_mi_lobpcg, and back
-int gamma_lobpcg_load(dftk_mi_kblock* kb, int M, const cd* Xuser, int64_t ldX, cd* Xh, int64_t ldh) {
-    if (!kb->sh_comm) return gamma_compress(kb, M, Xuser, ldX, Xh, ldh);
+int gamma_lobpcg_load(dftk_mi_kblock* kb, int M, const cd* Xuser, int64_t ldX, cd* Xh, int64_t ldh, bool align) {
+    if (!kb->sh_comm)
+        return align ? gamma_compress_aligned(kb, M, Xuser, ldX, Xh, ldh) : gamma_compress(kb, M, Xuser, ldX, Xh, ldh);
     GammaReal* gr = kb->gr;
     dftk_mi_basis* b = kb->basis;
     const int64_t hl = gamma_local_rows(kb), fl = local_rows(kb);
@@ -684,7 +685,9 @@ int gamma_lobpcg_load(dftk_mi_kblock* kb, int M, const cd* Xuser, int64_t ldX, c
     CHK(gamma_ensure_buf(kb, (size_t)fl * M));
     CHK(ew_copy(b, fl, M, Xuser, ldX, gr->buf, fl));
     CHK(tf.to_bands(gr->buf, R1, F));
-    CHK(gamma_compress(kb, tf.mine, F, kb->n_G, Gf, gr->n_half));
+    // (every rank holds WHOLE bands here: the phase of a band is decided by the rank that owns it)
+    CHK(align ? gamma_compress_aligned(kb, tf.mine, F, kb->n_G, Gf, gr->n_half)
+              : gamma_compress(kb, tf.mine, F, kb->n_G, Gf, gr->n_half));
     return th.to_slabs(Gf, R1, Xh);
 }
 
@@ -1025,6 +1028,14 @@ extern "C" int dftk_mi_gamma_compress(dftk_mi_kblock* kb, int m, const dftk_mi_c
     if (kb->sh_comm)   // row slabs in, row slabs out (collective over the block's communicator)
         return gamma_lobpcg_load(kb, m, reinterpret_cast<const cd*>(X_d), ldx, reinterpret_cast<cd*>(Xh_d), ldh);
     return gamma_compress(kb, m, reinterpret_cast<const cd*>(X_d), ldx, reinterpret_cast<cd*>(Xh_d), ldh);
+}
+
+extern "C" int dftk_mi_gamma_compress_aligned(dftk_mi_kblock* kb, int m, const dftk_mi_cplx* X_d, int64_t ldx,
+                                              dftk_mi_cplx* Xh_d, int64_t ldh) {
+    CHK(gamma_ready(kb));
+    if (m < 0 || !X_d || !Xh_d || ldx < local_rows(kb) || ldh < gamma_local_rows(kb)) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(kb->basis->device));
+    return gamma_lobpcg_load(kb, m, reinterpret_cast<const cd*>(X_d), ldx, reinterpret_cast<cd*>(Xh_d), ldh, true);
 }
 
 extern "C" int dftk_mi_gamma_expand(dftk_mi_kblock* kb, int m, const dftk_mi_cplx* Xh_d, int64_t ldh,

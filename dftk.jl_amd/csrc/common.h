@@ -258,6 +258,8 @@ int gamma_tables_host(int nx, int ny, int nz, int64_t n_G, const int64_t* mappin
 int gamma_enable(dftk_mi_kblock* kb, int on);
 void gamma_destroy(GammaReal* gr);
 int gamma_compress(dftk_mi_kblock* kb, int m, const cd* X, int64_t ldx, cd* H, int64_t ldh);
+// ... after rotating every column by the global phase that maximises its real-symmetric part (LOBPCG entry)
+int gamma_compress_aligned(dftk_mi_kblock* kb, int m, const cd* X, int64_t ldx, cd* H, int64_t ldh);
 int gamma_expand(dftk_mi_kblock* kb, int m, const cd* H, int64_t ldh, cd* X, int64_t ldx);
 int gamma_apply_H(dftk_mi_kblock* kb, int which, int nb, const cd* psi, int64_t ldpsi, cd* Hpsi, int64_t ldH);
 int gamma_density(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, const double* w_h, double* rho);
@@ -275,7 +277,7 @@ int64_t gamma_row0(const dftk_mi_kblock* kb);
 int gamma_apply_H_sharded(dftk_mi_kblock* kb, int which, int nb, const cd* psi, int64_t ldpsi, cd* Hpsi, int64_t ldH);
 int gamma_projectors_sharded(dftk_mi_kblock* kb);
 int gamma_density_sharded(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, const double* w_h, double* rho);
-int gamma_lobpcg_load(dftk_mi_kblock* kb, int M, const cd* Xuser, int64_t ldX, cd* Xh, int64_t ldh);
+int gamma_lobpcg_load(dftk_mi_kblock* kb, int M, const cd* Xuser, int64_t ldX, cd* Xh, int64_t ldh, bool align = false);
 int gamma_lobpcg_store(dftk_mi_kblock* kb, int M, const cd* Xh, int64_t ldh, cd* Xuser, int64_t ldX);
 // api.cpp: Hpsi (+)= P D P' psi on `rows` rows of projector storage P (leading dimension ldP); gemm_flags is OR-ed
 // into the two products (DFTK_MI_GEMM_REAL for half-format blocks); comm (nullable) all-reduces the projections

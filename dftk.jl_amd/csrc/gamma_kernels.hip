@@ -77,6 +77,58 @@ __global__ void k_gr_compress(int64_t nh, const int* __restrict__ g, const int* 
     H[j + (int64_t)blockIdx.y * ldh] = make_double2(s * (a.x + b.x), s * (a.y - b.y));
 }
 
+// compress with the phase alignment of the LOBPCG entry: every column is first rotated by exp(-i phi),
+// exp(2 i phi) = s / |s|, s = sum_G x(G) x(-G) -- the global phase that maximises its real-symmetric part (a real field
+// times any phase becomes +- itself: nothing is lost, e.g. when orbitals of a complex iteration are handed over).  A
+// column that is already real-symmetric has s > 0, phi = 0 exactly, and is compressed bit for bit as by k_gr_compress.
+// One workgroup per column: reduction pass over the pairs, then the write pass.
+__global__ __launch_bounds__(256) void k_gr_compress_aligned(int64_t nh, const int* __restrict__ g,
+                                                             const int* __restrict__ mg, const cd* __restrict__ X,
+                                                             int64_t ldx, cd* __restrict__ H, int64_t ldh) {
+    __shared__ double sh[2][4];
+    __shared__ double s_cs[2];
+    const cd* x = X + (int64_t)blockIdx.x * ldx;
+    double sr = 0.0, si = 0.0;
+    for (int64_t j = threadIdx.x; j < nh; j += 256) {
+        const cd a = x[g[j]], b = x[mg[j]];
+        const double w = j ? 2.0 : 1.0;
+        sr += w * (a.x * b.x - a.y * b.y);
+        si += w * (a.x * b.y + a.y * b.x);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sr += __shfl_down(sr, off, 64);
+        si += __shfl_down(si, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sh[0][threadIdx.x >> 6] = sr;
+        sh[1][threadIdx.x >> 6] = si;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tr = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3], ti = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+        double c = 1.0, sn = 0.0;
+        if ((tr != 0.0 || ti != 0.0) && isfinite(tr) && isfinite(ti) && !(ti == 0.0 && tr > 0.0)) {
+            const double phi = 0.5 * atan2(ti, tr);
+            c = cos(phi);
+            sn = sin(phi);
+        }
+        s_cs[0] = c;
+        s_cs[1] = sn;
+    }
+    __syncthreads();
+    const double c = s_cs[0], sn = s_cs[1];
+    for (int64_t j = threadIdx.x; j < nh; j += 256) {
+        cd a = x[g[j]], b = x[mg[j]];
+        if (sn != 0.0 || c != 1.0) {      // x * exp(-i phi)
+            a = make_double2(a.x * c + a.y * sn, a.y * c - a.x * sn);
+            b = make_double2(b.x * c + b.y * sn, b.y * c - b.x * sn);
+        }
+        const double s = j ? GR_ISQRT2 : 0.5;
+        H[j + (int64_t)blockIdx.x * ldh] = make_double2(s * (a.x + b.x), s * (a.y - b.y));
+    }
+}
+
 __global__ void k_gr_expand(int64_t nh, const int* __restrict__ g, const int* __restrict__ mg,
                             const cd* __restrict__ H, int64_t ldh, cd* __restrict__ X, int64_t ldx) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -249,6 +301,15 @@ int gamma_compress(dftk_mi_kblock* kb, int m, const cd* X, int64_t ldx, cd* H, i
     GammaReal* gr = kb->gr;
     hipLaunchKernelGGL(k_gr_compress, gr_grid(gr->n_half, m), dim3(256), 0, kb->basis->stream, gr->n_half, gr->d_g,
                        gr->d_mg, X, ldx, H, ldh);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int gamma_compress_aligned(dftk_mi_kblock* kb, int m, const cd* X, int64_t ldx, cd* H, int64_t ldh) {
+    if (m <= 0) return 0;
+    GammaReal* gr = kb->gr;
+    hipLaunchKernelGGL(k_gr_compress_aligned, dim3(m), dim3(256), 0, kb->basis->stream, gr->n_half, gr->d_g, gr->d_mg, X, ldx,
+                       H, ldh);
     HIPCHK(hipGetLastError());
     return 0;
 }

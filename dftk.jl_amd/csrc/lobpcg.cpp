@@ -508,7 +508,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
 
     Mat Xuser{Xp, ldX, N, M};
     if (real_mode)
-        CHK(gamma_lobpcg_load(kb, M, Xp, ldX, X.p, X.ld));
+        CHK(gamma_lobpcg_load(kb, M, Xp, ldX, X.p, X.ld, /*align=*/true));
     else
         CHK(ew_copy(b, N, M, Xuser.p, Xuser.ld, X.p, X.ld));
     std::vector<double> resid_history((size_t)M * (maxiter + 1), 0.0);

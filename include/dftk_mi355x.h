@@ -361,6 +361,12 @@ int dftk_mi_gamma_tables_host(int nx, int ny, int nz, int64_t n_G, const int64_t
  * back (exact inverse on real-symmetric vectors). */
 int dftk_mi_gamma_compress(dftk_mi_kblock* kb, int m, const dftk_mi_cplx* X_d, int64_t ldx, dftk_mi_cplx* Xh_d,
                            int64_t ldh);
+/* What dftk_mi_lobpcg does with its start vectors on a Gamma-real block: every column is rotated by the global phase
+ * exp(-i phi), exp(2 i phi) = s / |s|, s = sum_G x(G) x(-G), that maximises its real-symmetric part, then compressed.
+ * A real field times any phase (e.g. an orbital of a complex iteration) keeps all of its norm; a column that is already
+ * real-symmetric is compressed bit for bit as by dftk_mi_gamma_compress. */
+int dftk_mi_gamma_compress_aligned(dftk_mi_kblock* kb, int m, const dftk_mi_cplx* X_d, int64_t ldx, dftk_mi_cplx* Xh_d,
+                                   int64_t ldh);
 int dftk_mi_gamma_expand(dftk_mi_kblock* kb, int m, const dftk_mi_cplx* Xh_d, int64_t ldh, dftk_mi_cplx* X_d,
                          int64_t ldx);
 /* H psi on half-format blocks (`which` as dftk_mi_apply_H_parts). */

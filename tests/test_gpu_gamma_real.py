@@ -228,6 +228,48 @@ def test_lobpcg_real_mode_matches_complex(lib, terms):
     assert rn[:8].max() < 1e-9
 
 
+def test_lobpcg_entry_phase_alignment(lib):
+    """Entry of the Gamma-real LOBPCG (``dftk_mi_gamma_compress_aligned``): every start vector is rotated by the global
+    phase that maximises its real-symmetric part, then compressed -- device kernel vs the oracle's ``align_phase``;
+    real-symmetric columns pass bit for bit; a real field times ANY phase (incl. i, whose plain projection vanishes)
+    keeps all of its norm, so converged orbitals of the complex iteration are taken over losslessly: the Gamma-real
+    LOBPCG started from them converges at once instead of re-randomising columns."""
+    import oracle.gamma_real as ogr
+    obasis, H, bs, kb, g, mg, rng = gamma_block(lib, 10, (21, 21, 21), terms=("Kinetic", "AtomicLocal", "AtomicNonlocal"))
+    n, nh, M = kb.n_G, len(g), 12
+
+    def compress(fn, X):
+        Xd = dev(X.T.copy())
+        Hd = torch.full((X.shape[1], nh), float("nan"), dtype=torch.complex128, device="cuda")
+        check(fn(kb.h, X.shape[1], Xd.data_ptr(), n, Hd.data_ptr(), nh))
+        bs.sync()
+        return Hd.cpu().numpy().T
+
+    X = rng.standard_normal((n, 6)) + 1j * rng.standard_normal((n, 6))
+    got = compress(lib.dftk_mi_gamma_compress_aligned, X)
+    ref = to_half(ogr.align_phase(X, g, mg), g, mg)
+    assert relerr(got, ref) < 1e-13
+    assert np.all(np.linalg.norm(got, axis=0) >= np.linalg.norm(compress(lib.dftk_mi_gamma_compress, X), axis=0) - 1e-12)
+    S = from_half(to_half(X, g, mg), g, mg, n)                   # real-symmetric columns
+    assert np.array_equal(compress(lib.dftk_mi_gamma_compress_aligned, S), compress(lib.dftk_mi_gamma_compress, S))
+    ph = np.exp(1j * np.array([0.0, np.pi / 2, 0.3, -2.1, np.pi, 1.0]))
+    rot = compress(lib.dftk_mi_gamma_compress_aligned, S * ph[None, :])
+    base = compress(lib.dftk_mi_gamma_compress, S)
+    for c in range(6):                                            # +- the unrotated image: nothing lost
+        assert min(np.linalg.norm(rot[:, c] - base[:, c]), np.linalg.norm(rot[:, c] + base[:, c])) < 1e-12 * np.linalg.norm(base[:, c])
+    assert np.linalg.norm(compress(lib.dftk_mi_gamma_compress, S[:, :1] * 1j)) < 1e-12     # the plain projection of i * real
+    # warm start from the complex iteration's orbitals, each multiplied by an arbitrary phase
+    X0 = np.linalg.qr(rng.standard_normal((n, M)) + 1j * rng.standard_normal((n, M)))[0]
+    check(lib.dftk_mi_kblock_set_gamma_real(kb.h, 0))
+    lam_c, _, _, conv_c, _, Xc = run_lobpcg(lib, kb, X0, 1e-9, n_conv_check=8)
+    check(lib.dftk_mi_kblock_set_gamma_real(kb.h, 1))
+    # (non-degenerate eigenvectors of the real-symmetric operator are real fields times a phase)
+    warm = Xc * np.exp(1j * rng.uniform(0, 2 * np.pi, M))[None, :]
+    lam_w, res_w, nit_w, conv_w, nmv_w, Xw = run_lobpcg(lib, kb, warm, 1e-7, n_conv_check=8)
+    assert conv_c == 1 and conv_w == 1 and nit_w <= 3
+    np.testing.assert_allclose(lam_w[:8], lam_c[:8], atol=1e-9)
+
+
 def test_scf_gamma_real_equals_complex():
     """Gamma-only silicon supercell: the SCF with real-symmetric orbitals (automatic at k = 0) ends at the energies,
     density, eigenvalues and SCF length of the general complex path."""

@@ -467,6 +467,10 @@ __device__ __forceinline__ void jac_st(cd& dst, double re, double im) { dst = ma
 __device__ __forceinline__ void jac_st(double& dst, double re, double) { dst = re; }
 #define JB 16
 #define J2B (2 * JB)
+// DFTK_MI_HEEV_CLOCK=1 (flags bit 2 of k_jacobi_round): wall ticks (100 MHz) of the phases of pair workgroup 0 and of the first
+// update workgroup, summed over the launches of one dense_heev call: [0] launches, [1] pair: entry -> block problem in LDS,
+// [2] the inner rounds, [3] U written, [4] update workgroup entry -> exit, [5] shader cycles of the inner rounds
+__device__ unsigned long long g_jac_clk[8];
 
 __host__ __device__ __forceinline__ void tournament_pair(int nb, int round, int k, int& p, int& q) {
     // nb even, round in [0, nb-1), k in [0, nb/2): pair k of the round; round < 0: the fixed pairing (2k, 2k+1)
@@ -525,8 +529,11 @@ __device__ __forceinline__ void jacobi_pair_part(int pair_id, int nb, int round,
                                                  const typename JacEl<REAL>::T* __restrict__ Uprev,
                                                  typename JacEl<REAL>::T* __restrict__ Ubuf,
                                                  typename JacEl<REAL>::T (*S)[J2B][J2B + 1],
-                                                 typename JacEl<REAL>::T (*U)[J2B + 1]) {
+                                                 typename JacEl<REAL>::T (*U)[J2B + 1], bool clk) {
     typedef typename JacEl<REAL>::T ET;
+    const bool stamp = clk && pair_id == 0 && threadIdx.x == 0;
+    long long w0 = 0, w1 = 0, c1 = 0;
+    if (stamp) w0 = wall_clock64();
     const int mode = round < 0 ? 1 : 0;
     int bp, bq;
     tournament_pair(nb, round, pair_id, bp, bq);
@@ -607,6 +614,10 @@ __device__ __forceinline__ void jacobi_pair_part(int pair_id, int nb, int round,
         jac_st(U[r][c], r == c ? 1.0 : 0.0, 0.0);
     }
     __syncthreads();
+    if (stamp) {
+        w1 = wall_clock64();
+        c1 = clock64();
+    }
     const int k1 = tid >> 4, k2 = tid & 15;
     const int nrounds = mode == 0 ? JB : JB - 1;
     int cur = 0;
@@ -706,10 +717,23 @@ __device__ __forceinline__ void jacobi_pair_part(int pair_id, int nb, int round,
         __syncthreads();
         cur ^= 1;
     }
+    long long w2 = 0, c2 = 0;
+    if (stamp) {
+        w2 = wall_clock64();
+        c2 = clock64();
+    }
     ET* Uo = Ubuf + (int64_t)pair_id * J2B * J2B;
     for (int e = tid; e < J2B * J2B; e += 256) {
         const int c = e / J2B, r = e - c * J2B;
         Uo[e] = U[r][c];   // column-major 2b x 2b
+    }
+    if (stamp) {
+        const long long w3 = wall_clock64();
+        atomicAdd(&g_jac_clk[0], 1ull);
+        atomicAdd(&g_jac_clk[1], (unsigned long long)(w1 - w0));
+        atomicAdd(&g_jac_clk[2], (unsigned long long)(w2 - w1));
+        atomicAdd(&g_jac_clk[3], (unsigned long long)(w3 - w2));
+        atomicAdd(&g_jac_clk[5], (unsigned long long)(c2 - c1));
     }
 }
 
@@ -863,11 +887,16 @@ __global__ __launch_bounds__(256) void k_jacobi_round(int n, int nb, int round, 
     __shared__ typename JacEl<REAL>::T S[2][J2B][J2B + 1];
     __shared__ typename JacEl<REAL>::T U[J2B][J2B + 1];
     const int npair_wg = (flags & 1) ? nb / 2 : 0;
-    if ((int)blockIdx.x < npair_wg)
-        jacobi_pair_part<REAL>(blockIdx.x, nb, round, prev_round, (flags & 2) != 0, Win, lda, Uprev, Uout, S, U);
-    else
+    if ((int)blockIdx.x < npair_wg) {
+        jacobi_pair_part<REAL>(blockIdx.x, nb, round, prev_round, (flags & 2) != 0, Win, lda, Uprev, Uout, S, U, (flags & 4) != 0);
+    } else {
+        const bool stamp = (flags & 4) && (int)blockIdx.x == npair_wg && threadIdx.x == 0;
+        long long w0 = 0;
+        if (stamp) w0 = wall_clock64();
         jacobi_update_part<REAL>(blockIdx.x - npair_wg, n, nb, prev_round, Win, Wout, lda, V, ldv, Uprev, ntiles, vblocks,
                            S[0]);
+        if (stamp) atomicAdd(&g_jac_clk[4], (unsigned long long)(wall_clock64() - w0));
+    }
 }
 
 // out[0] = sum |offdiag|^2, out[1] = sum |diag|^2   (whole matrix); out[2 nblocks + block] = sum Im^2
@@ -1074,8 +1103,14 @@ static int heev_impl(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, c
     const int ntiles = npairs * (npairs + 1) / 2, vblocks = (np / 16 + 3) / 4;
     int cur = 0, uw = 0, pending_round = 0;
     bool pending = false;
+    static const bool clk = getenv("DFTK_MI_HEEV_CLOCK") != nullptr;
+    if (clk) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_jac_clk), z, sizeof(z), 0, hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+    }
     auto launch_round = [&](bool do_pair, int round) {
-        const int flags = (do_pair ? 1 : 0) | (pending ? 2 : 0);
+        const int flags = (do_pair ? 1 : 0) | (pending ? 2 : 0) | (clk ? 4 : 0);
         const int grid = (do_pair ? npairs : 0) + (pending ? ntiles + npairs * vblocks : 0);
         if (grid == 0) return;
         hipLaunchKernelGGL(k_jacobi_round<REAL>, dim3(grid), dim3(256), 0, b->stream, np, nb, round, pending_round, flags,
@@ -1112,6 +1147,15 @@ static int heev_impl(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, c
         skip_next_check = off > 1e-2 * fro;
     }
     HIPCHK(hipGetLastError());
+    if (clk) {
+        unsigned long long h[8];
+        HIPCHK(hipStreamSynchronize(b->stream));
+        HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_jac_clk), sizeof(h)));
+        const double nl = h[0] ? (double)h[0] : 1.0;
+        fprintf(stderr, "[heev clock] n=%d sweeps=%d launches=%llu  per launch (us): setup %.2f  inner rounds %.2f (%.0f shader "
+                        "cycles)  U store %.2f | update workgroup %.2f\n", n, sweep, h[0], h[1] / nl * 0.01, h[2] / nl * 0.01,
+                h[5] / nl, h[3] / nl * 0.01, h[4] / nl * 0.01);
+    }
     if (!done) {
         dftk_set_error("dense_heev: Jacobi did not converge in %d sweeps (n=%d)", maxsweeps, n);
         return DFTK_MI_NUM_EIGEN;

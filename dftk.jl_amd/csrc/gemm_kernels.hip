@@ -430,7 +430,28 @@ __global__ __launch_bounds__(GEMM_WAVES * 64, M3_MIN_BLOCKS(CONJA)) void k_zgemm
     const int id = blockIdx.x;
     const int xcd = id & 7, slot = id >> 3;
     int z, row_t, col_t;
-    if (upper & 4) {
+    if (upper & 16) {
+        // compact UPPER launch: only the LIVE tiles exist in the grid (row panel r keeps its column tiles >= r BM / BN), the
+        // work items (k-chunk, row panel, live column tile) in this order are dealt to the XCDs in 8 contiguous blocks: an
+        // XCD sees at most two k-chunks, the column tiles of a row panel sit next to each other, every XCD gets the same
+        // number of items and no dead workgroup passes through the dispatcher (with the full grid below 38-44 % of the
+        // workgroups of an UPPER launch leave at once; measured: the live ones then spread unevenly over the CUs as soon
+        // as an XCD holds more than ~50 of them)
+        constexpr int q = GEMM_BM / BN;
+        int L = 0;
+        for (int r = 0; r < gm; ++r) L += max(0, gn - r * q);
+        const int N = L * nsplit, per = (N + 7) >> 3;
+        const int item = xcd * per + slot;
+        if (slot >= per || item >= N) return;   // whole workgroup
+        z = item / L;
+        int t = item - z * L, r = 0;
+        while (t >= gn - r * q) {
+            t -= gn - r * q;
+            ++r;
+        }
+        row_t = r;
+        col_t = r * q + t;
+    } else if (upper & 4) {
         // K-split launches: all tiles of one k-chunk on the SAME XCD, so that both the A chunk and the
         // B chunk are fetched from HBM once and shared through that XCD's L2
         const int per = gm * gn;
@@ -919,6 +940,8 @@ struct Split {
     int nsplit, kchunk;
     bool zmajor;
     cd* slab;
+    bool compact = false;   // UPPER interior launch over the live tiles only (k_zgemm_3m, `upper & 16`)
+    int live = 0;           // live tiles of the launch (compact: grid = 8 ceil(live nsplit / 8))
 };
 // UPPER launches of the 3M / REAL kernels rotate the row panels over the XCDs (k_zgemm_3m, `upper & 8`);
 // DFTK_MI_GEMM_NO_ROT=1 keeps the plain mapping (measurements)
@@ -931,7 +954,7 @@ static int64_t gemm_slots2() {
     return senv ? atoll(senv) : 512;   // resident workgroups of the 2-per-CU kernels
 }
 static Split gemm_plan_split(int64_t m, int64_t n, int64_t k, int upper, const std::vector<int>& live_rows, int kind,
-                             int64_t slots) {
+                             int64_t slots, bool compact_ok = false) {
     const int64_t plane = (int64_t)m * n * (int64_t)sizeof(cd);
     static const bool no_zmajor = getenv("DFTK_MI_GEMM_NO_ZMAJOR") != nullptr;
     static std::map<std::vector<int64_t>, std::pair<int, int>> plan_cache;   // key -> (nsplit, zmajor)
@@ -944,9 +967,11 @@ static Split gemm_plan_split(int64_t m, int64_t n, int64_t k, int upper, const s
     int64_t total = 0;
     for (int v : live_rows) total += v;
     const int gm_s = (int)live_rows.size();
-    int best_ns = 1, best_zm = 0;
+    // mapping of the launch: 0 row-major, 1 z-major, 2 compact (live tiles only, UPPER interior launches of the 3M family)
+    int best_ns = 1, best_zm = compact_ok ? 2 : 0;
     if (k >= 128 && total > 0 && total < slots) {
-        const std::vector<int64_t> key = {m, n, k, (int64_t)(upper & 1), (int64_t)kind, slots, (int64_t)rot_rows};
+        const std::vector<int64_t> key = {m, n, k, (int64_t)(upper & 1), (int64_t)kind, slots, (int64_t)rot_rows,
+                                          (int64_t)compact_ok};
         auto it = plan_cache.find(key);
         if (it != plan_cache.end()) {
             best_ns = it->second.first;
@@ -965,10 +990,13 @@ static Split gemm_plan_split(int64_t m, int64_t n, int64_t k, int upper, const s
                 int kc = (int)((k + ns - 1) / ns);
                 kc = (kc + 7) & ~7;
                 if ((int)((k + kc - 1) / kc) != ns) continue;
-                for (int zm = 0; zm < 2; ++zm) {
-                    if (zm && (ns < 8 || no_zmajor || k < 2048)) continue;
+                for (int zm = 0; zm < 3; ++zm) {
+                    if (zm == 1 && (ns < 8 || no_zmajor || k < 2048)) continue;
+                    if (zm == 2 && !compact_ok) continue;
                     int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (zm) {
+                    if (zm == 2) {
+                        load[0] = (total * ns + 7) / 8;   // equal contiguous blocks of work items
+                    } else if (zm) {
                         for (int z = 0; z < ns; ++z) load[z & 7] += total;
                     } else {
                         const int64_t R = (int64_t)gm_s * ns;
@@ -982,7 +1010,7 @@ static Split gemm_plan_split(int64_t m, int64_t n, int64_t k, int upper, const s
                     int64_t mx = 0;
                     for (int x = 0; x < 8; ++x) mx = load[x] > mx ? load[x] : mx;
                     const double rounds = std::ceil((double)mx / per_xcd);
-                    const double cost = rounds * (kc / 8.0 + 12.0) + (ns > 1 ? slab_cost * ns : 0.0) - (zm ? 1e-3 : 0.0);
+                    const double cost = rounds * (kc / 8.0 + 12.0) + (ns > 1 ? slab_cost * ns : 0.0) - 1e-3 * zm;
                     if (cost < best) {
                         best = cost;
                         best_ns = ns;
@@ -995,14 +1023,18 @@ static Split gemm_plan_split(int64_t m, int64_t n, int64_t k, int upper, const s
         }
     }
     static const int force_ns = getenv("DFTK_MI_GEMM_FORCE_NS") ? atoi(getenv("DFTK_MI_GEMM_FORCE_NS")) : 0;   // experiments
+    static const int force_mode = getenv("DFTK_MI_GEMM_FORCE_MODE") ? atoi(getenv("DFTK_MI_GEMM_FORCE_MODE")) : 0;
     if (force_ns > 0 && kind >= 3 && (kind & 1) && k >= 4096) {
         best_ns = force_ns;
-        best_zm = 0;
+        best_zm = (force_mode == 2 && compact_ok) ? 2 : (force_mode == 1 ? 1 : 0);
     }
     int kc = (int)((k + best_ns - 1) / best_ns);
     kc = (kc + 7) & ~7;
     const int ns = (int)((k + kc - 1) / kc);
-    return Split{ns, kc, best_zm != 0 && ns >= 8, nullptr};
+    Split sp{ns, kc, best_zm == 1 && ns >= 8, nullptr};
+    sp.compact = best_zm == 2;
+    sp.live = (int)total;
+    return sp;
 }
 
 // Tiling of one product for the default (3M) kernel family: interior rectangle of full 128 x BN tiles, ragged
@@ -1050,7 +1082,13 @@ static GemmTiling gemm_tiling(bool conja, int64_t m, int64_t n, int64_t k, int u
     for (int e = 0; e < t.nbottom; ++e) rowsB[t.nright + e] = live(t.gmf, e) ? 1 : 0;
     // the 3M kernel is compiled for M3_MIN_BLOCKS workgroups per CU
     const int64_t slots3 = use3m ? (slots2 / 2) * M3_MIN_BLOCKS(conja) : slots2;
-    t.I = gemm_plan_split(m, n, k, upper, rowsI, use3m ? 3 : 1, slots3);
+    // compact UPPER launches (k_zgemm_3m, `upper & 16`): the kernel rebuilds the live tile list as "row panel r keeps its
+    // column tiles >= r BM / BN" -- only used when that is exactly the list above
+    static const bool no_compact = getenv("DFTK_MI_GEMM_NO_COMPACT") != nullptr;
+    bool compact_ok = use3m && (upper & 1) && !no_compact && GEMM_BM % t.BNt == 0;
+    for (int tr = 0; tr < t.gmI && compact_ok; ++tr)
+        compact_ok = rowsI[tr] == std::max(0, t.gnI - tr * (GEMM_BM / t.BNt));
+    t.I = gemm_plan_split(m, n, k, upper, rowsI, use3m ? 3 : 1, slots3, compact_ok);
     t.B = gemm_plan_split(m, n, k, upper, rowsB, use3m ? 4 : 2, slots3);
     return t;
 }
@@ -1060,7 +1098,7 @@ int zgemm_plan_host(char transA, int64_t m, int64_t n, int64_t k, int flags, int
     const GemmTiling t = gemm_tiling(conja, m, n, k, flags & 3,
                                      getenv("DFTK_MI_GEMM_4M") == nullptr || (flags & DFTK_MI_GEMM_REAL),
                                      (flags & DFTK_MI_GEMM_REAL) != 0);
-    const int v[12] = {t.BNt, t.gmf, t.gnf, t.nright, t.nbottom, t.I.nsplit, t.I.kchunk, t.I.zmajor ? 1 : 0,
+    const int v[12] = {t.BNt, t.gmf, t.gnf, t.nright, t.nbottom, t.I.nsplit, t.I.kchunk, t.I.compact ? 2 : t.I.zmajor ? 1 : 0,
                        t.B.nsplit, t.B.kchunk, t.B.zmajor ? 1 : 0, t.shift};
     for (int i = 0; i < 12; ++i) out[i] = v[i];
     return 0;
@@ -1186,11 +1224,14 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
     auto launch = [&](int mode, int gm_s, int gn_s, int rt0, int ct0, int lsplit, const Split& sp) -> int {
         if (gm_s <= 0 || gn_s <= 0) return 0;
         const bool zmajor = sp.zmajor;
-        const int64_t nblk = zmajor ? (int64_t)((sp.nsplit + 7) / 8) * 8 * gm_s * gn_s : grid_for(gm_s, gn_s, sp.nsplit);
+        const bool compact = sp.compact && mode == 1 && lsplit < 0 && use3m;
+        const int64_t nblk = compact  ? (((int64_t)sp.live * sp.nsplit + 7) / 8) * 8
+                             : zmajor ? (int64_t)((sp.nsplit + 7) / 8) * 8 * gm_s * gn_s
+                                      : grid_for(gm_s, gn_s, sp.nsplit);
         if (nblk > INT32_MAX) return DFTK_MI_EINVAL;
         dim3 grid((unsigned)nblk);
-        const int upper = (upper_in & 3) | (zmajor ? 4 : 0) |
-                          ((!zmajor && (upper_in & 1) && use3m && gemm_rotate_rows() && gm_s <= 4) ? 8 : 0);
+        const int upper = (upper_in & 3) | (compact ? 16 : zmajor ? 4 : 0) |
+                          ((!compact && !zmajor && (upper_in & 1) && use3m && gemm_rotate_rows() && gm_s <= 4) ? 8 : 0);
 #define DFTK_LAUNCH_LDS(CJ, FL)                                                                                        \
     hipLaunchKernelGGL((k_zgemm_lds<CJ, FL>), grid, dim3(GEMM_WAVES * 64), pad_lds, b->stream, (int)m, (int)n, (int)k, \
                        sp.kchunk, gm_s, gn_s, rt0, ct0, lsplit, upper, sp.nsplit, A, lda, B, ldb, C, ldc, alpha, beta, sp.slab)

@@ -124,10 +124,12 @@ def test_zgemm(lib, trans, m, n, k):
     assert relerr(Cn.cpu().numpy().T, opA @ B) < 1e-13
 
 
-@pytest.mark.parametrize("m,k", [(259, 3000), (777, 2500), (141, 4100), (64, 300), (5, 2100)])
+@pytest.mark.parametrize("m,k", [(259, 3000), (777, 2500), (141, 4100), (64, 300), (5, 2100), (1006, 9000), (1300, 300)])
 def test_zgemm_upper_only(lib, m, k):
     """DFTK_MI_GEMM_UPPER: tiles that intersect the upper triangle hold A^H B, the others are untouched;
-    split-K (interior and border planned separately) must agree with the unsplit product."""
+    split-K (interior and border planned separately) must agree with the unsplit product.  The interior launch runs
+    over the live tiles only (compact grid, contiguous XCD blocks): 1006 = 8 row panels with a K split, 1300 = more
+    live tiles than resident workgroups, no split."""
     rng = np.random.default_rng(m + k)
     bs = Basis(lib, 8, 8, 8)
     A = rng.standard_normal((k, m)) + 1j * rng.standard_normal((k, m))

@@ -367,8 +367,16 @@ def test_zgemm_launch_plan_invariants(lib, trans, m, n, k):
         if 0 < full < 512 and k >= 2048 and not flags:
             # at least half a round of the 512 resident workgroups, at most a few balanced rounds
             assert 256 <= full * p["nsI"] <= 4 * 512
-        if p["zmI"]:
+        if p["zmI"] == 1:
             assert p["nsI"] >= 8 and k >= 2048
+        # UPPER interior launches run over their live tiles only (mapping 2): row panel r keeps the column tiles >= 4 r
+        assert (p["zmI"] == 2) == bool(flags)
+        if flags:
+            gmi, gni = p["gmf"] + shift_r, p["gnf"] + p["shift"]
+            live = sum(max(0, gni - 4 * r) for r in range(gmi))
+            assert live == sum(1 for r in range(gmi) for c in range(gni) if r * 128 < (n if (shift and c == gni - 1) else (c + 1) * 32))
+            if 0 < live < 512 and k >= 2048:
+                assert 256 <= live * p["nsI"] <= 4 * 512
     if trans == "N" and m > 100000:
         assert _gemm_plan(lib, trans, m, n, k)["nsI"] == 1      # thousands of tiles: no K split
     # the REAL (half-sphere) products run 128 x 64 tiles

@@ -471,6 +471,11 @@ __device__ __forceinline__ void jac_st(double& dst, double re, double) { dst = r
 // update workgroup, summed over the launches of one dense_heev call: [0] launches, [1] pair: entry -> block problem in LDS,
 // [2] the inner rounds, [3] U written, [4] update workgroup entry -> exit, [5] shader cycles of the inner rounds
 __device__ unsigned long long g_jac_clk[8];
+// same switch: [4 i] = first workgroup entry, [4 i + 1] / [4 i + 2] = last exit of a pair / update workgroup (absolute wall
+// ticks) of launch i < 1024; sampled: every pair workgroup, every 16th update workgroup
+__device__ unsigned long long g_jac_span[4096];
+// entry / exit ticks of pair workgroup p < 64 of launch i < 1024: [(i * 64 + p) * 2 + {0, 1}]
+__device__ unsigned long long g_jac_pair[1024 * 64 * 2];
 
 __host__ __device__ __forceinline__ void tournament_pair(int nb, int round, int k, int& p, int& q) {
     // nb even, round in [0, nb-1), k in [0, nb/2): pair k of the round; round < 0: the fixed pairing (2k, 2k+1)
@@ -887,6 +892,25 @@ __global__ __launch_bounds__(256) void k_jacobi_round(int n, int nb, int round, 
     __shared__ typename JacEl<REAL>::T S[2][J2B][J2B + 1];
     __shared__ typename JacEl<REAL>::T U[J2B][J2B + 1];
     const int npair_wg = (flags & 1) ? nb / 2 : 0;
+    const int seq = flags >> 8;
+    const bool is_pair = (int)blockIdx.x < npair_wg;
+    const bool sampled = (flags & 4) && threadIdx.x == 0 && seq < 1024 && (is_pair || ((blockIdx.x - npair_wg) & 15) == 0);
+    if (sampled) {
+        const unsigned long long t = wall_clock64();
+        atomicMin(&g_jac_span[4 * seq], t);
+        if (is_pair && blockIdx.x < 64) g_jac_pair[((size_t)seq * 64 + blockIdx.x) * 2] = t;
+    }
+    struct SpanEnd {
+        int cell, pcell;
+        bool on;
+        __device__ ~SpanEnd() {
+            if (on) {
+                const unsigned long long t = wall_clock64();
+                atomicMax(&g_jac_span[cell], t);
+                if (pcell >= 0) g_jac_pair[pcell] = t;
+            }
+        }
+    } span_end{4 * seq + (is_pair ? 1 : 2), (is_pair && blockIdx.x < 64) ? (int)(((size_t)seq * 64 + blockIdx.x) * 2 + 1) : -1, sampled};
     if ((int)blockIdx.x < npair_wg) {
         jacobi_pair_part<REAL>(blockIdx.x, nb, round, prev_round, (flags & 2) != 0, Win, lda, Uprev, Uout, S, U, (flags & 4) != 0);
     } else {
@@ -1104,13 +1128,20 @@ static int heev_impl(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, c
     int cur = 0, uw = 0, pending_round = 0;
     bool pending = false;
     static const bool clk = getenv("DFTK_MI_HEEV_CLOCK") != nullptr;
+    int clk_seq = 0;
     if (clk) {
         unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        HIPCHK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_jac_clk), z, sizeof(z), 0, hipMemcpyHostToDevice, b->stream));
+        std::vector<unsigned long long> sp(4096);
+        for (int i = 0; i < 1024; ++i) {
+            sp[4 * i] = ~0ull;
+            sp[4 * i + 1] = sp[4 * i + 2] = sp[4 * i + 3] = 0ull;
+        }
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_jac_clk), z, sizeof(z)));
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_jac_span), sp.data(), sp.size() * sizeof(unsigned long long)));
         HIPCHK(hipStreamSynchronize(b->stream));
     }
     auto launch_round = [&](bool do_pair, int round) {
-        const int flags = (do_pair ? 1 : 0) | (pending ? 2 : 0) | (clk ? 4 : 0);
+        const int flags = (do_pair ? 1 : 0) | (pending ? 2 : 0) | (clk ? 4 | (clk_seq++ << 8) : 0);
         const int grid = (do_pair ? npairs : 0) + (pending ? ntiles + npairs * vblocks : 0);
         if (grid == 0) return;
         hipLaunchKernelGGL(k_jacobi_round<REAL>, dim3(grid), dim3(256), 0, b->stream, np, nb, round, pending_round, flags,
@@ -1155,6 +1186,63 @@ static int heev_impl(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, c
         fprintf(stderr, "[heev clock] n=%d sweeps=%d launches=%llu  per launch (us): setup %.2f  inner rounds %.2f (%.0f shader "
                         "cycles)  U store %.2f | update workgroup %.2f\n", n, sweep, h[0], h[1] / nl * 0.01, h[2] / nl * 0.01,
                 h[5] / nl, h[3] / nl * 0.01, h[4] / nl * 0.01);
+        std::vector<unsigned long long> sp(4096);
+        HIPCHK(hipMemcpyFromSymbol(sp.data(), HIP_SYMBOL(g_jac_span), sp.size() * sizeof(unsigned long long)));
+        const int nsp = clk_seq < 1024 ? clk_seq : 1024;
+        double pe = 0.0, ue = 0.0, gap = 0.0;
+        int ng = 0, np_ = 0, nu = 0;
+        for (int i = 0; i < nsp; ++i) {
+            const unsigned long long t0 = sp[4 * i], tp = sp[4 * i + 1], tu = sp[4 * i + 2];
+            if (tp) {
+                pe += (double)(tp - t0);
+                ++np_;
+            }
+            if (tu) {
+                ue += (double)(tu - t0);
+                ++nu;
+            }
+            const unsigned long long prev_end = i > 0 ? std::max(sp[4 * i - 3], sp[4 * i - 2]) : 0ull;
+            if (i > 0 && t0 > prev_end) {
+                gap += (double)(t0 - prev_end);
+                ++ng;
+            }
+        }
+        if (nsp > 1 && nb / 2 <= 64) {
+            std::vector<unsigned long long> pr((size_t)1024 * 64 * 2);
+            HIPCHK(hipMemcpyFromSymbol(pr.data(), HIP_SYMBOL(g_jac_pair), pr.size() * sizeof(unsigned long long)));
+            const int npw = nb / 2;
+            double ent_avg = 0.0, ent_max = 0.0, dur_avg = 0.0, dur_max = 0.0;
+            int cnt = 0;
+            for (int i = 1; i < nsp; ++i) {   // launches with a pair part
+                double emax = 0.0, dmax = 0.0;
+                bool ok = true;
+                for (int q = 0; q < npw; ++q) {
+                    const unsigned long long e = pr[((size_t)i * 64 + q) * 2], x = pr[((size_t)i * 64 + q) * 2 + 1];
+                    if (e < sp[4 * i] || x < e) {
+                        ok = false;
+                        break;
+                    }
+                    ent_avg += (double)(e - sp[4 * i]);
+                    dur_avg += (double)(x - e);
+                    emax = std::max(emax, (double)(e - sp[4 * i]));
+                    dmax = std::max(dmax, (double)(x - e));
+                    ++cnt;
+                }
+                if (ok) {
+                    ent_max += emax;
+                    dur_max += dmax;
+                }
+            }
+            if (cnt)
+                fprintf(stderr, "[heev clock] pair workgroups: entry after the launch's first entry avg %.2f us (latest %.2f), entry -> "
+                                "exit avg %.2f us (slowest %.2f)\n", ent_avg / cnt * 0.01, ent_max / (nsp - 1) * 0.01,
+                        dur_avg / cnt * 0.01, dur_max / (nsp - 1) * 0.01);
+        }
+        if (nsp > 1)
+            fprintf(stderr, "[heev clock] from the first workgroup entry of a launch: last pair workgroup exit %.2f us, last (sampled) "
+                            "update workgroup exit %.2f us; last exit -> first entry of the next launch %.2f us; launch period "
+                            "%.2f us\n", np_ ? pe / np_ * 0.01 : 0.0, nu ? ue / nu * 0.01 : 0.0, ng ? gap / ng * 0.01 : 0.0,
+                    (double)(sp[4 * (nsp - 1)] - sp[0]) / (nsp - 1) * 0.01);
     }
     if (!done) {
         dftk_set_error("dense_heev: Jacobi did not converge in %d sweeps (n=%d)", maxsweeps, n);

@@ -647,59 +647,64 @@ __device__ __forceinline__ void jacobi_pair_part(int pair_id, int nb, int round,
         // Hardware rsq/rcp seeds + Newton steps instead of the library sqrt/div sequences: every thread
         // evaluates two of these per round, so they must be short; c gets two steps (c^2 + |s|^2 = 1 to
         // round-off keeps U unitary), the angle itself needs far less than full precision.
-        auto rotation = [&](int p, int q, double& c, cd& s) {
-            cd beta;
-            beta = jac_ld(Sc[p][q]);
-            const double al = jac_ld(Sc[p][p]).x, ga = jac_ld(Sc[q][q]).x;
-            const double b2 = REAL ? beta.x * beta.x : beta.x * beta.x + beta.y * beta.y;
-            c = 1.0;
-            s = make_double2(0.0, 0.0);
-            if (b2 > 1e-300 && b2 > 1e-36 * (fabs(al * ga) + 1e-300)) {
-                const double d = 0.5 * (ga - al);
-                const double x = fma(d, d, b2);
-                double r = __builtin_amdgcn_rsq(x);
-                r = r * fma(-0.5 * x * r, r, 1.5);
-                const double den = fabs(d) + x * r;
-                double u = __builtin_amdgcn_rcp(den);
-                u = u * fma(-den, u, 2.0);
-                const double y = fma(b2 * u, u, 1.0);
-                double cc = __builtin_amdgcn_rsq(y);
-                cc = cc * fma(-0.5 * y * cc, cc, 1.5);
-                cc = cc * fma(-0.5 * y * cc, cc, 1.5);
-                c = cc;
-                const double f = (d >= 0.0 ? cc : -cc) * u;
-                s = make_double2(f * beta.x, REAL ? 0.0 : f * beta.y);
-            }
+        // The round is a pure latency chain (one wave per SIMD, 16 rounds per launch, DFTK_MI_HEEV_CLOCK): ALL LDS operands
+        // of the round are fetched in one batch, and the rotations are evaluated without branches (a skipped rotation is
+        // a select at the end; its intermediate inf / NaN never leaves the registers) so that the two dependent chains of
+        // a thread interleave instead of running one after the other behind their own LDS waits.
+        // both rotations of the thread side by side (A = slot k1, B = slot k2)
+        auto rotation2 = [&](cd beA, double alA, double gaA, cd beB, double alB, double gaB, double& cA, cd& sA, double& cB,
+                             cd& sB) {
+            const double b2A = REAL ? beA.x * beA.x : beA.x * beA.x + beA.y * beA.y;
+            const double b2B = REAL ? beB.x * beB.x : beB.x * beB.x + beB.y * beB.y;
+            const bool actA = b2A > 1e-300 && b2A > 1e-36 * (fabs(alA * gaA) + 1e-300);
+            const bool actB = b2B > 1e-300 && b2B > 1e-36 * (fabs(alB * gaB) + 1e-300);
+            const double dA = 0.5 * (gaA - alA), dB = 0.5 * (gaB - alB);
+            const double xA = fma(dA, dA, b2A), xB = fma(dB, dB, b2B);
+            double rA = __builtin_amdgcn_rsq(xA), rB = __builtin_amdgcn_rsq(xB);
+            const double hA = -0.5 * xA * rA, hB = -0.5 * xB * rB;
+            rA = rA * fma(hA, rA, 1.5);
+            rB = rB * fma(hB, rB, 1.5);
+            const double denA = fabs(dA) + xA * rA, denB = fabs(dB) + xB * rB;
+            double uA = __builtin_amdgcn_rcp(denA), uB = __builtin_amdgcn_rcp(denB);
+            uA = uA * fma(-denA, uA, 2.0);
+            uB = uB * fma(-denB, uB, 2.0);
+            const double yA = fma(b2A * uA, uA, 1.0), yB = fma(b2B * uB, uB, 1.0);
+            double ccA = __builtin_amdgcn_rsq(yA), ccB = __builtin_amdgcn_rsq(yB);
+            const double gA = -0.5 * yA, gB = -0.5 * yB;
+            ccA = ccA * fma(gA * ccA, ccA, 1.5);
+            ccB = ccB * fma(gB * ccB, ccB, 1.5);
+            ccA = ccA * fma(gA * ccA, ccA, 1.5);
+            ccB = ccB * fma(gB * ccB, ccB, 1.5);
+            const double fA = (dA >= 0.0 ? ccA : -ccA) * uA, fB = (dB >= 0.0 ? ccB : -ccB) * uB;
+            cA = actA ? ccA : 1.0;
+            cB = actB ? ccB : 1.0;
+            sA = make_double2(actA ? fA * beA.x : 0.0, (REAL || !actA) ? 0.0 : fA * beA.y);
+            sB = make_double2(actB ? fB * beB.x : 0.0, (REAL || !actB) ? 0.0 : fB * beB.y);
         };
         int p1, q1, p2, q2;
         pair_of(k1, p1, q1);
         pair_of(k2, p2, q2);
+        const cd be1 = jac_ld(Sc[p1][q1]), be2 = jac_ld(Sc[p2][q2]);
+        const double al1 = jac_ld(Sc[p1][p1]).x, ga1 = jac_ld(Sc[q1][q1]).x;
+        const double al2 = jac_ld(Sc[p2][p2]).x, ga2 = jac_ld(Sc[q2][q2]).x;
+        const ET a = Sc[p1][p2], b2 = Sc[p1][q2], c3 = Sc[q1][p2], d = Sc[q1][q2];
+        const ET x0p = U[k2][p1], x0q = U[k2][q1], x1p = U[k2 + JB][p1], x1q = U[k2 + JB][q1];
+        __builtin_amdgcn_sched_barrier(0);   // the 14 LDS reads above are issued before any of the arithmetic below
         double c1, c2;
         cd s1, s2;
-        rotation(p1, q1, c1, s1);
-        if (k1 == k2) {
-            c2 = c1;
-            s2 = s1;
-        } else {
-            rotation(p2, q2, c2, s2);
-        }
+        rotation2(be1, al1, ga1, be2, al2, ga2, c1, s1, c2, s2);   // (k1 == k2: the same inputs, the same rotation twice)
         if constexpr (REAL) {
-            const double a = Sc[p1][p2], b2 = Sc[p1][q2], c3 = Sc[q1][p2], d = Sc[q1][q2];
             const double ra = c1 * a - s1.x * c3, rb = c1 * b2 - s1.x * d;
             const double rc = s1.x * a + c1 * c3, rdd = s1.x * b2 + c1 * d;
             Sn[p1][p2] = c2 * ra - s2.x * rb;
             Sn[p1][q2] = s2.x * ra + c2 * rb;
             Sn[q1][p2] = c2 * rc - s2.x * rdd;
             Sn[q1][q2] = s2.x * rc + c2 * rdd;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int r = k2 + JB * h;
-                const double xp = U[r][p1], xq = U[r][q1];
-                U[r][p1] = c1 * xp - s1.x * xq;
-                U[r][q1] = s1.x * xp + c1 * xq;
-            }
+            U[k2][p1] = c1 * x0p - s1.x * x0q;
+            U[k2][q1] = s1.x * x0p + c1 * x0q;
+            U[k2 + JB][p1] = c1 * x1p - s1.x * x1q;
+            U[k2 + JB][q1] = s1.x * x1p + c1 * x1q;
         } else {
-            const cd a = Sc[p1][p2], b2 = Sc[p1][q2], c3 = Sc[q1][p2], d = Sc[q1][q2];
             // rows: (row_p, row_q) <- (c row_p - s row_q, conj(s) row_p + c row_q)
             const cd ra = make_double2(c1 * a.x - (s1.x * c3.x - s1.y * c3.y), c1 * a.y - (s1.x * c3.y + s1.y * c3.x));
             const cd rb = make_double2(c1 * b2.x - (s1.x * d.x - s1.y * d.y), c1 * b2.y - (s1.x * d.y + s1.y * d.x));
@@ -711,13 +716,10 @@ __device__ __forceinline__ void jacobi_pair_part(int pair_id, int nb, int round,
             Sn[q1][p2] = make_double2(c2 * rc.x - (s2.x * rdd.x + s2.y * rdd.y), c2 * rc.y - (s2.x * rdd.y - s2.y * rdd.x));
             Sn[q1][q2] = make_double2(s2.x * rc.x - s2.y * rc.y + c2 * rdd.x, s2.x * rc.y + s2.y * rc.x + c2 * rdd.y);
             // column rotations of U: rows k2 and k2 + 16, rotation k1
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int r = k2 + JB * h;
-                const cd xp = U[r][p1], xq = U[r][q1];
-                U[r][p1] = make_double2(c1 * xp.x - (s1.x * xq.x + s1.y * xq.y), c1 * xp.y - (s1.x * xq.y - s1.y * xq.x));
-                U[r][q1] = make_double2(s1.x * xp.x - s1.y * xp.y + c1 * xq.x, s1.x * xp.y + s1.y * xp.x + c1 * xq.y);
-            }
+            U[k2][p1] = make_double2(c1 * x0p.x - (s1.x * x0q.x + s1.y * x0q.y), c1 * x0p.y - (s1.x * x0q.y - s1.y * x0q.x));
+            U[k2][q1] = make_double2(s1.x * x0p.x - s1.y * x0p.y + c1 * x0q.x, s1.x * x0p.y + s1.y * x0p.x + c1 * x0q.y);
+            U[k2 + JB][p1] = make_double2(c1 * x1p.x - (s1.x * x1q.x + s1.y * x1q.y), c1 * x1p.y - (s1.x * x1q.y - s1.y * x1q.x));
+            U[k2 + JB][q1] = make_double2(s1.x * x1p.x - s1.y * x1p.y + c1 * x1q.x, s1.x * x1p.y + s1.y * x1p.x + c1 * x1q.y);
         }
         __syncthreads();
         cur ^= 1;

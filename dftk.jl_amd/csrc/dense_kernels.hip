@@ -881,10 +881,15 @@ __device__ __forceinline__ void jacobi_update_part(int id, int n, int nb, int ro
     }
 }
 
+// workgroups per CU the round kernel is compiled for (REAL: 83 VGPRs -> 80: one more resident workgroup per CU for the
+// update part, which is the longer one from ~1300 x 1300 on; the complex kernel needs its 130)
+#ifndef JAC_MIN_BLOCKS
+#define JAC_MIN_BLOCKS(REAL) ((REAL) ? 6 : 1)
+#endif
 // One launch per round: pair workgroups of `round` first (they are the critical path), then the update
 // workgroups of `prev_round`.  flags bit 0: pair part present, bit 1: a previous round is pending.
 template <bool REAL>
-__global__ __launch_bounds__(256) void k_jacobi_round(int n, int nb, int round, int prev_round, int flags,
+__global__ __launch_bounds__(256, JAC_MIN_BLOCKS(REAL)) void k_jacobi_round(int n, int nb, int round, int prev_round, int flags,
                                                       const typename JacEl<REAL>::T* __restrict__ Win,
                                                       typename JacEl<REAL>::T* __restrict__ Wout, int64_t lda,
                                                       typename JacEl<REAL>::T* __restrict__ V, int64_t ldv,

@@ -55,7 +55,9 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100, help="cap on the timed SCF steps (stops earlier at convergence)")
-    ap.add_argument("--warmup", type=int, default=1, help="SCF steps on a throw-away stepper before the timed run")
+    ap.add_argument("--warmup", type=int, default=3,
+                    help="SCF steps on a throw-away stepper before the timed run (3: the Anderson / mixing paths of the second and "
+                         "third step are warm as well -- their first-use cost is 50 ms, visible on the 0.4 s k-point SCFs)")
     ap.add_argument("--mode", choices=("gamma", "kpoints", "weak"), default="gamma")
     ap.add_argument("--supercell", type=int, default=5, help="n for the n x n x n Si supercell (5 = 1000 e-, 4 = configs[1])")
     ap.add_argument("--ecut", type=float, default=None)
@@ -387,6 +389,10 @@ def run_scf(dftk, lib, basis, args, barrier, world, dist, torch):
         nmv_steps.append(int(info["n_matvec_step"]))
         for k_, v_ in info["timers"].items():
             host_timers[k_] = host_timers.get(k_, 0.0) + v_
+        if os.environ.get("DFTK_MI_BENCH_STEP_TIMERS"):      # where a slow step spent its time (stderr, rank 0)
+            if int(os.environ.get("RANK", "0")) == 0:
+                print(f"[step {len(step_s)}] {step_s[-1] * 1e3:.1f} ms: "
+                      + ", ".join(f"{k_} {v_ * 1e3:.1f}" for k_, v_ in info["timers"].items()), file=sys.stderr)
         if info["converged"]:
             break
     info = stepper.finalize()                                # energies + Hamiltonian of the final state, as the reference

@@ -404,6 +404,13 @@ extern "C" int dftk_mi_kblock_create(dftk_mi_basis* b, int64_t n_G, const int64_
     kb->n_G = n_G;
     kb->n_lines = n_lines;
     kb->nzx = (int)t.zval.size();
+    {   // wrap-around contiguity of the sphere's z planes (index arithmetic instead of a table in k_zpass_reg)
+        int lo = 0;
+        while (lo < kb->nzx && t.zval[lo] == lo) ++lo;
+        bool ok = true;
+        for (int i = lo; i < kb->nzx; ++i) ok = ok && t.zval[i] == b->nz - (kb->nzx - i);
+        kb->z_lo = ok ? lo : -1;
+    }
     CHK(upload(cpos, &kb->d_cpos));
     CHK(upload(cx, &kb->d_cx));
     CHK(upload(line_start, &kb->d_line_start));

@@ -128,6 +128,8 @@ struct dftk_mi_kblock {
     int64_t n_G;
     int64_t n_lines;              // non-empty x-lines (iy, iz)
     int nzx;                      // distinct z planes touched by the sphere
+    int z_lo;                     // the sphere planes are {0 .. z_lo-1} u {nz-(nzx-z_lo) .. nz-1} (always so for a sphere
+                                  // of G vectors; -1 otherwise: the register-resident z kernels then stay off)
     // device tables (owned)
     int*   d_cpos;                // [n_G]   pos_x[ix] of each coefficient
     int*   d_line_start;          // [n_lines+1] first coefficient of each line

@@ -20,6 +20,7 @@
 #include "batch.h"
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 
 #define FFT_L 8
 #ifndef ZPASS_MIN_BLOCKS
@@ -511,6 +512,210 @@ __global__ __launch_bounds__(FFT_THREADS, ZPASS_MIN_BLOCKS) void k_zpass(FftAxis
     for (int zi = j; zi < nzx; zi += FFT_TPL) t2[(int64_t)zi * plane] = buf[zpos[zi] * FFT_LS + l];
 }
 
+// ---------------------------------------------------------------------------------------- stage C, register-resident
+// "Four-step" z pass for n = R1 * R2 (R1 = R1A * R1B, R2 = R2A * R2B, all factors in {2, 3, 4, 5}): every thread holds a
+// whole R1- or R2-point sub-transform in registers (Cooley-Tukey R?A x R?B with COMPILE-TIME twiddles), the tile goes
+// through LDS only for the transposition between the two sub-transforms:
+//   backward:  thread n2 < R2 loads x[R2 n1 + n2] straight from T2 (sphere planes by index arithmetic, zeros elsewhere),
+//              DFT_R1 over n1, twiddle w^(n2 k1), LDS [k1][n2];  thread k1 < R1 reads its row, DFT_R2 over n2 ->
+//              the natural-order values psi(z = k1 + R1 k2) -- multiplied by V(z) in registers;
+//   forward:   the SAME thread already holds the inputs of its R2-point sub-transform (over k2): DFT_R2, twiddle
+//              w^-(k1 k1'), LDS [k1'][k1];  thread k1' < R2 reads its row, DFT_R1 over k1 -> frequencies
+//              z' = k1' + R2 k2', the sphere planes of which go straight back to T2.
+// Two LDS round trips and three barriers per tile instead of five passes with a barrier each, no zero fill, no position
+// tables, and 45 % fewer instructions (the 16- and 12-point butterflies need no twiddle loads).
+namespace ctw {
+constexpr double PI = 3.14159265358979323846264338327950288;
+constexpr double sin_small(double x) {   // |x| <= pi/4: Taylor series to x^25
+    const double x2 = x * x;
+    double term = x, sum = x;
+    for (int k = 1; k <= 12; ++k) {
+        term *= -x2 / (double)((2 * k) * (2 * k + 1));
+        sum += term;
+    }
+    return sum;
+}
+constexpr double cos_small(double x) {
+    const double x2 = x * x;
+    double term = 1.0, sum = 1.0;
+    for (int k = 1; k <= 12; ++k) {
+        term *= -x2 / (double)((2 * k - 1) * (2 * k));
+        sum += term;
+    }
+    return sum;
+}
+struct CS {
+    double c, s;
+};
+constexpr CS cs(int m, int N) {   // exp(2 pi i m / N), evaluated by the compiler
+    m %= N;
+    if (m < 0) m += N;
+    const int k = (8 * m + N) / (2 * N);   // nearest quarter turn
+    const double delta = 2.0 * PI * (double)(4 * m - k * N) / (4.0 * (double)N);
+    const double c = cos_small(delta), s = sin_small(delta);
+    switch (k & 3) {
+        case 0: return CS{c, s};
+        case 1: return CS{-s, c};
+        case 2: return CS{-c, -s};
+        default: return CS{s, -c};
+    }
+}
+}   // namespace ctw
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+// a * exp(SGN 2 pi i M / N) with the twiddle folded into the instruction stream
+template <int N, int SGN, int M>
+__device__ __forceinline__ cd tw_mul_c(cd a) {
+    constexpr int m = ((M % N) + N) % N;
+    if constexpr (m == 0) {
+        return a;
+    } else if constexpr (2 * m == N) {
+        return make_double2(-a.x, -a.y);
+    } else if constexpr (4 * m == N) {
+        return SGN > 0 ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x);
+    } else if constexpr (4 * m == 3 * N) {
+        return SGN > 0 ? make_double2(a.y, -a.x) : make_double2(-a.y, a.x);
+    } else {
+        constexpr ctw::CS w = ctw::cs(m, N);
+        constexpr double c = w.c, s = (SGN > 0 ? w.s : -w.s);
+        return make_double2(fma(a.x, c, -a.y * s), fma(a.x, s, a.y * c));
+    }
+}
+// In-register DFT of RA * RB points: input index n = RB a + b, result x[RB c + d] = X[c + RA d]
+template <int RA, int RB, int SGN>
+__device__ __forceinline__ void dft_ct(cd (&x)[RA * RB]) {
+    static_for<0, RB>([&](auto bi) {
+        constexpr int b = decltype(bi)::value;
+        cd t[RA];
+#pragma unroll
+        for (int a = 0; a < RA; ++a) t[a] = x[RB * a + b];
+        dft_small<RA>(t, (double)SGN, nullptr, 0);
+        static_for<0, RA>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            x[RB * c + b] = tw_mul_c<RA * RB, SGN, b * c>(t[c]);
+        });
+    });
+    static_for<0, RA>([&](auto ci) {
+        constexpr int c = decltype(ci)::value;
+        cd u[RB];
+#pragma unroll
+        for (int b = 0; b < RB; ++b) u[b] = x[RB * c + b];
+        dft_small<RB>(u, (double)SGN, nullptr, 0);
+#pragma unroll
+        for (int d = 0; d < RB; ++d) x[RB * c + d] = u[d];
+    });
+}
+
+#ifndef ZREG_MIN_BLOCKS
+#define ZREG_MIN_BLOCKS 3   // waves per SIMD the kernel is compiled for (LDS: 24.8 KB per 128-thread workgroup at 192 -> 6 per CU = 3 waves per SIMD)
+#endif
+template <int R1A, int R1B, int R2A, int R2B>
+__global__ __launch_bounds__(FFT_L * ((R1A * R1B > R2A * R2B) ? R1A * R1B : R2A * R2B), ZREG_MIN_BLOCKS)
+void k_zpass_reg(FftAxis az, int nx, int nxp, int ny, int nzx, int z_lo, int nbands, const double* __restrict__ Vs,
+                 cd* __restrict__ T2, int64_t T2_stride) {
+    constexpr int R1 = R1A * R1B, R2 = R2A * R2B, N = R1 * R2;
+    constexpr int L = FFT_L;
+    constexpr int P1 = R2 * L + 1, P2 = R1 * L + 1;   // row pitches of the two transposition images (odd: conflict-free)
+    cd* buf = reinterpret_cast<cd*>(dftk_smem);
+    const int tid = threadIdx.x, l = tid & (L - 1), j = tid >> 3;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int band = slot % nbands;
+    const int grp = (slot / nbands) * 8 + xcd;
+    const int nxt = nxp / L;
+    if (grp >= nxt * ny) return;   // whole workgroup, before any barrier
+    const int y = grp / nxt;
+    const int x = (grp - y * nxt) * L + l;
+    const int64_t plane = (int64_t)ny * nxp;
+    const int64_t col = (int64_t)y * nxp + x;
+    cd* __restrict__ t2 = T2 + (int64_t)band * T2_stride + col;
+    const cd* __restrict__ twg = az.tw;        // exp(+2 pi i t / N)
+    const int zneg0 = N - (nzx - z_lo);        // first plane of the negative-frequency part
+    auto plane_of = [&](int z) { return z < z_lo ? z : (z >= zneg0 ? z - (N - nzx) : -1); };
+
+    // ---- backward, first sub-transform (threads n2 = j < R2)
+    if (j < R2) {
+        cd a[R1];
+        static_for<0, R1>([&](auto ni) {
+            constexpr int n1 = decltype(ni)::value;
+            const int zi = plane_of(R2 * n1 + j);
+            a[n1] = make_double2(0.0, 0.0);
+            if (zi >= 0) a[n1] = t2[(int64_t)zi * plane];
+        });
+        const cd w1 = twg[j], wA = twg[j * R1A];   // bases of the twiddles w^(j k1), k1 = c + R1A d
+        dft_ct<R1A, R1B, +1>(a);
+        cd wd = make_double2(1.0, 0.0);
+        static_for<0, R1B>([&](auto di) {
+            constexpr int d = decltype(di)::value;
+            if constexpr (d > 0) wd = (d == 1) ? wA : cmul(wd, wA);
+            cd w = wd;
+            static_for<0, R1A>([&](auto ci) {
+                constexpr int c = decltype(ci)::value;
+                if constexpr (c > 0) w = cmul(w, w1);
+                constexpr int k1 = c + R1A * d;
+                const cd v = (k1 == 0) ? a[R1B * c + d] : cmul(a[R1B * c + d], w);
+                buf[k1 * P1 + j * L + l] = v;
+            });
+        });
+    }
+    __syncthreads();
+    // ---- backward, second sub-transform; V; forward, first sub-transform (threads k1 = j < R1)
+    cd b2[R2];
+    double vv[R2];
+    if (j < R1) {
+        const double* __restrict__ vcol = Vs + col + (int64_t)j * plane;
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) vv[k2] = vcol[(int64_t)(R1 * k2) * plane];
+#pragma unroll
+        for (int n2 = 0; n2 < R2; ++n2) b2[n2] = buf[j * P1 + n2 * L + l];
+    }
+    __syncthreads();   // every row of the first image has been read: the second image may overwrite it
+    if (j < R1) {
+        dft_ct<R2A, R2B, +1>(b2);           // b2[R2B c + d] = psi(z = j + R1 (c + R2A d))
+        cd f[R2];
+        static_for<0, R2>([&](auto pi) {
+            constexpr int p = decltype(pi)::value;
+            constexpr int k2 = p / R2B + R2A * (p % R2B);
+            f[k2] = make_double2(b2[p].x * vv[k2], b2[p].y * vv[k2]);
+        });
+        const cd w1 = twg[j], wA = twg[j * R2A];   // twiddles conj(w)^(j k1'), k1' = c + R2A d
+        dft_ct<R2A, R2B, -1>(f);
+        cd wd = make_double2(1.0, 0.0);
+        static_for<0, R2B>([&](auto di) {
+            constexpr int d = decltype(di)::value;
+            if constexpr (d > 0) wd = (d == 1) ? wA : cmul(wd, wA);
+            cd w = wd;
+            static_for<0, R2A>([&](auto ci) {
+                constexpr int c = decltype(ci)::value;
+                if constexpr (c > 0) w = cmul(w, w1);
+                constexpr int k1p = c + R2A * d;
+                const cd wc = make_double2(w.x, -w.y);
+                const cd v = (k1p == 0) ? f[R2B * c + d] : cmul(f[R2B * c + d], wc);
+                buf[k1p * P2 + j * L + l] = v;
+            });
+        });
+    }
+    __syncthreads();
+    // ---- forward, second sub-transform (threads k1' = j < R2): frequencies z' = j + R2 (c + R1A d)
+    if (j < R2) {
+        cd a[R1];
+#pragma unroll
+        for (int k1 = 0; k1 < R1; ++k1) a[k1] = buf[j * P2 + k1 * L + l];
+        dft_ct<R1A, R1B, -1>(a);
+        static_for<0, R1>([&](auto pi) {
+            constexpr int p = decltype(pi)::value;
+            constexpr int k2p = p / R1B + R1A * (p % R1B);
+            const int zi = plane_of(j + R2 * k2p);
+            if (zi >= 0) t2[(int64_t)zi * plane] = a[p];
+        });
+    }
+}
+
 // ---------------------------------------------------------------------------------------- stage D
 template <bool GEN>
 __global__ __launch_bounds__(FFT_THREADS, YFWD_MIN_BLOCKS) void k_yfwd(FftAxis ay, int nxp, int ny,
@@ -753,6 +958,29 @@ static bool axis_generic(const FftAxis& ax) {
         }                                                                                                   \
     } while (0)
 
+// register-resident stage C (k_zpass_reg): launched for the axis lengths with an instantiated factorisation when the sphere's
+// z planes wrap around contiguously (kb->z_lo >= 0); DFTK_MI_FFT_REG=0 keeps the LDS-pass kernel.  Returns 1 if not applicable.
+template <int R1A, int R1B, int R2A, int R2B>
+static int launch_zpass_reg_t(dftk_mi_kblock* kb, int nbb, dim3 grid, int64_t s2) {
+    dftk_mi_basis* b = kb->basis;
+    constexpr int R1 = R1A * R1B, R2 = R2A * R2B, TPL = R1 > R2 ? R1 : R2;
+    constexpr int P1 = R2 * FFT_L + 1, P2 = R1 * FFT_L + 1;
+    const size_t lds = (size_t)std::max(R1 * P1, R2 * P2) * sizeof(cd);
+    CHK(set_lds_attr(k_zpass_reg<R1A, R1B, R2A, R2B>, lds));
+    hipLaunchKernelGGL((k_zpass_reg<R1A, R1B, R2A, R2B>), grid, dim3(FFT_L * TPL), lds, b->stream, b->ax[2], b->nx, b->nxp, b->ny,
+                       kb->nzx, kb->z_lo, nbb, (const double*)kb->d_Vs, b->T2, s2);
+    return 0;
+}
+static int launch_zpass_reg(dftk_mi_kblock* kb, int nbb, dim3 grid, int64_t s2) {
+    static const bool off = getenv("DFTK_MI_FFT_REG") != nullptr && atoi(getenv("DFTK_MI_FFT_REG")) == 0;
+    if (off || kb->z_lo < 0) return 1;
+    switch (kb->basis->nz) {
+        case 192: return launch_zpass_reg_t<4, 4, 4, 3>(kb, nbb, grid, s2);
+        case 150: return launch_zpass_reg_t<5, 3, 5, 2>(kb, nbb, grid, s2);
+        default: return 1;
+    }
+}
+
 // 1-D grid of k_zpass: (x tile, y) columns rounded up to a multiple of the 8 XCDs, times the bands of the launch
 static dim3 zpass_grid(const dftk_mi_basis* b, int nbands) {
     const int64_t groups = (int64_t)(b->nxp / FFT_L) * b->ny;
@@ -829,7 +1057,10 @@ int launch_local_apply(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi,
         const int pc = prof_begin(b, PROF_FFT_C, 2.0 * 16.0 * (double)kb->nzx * b->ny * b->nxp * nbb +
                                                      8.0 * (double)b->nz * b->ny * b->nxp);
         static const bool twg = getenv("DFTK_MI_FFT_TWG") != nullptr;
-        if (twg && !axis_generic(b->ax[2])) {
+        const int reg_st = launch_zpass_reg(kb, nbb, zpass_grid(b, nbb), st.s2);
+        if (reg_st < 0) return reg_st;
+        if (reg_st == 0) {
+        } else if (twg && !axis_generic(b->ax[2])) {
             const size_t lds = (size_t)b->nz * FFT_LS_YZ * sizeof(cd);
             CHK(set_lds_attr(k_zpass<0, false, true>, lds));
             hipLaunchKernelGGL((k_zpass<0, false, true>), zpass_grid(b, nbb), dim3(FFT_THREADS), lds, b->stream, b->ax[2],

@@ -330,6 +330,7 @@ extern __shared__ __attribute__((aligned(16))) char dftk_smem[];
 // grid is sized for the largest k-block and surplus workgroups of smaller ones leave at once.
 struct FftJob {
     const int *line_start, *cpos, *line_ypos, *zls, *zpos;
+    int z_lo;                 // register-resident z kernels: sphere planes with z < nz/2
     const double* kin;    // stage E: kinetic multiplier (or null)
     const double* Vs;     // stage C: this k-block's padded potential / N
     const cd* psi;        // the band's sphere coefficients (stage A input, stage E kinetic term)
@@ -613,105 +614,192 @@ __device__ __forceinline__ void dft_ct(cd (&x)[RA * RB]) {
 }
 
 #ifndef ZREG_MIN_BLOCKS
-#define ZREG_MIN_BLOCKS 3   // waves per SIMD the kernel is compiled for (LDS: 24.8 KB per 128-thread workgroup at 192 -> 6 per CU = 3 waves per SIMD)
+#define ZREG_MIN_BLOCKS 3   // waves per SIMD the register-resident kernels are compiled for (second argument of HIP's
+                            // __launch_bounds__ = waves per execution unit; LDS allows 6 workgroups of 2 waves at 192)
 #endif
+// One tile (FFT_L lines) of four-step transforms of length N = R1 R2.  Threads (l, j): l = line, j < max(R1, R2).
+template <int R1A, int R1B, int R2A, int R2B>
+struct FourStep {
+    static constexpr int R1 = R1A * R1B, R2 = R2A * R2B, N = R1 * R2, L = FFT_L;
+    static constexpr int TPL = R1 > R2 ? R1 : R2, THREADS = L * TPL;
+    static constexpr int P1 = R2 * L + 1, P2 = R1 * L + 1;   // row pitches of the two transposition images (odd: conflict-free)
+    static constexpr int LDS_ELEMS = R1 * P1 > R2 * P2 ? R1 * P1 : R2 * P2;
+    // natural index of register p of a finished sub-transform (dft_ct's output order)
+    static constexpr int k2_of(int p) { return p / R2B + R2A * (p % R2B); }    // DFT_R2 results: index k2
+    static constexpr int k2p_of(int p) { return p / R1B + R1A * (p % R1B); }   // DFT_R1 results: index k2'
+
+    // Backward transform (exp(+i)).  in(e): input element e in natural order (zero where the pruned pipeline has nothing).
+    // Thread j < R1 receives out[p] = X[j + R1 k2_of(p)].  Ends after the LDS reads: the caller places a barrier before the
+    // tile image is written again.
+    template <class IN>
+    static __device__ __forceinline__ void backward(cd* buf, const cd* __restrict__ twg, int l, int j, IN in, cd (&out)[R2]) {
+        if (j < R2) {
+            cd a[R1];
+            static_for<0, R1>([&](auto ni) {
+                constexpr int n1 = decltype(ni)::value;
+                a[n1] = in(R2 * n1 + j);
+            });
+            const cd w1 = twg[j], wA = twg[j * R1A];   // bases of the twiddles w^(j k1), k1 = c + R1A d
+            dft_ct<R1A, R1B, +1>(a);
+            cd wd = make_double2(1.0, 0.0);
+            static_for<0, R1B>([&](auto di) {
+                constexpr int d = decltype(di)::value;
+                if constexpr (d > 0) wd = (d == 1) ? wA : cmul(wd, wA);
+                cd w = wd;
+                static_for<0, R1A>([&](auto ci) {
+                    constexpr int c = decltype(ci)::value;
+                    if constexpr (c > 0) w = cmul(w, w1);
+                    constexpr int k1 = c + R1A * d;
+                    buf[k1 * P1 + j * L + l] = (k1 == 0) ? a[R1B * c + d] : cmul(a[R1B * c + d], w);
+                });
+            });
+        }
+        __syncthreads();
+        if (j < R1) {
+#pragma unroll
+            for (int n2 = 0; n2 < R2; ++n2) out[n2] = buf[j * P1 + n2 * L + l];
+            dft_ct<R2A, R2B, +1>(out);
+        }
+    }
+    // Forward transform (exp(-i)) of f[k2] = x[j + R1 k2] held by thread j < R1 (natural k2 order).  Thread j < R2 receives
+    // out[p] = X[j + R2 k2p_of(p)].  Starts by writing the tile image: barrier before if it may still be read.
+    static __device__ __forceinline__ void forward(cd* buf, const cd* __restrict__ twg, int l, int j, cd (&f)[R2],
+                                                   cd (&out)[R1]) {
+        if (j < R1) {
+            const cd w1 = twg[j], wA = twg[j * R2A];   // twiddles conj(w)^(j k1'), k1' = c + R2A d
+            dft_ct<R2A, R2B, -1>(f);
+            cd wd = make_double2(1.0, 0.0);
+            static_for<0, R2B>([&](auto di) {
+                constexpr int d = decltype(di)::value;
+                if constexpr (d > 0) wd = (d == 1) ? wA : cmul(wd, wA);
+                cd w = wd;
+                static_for<0, R2A>([&](auto ci) {
+                    constexpr int c = decltype(ci)::value;
+                    if constexpr (c > 0) w = cmul(w, w1);
+                    constexpr int k1p = c + R2A * d;
+                    buf[k1p * P2 + j * L + l] = (k1p == 0) ? f[R2B * c + d] : cmul(f[R2B * c + d], make_double2(w.x, -w.y));
+                });
+            });
+        }
+        __syncthreads();
+        if (j < R2) {
+#pragma unroll
+            for (int k1 = 0; k1 < R1; ++k1) out[k1] = buf[j * P2 + k1 * L + l];
+            dft_ct<R1A, R1B, -1>(out);
+        }
+    }
+};
+// wrap-around contiguous index sets (sphere planes along z, sphere lines of a plane along y): the first `lo` natural
+// indices and the last `cnt - lo` of n hold entries 0 .. cnt-1 in ascending order
+__device__ __forceinline__ int wrap_index(int e, int lo, int cnt, int n) {
+    return e < lo ? e : (e >= n - (cnt - lo) ? e - (n - cnt) : -1);
+}
+
+// stage C: backward z, multiply by V / N, forward z, in place on the sphere planes of T2
 template <int R1A, int R1B, int R2A, int R2B>
 __global__ __launch_bounds__(FFT_L * ((R1A * R1B > R2A * R2B) ? R1A * R1B : R2A * R2B), ZREG_MIN_BLOCKS)
 void k_zpass_reg(FftAxis az, int nx, int nxp, int ny, int nzx, int z_lo, int nbands, const double* __restrict__ Vs,
-                 cd* __restrict__ T2, int64_t T2_stride) {
-    constexpr int R1 = R1A * R1B, R2 = R2A * R2B, N = R1 * R2;
-    constexpr int L = FFT_L;
-    constexpr int P1 = R2 * L + 1, P2 = R1 * L + 1;   // row pitches of the two transposition images (odd: conflict-free)
+                 cd* __restrict__ T2, int64_t T2_stride, const FftJob* __restrict__ jobs) {
+    typedef FourStep<R1A, R1B, R2A, R2B> FS;
     cd* buf = reinterpret_cast<cd*>(dftk_smem);
-    const int tid = threadIdx.x, l = tid & (L - 1), j = tid >> 3;
+    const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int band = slot % nbands;
     const int grp = (slot / nbands) * 8 + xcd;
-    const int nxt = nxp / L;
+    const int nxt = nxp / FFT_L;
     if (grp >= nxt * ny) return;   // whole workgroup, before any barrier
+    if (jobs) {
+        const FftJob jb = jobs[band];
+        nzx = jb.nzx;
+        z_lo = jb.z_lo;
+        Vs = jb.Vs;
+    }
     const int y = grp / nxt;
-    const int x = (grp - y * nxt) * L + l;
+    const int x = (grp - y * nxt) * FFT_L + l;
     const int64_t plane = (int64_t)ny * nxp;
     const int64_t col = (int64_t)y * nxp + x;
     cd* __restrict__ t2 = T2 + (int64_t)band * T2_stride + col;
-    const cd* __restrict__ twg = az.tw;        // exp(+2 pi i t / N)
-    const int zneg0 = N - (nzx - z_lo);        // first plane of the negative-frequency part
-    auto plane_of = [&](int z) { return z < z_lo ? z : (z >= zneg0 ? z - (N - nzx) : -1); };
-
-    // ---- backward, first sub-transform (threads n2 = j < R2)
-    if (j < R2) {
-        cd a[R1];
-        static_for<0, R1>([&](auto ni) {
-            constexpr int n1 = decltype(ni)::value;
-            const int zi = plane_of(R2 * n1 + j);
-            a[n1] = make_double2(0.0, 0.0);
-            if (zi >= 0) a[n1] = t2[(int64_t)zi * plane];
-        });
-        const cd w1 = twg[j], wA = twg[j * R1A];   // bases of the twiddles w^(j k1), k1 = c + R1A d
-        dft_ct<R1A, R1B, +1>(a);
-        cd wd = make_double2(1.0, 0.0);
-        static_for<0, R1B>([&](auto di) {
-            constexpr int d = decltype(di)::value;
-            if constexpr (d > 0) wd = (d == 1) ? wA : cmul(wd, wA);
-            cd w = wd;
-            static_for<0, R1A>([&](auto ci) {
-                constexpr int c = decltype(ci)::value;
-                if constexpr (c > 0) w = cmul(w, w1);
-                constexpr int k1 = c + R1A * d;
-                const cd v = (k1 == 0) ? a[R1B * c + d] : cmul(a[R1B * c + d], w);
-                buf[k1 * P1 + j * L + l] = v;
-            });
-        });
-    }
-    __syncthreads();
-    // ---- backward, second sub-transform; V; forward, first sub-transform (threads k1 = j < R1)
-    cd b2[R2];
-    double vv[R2];
-    if (j < R1) {
+    auto in = [&](int e) -> cd {
+        const int zi = wrap_index(e, z_lo, nzx, FS::N);
+        cd v = make_double2(0.0, 0.0);
+        if (zi >= 0) v = t2[(int64_t)zi * plane];
+        return v;
+    };
+    cd psi[FS::R2];
+    double vv[FS::R2];
+    if (j < FS::R1) {   // potential column of this thread's z = j + R1 k2 (in flight during the backward transform)
         const double* __restrict__ vcol = Vs + col + (int64_t)j * plane;
 #pragma unroll
-        for (int k2 = 0; k2 < R2; ++k2) vv[k2] = vcol[(int64_t)(R1 * k2) * plane];
-#pragma unroll
-        for (int n2 = 0; n2 < R2; ++n2) b2[n2] = buf[j * P1 + n2 * L + l];
+        for (int k2 = 0; k2 < FS::R2; ++k2) vv[k2] = vcol[(int64_t)(FS::R1 * k2) * plane];
     }
-    __syncthreads();   // every row of the first image has been read: the second image may overwrite it
-    if (j < R1) {
-        dft_ct<R2A, R2B, +1>(b2);           // b2[R2B c + d] = psi(z = j + R1 (c + R2A d))
-        cd f[R2];
-        static_for<0, R2>([&](auto pi) {
+    FS::backward(buf, az.tw, l, j, in, psi);
+    cd f[FS::R2];
+    if (j < FS::R1) {
+        static_for<0, FS::R2>([&](auto pi) {
             constexpr int p = decltype(pi)::value;
-            constexpr int k2 = p / R2B + R2A * (p % R2B);
-            f[k2] = make_double2(b2[p].x * vv[k2], b2[p].y * vv[k2]);
-        });
-        const cd w1 = twg[j], wA = twg[j * R2A];   // twiddles conj(w)^(j k1'), k1' = c + R2A d
-        dft_ct<R2A, R2B, -1>(f);
-        cd wd = make_double2(1.0, 0.0);
-        static_for<0, R2B>([&](auto di) {
-            constexpr int d = decltype(di)::value;
-            if constexpr (d > 0) wd = (d == 1) ? wA : cmul(wd, wA);
-            cd w = wd;
-            static_for<0, R2A>([&](auto ci) {
-                constexpr int c = decltype(ci)::value;
-                if constexpr (c > 0) w = cmul(w, w1);
-                constexpr int k1p = c + R2A * d;
-                const cd wc = make_double2(w.x, -w.y);
-                const cd v = (k1p == 0) ? f[R2B * c + d] : cmul(f[R2B * c + d], wc);
-                buf[k1p * P2 + j * L + l] = v;
-            });
+            constexpr int k2 = FS::k2_of(p);
+            f[k2] = make_double2(psi[p].x * vv[k2], psi[p].y * vv[k2]);
         });
     }
-    __syncthreads();
-    // ---- forward, second sub-transform (threads k1' = j < R2): frequencies z' = j + R2 (c + R1A d)
-    if (j < R2) {
-        cd a[R1];
-#pragma unroll
-        for (int k1 = 0; k1 < R1; ++k1) a[k1] = buf[j * P2 + k1 * L + l];
-        dft_ct<R1A, R1B, -1>(a);
-        static_for<0, R1>([&](auto pi) {
+    __syncthreads();   // every row of the first image has been read
+    cd out[FS::R1];
+    FS::forward(buf, az.tw, l, j, f, out);
+    if (j < FS::R2) {
+        static_for<0, FS::R1>([&](auto pi) {
             constexpr int p = decltype(pi)::value;
-            constexpr int k2p = p / R1B + R1A * (p % R1B);
-            const int zi = plane_of(j + R2 * k2p);
-            if (zi >= 0) t2[(int64_t)zi * plane] = a[p];
+            const int zi = wrap_index(j + FS::R2 * FS::k2p_of(p), z_lo, nzx, FS::N);
+            if (zi >= 0) t2[(int64_t)zi * plane] = out[p];
+        });
+    }
+}
+
+// density: rho[z, y, x] += sum_band w Re^2 + wim Im^2 of the backward z transform; thread j < R1 accumulates its R2 planes
+template <int R1A, int R1B, int R2A, int R2B>
+__global__ __launch_bounds__(FFT_L * ((R1A * R1B > R2A * R2B) ? R1A * R1B : R2A * R2B), ZREG_MIN_BLOCKS)
+void k_zdensity_reg(FftAxis az, int nx, int nxp, int ny, int nzx, int z_lo, int nb, const double* __restrict__ w,
+                    const double* __restrict__ wim, const cd* __restrict__ T2, int64_t T2_stride,
+                    double* __restrict__ rho, const FftJob* __restrict__ jobs) {
+    typedef FourStep<R1A, R1B, R2A, R2B> FS;
+    cd* buf = reinterpret_cast<cd*>(dftk_smem);
+    const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
+    const int x = blockIdx.x * FFT_L + l;
+    const int y = blockIdx.y;
+    const int64_t plane = (int64_t)ny * nxp;
+    double acc[FS::R2];
+#pragma unroll
+    for (int p = 0; p < FS::R2; ++p) acc[p] = 0.0;
+    for (int ib = 0; ib < nb; ++ib) {
+        double wb, wi;
+        if (jobs) {
+            const FftJob jb = jobs[ib];
+            wb = jb.w;
+            wi = jb.wim;
+            nzx = jb.nzx;
+            z_lo = jb.z_lo;
+        } else {
+            wb = w[ib];
+            wi = wim ? wim[ib] : wb;
+        }
+        if (wb == 0.0 && wi == 0.0) continue;   // uniform across the block
+        const cd* __restrict__ t2 = T2 + (int64_t)ib * T2_stride + (int64_t)y * nxp + x;
+        auto in = [&](int e) -> cd {
+            const int zi = wrap_index(e, z_lo, nzx, FS::N);
+            cd v = make_double2(0.0, 0.0);
+            if (zi >= 0) v = t2[(int64_t)zi * plane];
+            return v;
+        };
+        cd psi[FS::R2];
+        FS::backward(buf, az.tw, l, j, in, psi);
+        if (j < FS::R1) {
+#pragma unroll
+            for (int p = 0; p < FS::R2; ++p) acc[p] = fma(wb, psi[p].x * psi[p].x, fma(wi, psi[p].y * psi[p].y, acc[p]));
+        }
+        __syncthreads();   // the tile image is rewritten by the next band
+    }
+    if (j < FS::R1 && x < nx) {
+        static_for<0, FS::R2>([&](auto pi) {
+            constexpr int p = decltype(pi)::value;
+            rho[((int64_t)(j + FS::R1 * FS::k2_of(p)) * ny + y) * nx + x] += acc[p];
         });
     }
 }
@@ -958,25 +1046,65 @@ static bool axis_generic(const FftAxis& ax) {
         }                                                                                                   \
     } while (0)
 
-// register-resident stage C (k_zpass_reg): launched for the axis lengths with an instantiated factorisation when the sphere's
-// z planes wrap around contiguously (kb->z_lo >= 0); DFTK_MI_FFT_REG=0 keeps the LDS-pass kernel.  Returns 1 if not applicable.
-template <int R1A, int R1B, int R2A, int R2B>
-static int launch_zpass_reg_t(dftk_mi_kblock* kb, int nbb, dim3 grid, int64_t s2) {
-    dftk_mi_basis* b = kb->basis;
-    constexpr int R1 = R1A * R1B, R2 = R2A * R2B, TPL = R1 > R2 ? R1 : R2;
-    constexpr int P1 = R2 * FFT_L + 1, P2 = R1 * FFT_L + 1;
-    const size_t lds = (size_t)std::max(R1 * P1, R2 * P2) * sizeof(cd);
-    CHK(set_lds_attr(k_zpass_reg<R1A, R1B, R2A, R2B>, lds));
-    hipLaunchKernelGGL((k_zpass_reg<R1A, R1B, R2A, R2B>), grid, dim3(FFT_L * TPL), lds, b->stream, b->ax[2], b->nx, b->nxp, b->ny,
-                       kb->nzx, kb->z_lo, nbb, (const double*)kb->d_Vs, b->T2, s2);
+// Register-resident z kernels (FourStep): used for the axis lengths with an instantiated factorisation n = R1 R2
+// (R1 = R1A R1B >= R2 = R2A R2B) when the sphere's z planes wrap around contiguously (kb->z_lo >= 0: always so for a sphere
+// of G vectors).  The y passes keep the LDS-pass kernels: they are HBM bound (4.9 / 3.9 TB/s at 192^3) and the
+// register-resident variants of stages B and D ran at exactly their speed (113.8 vs 112.9, 144.5 vs 141.4 us per launch).  DFTK_MI_FFT_REG=0 keeps the LDS-pass kernels everywhere, DFTK_MI_FFT_REG_MIN=n (default 64)
+// is the shortest axis they take (below that a tile has fewer than 64 threads).  The launchers return 1 if not applicable.
+#define REG_SIZES(X)                                                                                                      \
+    X(64, 4, 2, 4, 2) X(72, 3, 3, 4, 2) X(80, 5, 2, 4, 2) X(90, 5, 2, 3, 3) X(96, 4, 3, 4, 2) X(100, 5, 2, 5, 2)          \
+    X(108, 4, 3, 3, 3) X(120, 4, 3, 5, 2) X(128, 4, 4, 4, 2) X(144, 4, 3, 4, 3) X(150, 5, 3, 5, 2) X(160, 4, 4, 5, 2)     \
+    X(180, 5, 3, 4, 3) X(192, 4, 4, 4, 3) X(200, 5, 4, 5, 2) X(216, 6, 3, 4, 3) X(240, 4, 4, 5, 3) X(256, 4, 4, 4, 4)
+static bool fft_reg_on(int n) {
+    static const bool off = getenv("DFTK_MI_FFT_REG") != nullptr && atoi(getenv("DFTK_MI_FFT_REG")) == 0;
+    static const int nmin = getenv("DFTK_MI_FFT_REG_MIN") ? atoi(getenv("DFTK_MI_FFT_REG_MIN")) : 64;
+    return !off && n >= nmin;
+}
+struct RegZ {   // arguments of the z kernels
+    dftk_mi_basis* b;
+    hipStream_t stream;
+    dim3 grid;
+    int nzx, z_lo, nbands;
+    const double* Vs;
+    cd* T2;
+    int64_t s2;
+    const double *w, *wim;
+    double* rho;
+    const FftJob* jobs;
+};
+template <int A, int B, int C, int D>
+static int reg_zpass_t(const RegZ& r) {
+    typedef FourStep<A, B, C, D> FS;
+    const size_t lds = (size_t)FS::LDS_ELEMS * sizeof(cd);
+    CHK(set_lds_attr(k_zpass_reg<A, B, C, D>, lds));
+    hipLaunchKernelGGL((k_zpass_reg<A, B, C, D>), r.grid, dim3(FS::THREADS), lds, r.stream, r.b->ax[2], r.b->nx, r.b->nxp, r.b->ny,
+                       r.nzx, r.z_lo, r.nbands, r.Vs, r.T2, r.s2, r.jobs);
     return 0;
 }
-static int launch_zpass_reg(dftk_mi_kblock* kb, int nbb, dim3 grid, int64_t s2) {
-    static const bool off = getenv("DFTK_MI_FFT_REG") != nullptr && atoi(getenv("DFTK_MI_FFT_REG")) == 0;
-    if (off || kb->z_lo < 0) return 1;
-    switch (kb->basis->nz) {
-        case 192: return launch_zpass_reg_t<4, 4, 4, 3>(kb, nbb, grid, s2);
-        case 150: return launch_zpass_reg_t<5, 3, 5, 2>(kb, nbb, grid, s2);
+template <int A, int B, int C, int D>
+static int reg_zdens_t(const RegZ& r) {
+    typedef FourStep<A, B, C, D> FS;
+    const size_t lds = (size_t)FS::LDS_ELEMS * sizeof(cd);
+    CHK(set_lds_attr(k_zdensity_reg<A, B, C, D>, lds));
+    hipLaunchKernelGGL((k_zdensity_reg<A, B, C, D>), r.grid, dim3(FS::THREADS), lds, r.stream, r.b->ax[2], r.b->nx, r.b->nxp,
+                       r.b->ny, r.nzx, r.z_lo, r.nbands, r.w, r.wim, (const cd*)r.T2, r.s2, r.rho, r.jobs);
+    return 0;
+}
+static int reg_zpass(const RegZ& r, bool tables_ok) {
+    if (!tables_ok || !fft_reg_on(r.b->nz)) return 1;
+    switch (r.b->nz) {
+#define X(NN, A, B, C, D) case NN: return reg_zpass_t<A, B, C, D>(r);
+        REG_SIZES(X)
+#undef X
+        default: return 1;
+    }
+}
+static int reg_zdens(const RegZ& r, bool tables_ok) {
+    if (!tables_ok || !fft_reg_on(r.b->nz)) return 1;
+    switch (r.b->nz) {
+#define X(NN, A, B, C, D) case NN: return reg_zdens_t<A, B, C, D>(r);
+        REG_SIZES(X)
+#undef X
         default: return 1;
     }
 }
@@ -1057,7 +1185,9 @@ int launch_local_apply(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi,
         const int pc = prof_begin(b, PROF_FFT_C, 2.0 * 16.0 * (double)kb->nzx * b->ny * b->nxp * nbb +
                                                      8.0 * (double)b->nz * b->ny * b->nxp);
         static const bool twg = getenv("DFTK_MI_FFT_TWG") != nullptr;
-        const int reg_st = launch_zpass_reg(kb, nbb, zpass_grid(b, nbb), st.s2);
+        const RegZ rz{b, b->stream, zpass_grid(b, nbb), kb->nzx, kb->z_lo, nbb, kb->d_Vs, b->T2, st.s2, nullptr, nullptr, nullptr,
+                      nullptr};
+        const int reg_st = reg_zpass(rz, kb->z_lo >= 0);
         if (reg_st < 0) return reg_st;
         if (reg_st == 0) {
         } else if (twg && !axis_generic(b->ax[2])) {
@@ -1146,6 +1276,11 @@ int launch_density(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, con
         CHK(run_AB(kb, nbb, psi + (int64_t)b0 * ldpsi, ldpsi));
         const int pz = prof_begin(b, PROF_DENS_Z, 16.0 * (double)kb->nzx * b->ny * b->nxp * nbb +
                                                       16.0 * (double)b->nx * b->ny * b->nz);   // T2 per band + rho read-modify-write
+        const RegZ rz{b, b->stream, dim3(b->nxp / FFT_L, b->ny), kb->nzx, kb->z_lo, nbb, nullptr, b->T2, st.s2, w_d + b0,
+                      wim_d ? wim_d + b0 : (const double*)nullptr, rho, nullptr};
+        const int rs = reg_zdens(rz, kb->z_lo >= 0);
+        if (rs < 0) return rs;
+        if (rs == 1)
         LAUNCH_FFT(k_zdensity, b->ax[2], dim3(b->nxp / FFT_L, b->ny), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, kb->d_zpos, nbb, w_d + b0,
                            wim_d ? wim_d + b0 : (const double*)nullptr, b->T2, st.s2, rho, (const FftJob*)nullptr);
         prof_end(b, pz);
@@ -1173,6 +1308,7 @@ namespace {
 struct MultiPlan {
     std::vector<FftJob> jobs;
     int max_lines = 1, max_nzx = 1;
+    bool reg_z = true;   // every k-block's sphere planes wrap around contiguously (register-resident z kernels)
 };
 void add_jobs(MultiPlan& mp, const dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, cd* out, int64_t ldout,
               bool kinetic, const double* w, const double* wim) {
@@ -1183,6 +1319,7 @@ void add_jobs(MultiPlan& mp, const dftk_mi_kblock* kb, int nb, const cd* psi, in
         j.line_ypos = kb->d_line_ypos;
         j.zls = kb->d_zls;
         j.zpos = kb->d_zpos;
+        j.z_lo = kb->z_lo;
         j.kin = kinetic ? kb->d_kin : nullptr;
         j.Vs = kb->d_Vs;
         j.psi = psi + (int64_t)i * ldpsi;
@@ -1195,6 +1332,7 @@ void add_jobs(MultiPlan& mp, const dftk_mi_kblock* kb, int nb, const cd* psi, in
     }
     mp.max_lines = std::max(mp.max_lines, (int)kb->n_lines);
     mp.max_nzx = std::max(mp.max_nzx, kb->nzx);
+    mp.reg_z = mp.reg_z && kb->z_lo >= 0;
 }
 }  // namespace
 
@@ -1239,9 +1377,14 @@ int batch_exec_apply_H(BatchCtx* ctx, hipStream_t stream, std::vector<BOp*>& ops
         {
             const int64_t groups = (int64_t)nxt * b->ny;
             const dim3 grid((unsigned)(((groups + 7) / 8) * 8 * nb));
-            CHK(set_lds_attr(k_zpass<0, false>, lds_bytes(b->nz)));
-            hipLaunchKernelGGL((k_zpass<0, false>), grid, dim3(FFT_THREADS), lds_bytes(b->nz), stream, b->ax[2], b->nx, b->nxp,
-                               b->ny, 0, nb, (const int*)nullptr, (const double*)nullptr, T2, s2, (cd*)nullptr, dj);
+            const RegZ rz{b, stream, grid, 0, 0, nb, nullptr, T2, s2, nullptr, nullptr, nullptr, dj};
+            const int rs = reg_zpass(rz, mp.reg_z);
+            if (rs < 0) return rs;
+            if (rs == 1) {
+                CHK(set_lds_attr(k_zpass<0, false>, lds_bytes(b->nz)));
+                hipLaunchKernelGGL((k_zpass<0, false>), grid, dim3(FFT_THREADS), lds_bytes(b->nz), stream, b->ax[2], b->nx, b->nxp,
+                                   b->ny, 0, nb, (const int*)nullptr, (const double*)nullptr, T2, s2, (cd*)nullptr, dj);
+            }
         }
         hipLaunchKernelGGL((k_yfwd<false>), dim3(nxt, mp.max_nzx, nb), dim3(FFT_THREADS), lds_bytes(b->ny), stream, b->ax[1],
                            b->nxp, b->ny, (const int*)nullptr, (const int*)nullptr, (const cd*)T2, s2, T1, s1, dj);
@@ -1328,10 +1471,15 @@ int batch_exec_density(BatchCtx* ctx, hipStream_t stream, std::vector<BOp*>& ops
                            b->nxp, 0, (const int*)nullptr, (const int*)nullptr, (const cd*)nullptr, (int64_t)0, T1, s1, dj);
         hipLaunchKernelGGL((k_ybwd<false>), dim3(nxt, mp.max_nzx, nb), dim3(FFT_THREADS), lds_bytes(b->ny), stream, b->ax[1],
                            b->nxp, b->ny, (const int*)nullptr, (const int*)nullptr, (const cd*)T1, s1, T2, s2, dj);
-        CHK(set_lds_attr(k_zdensity<false>, lds_bytes(b->nz)));
-        hipLaunchKernelGGL((k_zdensity<false>), dim3(nxt, b->ny), dim3(FFT_THREADS), lds_bytes(b->nz), stream, b->ax[2], b->nx,
-                           b->nxp, b->ny, 0, (const int*)nullptr, nb, (const double*)nullptr, (const double*)nullptr,
-                           (const cd*)T2, s2, rho, dj);
+        const RegZ rz{b, stream, dim3(nxt, b->ny), 0, 0, nb, nullptr, T2, s2, nullptr, nullptr, rho, dj};
+        const int rs = reg_zdens(rz, mp.reg_z);
+        if (rs < 0) return rs;
+        if (rs == 1) {
+            CHK(set_lds_attr(k_zdensity<false>, lds_bytes(b->nz)));
+            hipLaunchKernelGGL((k_zdensity<false>), dim3(nxt, b->ny), dim3(FFT_THREADS), lds_bytes(b->nz), stream, b->ax[2], b->nx,
+                               b->nxp, b->ny, 0, (const int*)nullptr, nb, (const double*)nullptr, (const double*)nullptr,
+                               (const cd*)T2, s2, rho, dj);
+        }
     }
     HIPCHK(hipGetLastError());
     return 0;

@@ -188,3 +188,34 @@ def test_cfg5_apply_H_and_density():
     occ = np.linspace(2.0, 0.2, 11)
     rho = dftk.compute_density(case.basis, [psi], [occ])
     assert relerr(rho, case.torch_density(psi, occ)) < RTOL
+
+
+# ---- register-resident z kernels (fft_kernels.hip, FourStep): every instantiated axis length n = R1 R2 on a small cell
+@pytest.mark.parametrize("nz", [64, 72, 80, 90, 96, 100, 108, 120, 128, 144, 150, 160, 180, 192, 200, 216, 240, 256])
+def test_register_resident_z_kernels_match_dense_cube_restatement(nz):
+    """Local H psi (stages A-E with the fused potential) and the density of random sphere vectors on a (24, 30, nz) cube
+    for every instantiated four-step factorisation of nz, against torch.fft on the dense cube.  The sphere (Ecut 5 on
+    the 2x2x2 silicon cell, |G_z| index <= 10) touches 21 of the nz planes: pruned on both sides of the axis."""
+    lat, atoms, pos = dftk.silicon_cell((2, 2, 2))
+    model = dftk.model_DFT(lat, atoms, pos, functionals=("lda_x", "lda_c_pw"))
+    basis = dftk.PlaneWaveBasis(model, 5.0, dftk.ExplicitKpoints([[0, 0, 0]], [1.0]), device="cuda", fft_size=(24, 30, nz),
+                                build_terms=False)
+    kpt = basis.kpoints[0]
+    nx, ny, nz_ = basis.fft_size
+    assert nz_ == nz
+    N = nx * ny * nz
+    g = torch.Generator(device="cuda").manual_seed(nz)
+    V = torch.randn((nz, ny, nx), dtype=torch.float64, device="cuda", generator=g)
+    H = dftk.DftHamiltonianBlock(basis, kpt, V)
+    psi = torch.randn((11, kpt.n_G), dtype=torch.complex128, device="cuda", generator=g)
+    cube = torch.zeros((psi.shape[0], N), dtype=torch.complex128, device="cuda")
+    cube[:, kpt.mapping_device] = psi
+    psi_r = torch.fft.ifftn(cube.reshape(-1, nz, ny, nx), dim=(1, 2, 3), norm="forward")
+    ref = torch.fft.fftn(psi_r * V[None], dim=(1, 2, 3), norm="backward").reshape(-1, N)[:, kpt.mapping_device] / N
+    got = H.mul_(torch.empty_like(psi), psi, 1)        # local part only
+    assert relerr(got, ref) < RTOL
+    occ = np.linspace(2.0, 0.1, psi.shape[0])
+    rho = dftk.compute_density(basis, [psi], [occ])
+    psi_n = psi_r * basis.ifft_normalization
+    rho_ref = ((psi_n.real ** 2 + psi_n.imag ** 2) * torch.as_tensor(occ, device="cuda")[:, None, None, None]).sum(dim=0)
+    assert relerr(torch.as_tensor(rho, device="cuda").reshape(nz, ny, nx), rho_ref) < RTOL

@@ -48,7 +48,6 @@ for f in ("r03_bench_cfg2", "r03_bench_kpoints_al", "r03_bench_kpoints_al_lanes"
         print(f, "failed", e)
 PY
 DFTK_MI_GEMM_SHAPES=1 timeout 300 python tools/late_step_profile.py 5 8 6 > $O/r03_late_step_cfg5.txt 2> $O/late.err
-grep zgemm-shape $O/late.err | sort -t= -k7 -n -r | head -14 >> $O/r03_late_step_cfg5.txt
 timeout 300 python tools/fft_bench.py 5 64 2>&1 | grep -v amdgpu > $O/r03_fft_bench_192.txt
 timeout 300 python tools/heev_bench.py real 503 1006 1509 2>&1 | grep -v amdgpu > $O/r03_heev_bench.txt
 timeout 300 python tools/gemm_real_bench.py 264859 503 struct 2>&1 | grep -v amdgpu > $O/r03_gemm_struct_bench.txt

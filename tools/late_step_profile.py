@@ -22,25 +22,79 @@ skip = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 for _ in range(skip):
     st.step()
 torch.cuda.synchronize()
-check(lib.dftk_mi_prof_enable(basis.handle, 1))
-t0 = time.time()
-timers = {}
+# Only steps with ONE LOBPCG iteration enter the table (the typical late step; a step that needs 2-3 iterations would blur it):
+# the profiler is switched on per step and a step is kept or thrown away as a whole.  With DFTK_MI_GEMM_SHAPES=1 the library
+# prints the zgemm shape table of a step to stderr when the profiler is switched off: captured here and summed over the kept
+# steps.
+import re
+import tempfile
+
+
+def prof_off_capture():
+    """dftk_mi_prof_enable(0) with fd 2 redirected to a file: returns the [zgemm-shape] lines it printed."""
+    sys.stderr.flush()
+    with tempfile.TemporaryFile(mode="w+b") as tmp:
+        saved = os.dup(2)
+        os.dup2(tmp.fileno(), 2)
+        try:
+            check(lib.dftk_mi_prof_enable(basis.handle, 0))
+        finally:
+            os.dup2(saved, 2)
+            os.close(saved)
+        tmp.seek(0)
+        return [ln for ln in tmp.read().decode(errors="replace").splitlines() if ln.startswith("[zgemm-shape]")]
+
+
+shape_tab = {}
+names = {0: "zgemm", 11: "zgemm_struct", 1: "fftA", 2: "fftB", 3: "fftC", 4: "fftD", 5: "fftE", 6: "dens", 7: "heev", 8: "chol", 9: "applyH(total)"}
 nst = int(sys.argv[3]) if len(sys.argv) > 3 else 6
-for _ in range(nst):
+fam_ms = {f: 0.0 for f in names}
+fam_nl = {f: 0 for f in names}
+timers = {}
+wall = 0.0
+kept, tried, iters_seen = 0, 0, []
+while kept < nst and tried < 4 * nst:
+    tried += 1
+    check(lib.dftk_mi_prof_enable(basis.handle, 1))
+    t0 = time.time()
     info = st.step()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    n_it = int(round(float(np.mean(info["diagonalization"]["n_iter"]))))
+    iters_seen.append(n_it)
+    if n_it != 1:
+        prof_off_capture()      # discard this step's records
+        continue
+    vals = {}
+    for f in names:
+        ms, work, nl = C.c_double(), C.c_double(), C.c_int64()
+        check(lib.dftk_mi_prof_get(basis.handle, f, C.byref(ms), C.byref(work), C.byref(nl)))
+        vals[f] = (ms.value, nl.value)
+    for ln in prof_off_capture():
+        m = re.match(r"\[zgemm-shape\] (\S) m=(\d+) n=(\d+) k=(\d+) flags=(\d+) calls=(\d+) ms=([0-9.]+) TF/s=([0-9.]+)", ln)
+        if m:
+            key = (m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)))
+            e = shape_tab.setdefault(key, [0, 0.0, 0.0])
+            e[0] += int(m.group(6))
+            e[1] += float(m.group(7))
+            e[2] += float(m.group(8)) * float(m.group(7))      # TF/s x ms = Gflop
+    for f in names:
+        fam_ms[f] += vals[f][0]
+        fam_nl[f] += vals[f][1]
     for k, v in info["timers"].items():
         timers[k] = timers.get(k, 0.0) + v
-torch.cuda.synchronize()
-wall = time.time() - t0
-check(lib.dftk_mi_prof_enable(basis.handle, 0))
-names = {0: "zgemm", 11: "zgemm_struct", 1: "fftA", 2: "fftB", 3: "fftC", 4: "fftD", 5: "fftE", 6: "dens", 7: "heev", 8: "chol", 9: "applyH(total)"}
+    wall += dt
+    kept += 1
+    if info["converged"]:
+        break
+nst = max(kept, 1)
 tot = 0.0
 for f, nm in names.items():
-    ms, work, nl = C.c_double(), C.c_double(), C.c_int64()
-    check(lib.dftk_mi_prof_get(basis.handle, f, C.byref(ms), C.byref(work), C.byref(nl)))
-    print(f"{nm:14s} {ms.value / nst:8.2f} ms/step  {nl.value / nst:7.1f} launches/step")
+    print(f"{nm:14s} {fam_ms[f] / nst:8.2f} ms/step  {fam_nl[f] / nst:7.1f} launches/step")
     if f != 9:
-        tot += ms.value
-print(f"booked {tot / nst:.1f} ms/step of wall {1e3 * wall / nst:.1f} ms/step; host timers/step:",
-      {k: round(1e3 * v / nst, 1) for k, v in timers.items()}, "iters", info["diagonalization"]["n_iter"])
-# (DFTK_MI_GEMM_SHAPES=1: the per-shape zgemm table of these steps is printed to stderr by dftk_mi_prof_enable(0) above)
+        tot += fam_ms[f]
+print(f"booked {tot / nst:.1f} ms/step of wall {1e3 * wall / nst:.1f} ms/step over {kept} one-iteration steps "
+      f"(LOBPCG iterations of the steps tried: {iters_seen}); host timers/step:",
+      {k: round(1e3 * v / nst, 1) for k, v in timers.items()})
+for key, (calls, ms, gf) in sorted(shape_tab.items(), key=lambda kv: -kv[1][1])[:14]:
+    print(f"[zgemm-shape] {key[0]} m={key[1]} n={key[2]} k={key[3]} flags={key[4]} calls={calls} ms={ms:.3f} TF/s={gf / ms:.2f}")

@@ -15,7 +15,7 @@ import json
 import sys
 
 FAMILY_OF = [("k_zgemm", "zgemm_f64_mfma"), ("k_xbwd_scatter", "fft_A_xbwd_scatter"), ("k_ybwd", "fft_B_ybwd"),
-             ("k_zpass<0", "fft_C_z_fused_V"), ("k_yfwd", "fft_D_yfwd"), ("k_xfwd_gather", "fft_E_xfwd_gather"),
+             ("k_zpass<0", "fft_C_z_fused_V"), ("k_zpass_reg", "fft_C_z_fused_V"), ("k_yfwd", "fft_D_yfwd"), ("k_xfwd_gather", "fft_E_xfwd_gather"),
              ("k_zdensity", "density_z"), ("k_jacobi", "heev_jacobi")]
 
 

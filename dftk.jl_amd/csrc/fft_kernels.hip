@@ -622,23 +622,24 @@ template <int R1A, int R1B, int R2A, int R2B>
 struct FourStep {
     static constexpr int R1 = R1A * R1B, R2 = R2A * R2B, N = R1 * R2, L = FFT_L;
     static constexpr int TPL = R1 > R2 ? R1 : R2, THREADS = L * TPL;
-    static constexpr int P1 = R2 * L + 1, P2 = R1 * L + 1;   // row pitches of the two transposition images (odd: conflict-free)
+    // row pitches of the two transposition images: = 8 (mod 16) elements, so that the two rows a 16-lane group of a
+    // ds_read_b128 touches (8 lines x 2 consecutive j) lie 32 banks apart (a pitch of "row + 1" puts lane (l + 1, j) and
+    // lane (l, j + 1) on the same bank: PMC showed 35 % of the LDS cycles as bank conflicts)
+    static constexpr int P1 = R2 * L + ((R2 % 2 == 0) ? 8 : 0), P2 = R1 * L + ((R1 % 2 == 0) ? 8 : 0);
     static constexpr int LDS_ELEMS = R1 * P1 > R2 * P2 ? R1 * P1 : R2 * P2;
     // natural index of register p of a finished sub-transform (dft_ct's output order)
     static constexpr int k2_of(int p) { return p / R2B + R2A * (p % R2B); }    // DFT_R2 results: index k2
     static constexpr int k2p_of(int p) { return p / R1B + R1A * (p % R1B); }   // DFT_R1 results: index k2'
 
-    // Backward transform (exp(+i)).  in(e): input element e in natural order (zero where the pruned pipeline has nothing).
+    // Backward transform (exp(+i)).  in(n1): input element e = R2 n1 + j of this thread (n1 a std::integral_constant; zero
+    // where the pruned pipeline has nothing).
     // Thread j < R1 receives out[p] = X[j + R1 k2_of(p)].  Ends after the LDS reads: the caller places a barrier before the
     // tile image is written again.
     template <class IN>
     static __device__ __forceinline__ void backward(cd* buf, const cd* __restrict__ twg, int l, int j, IN in, cd (&out)[R2]) {
         if (j < R2) {
             cd a[R1];
-            static_for<0, R1>([&](auto ni) {
-                constexpr int n1 = decltype(ni)::value;
-                a[n1] = in(R2 * n1 + j);
-            });
+            static_for<0, R1>([&](auto ni) { a[decltype(ni)::value] = in(ni); });   // element e = R2 n1 + j
             const cd w1 = twg[j], wA = twg[j * R1A];   // bases of the twiddles w^(j k1), k1 = c + R1A d
             dft_ct<R1A, R1B, +1>(a);
             cd wd = make_double2(1.0, 0.0);
@@ -689,10 +690,15 @@ struct FourStep {
         }
     }
 };
-// wrap-around contiguous index sets (sphere planes along z, sphere lines of a plane along y): the first `lo` natural
-// indices and the last `cnt - lo` of n hold entries 0 .. cnt-1 in ascending order
-__device__ __forceinline__ int wrap_index(int e, int lo, int cnt, int n) {
-    return e < lo ? e : (e >= n - (cnt - lo) ? e - (n - cnt) : -1);
+// element at a 32-bit BYTE offset from a workgroup-uniform base: scalar base + one vector offset in the memory instruction
+// instead of a 64-bit multiply-add per element (every T2 / V / rho column of a launch spans < 2^32 bytes from its tile origin)
+template <class T>
+__device__ __forceinline__ T ld_off(const T* base, unsigned byte_off) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <class T>
+__device__ __forceinline__ void st_off(T* base, unsigned byte_off, T v) {
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
 // stage C: backward z, multiply by V / N, forward z, in place on the sphere planes of T2
@@ -716,21 +722,30 @@ void k_zpass_reg(FftAxis az, int nx, int nxp, int ny, int nzx, int z_lo, int nba
     }
     const int y = grp / nxt;
     const int x = (grp - y * nxt) * FFT_L + l;
-    const int64_t plane = (int64_t)ny * nxp;
-    const int64_t col = (int64_t)y * nxp + x;
-    cd* __restrict__ t2 = T2 + (int64_t)band * T2_stride + col;
-    auto in = [&](int e) -> cd {
-        const int zi = wrap_index(e, z_lo, nzx, FS::N);
+    const unsigned plane = (unsigned)ny * (unsigned)nxp;
+    const int64_t col0 = (int64_t)y * nxp + (x - l);               // tile origin: uniform over the workgroup
+    cd* __restrict__ t2 = T2 + (int64_t)band * T2_stride + col0;
+    // byte offsets of this thread's planes from the tile origin: plane zi = e for e < z_lo, e - (N - nzx) for e >= zneg0; the
+    // elements of a thread are R2 planes apart, i.e. a workgroup-uniform step
+    const unsigned planeB = plane * (unsigned)sizeof(cd), stepB = (unsigned)FS::R2 * planeB;
+    const unsigned off_lo = (unsigned)j * planeB + (unsigned)l * (unsigned)sizeof(cd);
+    const unsigned off_hi = off_lo - (unsigned)(FS::N - nzx) * planeB;   // (mod 2^32; only used where it is a valid offset)
+    const int zneg0 = FS::N - (nzx - z_lo);
+    auto in = [&](auto ni) -> cd {
+        constexpr int n1 = decltype(ni)::value;
+        const int e = FS::R2 * n1 + j;
+        const bool lo = e < z_lo, hi = e >= zneg0;
         cd v = make_double2(0.0, 0.0);
-        if (zi >= 0) v = t2[(int64_t)zi * plane];
+        if (lo || hi) v = ld_off(t2, (lo ? off_lo : off_hi) + (unsigned)n1 * stepB);
         return v;
     };
     cd psi[FS::R2];
     double vv[FS::R2];
     if (j < FS::R1) {   // potential column of this thread's z = j + R1 k2 (in flight during the backward transform)
-        const double* __restrict__ vcol = Vs + col + (int64_t)j * plane;
+        const double* __restrict__ vcol = Vs + col0;
+        const unsigned vb = ((unsigned)j * plane + (unsigned)l) * 8u;
 #pragma unroll
-        for (int k2 = 0; k2 < FS::R2; ++k2) vv[k2] = vcol[(int64_t)(FS::R1 * k2) * plane];
+        for (int k2 = 0; k2 < FS::R2; ++k2) vv[k2] = ld_off(vcol, vb + (unsigned)(FS::R1 * k2) * plane * 8u);
     }
     FS::backward(buf, az.tw, l, j, in, psi);
     cd f[FS::R2];
@@ -747,8 +762,10 @@ void k_zpass_reg(FftAxis az, int nx, int nxp, int ny, int nzx, int z_lo, int nba
     if (j < FS::R2) {
         static_for<0, FS::R1>([&](auto pi) {
             constexpr int p = decltype(pi)::value;
-            const int zi = wrap_index(j + FS::R2 * FS::k2p_of(p), z_lo, nzx, FS::N);
-            if (zi >= 0) t2[(int64_t)zi * plane] = out[p];
+            constexpr int k2p = FS::k2p_of(p);
+            const int e = j + FS::R2 * k2p;
+            const bool lo = e < z_lo, hi = e >= zneg0;
+            if (lo || hi) st_off(t2, (lo ? off_lo : off_hi) + (unsigned)k2p * stepB, out[p]);
         });
     }
 }
@@ -764,7 +781,7 @@ void k_zdensity_reg(FftAxis az, int nx, int nxp, int ny, int nzx, int z_lo, int 
     const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
     const int x = blockIdx.x * FFT_L + l;
     const int y = blockIdx.y;
-    const int64_t plane = (int64_t)ny * nxp;
+    const unsigned plane = (unsigned)ny * (unsigned)nxp;
     double acc[FS::R2];
 #pragma unroll
     for (int p = 0; p < FS::R2; ++p) acc[p] = 0.0;
@@ -781,11 +798,17 @@ void k_zdensity_reg(FftAxis az, int nx, int nxp, int ny, int nzx, int z_lo, int 
             wi = wim ? wim[ib] : wb;
         }
         if (wb == 0.0 && wi == 0.0) continue;   // uniform across the block
-        const cd* __restrict__ t2 = T2 + (int64_t)ib * T2_stride + (int64_t)y * nxp + x;
-        auto in = [&](int e) -> cd {
-            const int zi = wrap_index(e, z_lo, nzx, FS::N);
+        const cd* __restrict__ t2 = T2 + (int64_t)ib * T2_stride + (int64_t)y * nxp + (x - l);   // tile origin: uniform
+        const unsigned planeB = plane * (unsigned)sizeof(cd), stepB = (unsigned)FS::R2 * planeB;
+        const unsigned off_lo = (unsigned)j * planeB + (unsigned)l * (unsigned)sizeof(cd);
+        const unsigned off_hi = off_lo - (unsigned)(FS::N - nzx) * planeB;
+        const int zneg0 = FS::N - (nzx - z_lo);
+        auto in = [&](auto ni) -> cd {
+            constexpr int n1 = decltype(ni)::value;
+            const int e = FS::R2 * n1 + j;
+            const bool lo = e < z_lo, hi = e >= zneg0;
             cd v = make_double2(0.0, 0.0);
-            if (zi >= 0) v = t2[(int64_t)zi * plane];
+            if (lo || hi) v = ld_off(t2, (lo ? off_lo : off_hi) + (unsigned)n1 * stepB);
             return v;
         };
         cd psi[FS::R2];
@@ -797,9 +820,13 @@ void k_zdensity_reg(FftAxis az, int nx, int nxp, int ny, int nzx, int z_lo, int 
         __syncthreads();   // the tile image is rewritten by the next band
     }
     if (j < FS::R1 && x < nx) {
+        double* __restrict__ r0 = rho + (int64_t)y * nx + (x - l);   // tile origin of this y row: uniform
+        const unsigned zB = (unsigned)ny * (unsigned)nx * 8u;         // bytes between z planes of rho (the cube is < 2^32 bytes:
+        const unsigned ob = (unsigned)j * zB + (unsigned)l * 8u;     //  192^3 doubles = 57 MB; checked by the launcher)
         static_for<0, FS::R2>([&](auto pi) {
             constexpr int p = decltype(pi)::value;
-            rho[((int64_t)(j + FS::R1 * FS::k2_of(p)) * ny + y) * nx + x] += acc[p];
+            const unsigned off = ob + (unsigned)(FS::R1 * FS::k2_of(p)) * zB;
+            st_off(r0, off, ld_off((const double*)r0, off) + acc[p]);
         });
     }
 }
@@ -1060,6 +1087,10 @@ static bool fft_reg_on(int n) {
     static const int nmin = getenv("DFTK_MI_FFT_REG_MIN") ? atoi(getenv("DFTK_MI_FFT_REG_MIN")) : 64;
     return !off && n >= nmin;
 }
+// the z kernels address a band's T2 slab, the potential and the density cube with 32-bit byte offsets from a tile origin
+static bool fft_reg_fits(const dftk_mi_basis* b) {
+    return (uint64_t)b->nz * (uint64_t)b->ny * (uint64_t)b->nxp * sizeof(cd) < (1ull << 32);
+}
 struct RegZ {   // arguments of the z kernels
     dftk_mi_basis* b;
     hipStream_t stream;
@@ -1091,7 +1122,7 @@ static int reg_zdens_t(const RegZ& r) {
     return 0;
 }
 static int reg_zpass(const RegZ& r, bool tables_ok) {
-    if (!tables_ok || !fft_reg_on(r.b->nz)) return 1;
+    if (!tables_ok || !fft_reg_on(r.b->nz) || !fft_reg_fits(r.b)) return 1;
     switch (r.b->nz) {
 #define X(NN, A, B, C, D) case NN: return reg_zpass_t<A, B, C, D>(r);
         REG_SIZES(X)
@@ -1100,7 +1131,7 @@ static int reg_zpass(const RegZ& r, bool tables_ok) {
     }
 }
 static int reg_zdens(const RegZ& r, bool tables_ok) {
-    if (!tables_ok || !fft_reg_on(r.b->nz)) return 1;
+    if (!tables_ok || !fft_reg_on(r.b->nz) || !fft_reg_fits(r.b)) return 1;
     switch (r.b->nz) {
 #define X(NN, A, B, C, D) case NN: return reg_zdens_t<A, B, C, D>(r);
         REG_SIZES(X)

@@ -915,3 +915,83 @@ def test_multi_k_entries_argument_checks_without_gpu(lib):
     r, o, m, q = i64(-1), i64(-1), i64(-1), i64(-1)
     assert lib.dftk_mi_batch_stats(C.byref(r), C.byref(o), C.byref(m), C.byref(q)) == 0
     assert min(r.value, o.value, m.value, q.value) >= 0
+
+
+def _reg_sizes():
+    """The instantiated four-step factorisations n = (R1A R1B)(R2A R2B) of the register-resident z kernels, read from
+    REG_SIZES in csrc/fft_kernels.hip."""
+    import re
+    src = open(os.path.join(os.path.dirname(__file__), "..", "dftk.jl_amd", "csrc", "fft_kernels.hip")).read()
+    block = src[src.index("#define REG_SIZES(X)"):src.index("static bool fft_reg_on")]
+    return [tuple(int(v) for v in m) for m in re.findall(r"X\((\d+), (\d+), (\d+), (\d+), (\d+)\)", block)]
+
+
+def _dft(x, sgn):
+    n = len(x)
+    k = np.arange(n)
+    return np.exp(sgn * 2j * np.pi * np.outer(k, k) / n) @ x
+
+
+def _dft_ct(x, RA, RB, sgn):
+    """dft_ct of fft_kernels.hip: input index n = RB a + b, result x[RB c + d] = X[c + RA d] (in place)."""
+    x = x.copy()
+    N = RA * RB
+    for b in range(RB):
+        t = _dft(np.array([x[RB * a + b] for a in range(RA)]), sgn)
+        for c in range(RA):
+            x[RB * c + b] = t[c] * np.exp(sgn * 2j * np.pi * (b * c) / N)
+    for c in range(RA):
+        u = _dft(np.array([x[RB * c + b] for b in range(RB)]), sgn)
+        for d in range(RB):
+            x[RB * c + d] = u[d]
+    return x
+
+
+@pytest.mark.parametrize("size", _reg_sizes())
+def test_four_step_z_pass_index_maps(size):
+    """NumPy model of k_zpass_reg's data flow (FourStep::backward, the V multiply in natural order, FourStep::forward):
+    which thread holds which element after each sub-transform, the twiddles between them, the two transposition images.
+    Every instantiated length against numpy.fft, with a pruned input (sphere planes only) as the kernel sees it."""
+    n, R1A, R1B, R2A, R2B = size
+    R1, R2 = R1A * R1B, R2A * R2B
+    assert R1 * R2 == n and R1 >= R2 and all(2 <= r <= 6 for r in (R1A, R1B, R2A, R2B))
+    assert 8 * max(R1, R2) <= 1024                                  # threads of a tile
+    rng = np.random.default_rng(n)
+    z_lo, nzx = n // 4 + 1, 2 * (n // 4) + 1                        # planes {0..z_lo-1} u {n-(nzx-z_lo)..n-1}
+    x = np.zeros(n, complex)
+    idx = np.r_[0:z_lo, n - (nzx - z_lo):n]
+    x[idx] = rng.standard_normal(nzx) + 1j * rng.standard_normal(nzx)
+    V = rng.standard_normal(n)
+    tw = np.exp(2j * np.pi * np.arange(n) / n)
+    img1 = np.zeros((R1, R2), complex)                              # LDS image [k1][n2]
+    for j in range(R2):                                             # thread n2 = j
+        a = _dft_ct(np.array([x[R2 * n1 + j] for n1 in range(R1)]), R1A, R1B, +1)
+        for p in range(R1):
+            c, d = divmod(p, R1B)
+            k1 = c + R1A * d
+            img1[k1, j] = a[p] * tw[j * k1]
+    img2 = np.zeros((R2, R1), complex)                              # LDS image [k1'][k1]
+    mid = np.zeros(n, complex)
+    for j in range(R1):                                             # thread k1 = j
+        a2 = _dft_ct(img1[j, :].copy(), R2A, R2B, +1)
+        f = np.zeros(R2, complex)
+        for p in range(R2):
+            c, d = divmod(p, R2B)
+            k2 = c + R2A * d
+            mid[j + R1 * k2] = a2[p]
+            f[k2] = a2[p] * V[j + R1 * k2]
+        f = _dft_ct(f, R2A, R2B, -1)
+        for p in range(R2):
+            c, d = divmod(p, R2B)
+            k1p = c + R2A * d
+            img2[k1p, j] = f[p] * np.conj(tw[j * k1p])
+    out = np.zeros(n, complex)
+    for j in range(R2):                                             # thread k1' = j
+        a = _dft_ct(img2[j, :].copy(), R1A, R1B, -1)
+        for p in range(R1):
+            c, d = divmod(p, R1B)
+            out[j + R2 * (c + R1A * d)] = a[p]
+    ref_mid = np.fft.ifft(x) * n
+    ref = np.fft.fft(ref_mid * V)
+    assert np.abs(mid - ref_mid).max() < 1e-11 * np.abs(ref_mid).max()
+    assert np.abs(out - ref).max() < 1e-11 * np.abs(ref).max()

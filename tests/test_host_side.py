@@ -995,3 +995,42 @@ def test_four_step_z_pass_index_maps(size):
     ref = np.fft.fft(ref_mid * V)
     assert np.abs(mid - ref_mid).max() < 1e-11 * np.abs(ref_mid).max()
     assert np.abs(out - ref).max() < 1e-11 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("m,k,flags", [(259, 135491, 1), (503, 132430, 9), (1006, 132430, 9), (1509, 132430, 9), (777, 67746, 1),
+                                       (141, 4100, 1), (1300, 300, 1), (2000, 264859, 9)])
+def test_zgemm_compact_upper_grid_enumerates_the_live_tiles_once(lib, m, k, flags):
+    """Emulation of the `upper & 16` decode of k_zgemm_3m (compact UPPER launches): the grid 8 ceil(L ns / 8) holds every
+    (k-chunk, live tile) pair exactly once, no tile strictly below the diagonal, and each XCD (id % 8) a contiguous block
+    of at most ceil(L ns / 8) work items."""
+    p = _gemm_plan(lib, "C", m, m, k, flags)
+    assert p["zmI"] == 2
+    bn = p["bn"]
+    q = 128 // bn
+    shift_r = 1 if (m % 128 and m >= 128) else 0
+    gm, gn, ns = p["gmf"] + shift_r, p["gnf"] + p["shift"], p["nsI"]
+    if gm == 0 or gn == 0:
+        pytest.skip("no interior launch")
+    L = sum(max(0, gn - r * q) for r in range(gm))
+    N = L * ns
+    per = (N + 7) // 8
+    seen = {}
+    for wg in range(8 * per):
+        xcd, slot = wg & 7, wg >> 3
+        item = xcd * per + slot
+        if slot >= per or item >= N:
+            continue
+        z, t = divmod(item, L)
+        r = 0
+        while t >= gn - r * q:
+            t -= gn - r * q
+            r += 1
+        row_t, col_t = r, r * q + t
+        assert 0 <= row_t < gm and 0 <= col_t < gn and 0 <= z < ns
+        jend = m if (p["shift"] and col_t == gn - 1) else (col_t + 1) * bn
+        assert row_t * 128 < jend                                   # the tile intersects the upper triangle
+        assert (z, row_t, col_t) not in seen
+        seen[(z, row_t, col_t)] = xcd
+    live = [(r, c) for r in range(gm) for c in range(gn) if r * 128 < (m if (p["shift"] and c == gn - 1) else (c + 1) * bn)]
+    assert len(live) == L and len(seen) == L * ns
+    assert {(r, c) for (_, r, c) in seen} == set(live)

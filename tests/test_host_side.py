@@ -1034,3 +1034,40 @@ def test_zgemm_compact_upper_grid_enumerates_the_live_tiles_once(lib, m, k, flag
     live = [(r, c) for r in range(gm) for c in range(gn) if r * 128 < (m if (p["shift"] and c == gn - 1) else (c + 1) * bn)]
     assert len(live) == L and len(seen) == L * ns
     assert {(r, c) for (_, r, c) in seen} == set(live)
+
+
+def test_sphere_planes_wrap_around_contiguously_for_the_baseline_kpoints():
+    """The register-resident z kernels address the sphere's z planes by index arithmetic: they must be {0 .. z_lo-1} u
+    {nz-(nzx-z_lo) .. nz-1} (dftk_mi_kblock's z_lo, api.cpp).  Checked here on the host for every irreducible k-point of
+    the k-point BASELINE configs (cfg 3: fcc Al 36^3, cfg 4: graphene 30x30x120) and for a Gamma-only supercell."""
+    import ctypes as C
+    from dftk_jl_amd._lib import check
+    lib = dftk.load_library()
+
+    def planes_ok(b):
+        nx, ny, nz = b.fft_size
+        for kp in b.kpoints:
+            z = np.unique(np.asarray(kp.mapping) // (nx * ny))
+            lo = 0
+            while lo < len(z) and z[lo] == lo:
+                lo += 1
+            assert lo >= 1 and np.array_equal(z[lo:], nz - (len(z) - lo) + np.arange(len(z) - lo)), (kp.coordinate, z)
+
+    a = 7.6324708938577865                                           # test/testcases.jl:74, as bench.py --system al
+    lat = a / 2 * np.array([[0, 1, 1.0], [1, 0, 1.0], [1, 1, 0.0]])
+    Al = dftk.ElementPsp("Al", dftk.load_psp("Al", "pbe"))
+    model = dftk.model_DFT(lat, [Al], [np.zeros(3)], functionals=("gga_x_pbe", "gga_c_pbe"), temperature=1e-3,
+                           smearing="gaussian")
+    planes_ok(dftk.PlaneWaveBasis(model, 40.0, dftk.MonkhorstPack((6, 6, 6)), device="cpu", build_terms=False))
+    a, Lz = 4.66, 20.0                                               # examples/graphene.jl:15-30, as bench.py --system graphene
+    lat = np.array([[a / 2, a / 2, 0.0], [-a * np.sqrt(3) / 2, a * np.sqrt(3) / 2, 0.0], [0.0, 0.0, Lz]])
+    Cc = dftk.ElementPsp("C", dftk.load_psp("C", "pbe"))
+    pos = [np.array([1 / 3, -1 / 3, 0.0]), np.array([-1 / 3, 1 / 3, 0.0])]
+    model = dftk.model_DFT(lat, [Cc, Cc], pos, functionals=("gga_x_pbe", "gga_c_pbe"), temperature=1e-3,
+                           smearing="fermi_dirac")
+    b = dftk.PlaneWaveBasis(model, 40.0, dftk.MonkhorstPack((5, 5, 1)), device="cpu", build_terms=False)
+    assert b.fft_size[2] == 120                                      # the length the multi-k z kernels run at cfg 4
+    planes_ok(b)
+    lat, atoms, pos = dftk.silicon_cell((2, 2, 2))
+    planes_ok(dftk.PlaneWaveBasis(dftk.model_DFT(lat, atoms, pos), 30.0, dftk.ExplicitKpoints([[0, 0, 0]], [1.0]), device="cpu",
+                                  build_terms=False))

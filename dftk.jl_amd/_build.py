@@ -94,5 +94,31 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIBPATH
 
 
+ABI_CHECK_SRC = os.path.join(os.path.dirname(HERE), "tools", "abi_c_check.c")
+ABI_CHECK_BIN = os.path.join(os.path.dirname(HERE), "tools", "bin", "abi_c_check")
+
+
+def build_abi_check(force: bool = False) -> str:
+    """tools/abi_c_check.c -> tools/bin/abi_c_check: the plain-C consumer of include/dftk_mi355x.h, compiled by gcc
+    (-std=c99 -pedantic: the header must be C, not C++) and linked against the in-tree library (rpath relative to the
+    binary, so the pair travels to the GPU box)."""
+    build()
+    src_time = max(os.path.getmtime(p) for p in (ABI_CHECK_SRC, LIBPATH,
+                                                  os.path.join(os.path.dirname(HERE), "include", "dftk_mi355x.h")))
+    if not force and os.path.exists(ABI_CHECK_BIN) and os.path.getmtime(ABI_CHECK_BIN) >= src_time:
+        return ABI_CHECK_BIN
+    os.makedirs(os.path.dirname(ABI_CHECK_BIN), exist_ok=True)
+    rocm_lib = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O1",
+           "-I", os.path.join(os.path.dirname(HERE), "include"), ABI_CHECK_SRC, "-o", ABI_CHECK_BIN,
+           "-L", LIBDIR, "-ldftk_mi355x", "-L", rocm_lib, "-lamdhip64", "-lm",
+           "-Wl,-rpath,$ORIGIN/../../dftk.jl_amd/lib", f"-Wl,-rpath,{rocm_lib}"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("gcc failed on tools/abi_c_check.c:\n" + res.stdout + res.stderr)
+    return ABI_CHECK_BIN
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_abi_check(force=True))

@@ -234,8 +234,12 @@ class PlaneWaveBasis:
         # handful of k-points is better served by as many concurrent streams; DFTK_MI_KBATCH=1 forces the batched loop.
         env_kb = os.environ.get("DFTK_MI_KBATCH")
         kb_min = int(os.environ.get("DFTK_MI_KBATCH_MIN", "32"))
+        # The decision is taken from the GLOBAL k-point list: every rank of a k-parallel run must walk the same k-loop
+        # algorithm and the same chain of start vectors whatever its local share (9 of 72 k-points per rank at 8 GPUs
+        # stay batched, exactly as the one-rank run of the same workload).
+        n_k_global = len(self.kcoords_global)
         self.kbatch = (n_lanes is None and env_kb != "0" and "DFTK_MI_LANES" not in os.environ and len(kc) > 1
-                       and self.comm_pw.size == 1 and (env_kb == "1" or len(kc) >= kb_min))
+                       and self.comm_pw.size == 1 and (env_kb == "1" or n_k_global >= kb_min))
         if self.kbatch:
             n_lanes = 1
         if n_lanes is None:

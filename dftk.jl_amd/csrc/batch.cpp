@@ -27,8 +27,13 @@ struct BatchCtx {
     size_t cap = 0, off = 0;
     char *h_res = nullptr, *d_res = nullptr;
     size_t res_cap = 0, res_off = 0;
+    // device scratch of the executors: a bump allocator per round (every batch_scratch() pointer stays valid until the
+    // round's stream synchronisation; a request that does not fit opens a larger buffer and RETIRES the current one,
+    // which is freed only after that synchronisation)
     void* d_scratch = nullptr;
-    size_t scratch_bytes = 0;
+    size_t scratch_bytes = 0, scratch_off = 0;
+    int scratch_gen = 0;             // bumped when a larger buffer replaces the current one (see BatchScratchScope)
+    std::vector<void*> retired;
     std::vector<std::function<void()>> fixups;   // run after the round's stream synchronisation
     bool failed = false;
     int64_t n_rounds = 0, n_ops = 0, n_launch_groups = 0, n_sequential = 0;   // dftk_mi_batch_stats
@@ -79,18 +84,39 @@ int batch_results_fetch(BatchCtx* c) {
 }
 void batch_add_fixup(BatchCtx* c, std::function<void()> f) { c->fixups.push_back(std::move(f)); }
 void* batch_scratch(BatchCtx* c, size_t bytes) {
-    if (bytes > c->scratch_bytes) {
-        hipStreamSynchronize(c->stream);
-        if (c->d_scratch) hipFree(c->d_scratch);
+    const size_t al = (bytes + 255) & ~(size_t)255;
+    if (c->scratch_off + al > c->scratch_bytes) {
+        // nothing queued on the stream may lose its buffer: the old one is retired, not freed (batch_scratch_reset)
+        if (c->d_scratch) c->retired.push_back(c->d_scratch);
         c->d_scratch = nullptr;
-        c->scratch_bytes = 0;
-        if (dftk_scratch_malloc(&c->d_scratch, bytes + bytes / 4) != hipSuccess) {
+        const size_t want = std::max(al + al / 4, 2 * c->scratch_bytes);
+        c->scratch_bytes = c->scratch_off = 0;
+        c->scratch_gen += 1;
+        if (dftk_scratch_malloc(&c->d_scratch, want) != hipSuccess) {
+            c->d_scratch = nullptr;
             c->failed = true;
             return nullptr;
         }
-        c->scratch_bytes = bytes + bytes / 4;
+        c->scratch_bytes = want;
     }
-    return c->d_scratch;
+    void* p = static_cast<char*>(c->d_scratch) + c->scratch_off;
+    c->scratch_off += al;
+    return p;
+}
+// Executors bracket their requests with a scope: what an executor took is handed out again to the NEXT operation of the
+// round (stream order makes the reuse safe), while requests made INSIDE the scope (the split-K partials of the products an
+// apply_H executor runs) stack on top of it.  A mark taken in a buffer that has been replaced since releases to offset 0
+// of the new one (the outer allocation lives in the retired buffer).
+void batch_scratch_mark(BatchCtx* c, size_t* off, int* gen) {
+    *off = c->scratch_off;
+    *gen = c->scratch_gen;
+}
+void batch_scratch_release(BatchCtx* c, size_t off, int gen) { c->scratch_off = gen == c->scratch_gen ? off : 0; }
+// end of a round, AFTER its stream synchronisation: everything handed out is dead
+static void batch_scratch_reset(BatchCtx* c) {
+    c->scratch_off = 0;
+    for (void* p : c->retired) hipFree(p);
+    c->retired.clear();
 }
 
 namespace {
@@ -228,6 +254,7 @@ int flush(Recorder* r) {
     c->fixups.clear();
     c->off = 0;
     c->res_off = 0;
+    batch_scratch_reset(c);
     c->n_rounds += 1;
     for (auto& f : r->fibers) {
         f.fifo.clear();
@@ -387,6 +414,7 @@ int batch_run(dftk_mi_basis* b, std::vector<std::function<int()>>& bodies, std::
     g_last_stats[2] = c->n_launch_groups;
     g_last_stats[3] = c->n_sequential;
     hipStreamSynchronize(c->stream);
+    batch_scratch_reset(c);
     if (getenv("DFTK_MI_KBATCH_TRACE"))
         fprintf(stderr, "[kbatch] %zu fibers: %lld rounds, %lld ops, %lld merged launches, %lld one-by-one ops; ms: fibers %.2f, "
                 "launching %.2f, waiting %.2f, fix-ups %.2f\n", n, (long long)c->n_rounds, (long long)c->n_ops,

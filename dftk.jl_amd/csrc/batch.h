@@ -92,7 +92,21 @@ int batch_exec_density(BatchCtx* ctx, hipStream_t stream, std::vector<BOp*>& ops
 const void* batch_stage(BatchCtx* c, const void* src, size_t bytes);       // host table -> device (pinned ring + async copy)
 void* batch_result_slot(BatchCtx* c, size_t bytes, void** host_twin);      // device slot + pinned host twin for results
 int batch_results_fetch(BatchCtx* c);                                       // enqueue ONE copy of all result slots of the round
-void* batch_scratch(BatchCtx* c, size_t bytes);                             // device scratch, valid until the round ends
+// device scratch of the executors: a bump allocator.  A pointer stays valid until the enclosing BatchScratchScope ends
+// (later operations of the round then reuse the space in stream order) or, without a scope, until the round ends; it is
+// never freed or moved under a holder: a request that does not fit retires the buffer until the round's synchronisation
+void* batch_scratch(BatchCtx* c, size_t bytes);
+void batch_scratch_mark(BatchCtx* c, size_t* off, int* gen);
+void batch_scratch_release(BatchCtx* c, size_t off, int gen);
+struct BatchScratchScope {
+    BatchCtx* c;
+    size_t off;
+    int gen;
+    explicit BatchScratchScope(BatchCtx* ctx) : c(ctx) { batch_scratch_mark(c, &off, &gen); }
+    ~BatchScratchScope() { batch_scratch_release(c, off, gen); }
+    BatchScratchScope(const BatchScratchScope&) = delete;
+    BatchScratchScope& operator=(const BatchScratchScope&) = delete;
+};
 #include <functional>
 void batch_add_fixup(BatchCtx* c, std::function<void()> f);                // runs on the host after the round's sync
 // run the bodies as fibers of one batched call on the stream of `b`

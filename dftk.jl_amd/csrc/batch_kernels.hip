@@ -791,6 +791,7 @@ int batch_exec_group(BatchCtx* ctx, hipStream_t stream, int type, std::vector<BO
                                    0, 0);
             } else {
                 const int pm = tm * BG_T, pn = tn * BG_T;
+                BatchScratchScope scratch_scope(ctx);
                 cd* part = reinterpret_cast<cd*>(batch_scratch(ctx, cn.size() * (size_t)nsplit * pm * pn * sizeof(cd)));
                 if (!part) return DFTK_MI_EHIP;
                 hipLaunchKernelGGL(k_b_gemm_c, dim3(tm * tn, nsplit, (unsigned)cn.size()), dim3(256), 0, stream, d, tn, nsplit,
@@ -837,9 +838,12 @@ int batch_exec_group(BatchCtx* ctx, hipStream_t stream, int type, std::vector<BO
         return 0;
     }
     if (type == BOP_D2H) {
+        // validate the WHOLE group before the first slot / fix-up exists: a fall-back to the one-by-one path must not
+        // leave fix-ups behind that would overwrite its (correct) host data after the round's synchronisation
+        for (int i = 0; i < n_items; ++i)
+            if (ops[i]->bytes % 4) return 1;
         std::vector<CopyItem> items(n_items);
         for (int i = 0; i < n_items; ++i) {
-            if (ops[i]->bytes % 4) return 1;
             void* htwin = nullptr;
             void* dslot = batch_result_slot(ctx, ops[i]->bytes, &htwin);
             if (!dslot) return DFTK_MI_EHIP;

@@ -1388,6 +1388,7 @@ int batch_exec_apply_H(BatchCtx* ctx, hipStream_t stream, std::vector<BOp*>& ops
     // one scratch request for the whole call: T1 / T2 of a chunk of bands, then the two projection panels of all k-blocks
     size_t np_total = 0;
     for (BOp* o : ops) np_total += (size_t)o->kb->n_p * o->m;
+    BatchScratchScope scratch_scope(ctx);
     cd* T1 = reinterpret_cast<cd*>(batch_scratch(ctx, per_band * chunk + 2 * np_total * sizeof(cd)));
     if (!T1) return DFTK_MI_EHIP;
     cd* T2 = T1 + (size_t)s1 * chunk;
@@ -1490,6 +1491,7 @@ int batch_exec_density(BatchCtx* ctx, hipStream_t stream, std::vector<BOp*>& ops
     const size_t per_band = (size_t)(s1 + s2) * sizeof(cd);
     int chunk = (int)std::max<size_t>(1, std::min<size_t>(mp.jobs.size(), ((size_t)2 << 30) / per_band));
     if (chunk > 4096) chunk = 4096;
+    BatchScratchScope scratch_scope(ctx);
     cd* T1 = reinterpret_cast<cd*>(batch_scratch(ctx, per_band * chunk));
     if (!T1) return DFTK_MI_EHIP;
     cd* T2 = T1 + (size_t)s1 * chunk;

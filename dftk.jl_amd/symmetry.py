@@ -1,9 +1,11 @@
 """Crystal symmetries on the host + density symmetrisation on the device (mirror of src/SymOp.jl, src/symmetry.jl,
 src/bzmesh.jl:41-101).
 
-* ``symmetry_operations`` (symmetry.jl:66-125): the reference asks Spglib; here the same group is found by
-  enumerating the integer matrices W that preserve the lattice metric and the translations w that map every atom
-  onto an atom of its species ((U u)(x) = u(W x + w); S = W', tau = -W^-1 w, SymOp.jl:1-60).
+* ``symmetry_operations`` (symmetry.jl:66-125): the reference asks Spglib; here the same group is found the way
+  Spglib finds it -- reduce the cell, scan the 3^9 integer matrices with entries in {-1, 0, 1} for those preserving
+  the metric, then the translations w that map every atom onto an atom of its species ((U u)(x) = u(W x + w);
+  S = W', tau = -W^-1 w, SymOp.jl:1-60).  (The oracle uses a different search -- shells of integer vectors in the
+  unreduced cell -- so the two are independent restatements; both are pinned by the reference's Spglib counts.)
 * ``symmetries_preserving_kgrid / _rgrid`` (:163-211), ``irreducible_kcoords`` (bzmesh.jl:54-101, no time reversal
   as the reference): the k-points a ``PlaneWaveBasis`` really computes.
 * ``symmetrize_rho`` (:282-357): rho(G) <- 1/|S| sum_s e^{-2 pi i G.tau_s} rho(S_s^-1 G) on the device -- per
@@ -46,56 +48,87 @@ def _approx_integer(x, tol):
     return np.all(np.abs(x - np.round(x)) <= tol)
 
 
+def _reduced_cell(lattice):
+    """Minkowski-style reduction of the cell: returns (A, T) with A = lattice @ T, T unimodular integer, such that no
+    column of A gets shorter by adding integer combinations (coefficients in {-1, 0, 1}) of the other two.  In such a
+    basis every lattice automorphism has entries in {-1, 0, 1} -- the property Spglib's own point-group search relies
+    on after its Delaunay reduction (the reference: symmetry.jl:88-93 -> Spglib)."""
+    A = np.array(lattice, dtype=float)
+    T = np.eye(3, dtype=int)
+    combos = [c for c in itertools.product((-1, 0, 1), repeat=2) if any(c)]
+    for _ in range(200):
+        improved = False
+        for i in range(3):
+            j, k = [a for a in range(3) if a != i]
+            # Gauss step against each neighbour, then the mixed combinations
+            for other in (j, k):
+                mu = int(np.rint(A[:, i] @ A[:, other] / (A[:, other] @ A[:, other])))
+                if mu and (A[:, i] - mu * A[:, other]) @ (A[:, i] - mu * A[:, other]) < (A[:, i] @ A[:, i]) * (1 - 1e-12):
+                    A[:, i] -= mu * A[:, other]
+                    T[:, i] -= mu * T[:, other]
+                    improved = True
+            for x, y in combos:
+                cand = A[:, i] + x * A[:, j] + y * A[:, k]
+                if cand @ cand < (A[:, i] @ A[:, i]) * (1 - 1e-12):
+                    A[:, i] = cand
+                    T[:, i] += x * T[:, j] + y * T[:, k]
+                    improved = True
+        if not improved:
+            break
+    return A, T
+
+
+def _lattice_point_group(lattice, tol):
+    """All integer W (in the basis of ``lattice``) with W' G W = G, G = lattice' lattice: exhaustive scan of the
+    3^9 matrices with entries in {-1, 0, 1} in the reduced cell, mapped back with the reduction's unimodular T."""
+    A, T = _reduced_cell(lattice)
+    G = A.T @ A
+    entries = np.array(list(itertools.product((-1, 0, 1), repeat=9)), dtype=np.int64).reshape(-1, 3, 3)
+    Gw = np.einsum("nki,kl,nlj->nij", entries, G, entries)
+    keep = np.max(np.abs(Gw - G), axis=(1, 2)) <= tol * np.max(np.abs(G))
+    Tinv = np.rint(np.linalg.inv(T.astype(float))).astype(np.int64)
+    return [T @ Wr @ Tinv for Wr in entries[keep]]
+
+
 def symmetry_operations(lattice, atom_groups, positions, tol=SYMMETRY_TOLERANCE):
     """All (W, w) with W an integer matrix preserving the metric lattice' lattice and W a + w an atom of the same
-    species for every atom a (symmetry.jl:66-125)."""
+    species for every atom a (symmetry.jl:66-125: the reference delegates to Spglib; this is Spglib's scheme -- point
+    group of the REDUCED cell by exhaustive scan, then the translations that carry the sparsest species onto itself).
+    Pinned by the reference's own Spglib-derived counts in tests/test_host_side.py."""
     lattice = np.asarray(lattice, dtype=float)
     positions = [np.asarray(p, dtype=float) for p in positions]
     if not positions:
         return [identity()]
-    metric = lattice.T @ lattice
-    scale = np.max(np.abs(metric))
-    rng = range(-2, 3)
-    vecs = np.array(list(itertools.product(rng, rng, rng)), dtype=int)
-    lengths = np.einsum("ni,ij,nj->n", vecs, metric, vecs)
-    cols = [vecs[np.abs(lengths - metric[i, i]) <= tol * scale] for i in range(3)]
+    species_pos = [np.array([positions[i] for i in group]) for group in atom_groups if len(group)]
+    pivot = min(species_pos, key=len)
+
+    def maps_crystal(W, w):
+        for P in species_pos:
+            delta = (P @ W.T + w)[:, None, :] - P[None, :, :]
+            delta -= np.rint(delta)
+            if not np.all((np.abs(delta) <= tol).all(axis=2).any(axis=1)):
+                return False
+        return True
+
     ops = []
-    smallest = min(atom_groups, key=len)
-    a0 = positions[smallest[0]]
-    group_pos = [np.array([positions[i] for i in group]) for group in atom_groups]
-    for c0 in cols[0]:
-        for c1 in cols[1]:
-            if abs(c0 @ metric @ c1 - metric[0, 1]) > tol * scale:
+    for W in _lattice_point_group(lattice, tol):
+        image0 = W @ pivot[0]
+        for target in pivot:                      # W x_0 + w must be an atom of the pivot species
+            w = target - image0
+            if not maps_crystal(W, w):
                 continue
-            for c2 in cols[2]:
-                W = np.stack([c0, c1, c2], axis=1)
-                if abs(round(np.linalg.det(W))) != 1:
-                    continue
-                if np.max(np.abs(W.T @ metric @ W - metric)) > tol * scale:
-                    continue
-                for j in smallest:
-                    w = positions[j] - W @ a0
-                    ok = True
-                    for gp in group_pos:            # every image W a + w must be an atom of the same group (mod lattice)
-                        d = (gp @ W.T + w)[:, None, :] - gp[None, :, :]
-                        if not np.all(np.any(np.all(np.abs(d - np.round(d)) <= tol, axis=2), axis=1)):
-                            ok = False
-                            break
-                    if ok:
-                        op = SymOp.make(W, w)
-                        if not any(np.array_equal(op.W, o.W) and _approx_integer(op.w - o.w, tol) for o in ops):
-                            ops.append(op)
+            op = SymOp.make(W, w)
+            if not any(np.array_equal(op.W, o.W) and _approx_integer(op.w - o.w, tol) for o in ops):
+                ops.append(op)
     ops.sort(key=lambda o: (not o.isone(),))
-    # candidate columns are searched among integer vectors with entries in [-2, 2] (enough for reduced cells); on a badly
-    # skewed, non-reduced lattice that search can miss operations, and a set that is not a GROUP would silently give wrong
-    # irreducible weights -- so the closure is verified (SymOp.jl check_group) and anything else falls back to the identity
+    # a set that is not a GROUP would silently give wrong irreducible weights: the closure is verified
+    # (SymOp.jl check_group) and anything else falls back to the identity
     if 1 < len(ops) <= 192:
         try:
             check_group(ops, tol)
-        except AssertionError:
+        except ValueError:
             import warnings
-            warnings.warn("symmetry_operations: the detected operations do not form a group (non-reduced lattice?); "
-                          "using the identity only")
+            warnings.warn("symmetry_operations: the detected operations do not form a group; using the identity only")
             return [identity()]
     return ops
 
@@ -272,13 +305,17 @@ def symmetrize_rho(basis, rho, do_lowpass=True):
 
 
 def check_group(symmetries, tol=SYMMETRY_TOLERANCE):
-    """SymOp.jl ``check_group``: identity, inverses and products are in the set."""
+    """SymOp.jl ``check_group``: identity, inverses and products are in the set.  Raises ``ValueError`` (not an
+    ``assert``: the check must survive ``python -O``)."""
     def member(W, w):
         return any(np.array_equal(W, o.W) and _approx_integer(w - o.w, tol) for o in symmetries)
-    assert member(np.eye(3, dtype=int), np.zeros(3))
+    if not member(np.eye(3, dtype=int), np.zeros(3)):
+        raise ValueError("check_group: the identity is missing")
     for s in symmetries:
         Wi = np.round(np.linalg.inv(s.W.astype(float))).astype(int)
-        assert member(Wi, -Wi @ s.w)
+        if not member(Wi, -Wi @ s.w):
+            raise ValueError("check_group: an inverse is missing")
         for t in symmetries:
-            assert member(s.W @ t.W, s.w + s.W @ t.w)
+            if not member(s.W @ t.W, s.w + s.W @ t.w):
+                raise ValueError("check_group: a product is missing")
     return symmetries

@@ -618,18 +618,20 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, ei
                 # the irreducible k-points: int V_in rho_sym = int V_in rho_irr needs V_in invariant under basis.symmetries,
                 # which holds by construction (rho_in is the symmetric guess or a mix of symmetrised outputs, the atomic
                 # potentials carry the crystal symmetry; both SCF drivers only ever pass that V_in as ritz_potential).
+                # ONE decision for all k-points: either every band-wise kinetic energy is subtracted here, or the total
+                # E_kin is subtracted afterwards (ritz_fix[1]) -- a mixed list must not do both
+                use_bandwise = bool(kin_bands) and all(kb_ is not None for kb_ in kin_bands)
                 e = 0.0
                 for ik, psik in enumerate(psi):
                     occ = np.asarray(occupation[ik], dtype=float)
                     occ = np.where(np.abs(occ) >= ritz_occupation_threshold, occ, 0.0)
                     e_k = float(np.dot(occ, np.asarray(eigenvalues[ik], dtype=float)[:len(occ)]))
-                    if kin_bands and kin_bands[ik] is not None:
+                    if use_bandwise:
                         e_k -= float(np.dot(occ, kin_bands[ik]))
                     e += basis.kweights[ik] * e_k
                 E[name] = e
                 reduce_kpts.append(name)
-                ritz_fix = (float((rho * ritz_potential).sum().item() * basis.dvol),
-                            bool(kin_bands) and all(kb_ is not None for kb_ in kin_bands))
+                ritz_fix = (float((rho * ritz_potential).sum().item() * basis.dvol), use_bandwise)
             elif have_psi:
                 e = 0.0
                 for ik, psik in enumerate(psi):

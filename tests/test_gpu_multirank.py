@@ -202,6 +202,7 @@ if comm.rank == 0:
     print("RESULT " + json.dumps({"E": res["energies"].total, "terms": dict(res["energies"]),
                                   "lam": res["eigenvalues"][0].tolist(), "converged": bool(res["converged"]),
                                   "n_iter": res["n_iter"], "n_matvec": res["n_matvec"],
+                                  "history_drho": [float(x) for x in res["history_drho"]],
                                   "rho_sum": float(res["rho"].sum()) * basis.dvol}))
 dist.barrier(); dist.destroy_process_group()
 '''
@@ -251,6 +252,12 @@ def test_planewave_sharded_block_two_ranks_one_gpu(tmp_path):
     #  less depending on the summation order of the sharded reductions -- five seeds of the ONE-rank run alone give
     #  33 .. 38 steps; the energies, terms and eigenvalues above are the parity criteria)
     assert abs(got["n_iter"] - ref["n_iter"]) <= 15
+    # ... and a TIGHT step criterion above that round-off tail: up to tol = 1e-7 the two trajectories must need the same
+    # number of SCF steps (+- 2) -- a convergence regression of the sharded path shows here
+    def steps_to(hist, thr):
+        return next(i for i, d in enumerate(hist) if d < thr)
+    assert abs(steps_to(got["history_drho"], 1e-7) - steps_to(ref["history_drho"], 1e-7)) <= 2, \
+        (got["history_drho"], ref["history_drho"])
 
 
 def test_rccl_c_abi_single_rank_allreduce():
@@ -271,3 +278,22 @@ def test_rccl_c_abi_single_rank_allreduce():
     assert torch.equal(x, want)
     assert lib.dftk_mi_allreduce_sum_f64(comm, None, 4, None) < 0          # invalid argument, reported not crashed
     check(lib.dftk_mi_comm_destroy(comm))
+
+
+def test_c_consumer_of_the_header_drives_rccl_shard_apply_density_lobpcg():
+    """tools/abi_c_check.c (plain C against include/dftk_mi355x.h): unique id -> init_rank -> describe (ncclCommCount)
+    -> all-reduce -> zgemm with by-value complex scalars -> set_shard -> apply_H / density / LOBPCG on the slab, each
+    compared with the unsharded block inside the program.  One rank here (RCCL wants one device per rank; the same
+    binary takes N on a multi-GPU node: `tools/bin/abi_c_check 8`)."""
+    import subprocess
+    from dftk_jl_amd import _build
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    exe = _build.build_abi_check()
+    res = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, (res.returncode, res.stdout[-2000:], res.stderr[-2000:])
+    assert "abi_c_check OK ranks=1" in res.stdout
+    n_dev = torch.cuda.device_count()
+    if n_dev > 1:
+        res = subprocess.run([exe, str(n_dev)], capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, (res.returncode, res.stdout[-2000:], res.stderr[-2000:])
+        assert f"abi_c_check OK ranks={n_dev}" in res.stdout

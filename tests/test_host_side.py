@@ -586,9 +586,10 @@ def test_symmetry_host_logic_matches_oracle():
     lat, atoms, pos = dftk.silicon_cell((2, 1, 1))
     m = dftk.model_DFT(lat, atoms, pos, symmetries=True)
     oops = osy.symmetry_operations(lat, [list(range(len(pos)))], pos)
-    assert len(m.symmetries) == len(oops)
-    for a, b in zip(m.symmetries, oops):
-        assert np.array_equal(a.W, b.W) and np.allclose(a.w, b.w) and np.allclose(a.tau, b.tau)
+    assert len(m.symmetries) == len(oops) and m.symmetries[0].isone()
+    for a in m.symmetries:      # two different searches (reduced-cell scan vs. vector shells): same SET of operations
+        twins = [b for b in oops if np.array_equal(a.W, b.W) and np.allclose(np.mod(a.w - b.w + 0.5, 1.0), 0.5, atol=1e-9)]
+        assert len(twins) == 1 and np.allclose(np.mod(a.tau - twins[0].tau + 0.5, 1.0), 0.5, atol=1e-9)
     dftk.check_group(m.symmetries)
     lat, atoms, pos = dftk.silicon_cell()
     m = dftk.model_DFT(lat, atoms, pos, symmetries=True)
@@ -603,6 +604,78 @@ def test_symmetry_host_logic_matches_oracle():
     m0 = dftk.model_DFT(lat, atoms, pos)                                   # default: no symmetries
     b0 = dftk.PlaneWaveBasis(m0, 15, dftk.MonkhorstPack((4, 4, 4)), device="cpu", build_terms=False)
     assert b0.fft_size == (27, 27, 27) and len(b0.kpoints) == 64 and len(b0.symmetries) == 1
+
+
+REF_SI_A = 5.131570667152971
+REF_CELLS = {   # test/testcases.jl:10-28 (silicon), :49-58 (magnesium), :107-116 (platinum_hcp)
+    "silicon": (np.array([[0, REF_SI_A, REF_SI_A], [REF_SI_A, 0, REF_SI_A], [REF_SI_A, REF_SI_A, 0.0]]),
+                [np.ones(3) / 8, -np.ones(3) / 8]),
+    "magnesium": (np.array([[-3.0179389205999998, -3.0179389205999998, 0.0], [-5.2272235447000002, 5.2272235447000002, 0.0],
+                            [0.0, 0.0, -9.7736219469000005]]), [np.array([2 / 3, 1 / 3, 1 / 4]), np.array([1 / 3, 2 / 3, 3 / 4])]),
+    "platinum_hcp": (np.array([[10.0, 0, 0], [5.0, 8.66025403784439, 0], [0, 0, 16.33]]), [np.zeros(3), np.ones(3) / 3]),
+}
+# test/bzmesh.jl:62-80: (testcase, kgrid, irreducible k-points Spglib finds, supercell, kshift)
+REF_IRREDUCIBLE_COUNTS = [
+    ("silicon", (1, 1, 1), 1, (1, 1, 1), (0, 0, 0)), ("silicon", (1, 1, 5), 3, (1, 1, 1), (0, 0, 0)),
+    ("silicon", (2, 3, 2), 6, (1, 1, 1), (0, 0, 0)), ("silicon", (3, 3, 3), 4, (1, 1, 1), (0, 0, 0)),
+    ("silicon", (2, 3, 4), 14, (1, 1, 1), (0, 0, 0)), ("silicon", (9, 11, 13), 644, (1, 1, 1), (0, 0, 0)),
+    ("silicon", (3, 3, 3), 6, (1, 1, 1), (.5, .5, .5)), ("silicon", (3, 3, 3), 6, (1, 1, 1), (.5, 0, .5)),
+    ("silicon", (3, 3, 3), 6, (1, 1, 1), (0, .5, 0)),
+    ("silicon", (1, 4, 4), 7, (2, 1, 1), (0, 0, 0)), ("silicon", (1, 16, 16), 73, (4, 1, 1), (0, 0, 0)),
+    ("magnesium", (2, 3, 2), 8, (1, 1, 1), (0, 0, 0)), ("magnesium", (3, 3, 3), 6, (1, 1, 1), (0, 0, 0)),
+    ("magnesium", (2, 3, 4), 12, (1, 1, 1), (0, 0, 0)), ("magnesium", (9, 11, 13), 350, (1, 1, 1), (0, 0, 0)),
+    ("platinum_hcp", (5, 5, 5), 63, (1, 1, 1), (0, 0, 0)),
+]
+
+
+def _supercell(lat, pos, sc):
+    """Plain repetition of the cell (src/supercell.jl:5-20); only the SET of atoms matters to the symmetry search."""
+    sc = np.asarray(sc)
+    out = [(np.asarray(p) + np.array([i, j, k])) / sc for p in pos for k in range(sc[2]) for j in range(sc[1])
+           for i in range(sc[0])]
+    return lat * sc[None, :], out
+
+
+def test_mirror_symmetry_search_reproduces_the_reference_spglib_counts():
+    """The PRODUCT's symmetry search (dftk.jl_amd/symmetry.py, not the oracle's) against the numbers the reference pins
+    from Spglib: every ``test_reduction`` case of test/bzmesh.jl:62-80 (silicon incl. shifted meshes and 2x1x1 / 4x1x1
+    supercells, hcp magnesium, hcp platinum) with the reference's own reconstruction check (:45-57: the images of the
+    irreducible points are the whole mesh), the k-weights of test/testcases.jl:24-28 and :59-65, and the 48 operations
+    of the CuO2 cell of test/symmetry_issues.jl:9-24."""
+    from dftk_jl_amd import symmetry as sy
+    for name, size, n_irr, sc, shift in REF_IRREDUCIBLE_COUNTS:
+        lat, pos = REF_CELLS[name]
+        if sc != (1, 1, 1):
+            lat, pos = _supercell(lat, pos, sc)
+        ops = sy.symmetry_operations(lat, [list(range(len(pos)))], pos)
+        assert ops[0].isone()
+        keep = sy.symmetries_preserving_kgrid(ops, size, shift)
+        sy.check_group(keep)
+        kc, kw = sy.irreducible_kcoords(size, keep, shift)
+        assert len(kc) == n_irr, (name, size, shift, sc, len(kc))
+        assert abs(sum(kw) - 1) < 1e-13
+        red = {sy._grid_key(k, np.array(size), shift) for k in sy.reducible_kcoords(size, shift)}
+        img = {sy._grid_key(s.S @ k, np.array(size), shift) for k in kc for s in keep}
+        assert img == red, (name, size)
+    lat, pos = REF_CELLS["silicon"]
+    ops = sy.symmetry_operations(lat, [[0, 1]], pos)
+    assert len(ops) == 48
+    assert sorted(np.rint(np.array(sy.irreducible_kcoords((3, 3, 3), ops)[1]) * 27).astype(int)) == [1, 6, 8, 12]
+    lat, pos = REF_CELLS["magnesium"]
+    ops = sy.symmetry_operations(lat, [[0, 1]], pos)
+    assert len(ops) == 24
+    assert sorted(np.rint(np.array(sy.irreducible_kcoords((3, 3, 3), ops)[1]) * 27).astype(int)) == [1, 2, 2, 4, 6, 12]
+    a = 4.474
+    latc = np.array([[0, a, a], [a, 0, a], [a, a, 0.0]]).T
+    frac = [np.linalg.solve(latc, c) for c in (np.zeros(3), np.array([6.711, 2.237, 6.711]), np.array([6.711, 2.237, 2.237]))]
+    assert len(sy.symmetry_operations(latc, [[0], [1, 2]], frac)) == 48
+    # a skewed (non-reduced) description of the same silicon lattice: the cell reduction must find all 48 again
+    U = np.array([[1, 2, 0], [0, 1, 3], [0, 0, 1]])
+    lat, pos = REF_CELLS["silicon"]
+    assert len(sy.symmetry_operations(lat @ U, [[0, 1]], [np.linalg.solve(U.astype(float), p) for p in pos])) == 48
+    # check_group is an explicit exception (survives python -O)
+    with pytest.raises(ValueError):
+        sy.check_group(ops[:5])
 
 
 def test_scfres_dict_layout_on_host():
@@ -1071,3 +1144,18 @@ def test_sphere_planes_wrap_around_contiguously_for_the_baseline_kpoints():
     lat, atoms, pos = dftk.silicon_cell((2, 2, 2))
     planes_ok(dftk.PlaneWaveBasis(dftk.model_DFT(lat, atoms, pos), 30.0, dftk.ExplicitKpoints([[0, 0, 0]], [1.0]), device="cpu",
                                   build_terms=False))
+
+
+def test_header_is_plain_c_and_the_c_consumer_builds_and_fails_loudly_without_a_gpu():
+    """include/dftk_mi355x.h compiled as C99 (-pedantic -Werror) by gcc through tools/abi_c_check.c -- the C consumer a
+    Julia `ccall` stands for (struct-by-value `dftk_mi_cplx`, `char id[128]`, callback typedefs).  Linked against the
+    in-tree library; on a box without a GPU it must refuse to do anything (exit code 3, no CPU fallback)."""
+    import subprocess
+    from dftk_jl_amd import _build
+    exe = _build.build_abi_check()
+    assert os.path.exists(exe)
+    import torch
+    if not torch.cuda.is_available():
+        res = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=120)
+        assert res.returncode == 3, (res.returncode, res.stdout, res.stderr)
+        assert "no CPU fallback" in res.stderr

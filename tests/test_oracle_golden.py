@@ -606,8 +606,8 @@ SI_POS = [np.ones(3) / 8, -np.ones(3) / 8]
 
 
 def test_symmetry_detection_and_kmesh_reduction_reference_counts():
-    """test/bzmesh_symmetry.jl:58-68 (irreducible k-point counts of silicon for several Monkhorst-Pack meshes and
-    shifts, incl. supercells), test/testcases.jl:24-28 (weights 1, 8, 6, 12 / 27 of the 3x3x3 mesh),
+    """test/bzmesh.jl:62-80 (irreducible k-point counts of silicon for several Monkhorst-Pack meshes and
+    shifts, incl. supercells; hcp magnesium and platinum at the end of this test), test/testcases.jl:24-28 (weights 1, 8, 6, 12 / 27 of the 3x3x3 mesh),
     test/symmetry_issues.jl:9-24 (CuO2: 48 operations) -- Spglib's answers, reproduced by the metric search."""
     from oracle import symmetry as sy
     ops = sy.symmetry_operations(SI_LAT, [[0, 1]], SI_POS)
@@ -638,6 +638,15 @@ def test_symmetry_detection_and_kmesh_reduction_reference_counts():
     latc = np.array([[0, a, a], [a, 0, a], [a, a, 0.0]]).T
     frac = [np.linalg.solve(latc, c) for c in (np.zeros(3), np.array([6.711, 2.237, 6.711]), np.array([6.711, 2.237, 2.237]))]
     assert len(sy.symmetry_operations(latc, [[0], [1, 2]], frac)) == 48
+    # hcp cells (test/bzmesh.jl:76-80; lattices and positions test/testcases.jl:49-58, :107-116)
+    mg = np.array([[-3.0179389205999998, -3.0179389205999998, 0.0], [-5.2272235447000002, 5.2272235447000002, 0.0],
+                   [0.0, 0.0, -9.7736219469000005]])
+    mg_ops = sy.symmetry_operations(mg, [[0, 1]], [np.array([2 / 3, 1 / 3, 1 / 4]), np.array([1 / 3, 2 / 3, 3 / 4])])
+    for size, n_irr in [((2, 3, 2), 8), ((3, 3, 3), 6), ((2, 3, 4), 12), ((9, 11, 13), 350)]:
+        assert len(sy.irreducible_kcoords(size, sy.symmetries_preserving_kgrid(mg_ops, size))[0]) == n_irr, size
+    pt = np.array([[10.0, 0, 0], [5.0, 8.66025403784439, 0], [0, 0, 16.33]])
+    pt_ops = sy.symmetry_operations(pt, [[0, 1]], [np.zeros(3), np.ones(3) / 3])
+    assert len(sy.irreducible_kcoords((5, 5, 5), sy.symmetries_preserving_kgrid(pt_ops, (5, 5, 5)))[0]) == 63
 
 
 def test_symmetrised_scf_equals_unsymmetrised():

@@ -47,7 +47,15 @@ F64_MFMA_PEAK_TF = 78.6      # MI355X fp64 matrix peak (64
 
 FAMILIES = {0: "zgemm_f64_mfma", 1: "fft_A_xbwd_scatter", 2: "fft_B_ybwd", 3: "fft_C_z_fused_V", 4: "fft_D_yfwd",
             5: "fft_E_xfwd_gather", 6: "density_z", 7: "heev_jacobi", 8: "potrf_trtri", 9: "apply_H_total",
-            11: "zgemm_f64_mfma_structured", 13: "collectives"}
+            11: "zgemm_f64_mfma_structured", 13: "collectives", 15: "elementwise_nG_sized", 16: "host_waits"}
+XGMI_LINK_GBS = 153.0        # 7 links x ~153 GB/s per GPU, ring collectives are per-link bound
+COLLECTIVE_LATENCY_US = 25.0 # ASSUMED per-collective launch + synchronisation latency of RCCL on one node (not measured here)
+PARITY_TOL_HA_PER_ATOM = 1e-8   # north star; the reference accepts 1e-9 .. 1e-10 Ha CPU <-> GPU (test/gpu.jl:30-31,113-114)
+PARITY_SCF_TOL = 1e-8        # density tolerance the parity legs are converged to (E error ~ drho^2, eigenvalues ~ drho)
+GOLDEN = {   # supercell n -> (fixture, k-mesh-compatible cube edge, primitive cells): SURVEY appendix B identity
+    5: ("baseline_cfg5_prim_5x5x5_ecut30_fft40.json", 200, 125),
+    4: ("baseline_cfg2_prim_4x4x4_ecut30_fft40.json", 160, 64),
+}
 KERNEL_FAMS = (0, 1, 2, 3, 4, 5, 6)      # candidates for "the dominant kernel" (0 stands for 0 + 11)
 
 
@@ -79,6 +87,10 @@ def parse():
                     help="count kernel-family launches from the warm-up on (lines the counts up with a whole-process "
                          "rocprofv3 --pmc pass; tools/pmc_traffic_bench.sh)")
     ap.add_argument("--cpu-sample-bands", type=int, default=0, help="0 = one band per host core (max 256)")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the untimed parity legs (continuation of the timed SCFs to convergence, golden-fixture run)")
+    ap.add_argument("--no-amdahl-probe", action="store_true",
+                    help="--mode kpoints, N = 1: skip the timed SCF steps on one rank's share of the k-points (Amdahl model)")
     return ap.parse_args()
 
 
@@ -378,7 +390,11 @@ def run_scf(dftk, lib, basis, args, barrier, world, dist, torch):
     iters, diagtols, step_s, nmv_steps = [], [], [], []
     host_timers = {}
     t0 = time.time()
-    stepper = dftk.ScfStepper(basis, tol=args.tol)          # guess_density is part of self_consistent_field
+    # guess_density is part of self_consistent_field.  The stepper's own convergence test is the (tighter) PARITY
+    # tolerance so that it can be continued, untimed, after the timed loop; the timed loop stops at --tol exactly as
+    # self_consistent_field would (the only difference: the last timed step also mixes, ~4 ms inside the timed region)
+    ptol = min(PARITY_SCF_TOL, args.tol)
+    stepper = dftk.ScfStepper(basis, tol=args.tol, is_converged=lambda info_: info_["history_drho"][-1] < ptol)
     info = None
     for _ in range(max(args.steps, 1)):
         ts = time.time()
@@ -393,9 +409,10 @@ def run_scf(dftk, lib, basis, args, barrier, world, dist, torch):
             if int(os.environ.get("RANK", "0")) == 0:
                 print(f"[step {len(step_s)}] {step_s[-1] * 1e3:.1f} ms: "
                       + ", ".join(f"{k_} {v_ * 1e3:.1f}" for k_, v_ in info["timers"].items()), file=sys.stderr)
-        if info["converged"]:
+        if info["history_drho"][-1] < args.tol:
             break
-    info = stepper.finalize()                                # energies + Hamiltonian of the final state, as the reference
+    info = dict(stepper.finalize())                          # energies + Hamiltonian of the final state, as the reference
+    info["converged"] = bool(info["history_drho"][-1] < args.tol)
     barrier()
     elapsed = time.time() - t0
     check(lib.dftk_mi_prof_enable(basis.handle, 0))
@@ -403,9 +420,55 @@ def run_scf(dftk, lib, basis, args, barrier, world, dist, torch):
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    fam = {f: prof_get(lib, basis, f) for f in list(FAMILIES) + [10, 12, 14]}
+    fam = {f: prof_get(lib, basis, f) for f in list(FAMILIES) + [10, 12, 14, 17, 18]}
     return dict(info=info, elapsed=elapsed, iters=iters, diagtols=diagtols, step_s=step_s, nmv_steps=nmv_steps,
-                host_timers=host_timers, fam=fam)
+                host_timers=host_timers, fam=fam, stepper=stepper)
+
+
+def continue_to_parity(stepper, max_extra=80):
+    """UNTIMED: carry the stepper of a timed (possibly capped) SCF on to the parity tolerance and return the converged
+    total energy / spectrum -- what the parity block of the JSON line is computed from."""
+    t0 = time.time()
+    extra = 0
+    info = stepper.info
+    while not info.get("converged") and extra < max_extra:
+        info = stepper.step()
+        extra += 1
+    info = stepper.finalize()
+    nconv = int(info["n_bands_converge"])
+    return {"converged": bool(info["converged"]), "E_total": float(info["energies"].total),
+            "eigenvalues": [np.asarray(l_, dtype=float)[:nconv].copy() for l_ in info["eigenvalues"]],
+            "extra_steps": extra, "steps_total": int(info["n_iter"]), "drho": float(info["history_drho"][-1]),
+            "wall_s": round(time.time() - t0, 2)}
+
+
+def golden_leg(dftk, model, ecut, n_super, device):
+    """Parity against the ORACLE at the headline size: the supercell at Gamma with the cube that makes it identical to
+    the oracle's primitive cell on the n x n x n k-mesh at 40^3 (cell_to_supercell, src/supercell.jl:27-53).  The
+    production cube of the 5x5x5 cell is 192 = 5 x 38.4: no integer primitive cube exists for it, 200 = 5 x 40 is the
+    nearest cube for which the identity is exact; the fixture was produced by tools/make_golden_baseline.py."""
+    name, cube, n_prim = GOLDEN[n_super]
+    with open(os.path.join(ROOT, "tests", "golden", name)) as fh:
+        g = json.load(fh)
+    assert abs(g["Ecut"] - ecut) < 1e-12 and tuple(g["functionals"]) == ("lda_x", "lda_c_pw")
+    t0 = time.time()
+    basis = dftk.PlaneWaveBasis(model, ecut, dftk.MonkhorstPack((1, 1, 1)), device=device, fft_size=(cube,) * 3)
+    res = dftk.self_consistent_field(basis, tol=PARITY_SCF_TOL)
+    n_atoms = len(model.positions)
+    n_occ = model.n_electrons // 2
+    union = np.sort(np.concatenate([np.array(lam)[:4] for lam in g["eigenvalues"]]))[:n_occ]
+    got = np.sort(np.asarray(res["eigenvalues"][0]))[:n_occ]
+    out = {"fixture": f"tests/golden/{name}", "cube": cube, "converged": bool(res["converged"]), "steps": int(res["n_iter"]),
+           "wall_s": round(time.time() - t0, 2),
+           "dE_total_vs_golden_per_atom": float(res["energies"].total - n_prim * g["E_total"]) / n_atoms,
+           "max_deigenvalue_vs_golden": float(np.max(np.abs(got - union))),
+           "max_dterm_per_primitive_cell": float(max(abs(res["energies"][k_] / n_prim - v_) for k_, v_ in g["energies"].items())),
+           "why_this_cube": (f"the oracle restates the supercell as the primitive cell on the {n_super}^3 k-mesh at 40^3, an identity "
+                             f"that needs a cube of {n_super} x 40 = {cube}; the production cube ({'x'.join(map(str, (192,) * 3)) if n_super == 5 else '150^3'}) "
+                             f"has no integer primitive counterpart, so it is tied to this leg through "
+                             f"dE_total_real_vs_complex (same cube, the reference's own iteration)")}
+    del res, basis
+    return out
 
 
 def roofline_of(fam, n_gpus, workload):
@@ -494,6 +557,109 @@ def sharded_self_check(dftk, basis, comm_size):
         ref = full.conj() @ Hfull.T
         out["gram_vs_gathered"] = float((gram - ref).abs().max() / ref.abs().max())
     return out
+
+
+# ------------------------------------------------------------------------------------------ Amdahl model
+def _t_allreduce_ms(n_gpus, calls, nbytes):
+    """Ring all-reduce on point-to-point xGMI (SURVEY section 2.4 / 8d Unit E): 2 (p - 1) / p x bytes per link."""
+    return calls * COLLECTIVE_LATENCY_US * 1e-3 + 2.0 * (n_gpus - 1) / n_gpus * nbytes / (XGMI_LINK_GBS * 1e9) * 1e3
+
+
+def _t_alltoall_ms(n_gpus, calls, nbytes_total):
+    """Slab <-> band transposition of blocks totalling `nbytes_total` (all ranks together): every GPU sends 1 / p^2 of
+    it to each peer over that peer's own link."""
+    return calls * COLLECTIVE_LATENCY_US * 1e-3 + nbytes_total / n_gpus ** 2 / (XGMI_LINK_GBS * 1e9) * 1e3
+
+
+def amdahl_gamma(run, steps, n_cube):
+    """--mode gamma measured on ONE GPU -> predicted plane-wave-sharded step on N GPUs.  Row-local work (GEMMs, FFT
+    pipeline over this rank's bands, density, n_G-sized element-wise kernels: families timed with HIP events) divides by
+    N; everything else of the step's wall time is REPLICATED (Rayleigh-Ritz heev, Cholesky + inverse, the host
+    synchronisations of the LOBPCG control flow, the cube-sized potential / mixing / energy work, Python glue); the
+    collectives a sharded run performs are counted by the library on one rank too (families 17 / 18) and priced with
+    the xGMI link bandwidth plus an assumed latency per call."""
+    fam = run["fam"]
+    wall = 1e3 * run["elapsed"] / steps
+    sharded_f = {FAMILIES.get(f, str(f)): fam[f][0] / steps for f in (0, 11, 1, 2, 3, 4, 5, 6, 15)}
+    sharded = sum(sharded_f.values())
+    named = {"heev_jacobi": fam[7][0] / steps, "potrf_trtri": fam[8][0] / steps,
+             "host_waits_wall": fam[16][0] / steps, "host_waits_count": fam[16][2] / steps}
+    for k_ in ("energy_hamiltonian", "energies", "mixing"):
+        named["host_timer_" + k_] = 1e3 * run["host_timers"].get(k_, 0.0) / steps
+    replicated = wall - sharded
+    ar_calls, ar_bytes = fam[17][2] / steps, fam[17][1] / steps
+    a2a_calls, a2a_bytes = fam[18][2] / steps, fam[18][1] / steps
+    pred, sp, comm = {}, {}, {}
+    for n in (2, 4, 8):
+        c = (_t_allreduce_ms(n, ar_calls + 1, ar_bytes + 8.0 * n_cube)        # + the density all-reduce of the step
+             + _t_alltoall_ms(n, a2a_calls, a2a_bytes))
+        comm[str(n)] = round(c, 2)
+        pred[str(n)] = round(replicated + sharded / n + c, 2)
+        sp[str(n)] = round(wall / pred[str(n)], 2)
+    return {"mode": "gamma (plane-wave row slabs of the one k-block)", "measured_on_gpus": 1,
+            "per_step_ms": {"wall": round(wall, 2), "sharded": round(sharded, 2), "replicated": round(replicated, 2)},
+            "sharded_families_ms": {k_: round(v_, 2) for k_, v_ in sharded_f.items()},
+            "replicated_named_ms": {k_: round(v_, 2) for k_, v_ in named.items()},
+            "collectives_per_step": {"allreduce_calls": round(ar_calls + 1, 1), "allreduce_MB": round((ar_bytes + 8.0 * n_cube) / 1e6, 1),
+                                     "alltoall_calls": round(a2a_calls, 1), "alltoall_MB_all_ranks": round(a2a_bytes / 1e6, 1)},
+            "comm_ms_per_step": comm, "predicted_ms_per_step": pred, "predicted_speedup": sp,
+            "amdahl_limit": round(wall / replicated, 2),
+            "assumptions": (f"xGMI {XGMI_LINK_GBS:g} GB/s per link (SURVEY 2.4), {COLLECTIVE_LATENCY_US:g} us per collective (assumed, not "
+                            "measured), ring all-reduce 2(p-1)/p bytes per link, all-to-all 1/p^2 of the block per link; no "
+                            "overlap of communication with compute; per-rank kernels keep their one-GPU efficiency at 1/N "
+                            "of the rows (optimistic for N = 8: tiles of 128 rows, 16 554 rows per rank)")}
+
+
+def amdahl_kpoints(dftk, basis, model, ecut, device, run, steps, args):
+    """--mode kpoints measured on ONE GPU: the step time of ONE RANK'S SHARE is measured directly -- a whole SCF on the
+    first ceil(n_k / N) irreducible k-points (weights renormalised: a legitimate, smaller k-mesh problem that does all
+    the replicated cube work of a step: PBE potential, LDOS pass over its k-points, Fermi level, mixing, energies) --
+    so that the latency-bound lock-step batching is priced at the local k-point count, not divided by N."""
+    wall = 1e3 * float(np.median(run["step_s"][2:] or run["step_s"]))
+    n_k = len(basis.kcoords_global)
+    n_cube = basis.N
+    saved = os.environ.get("DFTK_MI_KBATCH")
+    if basis.kbatch:
+        os.environ["DFTK_MI_KBATCH"] = "1"        # a real N-rank run decides from the GLOBAL count (basis.py): stays batched
+    share, pred, sp, comm, nloc = {}, {}, {}, {}, {}
+    try:
+        for n in (2, 4, 8):
+            n_loc = -(-n_k // n)
+            kc = [np.asarray(k_) for k_ in basis.kcoords_global[:n_loc]]
+            kw = np.asarray(basis.kweights_global[:n_loc], dtype=float)
+            sub = dftk.PlaneWaveBasis(model, ecut, dftk.ExplicitKpoints(kc, list(kw / kw.sum())), device=device,
+                                      fft_size=basis.fft_size)
+            st = dftk.ScfStepper(sub, tol=args.tol)
+            ts = []
+            for i in range(8):
+                t0 = time.time()
+                info = st.step()
+                ts.append(time.time() - t0)
+                if info["converged"]:
+                    break
+            t_share = 1e3 * float(np.median(ts[2:] or ts))
+            # one density all-reduce per step (+ one for the LDOS of a metal) and the eigenvalue gather
+            c = _t_allreduce_ms(n, 2 if model.temperature > 0 else 1, (2 if model.temperature > 0 else 1) * 8.0 * n_cube) \
+                + COLLECTIVE_LATENCY_US * 1e-3
+            nloc[str(n)], share[str(n)], comm[str(n)] = n_loc, round(t_share, 2), round(c, 3)
+            pred[str(n)] = round(t_share + c, 2)
+            sp[str(n)] = round(wall / pred[str(n)], 2)
+            del st, sub
+    finally:
+        if saved is None:
+            os.environ.pop("DFTK_MI_KBATCH", None)
+        else:
+            os.environ["DFTK_MI_KBATCH"] = saved
+    timers = {k_: round(1e3 * v_ / steps, 2) for k_, v_ in run["host_timers"].items()}
+    return {"mode": "kpoints (k-point sharding, one density all-reduce per step)", "measured_on_gpus": 1,
+            "per_step_ms": {"wall_median_late_step": round(wall, 2), "host_timers": timers},
+            "k_points": n_k, "k_points_per_rank": nloc, "measured_share_step_ms": share, "comm_ms_per_step": comm,
+            "predicted_ms_per_step": pred, "predicted_speedup": sp,
+            "replicated_floor_ms": share.get("8"),
+            "assumptions": (f"measured_share_step_ms[N] = median late SCF step of a self-consistent run on the first ceil(n_k/N) "
+                            f"irreducible k-points (renormalised weights), same cube, same functional, lock-step batching as in the "
+                            f"N-rank run; + all-reduce of rho ({8.0 * n_cube / 1e6:.2f} MB) at {XGMI_LINK_GBS:g} GB/s per link and "
+                            f"{COLLECTIVE_LATENCY_US:g} us per collective (assumed)")}
 
 
 # ------------------------------------------------------------------------------------------ main
@@ -585,6 +751,8 @@ def main():
 
     # what the library's communicator (the data path of every collective) really is: proves N ranks met over RCCL
     comm_info = comm.describe() if hasattr(comm, "describe") else {"n_ranks": comm.size}
+    if int(comm_info.get("n_ranks", -1)) != world:
+        raise SystemExit(f"rank {rank}: the library's communicator reports {comm_info} but WORLD_SIZE is {world}")
     self_check = None
     if world > 1 and args.mode == "gamma":
         self_check = sharded_self_check(dftk, basis, world)
@@ -594,6 +762,16 @@ def main():
 
     run = run_scf(dftk, lib, basis, args, barrier, world, dist, torch)
     info, elapsed, fam = run["info"], run["elapsed"], run["fam"]
+    n_atoms = len(model.positions)
+    parity, late_info = None, info
+    if not args.no_parity:
+        # UNTIMED: the timed stepper carried on to the parity tolerance (all ranks take part; its energy is what the
+        # 1 / 2 / 4 / 8 GPU lines of a scaling run are compared through)
+        par = continue_to_parity(run["stepper"])
+        late_info = run["stepper"].info           # the converged state: what the CPU leg's "late step" starts from
+        parity = {"tolerance_Ha_per_atom": PARITY_TOL_HA_PER_ATOM, "scf_tol": min(PARITY_SCF_TOL, args.tol), "n_atoms": n_atoms,
+                  "timed_leg": {k_: par[k_] for k_ in ("converged", "E_total", "extra_steps", "steps_total", "drho", "wall_s")}}
+    amdahl = None
     steps_run = info["n_iter"]
     n_matvec = info["n_matvec"]                  # already summed over the k-point ranks
     kblocks = n_gpus if (args.mode == "weak" and n_gpus > 1) else 1
@@ -636,8 +814,17 @@ def main():
     if (world == 1 and args.mode == "gamma" and not args.no_gamma_real and not args.no_complex_leg
             and bool(getattr(basis.kpoints[0], "gamma_real", False))):
         cbasis = dftk.PlaneWaveBasis(model, ecut, dftk.MonkhorstPack((1, 1, 1)), device=device, gamma_real=False)
+        run.pop("stepper", None)                     # (the real leg's orbitals and LOBPCG workspace are not needed any more)
+        torch.cuda.empty_cache()
         crun = run_scf(dftk, lib, cbasis, args, barrier, world, dist, torch)
         ci = crun["info"]
+        if parity is not None:
+            cpar = continue_to_parity(crun["stepper"])
+            parity["complex_leg"] = {k_: cpar[k_] for k_ in ("converged", "E_total", "extra_steps", "steps_total", "drho", "wall_s")}
+            parity["dE_total_real_vs_complex_per_atom"] = (par["E_total"] - cpar["E_total"]) / n_atoms
+            parity["max_deigenvalue_real_vs_complex"] = float(max(
+                np.max(np.abs(a_ - b_[:len(a_)])) for a_, b_ in zip(par["eigenvalues"], cpar["eigenvalues"])))
+        crun.pop("stepper", None)
         croof = roofline_of(crun["fam"], 1, workload)
         out["config"]["complex_iteration"] = {
             "what": "the same self_consistent_field with gamma_real=False: LOBPCG on general complex orbitals exactly as "
@@ -657,7 +844,37 @@ def main():
         del crun, ci, cbasis
         torch.cuda.empty_cache()
 
+    run.pop("stepper", None)
+    torch.cuda.empty_cache()
+    # ---- parity against the ORACLE's golden fixture (untimed), Amdahl model (measured on this one GPU)
+    if (world == 1 and parity is not None and args.mode == "gamma" and args.supercell in GOLDEN and ecut == 30.0
+            and not args.no_gamma_real):
+        parity["golden"] = golden_leg(dftk, model, ecut, args.supercell, device)
+        torch.cuda.empty_cache()
+    if world == 1 and args.mode == "gamma":
+        amdahl = amdahl_gamma(run, steps_run, basis.N)
+    elif world == 1 and args.mode == "kpoints" and not args.no_amdahl_probe:
+        amdahl = amdahl_kpoints(dftk, basis, model, ecut, device, run, steps_run, args)
+    parity_failed = []
     if rank == 0:
+        if parity is not None:
+            checks = {"timed_leg converged": parity["timed_leg"]["converged"]}
+            if "complex_leg" in parity:
+                checks["complex_leg converged"] = parity["complex_leg"]["converged"]
+                checks["|dE real vs complex| per atom"] = abs(parity["dE_total_real_vs_complex_per_atom"]) < PARITY_TOL_HA_PER_ATOM
+                checks["eigenvalues real vs complex"] = parity["max_deigenvalue_real_vs_complex"] < 1e-7
+            if "golden" in parity:
+                checks["golden leg converged"] = parity["golden"]["converged"]
+                checks["|dE vs golden| per atom"] = abs(parity["golden"]["dE_total_vs_golden_per_atom"]) < PARITY_TOL_HA_PER_ATOM
+                checks["eigenvalues vs golden"] = parity["golden"]["max_deigenvalue_vs_golden"] < 1e-7
+            parity_failed = [k_ for k_, ok_ in checks.items() if not ok_]
+            parity["checks"] = {k_: bool(v_) for k_, v_ in checks.items()}
+            parity["pass"] = not parity_failed
+            parity["note"] = ("untimed legs run after the timed region: the timed steppers continued to scf_tol (both the "
+                              "real-symmetric and the reference's complex iteration, production cube), and -- N = 1 -- a whole SCF at "
+                              "the k-mesh-compatible cube against the oracle fixture; the run exits non-zero when a check fails")
+        out["config"]["parity"] = parity
+        out["amdahl"] = amdahl
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:
                 if args.mode == "kpoints":
@@ -667,19 +884,19 @@ def main():
                     # the CPU leg is the REFERENCE's iteration: general complex orbitals, complex zgemm flops
                     per_step = {"n_matvec": n_matvec / steps_run, "zgemm_flops": fam[14][1] / steps_run}
                     n_smp = args.cpu_sample_bands or min(os.cpu_count(), 256)
-                    model_leg = cpu_baseline_gamma(basis, info, n_smp, per_step)
+                    model_leg = cpu_baseline_gamma(basis, late_info, n_smp, per_step)
                     out["cpu_baseline"] = model_leg
                     # a REAL timed step when the sampled model says it fits the budget
                     # tolerance of a TYPICAL late step: the median diagtol of the timed run (from the converged
                     # orbitals LOBPCG then needs the one iteration that most steps of this SCF take)
                     tol_mid = float(np.median(run["diagtols"][2:] or run["diagtols"]))
-                    t_dev, dinfo = device_late_step(dftk, basis, info, args.tol, tol_mid)
-                    late_model = (2 * info["psi"][0].shape[0] / model_leg["hpsi_applies_per_s"]
+                    t_dev, dinfo = device_late_step(dftk, basis, late_info, args.tol, tol_mid)
+                    late_model = (2 * late_info["psi"][0].shape[0] / model_leg["hpsi_applies_per_s"]
                                   + model_leg["model_terms"]["density_s_per_band"] * (basis.model.n_electrons // 2)
                                   + model_leg["model_terms"]["late_step_zgemm_s"])
                     timed = None
                     if late_model < args.cpu_step_budget:
-                        timed = cpu_timed_late_step(basis, info, float(dinfo["diagtol"]), args.cpu_step_budget, dinfo)
+                        timed = cpu_timed_late_step(basis, late_info, float(dinfo["diagtol"]), args.cpu_step_budget, dinfo)
                     if timed is not None:
                         timed["device_step_s"] = round(t_dev, 4)
                         timed["device_lobpcg_iterations"] = float(np.mean(dinfo["diagonalization"]["n_iter"]))
@@ -708,6 +925,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if parity_failed:
+        raise SystemExit(f"PARITY FAILED: {parity_failed} (config.parity of the JSON line above)")
 
 
 if __name__ == "__main__":

@@ -28,3 +28,4 @@ from .scf import (self_consistent_field, next_density, compute_occupation, Adapt
 from .io import scfres_to_dict, save_scfres, load_scfres, basis_to_dict, model_to_dict  # noqa: F401,E402
 from .symmetry import (SymOp, symmetry_operations, symmetrize_rho, irreducible_kcoords,  # noqa: F401,E402
                        symmetries_preserving_kgrid, symmetries_preserving_rgrid, check_group)
+from .memory_usage import estimate_memory_usage, plan_planewave_sharded, MemoryStatistics  # noqa: F401,E402

@@ -1,5 +1,6 @@
 // api.cpp -- the extern "C" boundary (include/dftk_mi355x.h), handles and host-side planning.
 #include "common.h"
+#include <chrono>
 #include "batch.h"
 #include <algorithm>
 #include <cmath>
@@ -63,6 +64,24 @@ void prof_end(dftk_mi_basis* b, int slot) {
     Prof* p = b->prof;
     if (p->open > 0) p->open -= 1;
     if ((size_t)slot < p->pending.size()) hipEventRecord(p->pending[slot].b, b->stream);
+}
+void prof_count(dftk_mi_basis* b, int fam, double work) {
+    Prof* p = b->prof;
+    if (!p || !p->on) return;
+    p->work[fam] += work;
+    p->launches[fam] += 1;
+}
+int host_wait(dftk_mi_basis* b) {
+    Prof* p = b->prof;
+    if (!p || !p->on) {
+        HIPCHK(hipStreamSynchronize(b->stream));
+        return 0;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(hipStreamSynchronize(b->stream));
+    p->ms[PROF_HOST_WAIT] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    p->launches[PROF_HOST_WAIT] += 1;
+    return 0;
 }
 int prof_resolve(dftk_mi_basis* b) {
     Prof* p = b->prof;
@@ -322,6 +341,7 @@ extern "C" int dftk_mi_basis_create(int nx, int ny, int nz, double unit_cell_vol
     }
     HIPCHK(hipMalloc((void**)&b->d_scalars, 256 * sizeof(double)));
     HIPCHK(hipHostMalloc((void**)&b->h_scalars, 256 * sizeof(double)));
+    HIPCHK(hipHostMalloc((void**)&b->h_fetch, HOST_FETCH_BYTES, hipHostMallocMapped));
     *out = b;
     return 0;
 }
@@ -338,6 +358,7 @@ extern "C" int dftk_mi_basis_destroy(dftk_mi_basis* b) {
     if (b->dense_ws) hipFree(b->dense_ws);
     if (b->d_scalars) hipFree(b->d_scalars);
     if (b->h_scalars) hipHostFree(b->h_scalars);
+    if (b->h_fetch) hipHostFree(b->h_fetch);
     if (b->prof) {
         prof_resolve(b);
         for (auto& pr : b->prof->pool) {
@@ -830,6 +851,11 @@ extern "C" int dftk_mi_apply_H_parts(dftk_mi_kblock* kb, int which, int n_bands,
     } guard{kb->basis, slot};
     if (!kb->sh_comm) {
         // local (+ kinetic fused into the gather epilogue), or kinetic only / zero
+        if (local) {   // what the sharded branch below would move and reduce (input of bench.py's Amdahl model)
+            prof_count(kb->basis, PROF_A2A_MODEL, 16.0 * (double)kb->n_G * n_bands);
+            prof_count(kb->basis, PROF_A2A_MODEL, 16.0 * (double)kb->n_G * n_bands);
+        }
+        if (nonlocal && kb->n_p > 0) prof_count(kb->basis, PROF_AR_MODEL, 16.0 * (double)kb->n_p * n_bands);
         CHK(launch_local_apply(kb, n_bands, psi, ld_psi, H, ld_Hpsi, kinetic, local));
     } else {
         // row-slab sharded block: the FFT pipeline needs whole bands -> slab -> band all-to-all, every rank
@@ -983,7 +1009,10 @@ extern "C" int dftk_mi_density_accumulate(dftk_mi_kblock* kb, int n_bands, const
     if (!kb || !psi_d || !weight_h || !rho_d || n_bands < 0 || ld_psi < local_rows(kb)) return DFTK_MI_EINVAL;
     if (n_bands == 0) return 0;
     HIPCHK(hipSetDevice(kb->basis->device));
-    if (!kb->sh_comm) return launch_density(kb, n_bands, reinterpret_cast<const cd*>(psi_d), ld_psi, weight_h, rho_d);
+    if (!kb->sh_comm) {
+        prof_count(kb->basis, PROF_A2A_MODEL, 16.0 * (double)kb->n_G * n_bands);   // (the transpose of the sharded branch)
+        return launch_density(kb, n_bands, reinterpret_cast<const cd*>(psi_d), ld_psi, weight_h, rho_d);
+    }
     // sharded block: every rank accumulates |psi|^2 of its share of the bands into ITS rho (partial sum);
     // the caller's density all-reduce (mpi_sum!(rho, comm), densities.jl:46) completes it
     if (ld_psi != local_rows(kb)) {
@@ -1071,6 +1100,7 @@ extern "C" int dftk_mi_density_accumulate_real(dftk_mi_kblock* kb, int n_bands, 
     if (!kb || !psi_d || !weight_h || !rho_d || n_bands < 0 || ld_psi < local_rows(kb)) return DFTK_MI_EINVAL;
     if (n_bands == 0) return 0;
     HIPCHK(hipSetDevice(kb->basis->device));
+    if (!kb->sh_comm) prof_count(kb->basis, PROF_A2A_MODEL, 8.0 * (double)kb->n_G * n_bands);   // half-format slabs -> bands
     return gamma_density(kb, n_bands, reinterpret_cast<const cd*>(psi_d), ld_psi, weight_h, rho_d);
 }
 

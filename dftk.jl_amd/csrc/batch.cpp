@@ -306,8 +306,7 @@ int dev_h2d(dftk_mi_basis* b, void* dst_d, const void* src_h, size_t bytes) {
 }
 int dev_stream_sync(dftk_mi_basis* b) {
     if (batching()) return batch_sync();
-    HIPCHK(hipStreamSynchronize(b->stream));
-    return 0;
+    return host_wait(b);
 }
 int dev_d2h_sync(dftk_mi_basis* b, void* dst_h, const void* src_d, size_t bytes) {
     if (batching()) {
@@ -319,9 +318,7 @@ int dev_d2h_sync(dftk_mi_basis* b, void* dst_h, const void* src_d, size_t bytes)
         o.bytes = bytes;
         return batch_record_sync(std::move(o));
     }
-    HIPCHK(hipMemcpyAsync(dst_h, src_d, bytes, hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
-    return 0;
+    return host_fetch(b, dst_h, src_d, bytes);
 }
 
 static thread_local int64_t g_last_stats[4] = {0, 0, 0, 0};

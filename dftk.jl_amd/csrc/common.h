@@ -59,6 +59,7 @@ struct dftk_mi_basis {
     void* ws; size_t ws_bytes;
     double* d_scalars;            // small device buffer for reductions (256 doubles)
     double* h_scalars;            // pinned host mirror
+    char* h_fetch;                // pinned, device-visible landing zone of host_fetch() (zero-copy device -> host results)
     int use_mfma;                 // 0 => naive GEMM kernels (env DFTK_MI_GEMM=naive)
     struct Prof* prof;            // per-family HIP-event timing (dftk_mi_prof_*)
     // workspace of the dense factorizations (heev ping-pong copies, rotation buffers); owned by the basis so
@@ -88,7 +89,14 @@ enum ProfFamily {
     PROF_COMM = 13,          // collectives of a sharded k-block (work = bytes handed to the communicator)
     PROF_ZGEMM_CPLX = 14,    // no timing: useful flops of all zgemm calls as if none were REAL (a DFTK_MI_GEMM_REAL call
                              // stands for a complex product of twice its flops): what the general complex path needs
-    PROF_NFAM = 16
+    PROF_EW = 15,            // n_G-sized element-wise / column-reduction kernels of the LOBPCG driver and the Gamma-real
+                             // pack / unpack passes (work = algorithmic bytes): row-local, i.e. SHARDED work of a
+                             // plane-wave-sharded block
+    PROF_HOST_WAIT = 16,     // no events: launches = host synchronisations inside the library, ms = wall ms the host waited
+    PROF_AR_MODEL = 17,      // no timing: the all-reduces a plane-wave-sharded run of the same calls performs (launches =
+                             // calls, work = bytes) -- counted on ONE rank too: the input of bench.py's Amdahl model
+    PROF_A2A_MODEL = 18,     // no timing: its slab <-> band transposes (launches, work = bytes of the blocks moved)
+    PROF_NFAM = 24
 };
 struct Prof {
     bool on = false;
@@ -105,6 +113,22 @@ struct Prof {
 int prof_begin(dftk_mi_basis* b, int fam, double work, uint64_t tag = 0);   // returns slot index or -1
 void prof_end(dftk_mi_basis* b, int slot);
 int prof_resolve(dftk_mi_basis* b);
+struct ProfScope {   // RAII pair of prof_begin / prof_end
+    dftk_mi_basis* b;
+    int slot;
+    ProfScope(dftk_mi_basis* basis, int fam, double work) : b(basis), slot(prof_begin(basis, fam, work)) {}
+    ~ProfScope() { prof_end(b, slot); }
+    ProfScope(const ProfScope&) = delete;
+    ProfScope& operator=(const ProfScope&) = delete;
+};
+void prof_count(dftk_mi_basis* b, int fam, double work);   // count-only families (no events)
+// Every host synchronisation of the library's drivers goes through these two (counted in PROF_HOST_WAIT):
+// host_wait = hipStreamSynchronize(b->stream); host_fetch = small device -> host result WITHOUT a blit: a copy kernel
+// writes into pinned host memory mapped into the device's address space (no __amd_rocclr_copyBuffer dispatch, no staging
+// through pageable memory), then one stream synchronisation.
+const size_t HOST_FETCH_BYTES = 256 * 1024;
+int host_wait(dftk_mi_basis* b);
+int host_fetch(dftk_mi_basis* b, void* dst_h, const void* src_d, size_t bytes);
 
 // real-symmetric orbitals of a Gamma-point block (gamma_kernels.hip)
 struct GammaReal {

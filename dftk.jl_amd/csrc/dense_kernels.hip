@@ -1004,10 +1004,31 @@ static int dws_ensure(dftk_mi_basis* b, void** buf, size_t* cur, size_t bytes) {
     return 0;
 }
 
-static int fetch_scalars(dftk_mi_basis* b, int count) {
-    HIPCHK(hipMemcpyAsync(b->h_scalars, b->d_scalars, count * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
+// device -> pinned host words (host_fetch): the destination is host memory mapped into the device's address space
+__global__ void k_fetch_words(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+int host_fetch(dftk_mi_basis* b, void* dst_h, const void* src_d, size_t bytes) {
+    if (bytes == 0) return host_wait(b);
+    // DFTK_MI_FETCH_BLIT=1: the runtime's copy (a blit dispatch + staging), kept for the A/B of profiles/r04_host_fetch_ab.txt
+    static const bool blit = getenv("DFTK_MI_FETCH_BLIT") != nullptr;
+    if (blit || bytes > HOST_FETCH_BYTES || (bytes & 3) || (reinterpret_cast<uintptr_t>(src_d) & 3) || !b->h_fetch) {
+        HIPCHK(hipMemcpyAsync(dst_h, src_d, bytes, hipMemcpyDeviceToHost, b->stream));
+        return host_wait(b);
+    }
+    const size_t words = bytes / 4;
+    const unsigned blocks = (unsigned)std::min<size_t>(32, (words + 255) / 256);
+    hipLaunchKernelGGL(k_fetch_words, dim3(blocks), dim3(256), 0, b->stream, reinterpret_cast<const uint32_t*>(src_d),
+                       reinterpret_cast<uint32_t*>(b->h_fetch), words);
+    HIPCHK(hipGetLastError());
+    CHK(host_wait(b));
+    std::memcpy(dst_h, b->h_fetch, bytes);
     return 0;
+}
+
+static int fetch_scalars(dftk_mi_basis* b, int count) {
+    return host_fetch(b, b->h_scalars, b->d_scalars, count * sizeof(double));
 }
 
 int dense_potrf_trtri(dftk_mi_basis* b, int n, cd* A, int64_t lda, cd* invR, int64_t ldi, double* normest_R,
@@ -1171,8 +1192,7 @@ static int heev_impl(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, c
         }
         launch_round(false, 0);   // drain the pipeline: the check needs the matrix after the last round
         hipLaunchKernelGGL(k_offdiag_norm<ET>, dim3(redblocks), dim3(256), 0, b->stream, np, Wb[cur], (int64_t)np, d_red);
-        HIPCHK(hipMemcpyAsync(hred.data(), d_red, hred.size() * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-        HIPCHK(hipStreamSynchronize(b->stream));
+        CHK(host_fetch(b, hred.data(), d_red, hred.size() * sizeof(double)));
         double o2 = 0.0;
         for (int i = 0; i < redblocks; ++i) o2 += hred[2 * i];
         if (!std::isfinite(o2)) return DFTK_MI_NUM_NONFINITE;
@@ -1258,8 +1278,7 @@ static int heev_impl(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, c
     // eigenvalues = diag(W); sort ascending on the host, gather eigenvector columns
     hipLaunchKernelGGL(k_extract_diag<ET>, dim3((np + 255) / 256), dim3(256), 0, b->stream, np, Wb[cur], (int64_t)np, d_diag);
     std::vector<double> diag(np);
-    HIPCHK(hipMemcpyAsync(diag.data(), d_diag, np * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
+    CHK(host_fetch(b, diag.data(), d_diag, np * sizeof(double)));
     std::vector<int> perm(np);
     std::iota(perm.begin(), perm.end(), 0);
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int c) { return diag[a] < diag[c]; });
@@ -1272,7 +1291,7 @@ static int heev_impl(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, c
         hipLaunchKernelGGL(k_gather_cols, dim3((n + 255) / 256, n), dim3(256), 0, b->stream, (int64_t)n, Vw, (int64_t)np,
                            d_perm, V, ldv);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(b->stream));   // perm (host vector) must outlive the copy
+    CHK(host_wait(b));   // perm (host vector) must outlive the copy
     return 0;
 }
 
@@ -1296,8 +1315,7 @@ int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, 
     double* d_red = reinterpret_cast<double*>(b->dense_ws);
     hipLaunchKernelGGL(k_offdiag_norm<cd>, dim3(redblocks), dim3(256), 0, b->stream, n, A, lda, d_red);
     std::vector<double> hred(3 * redblocks);
-    HIPCHK(hipMemcpyAsync(hred.data(), d_red, hred.size() * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
+    CHK(host_fetch(b, hred.data(), d_red, hred.size() * sizeof(double)));
     double off2 = 0.0, dg2 = 0.0, im2 = 0.0;
     for (int i = 0; i < redblocks; ++i) {
         off2 += hred[2 * i];
@@ -1331,6 +1349,7 @@ int ew_colnorms(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, do
         o.type = BOP_COLRED; o.mode = 0; o.n = n; o.m = m; o.A = X; o.lda = ldx; o.C = out_d;
         return batch_record(std::move(o));
     }
+    ProfScope prof_scope(b, PROF_EW, n >= 4096 ? 16.0 * (double)n * m : 0.0);
     hipLaunchKernelGGL(k_col_reduce, dim3(m), dim3(256), 0, b->stream, 0, n, X, ldx, (const cd*)nullptr, (int64_t)0,
                        (const double*)nullptr, out_d);
     HIPCHK(hipGetLastError());
@@ -1345,6 +1364,7 @@ int ew_coldots(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, con
         o.type = BOP_COLRED; o.mode = 1; o.n = n; o.m = m; o.A = X; o.lda = ldx; o.B = Y; o.ldb = ldy; o.C = out_re_d;
         return batch_record(std::move(o));
     }
+    ProfScope prof_scope(b, PROF_EW, n >= 4096 ? 32.0 * (double)n * m : 0.0);
     hipLaunchKernelGGL(k_col_reduce, dim3(m), dim3(256), 0, b->stream, 1, n, X, ldx, Y, ldy, (const double*)nullptr,
                        out_re_d);
     HIPCHK(hipGetLastError());
@@ -1359,6 +1379,7 @@ int ew_coldots_im(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, 
         o.type = BOP_COLRED; o.mode = 4; o.n = n; o.m = m; o.A = X; o.lda = ldx; o.B = Y; o.ldb = ldy; o.C = out_im_d;
         return batch_record(std::move(o));
     }
+    ProfScope prof_scope(b, PROF_EW, n >= 4096 ? 32.0 * (double)n * m : 0.0);
     hipLaunchKernelGGL(k_col_reduce, dim3(m), dim3(256), 0, b->stream, 4, n, X, ldx, Y, ldy, (const double*)nullptr,
                        out_im_d);
     HIPCHK(hipGetLastError());
@@ -1373,6 +1394,7 @@ int ew_weighted_colsums(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t
         o.type = BOP_COLRED; o.mode = 2; o.n = n; o.m = m; o.A = X; o.lda = ldx; o.W = w_d; o.C = out_d;
         return batch_record(std::move(o));
     }
+    ProfScope prof_scope(b, PROF_EW, n >= 4096 ? 16.0 * (double)n * m : 0.0);
     hipLaunchKernelGGL(k_col_reduce, dim3(m), dim3(256), 0, b->stream, 2, n, X, ldx, (const cd*)nullptr, (int64_t)0,
                        w_d, out_d);
     HIPCHK(hipGetLastError());
@@ -1411,6 +1433,7 @@ int ew_frob2(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, doubl
         o.type = BOP_COLRED; o.mode = 3; o.n = n; o.m = m; o.A = X; o.lda = ldx; o.C = out_d;
         return batch_record(std::move(o));
     }
+    ProfScope prof_scope(b, PROF_EW, n >= 4096 ? 16.0 * (double)n * m : 0.0);
     hipLaunchKernelGGL(k_col_reduce, dim3(m), dim3(256), 0, b->stream, 3, n, X, ldx, (const cd*)nullptr, (int64_t)0,
                        (const double*)nullptr, out_d);
     HIPCHK(hipGetLastError());
@@ -1427,6 +1450,7 @@ int ew_residual(dftk_mi_basis* b, int64_t n, int m, const cd* AX, int64_t lda, c
         o.D = norms_d; o.W2 = kin; o.E = mean_kin_d; o.F = xx_d;
         return batch_record(std::move(o));
     }
+    ProfScope prof_scope(b, PROF_EW, n >= 4096 ? 48.0 * (double)n * m : 0.0);
     hipLaunchKernelGGL(k_residual, dim3(m), dim3(256), 0, b->stream, n, AX, lda, X, ldx, lam_d, R, ldr, norms_d, kin,
                        mean_kin_d, xx_d);
     HIPCHK(hipGetLastError());
@@ -1442,6 +1466,7 @@ int ew_tpa(dftk_mi_basis* b, int64_t n, int m, const cd* src, int64_t lds, cd* d
         o.D = norms_d; o.s0 = default_shift;
         return batch_record(std::move(o));
     }
+    ProfScope prof_scope(b, PROF_EW, n >= 4096 ? 32.0 * (double)n * m : 0.0);
     hipLaunchKernelGGL(k_tpa, dim3(m), dim3(256), 0, b->stream, n, src, lds, dst, ldd, kin, mean_kin_d, norms_d,
                        default_shift);
     HIPCHK(hipGetLastError());
@@ -1455,6 +1480,7 @@ int ew_scale_cols(dftk_mi_basis* b, int64_t n, int m, cd* X, int64_t ldx, const 
         o.type = BOP_SCALE; o.n = n; o.m = m; o.C = X; o.ldc = ldx; o.W = s_d; o.flags = invert ? 1 : 0;
         return batch_record(std::move(o));
     }
+    ProfScope prof_scope(b, PROF_EW, n >= 4096 ? 32.0 * (double)n * m : 0.0);
     hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, n, m, X, ldx, s_d,
                        invert ? 1 : 0);
     HIPCHK(hipGetLastError());
@@ -1468,6 +1494,7 @@ int ew_copy(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, cd* Y,
         o.type = BOP_COPY; o.n = n; o.m = m; o.A = X; o.lda = ldx; o.C = Y; o.ldc = ldy;
         return batch_record(std::move(o));
     }
+    ProfScope prof_scope(b, PROF_EW, n >= 4096 ? 32.0 * (double)n * m : 0.0);
     hipLaunchKernelGGL(k_copy, dim3((unsigned)((n + 255) / 256), m), dim3(256), 0, b->stream, n, m, X, ldx, Y, ldy);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1504,6 +1531,7 @@ int ew_gather_cols(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx,
         o.type = BOP_GATHER; o.n = n; o.m = m; o.A = X; o.lda = ldx; o.W = perm_d; o.C = Y; o.ldc = ldy;
         return batch_record(std::move(o));
     }
+    ProfScope prof_scope(b, PROF_EW, n >= 4096 ? 32.0 * (double)n * m : 0.0);
     hipLaunchKernelGGL(k_gather_cols, dim3((unsigned)((n + 255) / 256), m), dim3(256), 0, b->stream, n, X, ldx,
                        perm_d, Y, ldy);
     HIPCHK(hipGetLastError());

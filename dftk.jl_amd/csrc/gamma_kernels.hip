@@ -299,6 +299,7 @@ int gamma_ensure_buf(dftk_mi_kblock* kb, size_t elems) {
 int gamma_compress(dftk_mi_kblock* kb, int m, const cd* X, int64_t ldx, cd* H, int64_t ldh) {
     if (m <= 0) return 0;
     GammaReal* gr = kb->gr;
+    ProfScope prof_scope(kb->basis, PROF_EW, 48.0 * (double)gr->n_half * m);
     hipLaunchKernelGGL(k_gr_compress, gr_grid(gr->n_half, m), dim3(256), 0, kb->basis->stream, gr->n_half, gr->d_g,
                        gr->d_mg, X, ldx, H, ldh);
     HIPCHK(hipGetLastError());
@@ -308,6 +309,7 @@ int gamma_compress(dftk_mi_kblock* kb, int m, const cd* X, int64_t ldx, cd* H, i
 int gamma_compress_aligned(dftk_mi_kblock* kb, int m, const cd* X, int64_t ldx, cd* H, int64_t ldh) {
     if (m <= 0) return 0;
     GammaReal* gr = kb->gr;
+    ProfScope prof_scope(kb->basis, PROF_EW, 64.0 * (double)gr->n_half * m);
     hipLaunchKernelGGL(k_gr_compress_aligned, dim3(m), dim3(256), 0, kb->basis->stream, gr->n_half, gr->d_g, gr->d_mg, X, ldx,
                        H, ldh);
     HIPCHK(hipGetLastError());
@@ -317,6 +319,7 @@ int gamma_compress_aligned(dftk_mi_kblock* kb, int m, const cd* X, int64_t ldx, 
 int gamma_expand(dftk_mi_kblock* kb, int m, const cd* H, int64_t ldh, cd* X, int64_t ldx) {
     if (m <= 0) return 0;
     GammaReal* gr = kb->gr;
+    ProfScope prof_scope(kb->basis, PROF_EW, 48.0 * (double)gr->n_half * m);
     hipLaunchKernelGGL(k_gr_expand, gr_grid(gr->n_half, m), dim3(256), 0, kb->basis->stream, gr->n_half, gr->d_g,
                        gr->d_mg, H, ldh, X, ldx);
     HIPCHK(hipGetLastError());
@@ -366,6 +369,7 @@ static int gr_projectors(dftk_mi_kblock* kb) {
 int gamma_pack_pairs(dftk_mi_kblock* kb, int nb, const cd* H, int64_t ldh, cd* Z, int64_t ldz) {
     if (nb <= 0) return 0;
     GammaReal* gr = kb->gr;
+    ProfScope prof_scope(kb->basis, PROF_EW, 32.0 * (double)gr->n_half * nb);
     hipLaunchKernelGGL(k_gr_pack, gr_grid(gr->n_half, (nb + 1) / 2), dim3(256), 0, kb->basis->stream, gr->n_half, nb,
                        gr->d_g, gr->d_mg, H, ldh, Z, ldz);
     HIPCHK(hipGetLastError());
@@ -374,6 +378,7 @@ int gamma_pack_pairs(dftk_mi_kblock* kb, int nb, const cd* H, int64_t ldh, cd* Z
 int gamma_unpack_pairs(dftk_mi_kblock* kb, int nb, const cd* W, int64_t ldw, cd* H, int64_t ldh) {
     if (nb <= 0) return 0;
     GammaReal* gr = kb->gr;
+    ProfScope prof_scope(kb->basis, PROF_EW, 32.0 * (double)gr->n_half * nb);
     hipLaunchKernelGGL(k_gr_unpack, gr_grid(gr->n_half, (nb + 1) / 2), dim3(256), 0, kb->basis->stream, gr->n_half, nb,
                        gr->d_g, gr->d_mg, W, ldw, H, ldh);
     HIPCHK(hipGetLastError());
@@ -381,6 +386,7 @@ int gamma_unpack_pairs(dftk_mi_kblock* kb, int nb, const cd* W, int64_t ldw, cd*
 }
 int gamma_pack_full(dftk_mi_kblock* kb, int nb, const cd* X, int64_t ldx, cd* Z, int64_t ldz) {
     if (nb <= 0) return 0;
+    ProfScope prof_scope(kb->basis, PROF_EW, 32.0 * (double)kb->n_G * nb);
     hipLaunchKernelGGL(k_gr_pack_full, gr_grid(kb->n_G, (nb + 1) / 2), dim3(256), 0, kb->basis->stream, kb->n_G, nb, X,
                        ldx, Z, ldz);
     HIPCHK(hipGetLastError());
@@ -405,6 +411,10 @@ int gamma_apply_H(dftk_mi_kblock* kb, int which, int nb, const cd* psi, int64_t 
     CHK(gamma_ensure_buf(kb, 2 * (size_t)kb->n_G * nb2));
     cd* Z = gr->buf;
     cd* W = gr->buf + (size_t)kb->n_G * nb2;
+    // (a plane-wave-sharded run transposes the slab of nb half-format bands to whole bands and back around this pipeline)
+    prof_count(b, PROF_A2A_MODEL, 16.0 * (double)gr->n_half * nb);   // slabs -> bands
+    prof_count(b, PROF_A2A_MODEL, 16.0 * (double)gr->n_half * nb);   // bands -> slabs
+    if ((which & 4) && kb->n_p > 0) prof_count(b, PROF_AR_MODEL, 16.0 * (double)kb->n_p * nb);   // P' psi partial sums
     CHK(gamma_pack_pairs(kb, nb, psi, ldpsi, Z, kb->n_G));
     CHK(launch_local_apply(kb, nb2, Z, kb->n_G, W, kb->n_G, kinetic, local));
     CHK(gamma_unpack_pairs(kb, nb, W, kb->n_G, Hpsi, ldH));

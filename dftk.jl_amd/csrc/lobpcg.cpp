@@ -63,9 +63,20 @@ struct Ctx {
     // every column reduction is a LOCAL partial sum followed by an all-reduce over the block's communicator
     // (no-ops for an unsharded block).  reduce_norms: the buffer holds sqrt(local sums).
     dftk_mi_comm* comm = nullptr;
-    int reduce_c(cd* d, size_t n) { return comm ? comm_allreduce(comm, c_b(), reinterpret_cast<double*>(d), 2 * n) : 0; }
-    int reduce_d(double* d, size_t n) { return comm ? comm_allreduce(comm, c_b(), d, n) : 0; }
-    int reduce_norms(double* d, size_t n) { return comm ? comm_allreduce_norms(comm, c_b(), d, n) : 0; }
+    // (every call outside a NoComm scope is also booked in PROF_AR_MODEL: on ONE rank that is the list of all-reduces
+    //  a plane-wave-sharded run of the same iteration performs -- bench.py's Amdahl model is built from it)
+    int reduce_c(cd* d, size_t n) {
+        if (!small) prof_count(b, PROF_AR_MODEL, 16.0 * (double)n);
+        return comm ? comm_allreduce(comm, c_b(), reinterpret_cast<double*>(d), 2 * n) : 0;
+    }
+    int reduce_d(double* d, size_t n) {
+        if (!small) prof_count(b, PROF_AR_MODEL, 8.0 * (double)n);
+        return comm ? comm_allreduce(comm, c_b(), d, n) : 0;
+    }
+    int reduce_norms(double* d, size_t n) {
+        if (!small) prof_count(b, PROF_AR_MODEL, 8.0 * (double)n);
+        return comm ? comm_allreduce_norms(comm, c_b(), d, n) : 0;
+    }
     dftk_mi_basis* c_b() { return b; }
 };
 
@@ -444,7 +455,7 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     const size_t dbl = 9 * (size_t)(M + 8);
     const size_t need = (nbig * blk + small_elems) * sizeof(cd) + dbl * sizeof(double) + m3 * sizeof(int) + 1024;
     if (need > kb->lob_bytes) {
-        HIPCHK(hipStreamSynchronize(b->stream));
+        CHK(host_wait(b));
         if (kb->lob_buf) HIPCHK(hipFree(kb->lob_buf));
         kb->lob_buf = nullptr;
         kb->lob_bytes = 0;
@@ -607,10 +618,9 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
         CHK(h2d(b, d_lam, full_lam.data() + lo, nact * sizeof(double)));
         // residuals; the same pass over the new X yields precondprep!'s mean kinetic energies and <x,x>
         CHK(ew_residual(b, N, nact, nAX.p, nAX.ld, nX.p, nX.ld, d_lam, nR.p, nR.ld, d_norms, kin, d_mk, d_xx));
-        if (comm) {   // norms hold sqrt(local sums); mean_kin and <x,x> are plain sums (adjacent slots)
-            CHK(c.reduce_norms(d_norms, nact));
-            CHK(c.reduce_d(d_mk, (size_t)(M + 8) + nact));
-        }
+        // norms hold sqrt(local sums); mean_kin and <x,x> are plain sums (adjacent slots)   (no-ops for an unsharded block)
+        CHK(c.reduce_norms(d_norms, nact));
+        CHK(c.reduce_d(d_mk, (size_t)(M + 8) + nact));
         // norms, mean kinetic energies and <x,x> sit (M + 8) apart: ONE fetch; <x,x> is checked further down
         CHK(d2h(c, d_norms, 2 * (M + 8) + nact));
         std::vector<double> h_xx(c.h.begin() + 2 * (M + 8), c.h.begin() + 2 * (M + 8) + nact);

@@ -174,16 +174,27 @@ class AndersonAcceleration:
     """anderson.jl:36-130.  The history (<= m cube-sized vectors) stays in HBM; the m x m
     least-squares problem min |Pf_n + M beta| is solved on the host from the Gram matrix
     M'M (cond(R)^2 = cond(M'M) gives the reference's conditioning test on the QR factor).
-    Only elementwise products / row sums / axpys touch the cube-sized vectors."""
+    Only elementwise products / row sums / axpys touch the cube-sized vectors.  The inner products <r_i, r_j> of
+    the history are kept from step to step: a step computes only the nh + 1 products with the new residual, in ONE
+    stacked reduction and ONE host fetch (a fetch is a device synchronisation; the full Gram matrix was ~13 of them
+    and ~55 cube-sized reductions per step)."""
 
     def __init__(self, m=10, maxcond=1e6, errorfactor=1e5):
         self.iterates, self.residuals, self.errors = [], [], []
+        self.gram = np.zeros((0, 0))          # gram[i, j] = <residuals[i], residuals[j]>
         self.m, self.maxcond, self.errorfactor = m, maxcond, errorfactor
 
-    def _push(self, x, r):
+    def _push(self, x, r, row, rr_new):
+        """Append (x, r); ``row[i]`` = <residuals[i], r>, ``rr_new`` = <r, r>."""
         self.iterates.append(x.reshape(-1).clone())
         self.residuals.append(r.reshape(-1).clone())
-        self.errors.append(float(torch.linalg.norm(r).item()))
+        self.errors.append(math.sqrt(max(rr_new, 0.0)))
+        n = self.gram.shape[0]
+        g = np.zeros((n + 1, n + 1))
+        g[:n, :n] = self.gram
+        g[:n, n] = g[n, :n] = row
+        g[n, n] = rr_new
+        self.gram = g
         if len(self.iterates) > self.m:
             self._delete([0])
 
@@ -191,31 +202,28 @@ class AndersonAcceleration:
         for i in sorted(idxs, reverse=True):
             for lst in (self.iterates, self.residuals, self.errors):
                 lst.pop(i)
+        keep = [i for i in range(self.gram.shape[0]) if i not in set(idxs)]
+        self.gram = self.gram[np.ix_(keep, keep)]
 
     def __call__(self, x, alpha, Pfx):
         if self.m == 0:
             return x + alpha * Pfx
+        pf = Pfx.reshape(-1)
+        xf = x.reshape(-1)
+        # <r_i, pf> for the whole history and <pf, pf>: one stacked reduction, one fetch
+        vals = torch.stack([(ri * pf).sum() for ri in self.residuals] + [(pf * pf).sum()]).cpu().numpy()
+        rp_all, pp = vals[:-1].astype(float), float(vals[-1])
         if not self.iterates:
-            self._push(x, Pfx)
+            self._push(x, Pfx, rp_all, pp)
             return x + alpha * Pfx
-        err_n = float(torch.linalg.norm(Pfx).item())
+        err_n = math.sqrt(max(pp, 0.0))
         min_error = min(self.errors + [err_n])
         drop = [i for i, e in enumerate(self.errors[:-1]) if e > self.errorfactor * min_error]
         if drop:
             self._delete(drop)
-        pf = Pfx.reshape(-1)
-        xf = x.reshape(-1)
-        # inner products <r_i, r_j>, <r_i, pf>, <pf, pf> (one fused reduction per history entry)
+            rp_all = np.delete(rp_all, drop)
         nh = len(self.residuals)
-        rr = np.zeros((nh, nh))
-        rp = np.zeros(nh)
-        for i in range(nh):
-            ri = self.residuals[i]
-            vals = torch.stack([(ri * self.residuals[j]).sum() for j in range(i, nh)] + [(ri * pf).sum()]).cpu().numpy()
-            rr[i, i:] = vals[:-1]
-            rr[i:, i] = vals[:-1]
-            rp[i] = vals[-1]
-        pp = float((pf * pf).sum().item())
+        rr, rp = self.gram, rp_all
         keep = list(range(nh))
         while True:
             # M[:, j] = r_j - pf  =>  G = M'M, b = M'pf
@@ -229,7 +237,9 @@ class AndersonAcceleration:
                 continue
             break
         if len(keep) < nh:
-            self._delete([k for k in range(nh) if k not in keep])
+            gone = [k for k in range(nh) if k not in keep]
+            self._delete(gone)
+            rp = np.delete(rp, gone)
         betas = -np.linalg.lstsq(G, bvec, rcond=None)[0]
         xn = xf + alpha * pf
         sb = float(np.sum(betas))
@@ -238,7 +248,7 @@ class AndersonAcceleration:
         for ib, beta in enumerate(betas):
             xn.add_(self.iterates[ib], alpha=float(beta))
             xn.add_(self.residuals[ib], alpha=float(beta) * alpha)
-        self._push(x, Pfx)
+        self._push(x, Pfx, rp, pp)
         return xn.reshape(x.shape)
 
 

@@ -194,6 +194,8 @@ rho = dftk.compute_density(basis, [psi], occ)
 parts = comm.gather_lists((kpt.row0, psi.cpu().numpy(), Hpsi.cpu().numpy()))
 # (2) a whole SCF
 res = dftk.self_consistent_field(basis, tol=1e-9)
+# (3) the same SCF with a FIXED tight diagonalisation tolerance: every step is then determined to round-off
+res_fixed = dftk.self_consistent_field(basis, tol=1e-7, determine_tol=lambda n_iter, hist: 1e-9)
 if comm.rank == 0:
     full_psi = np.concatenate([p[1] for p in sorted(parts, key=lambda t: t[0])], axis=1)
     full_H = np.concatenate([p[2] for p in sorted(parts, key=lambda t: t[0])], axis=1)
@@ -202,7 +204,7 @@ if comm.rank == 0:
     print("RESULT " + json.dumps({"E": res["energies"].total, "terms": dict(res["energies"]),
                                   "lam": res["eigenvalues"][0].tolist(), "converged": bool(res["converged"]),
                                   "n_iter": res["n_iter"], "n_matvec": res["n_matvec"],
-                                  "history_drho": [float(x) for x in res["history_drho"]],
+                                  "history_drho_fixed_diagtol": [float(x) for x in res_fixed["history_drho"]],
                                   "rho_sum": float(res["rho"].sum()) * basis.dvol}))
 dist.barrier(); dist.destroy_process_group()
 '''
@@ -252,12 +254,15 @@ def test_planewave_sharded_block_two_ranks_one_gpu(tmp_path):
     #  less depending on the summation order of the sharded reductions -- five seeds of the ONE-rank run alone give
     #  33 .. 38 steps; the energies, terms and eigenvalues above are the parity criteria)
     assert abs(got["n_iter"] - ref["n_iter"]) <= 15
-    # ... and a TIGHT step criterion above that round-off tail: up to tol = 1e-7 the two trajectories must need the same
-    # number of SCF steps (+- 2) -- a convergence regression of the sharded path shows here
-    def steps_to(hist, thr):
-        return next(i for i, d in enumerate(hist) if d < thr)
-    assert abs(steps_to(got["history_drho"], 1e-7) - steps_to(ref["history_drho"], 1e-7)) <= 2, \
-        (got["history_drho"], ref["history_drho"])
+    # ... and a TIGHT criterion where one exists.  With the adaptive tolerance a step's output is only determined to
+    # diagtol (0.025 on the first steps), so trajectories part at the 1e-4 level from step 1 on and the step count is
+    # not a sharp observable.  With a FIXED tight diagonalisation tolerance every SCF step is a deterministic map up to
+    # round-off: the sharded run must then walk the SAME density-change history and stop at the same step.
+    ref_fixed = dftk.self_consistent_field(basis, tol=1e-7, determine_tol=lambda n_iter, hist: 1e-9)
+    h_got, h_ref = got["history_drho_fixed_diagtol"], ref_fixed["history_drho"]
+    assert ref_fixed["converged"] and abs(len(h_got) - len(h_ref)) <= 1, (h_got, h_ref)
+    n_cmp = min(len(h_got), len(h_ref), 8)
+    np.testing.assert_allclose(h_got[:n_cmp], h_ref[:n_cmp], rtol=1e-4)
 
 
 def test_rccl_c_abi_single_rank_allreduce():

@@ -1159,3 +1159,34 @@ def test_header_is_plain_c_and_the_c_consumer_builds_and_fails_loudly_without_a_
         res = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=120)
         assert res.returncode == 3, (res.returncode, res.stdout, res.stderr)
         assert "no CPU fallback" in res.stderr
+
+
+def test_memory_statistics_and_plan_for_the_literal_4096_electron_cell():
+    """``estimate_memory_usage`` (src/memory_usage.jl:35-87: psi_k, P_k, rho bytes and the 1 P + 2 psi + 6 psi_k + 12 rho
+    peak) and the per-GPU plan of the plane-wave-sharded Gamma block: the headline 1000-electron cell fits one
+    MI355X several times over; the LITERAL BASELINE configs[4] string (Si 8x8x8, 1024 atoms, 4096 electrons) does not
+    fit one GPU in any layout but fits 4 and 8 GPUs with the existing row-slab sharding and DENSE projector slabs
+    (no on-the-fly projectors needed) -- the question SURVEY appendix B left open."""
+    from dftk_jl_amd import memory_usage as mu
+    lat, atoms, pos = dftk.silicon_cell((5, 5, 5))
+    model = dftk.model_DFT(lat, atoms, pos)
+    st = dftk.estimate_memory_usage(model, 30.0)
+    assert (st.n_kpoints, st.n_Gk, st.n_bands, st.n_nonlocal_projectors) == (1, 264859, 503, 1250)
+    assert st.psik_bytes == 16 * 264859 * 503 and st.nonlocal_Pk_bytes == 16 * 264859 * 1250
+    assert st.rho_bytes == 8 * 192 ** 3
+    assert st.scf_peak_bytes == st.nonlocal_P_bytes + 2 * st.psi_bytes + 6 * st.psik_bytes + 12 * st.rho_bytes
+    one = dftk.plan_planewave_sharded(model, 30.0, 1)
+    assert one["fits"] and one["fft_size"] == (192, 192, 192) and one["n_half"] == 132430
+    assert one["bytes_per_rank"]["lobpcg_blocks"] == 14 * 132430 * 503 * 16          # DESIGN section 3.4: 14 blocks
+    assert 25e9 < one["total_bytes_per_rank"] < 45e9
+    lat, atoms, pos = dftk.silicon_cell((8, 8, 8))
+    big = dftk.model_DFT(lat, atoms, pos)
+    assert big.n_electrons == 4096 and len(pos) == 1024
+    plans = {p: dftk.plan_planewave_sharded(big, 30.0, p) for p in (1, 2, 4, 8)}
+    assert plans[1]["fft_size"] == (300, 300, 300) and plans[1]["n_bands"] == 2051 and plans[1]["n_projectors"] == 5120
+    assert not plans[1]["fits"] and plans[1]["reference_layout"]["scf_peak_bytes"] > 288e9
+    assert plans[4]["fits"] and plans[8]["fits"]
+    assert plans[8]["total_bytes_per_rank"] < 100e9
+    assert plans[8]["communication"]["gram_allreduce_bytes"] == 16 * (3 * 2051) ** 2
+    assert not plans[8]["limits"]["register_resident_z_kernels"] and plans[8]["limits"]["fft_axis_lds_ok"]
+    assert "DOES NOT FIT" in mu.format_plan(plans[1]) and "fits" in mu.format_plan(plans[8])

@@ -621,7 +621,7 @@ def amdahl_kpoints(dftk, basis, model, ecut, device, run, steps, args):
     saved = os.environ.get("DFTK_MI_KBATCH")
     if basis.kbatch:
         os.environ["DFTK_MI_KBATCH"] = "1"        # a real N-rank run decides from the GLOBAL count (basis.py): stays batched
-    share, pred, sp, comm, nloc = {}, {}, {}, {}, {}
+    share, pred, sp, comm, nloc, share_timers = {}, {}, {}, {}, {}, {}
     try:
         for n in (2, 4, 8):
             n_loc = -(-n_k // n)
@@ -638,6 +638,7 @@ def amdahl_kpoints(dftk, basis, model, ecut, device, run, steps, args):
                 if info["converged"]:
                     break
             t_share = 1e3 * float(np.median(ts[2:] or ts))
+            share_timers[str(n)] = {k_: round(1e3 * v_, 2) for k_, v_ in info["timers"].items()}   # of the last step
             # one density all-reduce per step (+ one for the LDOS of a metal) and the eigenvalue gather
             c = _t_allreduce_ms(n, 2 if model.temperature > 0 else 1, (2 if model.temperature > 0 else 1) * 8.0 * n_cube) \
                 + COLLECTIVE_LATENCY_US * 1e-3
@@ -653,7 +654,8 @@ def amdahl_kpoints(dftk, basis, model, ecut, device, run, steps, args):
     timers = {k_: round(1e3 * v_ / steps, 2) for k_, v_ in run["host_timers"].items()}
     return {"mode": "kpoints (k-point sharding, one density all-reduce per step)", "measured_on_gpus": 1,
             "per_step_ms": {"wall_median_late_step": round(wall, 2), "host_timers": timers},
-            "k_points": n_k, "k_points_per_rank": nloc, "measured_share_step_ms": share, "comm_ms_per_step": comm,
+            "k_points": n_k, "k_points_per_rank": nloc, "measured_share_step_ms": share,
+            "share_step_host_timers_ms": share_timers, "comm_ms_per_step": comm,
             "predicted_ms_per_step": pred, "predicted_speedup": sp,
             "replicated_floor_ms": share.get("8"),
             "assumptions": (f"measured_share_step_ms[N] = median late SCF step of a self-consistent run on the first ceil(n_k/N) "

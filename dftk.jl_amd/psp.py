@@ -64,8 +64,11 @@ _TABLE = {
                    [[[9.52284179]], []], "C GTH-PADE-q4"),
     ("C", "pbe"): (4, 0.33847124, [-8.80367398, 1.33921085], [0.30257575, 0.29150694],
                    [[[9.62248665]], []], "C GTH-PBE-q4"),
+    ("Fe", "lda"): (8, 0.61, [], [0.45448200, 0.63890282, 0.30873177],
+                    [[[3.01664046, -1.00040646, 0.79478164], [2.58303836, -2.05211737], [3.25763534]],
+                     [[1.49964199, -0.13812935], [0.32687369]], [[-9.14535371]]], "Fe GTH-PADE-q8"),
 }
-ATOMIC_NUMBER = {"H": 1, "C": 6, "Al": 13, "Si": 14}
+ATOMIC_NUMBER = {"H": 1, "C": 6, "Al": 13, "Si": 14, "Fe": 26}
 
 
 def load_psp(symbol: str, functional: str = "lda") -> PspHgh:

@@ -89,7 +89,8 @@ class ElementPsp:
 
 @dataclass
 class Model:
-    """Subset of ``struct Model`` (src/Model.jl) used on the hot path (spin-unpolarised)."""
+    """Subset of ``struct Model`` (src/Model.jl) used on the hot path: ``spin_polarization`` none or collinear
+    (Model.jl:29-39, :190-196; inferred from ``magnetic_moments`` as ``determine_spin_polarization`` does)."""
     lattice: np.ndarray
     atoms: list
     positions: list
@@ -102,6 +103,10 @@ class Model:
     # Model.jl:104-110: true = automatic detection, false = identity only, or an explicit list of SymOp.
     # (Default false here: the pinned reference tests of this oracle run explicit / unreduced k-lists.)
     symmetries: object = False
+    # per-atom initial magnetic moments in units of mu_B (z components; Model.jl:91-118): used to infer the spin
+    # polarisation and to break the symmetries, NOT stored as the state of the calculation
+    magnetic_moments: tuple = ()
+    spin_polarization: str | None = None      # "none" | "collinear"; None = infer from magnetic_moments
 
     def __post_init__(self):
         self.lattice = np.asarray(self.lattice, dtype=float)
@@ -121,13 +126,35 @@ class Model:
                 groups.append([i])
                 seen.append(a)
         self.atom_groups = groups
-        self.n_spin_components = 1
-        self.filled_occupation = 2  # spin_polarization == :none (Model.jl:352-360)
+        self.magnetic_moments = tuple(float(np.asarray(m, dtype=float).reshape(-1)[-1]) for m in self.magnetic_moments)
+        if self.magnetic_moments and len(self.magnetic_moments) != len(self.atoms):
+            raise ValueError("Length of atoms and magnetic_moments vectors need to agree.")
+        if self.spin_polarization is None:            # determine_spin_polarization (Model.jl)
+            self.spin_polarization = "collinear" if any(m != 0 for m in self.magnetic_moments) else "none"
+        if self.spin_polarization not in ("none", "collinear"):
+            raise NotImplementedError(f"spin_polarization = {self.spin_polarization}")
+        self.n_spin_components = 2 if self.spin_polarization == "collinear" else 1        # Model.jl:196, :366-372
+        self.filled_occupation = 1 if self.spin_polarization == "collinear" else 2        # Model.jl:352-360
+        if self.n_electrons % (self.n_spin_components * self.filled_occupation) != 0 and self.temperature == 0:
+            raise ValueError("Odd number of electrons without smearing (occupation.jl:163-172)")
         if self.temperature > 0 and self.smearing == "none":
             self.smearing = "fermi_dirac"
         from . import symmetry as _sym
         if self.symmetries is True:
-            self.symmetries = _sym.symmetry_operations(self.lattice, self.atom_groups, self.positions)
+            if self.spin_polarization == "collinear" and not self.magnetic_moments:
+                self.symmetries = [_sym.identity()]      # default_symmetries (Model.jl:330-332): breaking unknown
+            else:
+                # atoms carrying different moments are different "species" for the symmetry search (symmetry.jl:66-125
+                # hands the moments to Spglib)
+                groups = self.atom_groups
+                if self.magnetic_moments:
+                    groups = []
+                    for g in self.atom_groups:
+                        by_m = {}
+                        for i in g:
+                            by_m.setdefault(round(self.magnetic_moments[i], 10), []).append(i)
+                        groups.extend(by_m.values())
+                self.symmetries = _sym.symmetry_operations(self.lattice, groups, self.positions)
         elif self.symmetries is False or self.symmetries is None:
             self.symmetries = [_sym.identity()]
 
@@ -251,6 +278,12 @@ class PlaneWaveBasis:
         self.fft_normalization = math.sqrt(model.unit_cell_volume) / self.N
         self.Gx, self.Gy, self.Gz = G_axis(nx), G_axis(ny), G_axis(nz)
         self.kpoints = [self._build_kpoint(k) for k in self.kcoords]
+        self.n_kcoords = len(self.kcoords)
+        if model.n_spin_components == 2:
+            # collinear spin: the k-point list is doubled -- all spin-up blocks, then all spin-down blocks -- and so are
+            # the weights, which then sum to n_spin_components (build_kpoints Kpoint.jl:58-74, PlaneWaveBasis.jl:218-232)
+            self.kpoints = self.kpoints + [Kpoint(2, k.coordinate, k.G_vectors, k.mapping) for k in self.kpoints]
+            self.kweights = self.kweights + self.kweights
         self.terms = None
         if build_terms:
             from .terms import instantiate_terms

@@ -34,12 +34,12 @@ def default_smearing_temperature(model):
 
 
 def compute_dos(eps, basis, eigenvalues, smearing, temperature):
-    """dos.jl:18-34 (one spin component)."""
+    """dos.jl:18-34: one entry per spin component (the k-point list holds all spin-up blocks, then all spin-down)."""
     filled = basis.model.filled_occupation
-    D = 0.0
-    for w, ek in zip(basis.kweights, eigenvalues):
+    D = np.zeros(basis.model.n_spin_components)
+    for kpt, w, ek in zip(basis.kpoints, basis.kweights, eigenvalues):
         x = (np.asarray(ek) - eps) / temperature
-        D -= filled * w / temperature * float(np.sum(occupation_derivative(smearing, x)))
+        D[kpt.spin - 1] -= filled * w / temperature * float(np.sum(occupation_derivative(smearing, x)))
     return D
 
 
@@ -103,18 +103,34 @@ class SimpleMixing:
         return dF
 
 
-class KerkerMixing:
-    """mixing.jl:54-105 (one spin component)."""
+def _tot(x):
+    return x if x.ndim == 3 else x.sum(axis=0)
 
-    def __init__(self, kTF=0.8):
-        self.kTF = kTF
+
+def _from_total_and_spin(tot, spin):
+    return np.stack([(tot + spin) / 2, (tot - spin) / 2])           # rho_from_total_and_spin (densities.jl:158-166)
+
+
+class KerkerMixing:
+    """mixing.jl:54-105: the total density is preconditioned with G^2 / (kTF^2 + G^2); the spin density is left alone
+    unless ``dDOS_vol`` = (DOS_up - DOS_down) / volume is given (:62-84)."""
+
+    def __init__(self, kTF=0.8, dDOS_vol=0.0):
+        self.kTF, self.dDOS_vol = kTF, dDOS_vol
 
     def mix_density(self, basis, dF, **kw):
         G2 = np.sum(basis.G_vectors_cart_cube() ** 2, axis=-1)
-        dF_f = basis.fft_cube(dF)
-        drho_f = basis.enforce_real(dF_f * G2 / (self.kTF ** 2 + G2))
-        drho = basis.irfft_cube(drho_f)
-        return drho + (np.mean(dF) - np.mean(drho))       # copy the DC component, otherwise it never gets updated
+        dFtot = _tot(dF)
+        dFtot_f = basis.fft_cube(dFtot)
+        drho = basis.irfft_cube(basis.enforce_real(dFtot_f * G2 / (self.kTF ** 2 + G2)))
+        drho = drho + (np.mean(dFtot) - np.mean(drho))    # copy the DC component, otherwise it never gets updated
+        if dF.ndim == 3:
+            return drho
+        dFspin = dF[0] - dF[1]
+        if abs(self.dDOS_vol) < np.finfo(float).eps:
+            return _from_total_and_spin(drho, dFspin)
+        dspin_f = basis.fft_cube(dFspin) - dFtot_f * (4 * math.pi * self.dDOS_vol) / (self.kTF ** 2 + G2)
+        return _from_total_and_spin(drho, basis.irfft_cube(basis.enforce_real(dspin_f)))
 
 
 class KerkerDosMixing:
@@ -130,7 +146,8 @@ class KerkerDosMixing:
         if T == 0:
             return dF
         dos_per_vol = compute_dos(eF, basis, eigenvalues, sm, T) / basis.model.unit_cell_volume
-        return KerkerMixing(kTF=math.sqrt(4 * math.pi * dos_per_vol)).mix_density(basis, dF)
+        ddos = dos_per_vol[0] - dos_per_vol[1] if len(dos_per_vol) == 2 else 0.0
+        return KerkerMixing(kTF=math.sqrt(4 * math.pi * float(np.sum(dos_per_vol))), dDOS_vol=ddos).mix_density(basis, dF)
 
 
 class DielectricMixing:
@@ -147,7 +164,11 @@ class DielectricMixing:
             return KerkerMixing(kTF).mix_density(basis, dF)
         C0 = 1 - er
         G2 = np.sum(basis.G_vectors_cart_cube() ** 2, axis=-1)
-        drho = basis.irfft_cube(basis.fft_cube(dF) * (kTF ** 2 - C0 * G2) / (er * kTF ** 2 - C0 * G2))
+        mult = (kTF ** 2 - C0 * G2) / (er * kTF ** 2 - C0 * G2)
+        if dF.ndim == 4:      # "applied to rho and rho_spin in the same way" (mixing.jl:152): per channel, one DC shift
+            drho = np.stack([basis.irfft_cube(basis.fft_cube(x) * mult) for x in dF])
+        else:
+            drho = basis.irfft_cube(basis.fft_cube(dF) * mult)
         return drho + (np.mean(dF) - np.mean(drho))
 
 
@@ -189,6 +210,8 @@ class DielectricModel:
         mult = C0 * kTF ** 2 * G2 / (4 * math.pi) / (kTF ** 2 - C0 * G2)
 
         def apply(drho, dV, alpha=1.0):
+            if dV.ndim == 4:
+                return drho + alpha * np.stack([basis.irfft_cube(mult * basis.fft_cube(v)) for v in dV])
             return drho + alpha * basis.irfft_cube(mult * basis.fft_cube(dV))
         return apply
 
@@ -211,7 +234,10 @@ class Chi0Mixing:
 
         def dielectric_adjoint(x):
             count[0] += 1
-            dV = basis.irfft_cube(poisson * basis.fft_cube(x)) if poisson is not None else np.zeros_like(x)
+            # apply_kernel with RPA = true: the Hartree kernel acts on the TOTAL density, the same dV for both spins
+            dV = basis.irfft_cube(poisson * basis.fft_cube(_tot(x))) if poisson is not None else np.zeros_like(_tot(x))
+            if x.ndim == 4:
+                dV = np.stack([dV, dV])
             dV = dV - np.mean(dV)
             out = x.copy()
             for a in applies:

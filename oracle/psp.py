@@ -125,9 +125,14 @@ HGH_TABLE = {
                        rp=[0.30257575, 0.29150694],
                        h=[_sym([9.62248665]), np.zeros((0, 0))],
                        description="C GTH-PBE-q4"),
+    # Fe GTH-PADE-q8 (LDA): s, p, d channels with 3, 2, 1 radial projectors
+    ("Fe", "lda"): dict(Zion=8, rloc=0.61, cloc=[], rp=[0.45448200, 0.63890282, 0.30873177],
+                        h=[_sym([3.01664046, -1.00040646, 0.79478164], [2.58303836, -2.05211737], [3.25763534]),
+                           _sym([1.49964199, -0.13812935], [0.32687369]), _sym([-9.14535371])],
+                        description="Fe GTH-PADE-q8 GTH-LDA-q8"),
 }
 
-ATOMIC_NUMBER = {"H": 1, "C": 6, "Al": 13, "Si": 14}
+ATOMIC_NUMBER = {"H": 1, "C": 6, "Al": 13, "Si": 14, "Fe": 26}
 
 
 def load_psp_hgh(symbol: str, functional: str = "lda") -> PspHgh:

@@ -23,16 +23,18 @@ EPS = np.finfo(float).eps
 def compute_density(basis, psi, occupation, occupation_threshold=0.0):
     """rho(r) = sum_k w_k sum_n f_nk |psi_nk(r)|^2 (densities.jl:13-57)."""
     nx, ny, nz = basis.fft_size
-    rho = np.zeros((nz, ny, nx))
+    n_spin = basis.model.n_spin_components
+    rho = np.zeros((n_spin, nz, ny, nx))                           # rho[:, :, :, kpt.spin] (densities.jl:29, :39)
     for ik, kpt in enumerate(basis.kpoints):
         occ = np.asarray(occupation[ik], dtype=float)
         for n in range(len(occ)):
             if abs(occ[n]) < occupation_threshold:
                 continue
             psi_real = basis.ifft(kpt, psi[ik][:, n], normalize=False)
-            rho += occ[n] * basis.kweights[ik] * basis.ifft_normalization ** 2 * np.abs(psi_real) ** 2
+            rho[kpt.spin - 1] += occ[n] * basis.kweights[ik] * basis.ifft_normalization ** 2 * np.abs(psi_real) ** 2
     from .symmetry import symmetrize_rho
-    return symmetrize_rho(basis, rho, do_lowpass=False)          # densities.jl:47
+    rho = np.stack([symmetrize_rho(basis, r, do_lowpass=False) for r in rho])          # densities.jl:47
+    return rho if n_spin == 2 else rho[0]
 
 
 # ----------------------------------------------------------------------------- occupations
@@ -74,7 +76,7 @@ def _excess(basis, eigenvalues, eF, temperature, smearing):
 def _guess_fermi_level_intocc(basis, eigenvalues):
     """occupation.jl:190-211."""
     filled = basis.model.filled_occupation
-    n_fill = -(-basis.model.n_electrons // filled)
+    n_fill = -(-basis.model.n_electrons // (basis.model.n_spin_components * filled))
     homo = max(ek[n_fill - 1] for ek in eigenvalues)
     lumo = min((np.min(ek[n_fill:]) if len(ek) > n_fill else math.inf) for ek in eigenvalues)
     return homo + 1 if lumo == math.inf else (homo + lumo) / 2

@@ -229,7 +229,97 @@ def _lda_c_pw(rho):
     return rho * eps, v
 
 
-_FUNCTIONALS = {"lda_x": _lda_x, "lda_c_vwn": _lda_c_vwn, "lda_c_pw": _lda_c_pw}
+_TETER_A = (0.4581652932831429, 2.217058676663745, 0.7405551735357053, 0.01968227878617998)
+_TETER_DA = (0.119086804055547, 0.6157402568883345, 0.1574201515892867, 0.003532336663397157)
+_TETER_B = (1.0, 4.504130959426697, 1.110667363742916, 0.02359291751427506)
+_TETER_DB = (0.0, 0.2673612973836267, 0.2052004607777787, 0.004200005045691381)
+
+
+def _teter_eps(rs, fz):
+    """Goedecker, Teter, Hutter 1996 (PRB 54, 1703) Pade fit of the LDA XC energy per particle (libxc
+    ``lda_xc_teter93``): -(sum a_i rs^i) / (sum b_i rs^(i+1)) with a_i, b_i linear in the spin interpolation f(zeta)."""
+    a = [_TETER_A[i] + _TETER_DA[i] * fz for i in range(4)]
+    b = [_TETER_B[i] + _TETER_DB[i] * fz for i in range(4)]
+    num = a[0] + rs * (a[1] + rs * (a[2] + rs * a[3]))
+    den = rs * (b[0] + rs * (b[1] + rs * (b[2] + rs * b[3])))
+    return -num / den
+
+
+def _lda_xc_teter93(rho):
+    """Unpolarised ``lda_xc_teter93``: (e, v) with v = d(rho eps)/d rho."""
+    rs = np.cbrt(3 / (4 * math.pi * rho))
+    eps = _teter_eps(rs, 0.0)
+    h = 1e-30
+    deps = np.imag(_teter_eps(rs + 1j * h, 0.0)) / h
+    return rho * eps, eps - rs / 3 * deps
+
+
+_FUNCTIONALS = {"lda_x": _lda_x, "lda_c_vwn": _lda_c_vwn, "lda_c_pw": _lda_c_pw, "lda_xc_teter93": _lda_xc_teter93}
+
+
+# ---- collinear spin (LDA): energy densities e(rho_up, rho_down) written with analytic primitives only; the potentials
+# v_s = de/d rho_s come from the complex-step method (as for the GGAs below: no hand-derived formulas to get wrong)
+def _zeta_terms(ra, rb):
+    rt = ra + rb
+    xa, xb = 2 * ra / rt, 2 * rb / rt                 # 1 + zeta, 1 - zeta
+    p43 = np.exp(4.0 / 3.0 * np.log(xa)) + np.exp(4.0 / 3.0 * np.log(xb))
+    fz = (p43 - 2) / (2 ** (4.0 / 3.0) - 2)           # f(zeta), f(0) = 0, f(+-1) = 1
+    rs = np.exp(-np.log(4 * math.pi * rt / 3) / 3)
+    return rt, (ra - rb) / rt, fz, rs
+
+
+def _lda_x_spin_e(ra, rb):
+    """Spin-scaling relation E_x[ra, rb] = (E_x[2 ra] + E_x[2 rb]) / 2 (libxc ``lda_x`` polarised)."""
+    cx = -0.75 * (3 / math.pi) ** (1 / 3)
+    return cx * 2 ** (1.0 / 3.0) * (np.exp(4.0 / 3.0 * np.log(ra)) + np.exp(4.0 / 3.0 * np.log(rb)))
+
+
+def _pw92_G(rs, A, a1, b1, b2, b3, b4):
+    sq = np.sqrt(rs)
+    return -2 * A * (1 + a1 * rs) * np.log(1 + 1 / (2 * A * (b1 * sq + b2 * rs + b3 * rs * sq + b4 * rs * rs)))
+
+
+def _lda_c_pw_spin_e(ra, rb):
+    """Perdew-Wang 1992 with the spin interpolation of their eq. (8) (libxc ``lda_c_pw``, original parameters,
+    f''(0) = 1.709921).  PARITY UNPINNED like the unpolarised form."""
+    rt, zeta, fz, rs = _zeta_terms(ra, rb)
+    e0 = _pw92_G(rs, 0.031091, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294)
+    e1 = _pw92_G(rs, 0.015545, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517)
+    mac = _pw92_G(rs, 0.016887, 0.11125, 10.357, 3.6231, 0.88026, 0.49671)     # = -alpha_c
+    z4 = zeta ** 4
+    return rt * (e0 - mac * fz / 1.709921 * (1 - z4) + (e1 - e0) * fz * z4)
+
+
+def _lda_xc_teter93_spin_e(ra, rb):
+    rt, _, fz, rs = _zeta_terms(ra, rb)
+    return rt * _teter_eps(rs, fz)
+
+
+_SPIN_FUNCTIONALS = {"lda_x": _lda_x_spin_e, "lda_c_pw": _lda_c_pw_spin_e, "lda_xc_teter93": _lda_xc_teter93_spin_e}
+_SPIN_FLOOR = 1e-20      # a spin channel is never evaluated below this density (log / fractional powers)
+
+
+def xc_energy_potential_spin(basis, rho):
+    """Collinear LDA: rho has shape (2, nz, ny, nx) = (up, down); returns E_xc and the potential per spin channel
+    (xc.jl:84-160 with n_spin = 2).  Gradient-corrected functionals with spin are not restated."""
+    missing = [f for f in basis.model.functionals if f not in _SPIN_FUNCTIONALS]
+    if missing:
+        raise NotImplementedError(f"collinear spin: no spin-polarised restatement of {missing}")
+    ra = np.maximum(rho[0], _SPIN_FLOOR)
+    rb = np.maximum(rho[1], _SPIN_FLOOR)
+    h = 1e-30
+    e = np.zeros_like(ra)
+    v = np.zeros_like(rho)
+    for name in basis.model.functionals:
+        fun = _SPIN_FUNCTIONALS[name]
+        e += fun(ra, rb)
+        v[0] += np.imag(fun(ra + 1j * h, rb.astype(complex))) / h
+        v[1] += np.imag(fun(ra.astype(complex), rb + 1j * h)) / h
+    empty = (rho[0] + rho[1]) <= 2 * _SPIN_FLOOR
+    if np.any(empty):
+        e[empty] = 0.0
+        v[:, empty] = 0.0
+    return float(np.sum(e) * basis.dvol), v
 
 
 # GGA functionals: energy density per volume e(rho, sigma), sigma = |grad rho|^2.  Written with analytic
@@ -337,8 +427,8 @@ def atom_decay_length(n_elec_core, n_elec_valence):
     return data[min(n_elec_valence, len(data)) - 1]
 
 
-def guess_density(basis):
-    """Gaussian superposition, renormalised to n_electrons (density_methods.jl:111-125,158-181,236-244)."""
+def _gaussian_superposition(basis, coefficients):
+    """atomic_density_superposition (density_methods.jl:158-181) with the Gaussian valence densities (:236-244)."""
     model = basis.model
     gx, gy, gz = basis.G_vectors_cube()
     Gcart = basis.G_vectors_cart_cube()
@@ -349,14 +439,46 @@ def guess_density(basis):
         ff = el.charge_ionic * np.exp(-(Gnorm * atom_decay_length(el.n_elec_core, el.charge_ionic)) ** 2)
         for ia in group:
             r = model.positions[ia]
-            rho_G += (np.exp(-2j * math.pi * (gx * r[0] + gy * r[1] + gz * r[2])) * ff
+            rho_G += (coefficients[ia] * np.exp(-2j * math.pi * (gx * r[0] + gy * r[1] + gz * r[2])) * ff
                       / math.sqrt(model.unit_cell_volume))
     rho_G = basis.enforce_real(rho_G)
-    rho = basis.irfft_cube(rho_G)
+    return basis.irfft_cube(rho_G)
+
+
+def guess_density(basis, magnetic_moments=()):
+    """Gaussian superposition, renormalised to n_electrons (density_methods.jl:35-38, :102-152).  For a collinear
+    model the result has shape (2, nz, ny, nx) = ((tot + spin) / 2, (tot - spin) / 2), the spin density being the same
+    superposition with the coefficients magnetic_moment / n_elec_valence per atom (zero without moments)."""
+    model = basis.model
+    rho_tot = _gaussian_superposition(basis, np.ones(len(model.atoms)))
+    if model.n_spin_components == 1:
+        if len(magnetic_moments) and any(m != 0 for m in np.asarray(magnetic_moments, dtype=float).reshape(-1)):
+            raise ValueError("Initial magnetic moments can only be used with collinear models.")
+        rho = rho_tot
+    else:
+        mm = [float(np.asarray(m, dtype=float).reshape(-1)[-1]) for m in magnetic_moments]
+        if not mm or all(m == 0 for m in mm):
+            rho_spin = np.zeros_like(rho_tot)
+        else:
+            if len(mm) != len(model.atoms):
+                raise ValueError("one magnetic moment per atom")
+            for m, a in zip(mm, model.atoms):
+                if m > a.charge_ionic:
+                    raise ValueError(f"Magnetic moment {m} too large for {a.symbol} with {a.charge_ionic} valence electrons")
+            rho_spin = _gaussian_superposition(basis, [m / a.charge_ionic for m, a in zip(mm, model.atoms)])
+        rho = np.stack([(rho_tot + rho_spin) / 2, (rho_tot - rho_spin) / 2])
     N = np.sum(rho) * model.unit_cell_volume / basis.N
     if N > 0:
         rho = rho * (model.n_electrons / N)
     return rho
+
+
+def total_density(rho):
+    return rho if rho.ndim == 3 else rho.sum(axis=0)                 # densities.jl:149
+
+
+def spin_density(rho):
+    return np.zeros_like(rho) if rho.ndim == 3 else rho[0] - rho[1]  # densities.jl:150-156
 
 
 # ----------------------------------------------------------------------------- terms container
@@ -468,6 +590,12 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, eigenvalues=None, eF=No
         pot = v.copy() if pot is None else pot + v
 
     have_psi = psi is not None and occupation is not None
+    n_spin = model.n_spin_components
+    rho_spin_resolved = rho
+    if rho is not None and n_spin == 2:
+        # density-functional terms of the TOTAL density add the same potential to both spin channels; only Xc
+        # distinguishes them (potential has shape (2, nz, ny, nx) then, ops pick potential[kpt.spin], xc.jl:163-175)
+        rho = total_density(rho)
     for name in T.names:
         if name == "Kinetic":
             if have_psi:
@@ -503,8 +631,12 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, eigenvalues=None, eF=No
             add_pot(basis.irfft_cube(pot_G))
             E[name] = float(np.real(np.vdot(pot_G, rho_G)) / 2)
         elif name == "Xc":
-            exc, vxc = xc_energy_potential(basis, rho)
-            add_pot(vxc)
+            if n_spin == 2:
+                exc, vxc = xc_energy_potential_spin(basis, rho_spin_resolved)
+                add_pot(vxc)                                     # (2, nz, ny, nx) from here on (numpy broadcasting)
+            else:
+                exc, vxc = xc_energy_potential(basis, rho)
+                add_pot(vxc)
             E[name] = exc
         elif name == "Entropy":
             if model.temperature == 0:
@@ -520,9 +652,11 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, eigenvalues=None, eF=No
                 E[name] = e
         else:
             raise NotImplementedError(name)
+    def pot_of(kpt):
+        return pot[kpt.spin - 1] if (pot is not None and pot.ndim == 4) else pot
     ham = [HamiltonianBlock(basis, kpt,
                             T.kinetic[ik] if T.kinetic is not None else None,
-                            pot,
+                            pot_of(kpt),
                             T.P[ik] if T.P is not None else None, T.D)
            for ik, kpt in enumerate(basis.kpoints)]
     return E, ham

@@ -261,7 +261,9 @@ def test_planewave_sharded_block_two_ranks_one_gpu(tmp_path):
     ref_fixed = dftk.self_consistent_field(basis, tol=1e-7, determine_tol=lambda n_iter, hist: 1e-9)
     h_got, h_ref = got["history_drho_fixed_diagtol"], ref_fixed["history_drho"]
     assert ref_fixed["converged"] and abs(len(h_got) - len(h_ref)) <= 1, (h_got, h_ref)
-    n_cmp = min(len(h_got), len(h_ref), 8)
+    # (entries far above the diagonalisation tolerance: below ~1e-5 the 1e-9 eigensolver residuals start to show)
+    n_cmp = min(len(h_got), len(h_ref), sum(1 for d in h_ref if d > 1e-5))
+    assert n_cmp >= 4
     np.testing.assert_allclose(h_got[:n_cmp], h_ref[:n_cmp], rtol=1e-4)
 
 

@@ -68,7 +68,7 @@ static double rnd(void) {
 static void* dev_upload(const void* h, size_t bytes) {
     void* d = NULL;
     if (hipMalloc(&d, bytes ? bytes : 16) != 0) return NULL;
-    if (bytes && hipMemcpy(d, h, bytes, 1) != 0) return NULL;
+    if (h && bytes && hipMemcpy(d, h, bytes, 1) != 0) return NULL;   /* h == NULL: uninitialised output buffer */
     return d;
 }
 

@@ -42,6 +42,10 @@ _SIGNATURES = {
     "dftk_mi_apply_H_parts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, _i64, C.c_void_p, _i64]),
     "dftk_mi_local_potential": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                           C.c_void_p]),
+    "dftk_mi_local_potential_collinear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                    C.c_void_p]),
+    "dftk_mi_density_accumulate_spin": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, C.c_void_p, C.c_int,
+                                                  C.c_int]),
     "dftk_mi_kpoint_sphere_host": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, _i64,
                                              C.POINTER(_i64), C.c_void_p, C.c_void_p, C.c_void_p]),
     "dftk_mi_build_projectors_hgh": (C.c_int, [C.c_void_p, _i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int,

@@ -253,6 +253,12 @@ class PlaneWaveBasis:
         self.n_lanes = n_lanes
         self._pool = None
         self.kpoints = [Kpoint(self, k, lane=i % n_lanes) for i, k in enumerate(kc)]
+        self.n_kcoords_local = len(kc)
+        if model.n_spin_components == 2:
+            # collinear spin: all spin-up k-blocks, then all spin-down ones, weights repeated -- they sum to
+            # n_spin_components over the ranks (build_kpoints Kpoint.jl:58-74, PlaneWaveBasis.jl:50-53, :218-232)
+            self.kpoints = self.kpoints + [Kpoint(self, k, spin=2, lane=(len(kc) + i) % n_lanes) for i, k in enumerate(kc)]
+            self.kweights = list(self.kweights) + list(self.kweights)
         # the full cube as a degenerate "sphere": gives hand-written cube FFTs for Hartree etc.
         self._cube_handle = C.c_void_p()
         if self.handle is not None:

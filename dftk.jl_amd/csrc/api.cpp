@@ -883,10 +883,18 @@ extern "C" int dftk_mi_apply_H(dftk_mi_kblock* kb, int n_bands, const dftk_mi_cp
 extern "C" int dftk_mi_local_potential(dftk_mi_kblock* cube_kb, const double* rho_d, const double* V_loc_d,
                                        const double* poisson_green_d, int xc_functionals, double* V_out_d,
                                        double* energies_h) {
-    if (!cube_kb || !rho_d || !energies_h || (xc_functionals & ~7) || cube_kb->sh_comm) return DFTK_MI_EINVAL;
+    if (!cube_kb || !rho_d || !energies_h || (xc_functionals & ~(7 | 32)) || cube_kb->sh_comm) return DFTK_MI_EINVAL;
     HIPCHK(hipSetDevice(cube_kb->basis->device));
     return local_potential_lda(cube_kb, nullptr, rho_d, V_loc_d, poisson_green_d, xc_functionals, 0.0, V_out_d,
                                energies_h);
+}
+
+extern "C" int dftk_mi_local_potential_collinear(dftk_mi_kblock* cube_kb, const double* rho_d, const double* V_loc_d,
+                                                 const double* poisson_green_d, int xc_functionals, double* V_out_d,
+                                                 double* energies_h) {
+    if (!cube_kb || !rho_d || !energies_h || cube_kb->sh_comm) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(cube_kb->basis->device));
+    return local_potential_collinear(cube_kb, rho_d, V_loc_d, poisson_green_d, xc_functionals, V_out_d, energies_h);
 }
 
 // Julia's column-major 3x3 (entry (i, j) at i + 3 j) -> the kernels' row-major copy
@@ -1025,6 +1033,15 @@ extern "C" int dftk_mi_density_accumulate(dftk_mi_kblock* kb, int n_bands, const
     CHK(t.to_bands(reinterpret_cast<const cd*>(psi_d), R1, F));
     if (t.mine == 0) return 0;
     return launch_density(kb, t.mine, F, kb->n_G, weight_h + t.c0[t.me], rho_d);
+}
+
+// compute_density's accumulation with the spin index of the k-block spelled out (densities.jl:39:
+// rho[:, :, :, kpt.spin] += ...): rho_d holds n_spin cubes, the bands of this block go to cube `spin` (0-based)
+extern "C" int dftk_mi_density_accumulate_spin(dftk_mi_kblock* kb, int n_bands, const dftk_mi_cplx* psi_d, int64_t ld_psi,
+                                               const double* weight_h, double* rho_d, int spin, int n_spin) {
+    if (!kb || !rho_d || n_spin < 1 || n_spin > 2 || spin < 0 || spin >= n_spin) return DFTK_MI_EINVAL;
+    const int64_t N = (int64_t)kb->basis->nx * kb->basis->ny * kb->basis->nz;
+    return dftk_mi_density_accumulate(kb, n_bands, psi_d, ld_psi, weight_h, rho_d + (int64_t)spin * N);
 }
 
 // ------------------------------------------------------------------------------------ Gamma-real extension

@@ -257,6 +257,8 @@ int comm_alltoallv(dftk_mi_comm* c, dftk_mi_basis* b, const cd* send, const size
                    cd* recv, const size_t* roff, const size_t* rcnt);
 
 // xc_kernels.hip
+int local_potential_collinear(dftk_mi_kblock* cube_kb, const double* rho, const double* vloc, const double* green,
+                              int fun_mask, double* V_out, double* energies_h);
 int local_potential_lda(dftk_mi_kblock* cube_kb, const double* recip_h, const double* rho, const double* vloc,
                         const double* green, int fun_mask, double threshold, double* V_out, double* energies_h);
 

@@ -85,43 +85,6 @@ __device__ __forceinline__ void lda_c_pw(double rho, double& e, double& v) {
     v = eps - rs / 3.0 * deps;
 }
 
-// V = V_loc + V_H + v_xc ; partials: [0] sum e_xc, [1] sum rho V_loc
-__global__ __launch_bounds__(256) void k_xc_sum(int64_t n, const double* __restrict__ rho, const cd* __restrict__ vh_cube,
-                                                double vh_scale, const double* __restrict__ vloc, int fun_mask,
-                                                const double* __restrict__ e_extra, const double* __restrict__ v_extra,
-                                                double* __restrict__ V, double* __restrict__ partial) {
-    __shared__ double sh[4];
-    double acc_xc = 0.0, acc_loc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const double r = rho[i];
-        double e = 0.0, v = 0.0;
-        if (fun_mask != 0 && r > 1e-300) {
-            double ei, vi;
-            if (fun_mask & 1) { lda_x(r, ei, vi); e += ei; v += vi; }
-            if (fun_mask & 2) { lda_c_vwn(r, ei, vi); e += ei; v += vi; }
-            if (fun_mask & 4) { lda_c_pw(r, ei, vi); e += ei; v += vi; }
-        }
-        if (e_extra) {                       // GGA part: e(rho, sigma) and v_rho - 2 div(v_sigma grad rho), precomputed
-            e += e_extra[i];
-            v += v_extra[i];
-        }
-        acc_xc += e;
-        double tot = v;
-        if (vloc) {
-            const double vl = vloc[i];
-            acc_loc += r * vl;
-            tot += vl;
-        }
-        if (vh_cube) tot += vh_scale * vh_cube[i].x;
-        if (V) V[i] = tot;
-    }
-    const double s0 = block_sum(acc_xc, sh);
-    const double s1 = block_sum(acc_loc, sh);
-    if (threadIdx.x == 0) {
-        partial[blockIdx.x] = s0;
-        partial[XC_BLOCKS + blockIdx.x] = s1;
-    }
-}
 // ---- GGA (PBE): e(rho, sigma) with forward-mode derivatives d/d rho, d/d sigma carried through the closed forms
 // (libxc's gga_x_pbe / gga_c_pbe on lda_c_pw_mod; Perdew, Burke, Ernzerhof 1996).  A dual number (v, dr, ds) makes
 // the potential terms exact derivatives of exactly the energy expression -- no hand-derived formulas.
@@ -186,6 +149,137 @@ __global__ __launch_bounds__(256) void k_gga(int64_t n, const double* __restrict
         vsigma[i] = acc.ds;
     }
 }
+// ---- collinear spin, LDA: e(rho_up, rho_down) with forward-mode derivatives; the two derivative slots of D3 carry
+// d/d rho_up and d/d rho_down here.  Closed forms as libxc's polarised lda_x (spin-scaling relation), lda_c_pw (PW92 eq. 8
+// interpolation in zeta, f''(0) = 1.709921) and lda_xc_teter93 (Goedecker, Teter, Hutter 1996: Pade coefficients linear in
+// f(zeta)).  The unpolarised lda_xc_teter93 is the same form at rho_up = rho_down.
+__device__ __forceinline__ D3 dpow43(D3 a) { return a * dcbrt(a); }
+__device__ __forceinline__ D3 spin_fzeta(D3 ra, D3 rb, D3 rt) {
+    const D3 xa = 2.0 * (ra / rt), xb = 2.0 * (rb / rt);
+    return (1.0 / (2.5198420997897464 - 2.0)) * (dpow43(xa) + dpow43(xb) + dc(-2.0));   // 2^(4/3) - 2
+}
+__device__ __forceinline__ D3 pw92_G(D3 rs, D3 sq, double A, double a1, double b1, double b2, double b3, double b4) {
+    const D3 den = 2.0 * A * (b1 * sq + b2 * rs + b3 * (rs * sq) + b4 * (rs * rs));
+    return (-2.0 * A) * ((1.0 + a1 * rs) * dlog1p(dc(1.0) / den));
+}
+__device__ __forceinline__ D3 lda_x_spin(D3 ra, D3 rb) {
+    const double cx = -0.73855876638202240588 * 1.2599210498948732;   // -3/4 (3/pi)^(1/3) 2^(1/3)
+    return cx * (dpow43(ra) + dpow43(rb));
+}
+__device__ __forceinline__ D3 lda_c_pw_spin(D3 ra, D3 rb) {
+    const D3 rt = ra + rb;
+    const D3 fz = spin_fzeta(ra, rb, rt);
+    const D3 z = (ra - rb) / rt;
+    const D3 z2 = z * z, z4 = z2 * z2;
+    const D3 rs = dcbrt(dc(3.0 / (4.0 * M_PI)) / rt);
+    const D3 sq = dsqrt(rs);
+    const D3 e0 = pw92_G(rs, sq, 0.031091, 0.21370, 7.5957, 3.5876, 1.6382, 0.49294);
+    const D3 e1 = pw92_G(rs, sq, 0.015545, 0.20548, 14.1189, 6.1977, 3.3662, 0.62517);
+    const D3 mac = pw92_G(rs, sq, 0.016887, 0.11125, 10.357, 3.6231, 0.88026, 0.49671);   // = -alpha_c
+    return rt * (e0 - (1.0 / 1.709921) * (mac * fz * (dc(1.0) - z4)) + (e1 - e0) * (fz * z4));
+}
+__device__ __forceinline__ D3 lda_xc_teter93_spin(D3 ra, D3 rb) {
+    const double a[4] = {0.4581652932831429, 2.217058676663745, 0.7405551735357053, 0.01968227878617998};
+    const double da[4] = {0.119086804055547, 0.6157402568883345, 0.1574201515892867, 0.003532336663397157};
+    const double bb[4] = {1.0, 4.504130959426697, 1.110667363742916, 0.02359291751427506};
+    const double db[4] = {0.0, 0.2673612973836267, 0.2052004607777787, 0.004200005045691381};
+    const D3 rt = ra + rb;
+    const D3 fz = spin_fzeta(ra, rb, rt);
+    const D3 rs = dcbrt(dc(3.0 / (4.0 * M_PI)) / rt);
+    const D3 num = (a[0] + da[0] * fz) + rs * ((a[1] + da[1] * fz) + rs * ((a[2] + da[2] * fz) + rs * (a[3] + da[3] * fz)));
+    const D3 den = rs * ((bb[0] + db[0] * fz) + rs * ((bb[1] + db[1] * fz) + rs * ((bb[2] + db[2] * fz) + rs * (bb[3] + db[3] * fz))));
+    return dc(-1.0) * (rt * (num / den));
+}
+// fun_mask bits: 1 lda_x, 4 lda_c_pw, 32 lda_xc_teter93
+__device__ __forceinline__ D3 lda_spin_sum(double rho_up, double rho_dn, int fun_mask) {
+    const double floor_ = 1e-20;                       // a spin channel is never evaluated below this density
+    const D3 ra = D3{rho_up > floor_ ? rho_up : floor_, 1.0, 0.0}, rb = D3{rho_dn > floor_ ? rho_dn : floor_, 0.0, 1.0};
+    D3 acc = dc(0.0);
+    if (rho_up + rho_dn <= 2.0 * floor_) return acc;
+    if (fun_mask & 1) acc = acc + lda_x_spin(ra, rb);
+    if (fun_mask & 4) acc = acc + lda_c_pw_spin(ra, rb);
+    if (fun_mask & 32) acc = acc + lda_xc_teter93_spin(ra, rb);
+    return acc;
+}
+
+// V = V_loc + V_H + v_xc ; partials: [0] sum e_xc, [1] sum rho V_loc
+__global__ __launch_bounds__(256) void k_xc_sum(int64_t n, const double* __restrict__ rho, const cd* __restrict__ vh_cube,
+                                                double vh_scale, const double* __restrict__ vloc, int fun_mask,
+                                                const double* __restrict__ e_extra, const double* __restrict__ v_extra,
+                                                double* __restrict__ V, double* __restrict__ partial) {
+    __shared__ double sh[4];
+    double acc_xc = 0.0, acc_loc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double r = rho[i];
+        double e = 0.0, v = 0.0;
+        if (fun_mask != 0 && r > 1e-300) {
+            double ei, vi;
+            if (fun_mask & 1) { lda_x(r, ei, vi); e += ei; v += vi; }
+            if (fun_mask & 2) { lda_c_vwn(r, ei, vi); e += ei; v += vi; }
+            if (fun_mask & 4) { lda_c_pw(r, ei, vi); e += ei; v += vi; }
+            if (fun_mask & 32) {               // lda_xc_teter93: the polarised form at rho_up = rho_down = rho / 2
+                const D3 t = lda_spin_sum(0.5 * r, 0.5 * r, 32);
+                e += t.v;
+                v += t.dr;
+            }
+        }
+        if (e_extra) {                       // GGA part: e(rho, sigma) and v_rho - 2 div(v_sigma grad rho), precomputed
+            e += e_extra[i];
+            v += v_extra[i];
+        }
+        acc_xc += e;
+        double tot = v;
+        if (vloc) {
+            const double vl = vloc[i];
+            acc_loc += r * vl;
+            tot += vl;
+        }
+        if (vh_cube) tot += vh_scale * vh_cube[i].x;
+        if (V) V[i] = tot;
+    }
+    const double s0 = block_sum(acc_xc, sh);
+    const double s1 = block_sum(acc_loc, sh);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = s0;
+        partial[XC_BLOCKS + blockIdx.x] = s1;
+    }
+}
+// rho_tot as a complex cube (input of the Hartree pass of a collinear model)
+__global__ __launch_bounds__(256) void k_total_to_complex(int64_t n, const double* __restrict__ up, const double* __restrict__ dn,
+                                                          cd* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = make_double2(up[i] + dn[i], 0.0);
+}
+// V_s = V_loc + V_H[rho_tot] + v_xc,s(rho_up, rho_down), s = up, down ; partials: [0] sum e_xc, [1] sum rho_tot V_loc
+__global__ __launch_bounds__(256) void k_xc_sum_spin(int64_t n, const double* __restrict__ up, const double* __restrict__ dn,
+                                                     const cd* __restrict__ vh_cube, double vh_scale,
+                                                     const double* __restrict__ vloc, int fun_mask, double* __restrict__ V_up,
+                                                     double* __restrict__ V_dn, double* __restrict__ partial) {
+    __shared__ double sh[4];
+    double acc_xc = 0.0, acc_loc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double ra = up[i], rb = dn[i];
+        const D3 e = lda_spin_sum(ra, rb, fun_mask);
+        acc_xc += e.v;
+        double common = 0.0;
+        if (vloc) {
+            const double vl = vloc[i];
+            acc_loc += (ra + rb) * vl;
+            common += vl;
+        }
+        if (vh_cube) common += vh_scale * vh_cube[i].x;
+        if (V_up) {
+            V_up[i] = common + e.dr;
+            V_dn[i] = common + e.ds;
+        }
+    }
+    const double s0 = block_sum(acc_xc, sh);
+    const double s1 = block_sum(acc_loc, sh);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = s0;
+        partial[XC_BLOCKS + blockIdx.x] = s1;
+    }
+}
 }  // namespace dftk_xc
 using namespace dftk_xc;
 
@@ -205,6 +299,50 @@ int cube_gradient_multiply(dftk_mi_kblock* cube_kb, const double* recip_h, int a
 int cube_backward_real(dftk_mi_kblock* cube_kb, const cd* c, cd* tmp, double scale, double* out);
 int cube_sigma(dftk_mi_basis* b, int64_t N, const double* gx, const double* gy, const double* gz, double* sigma);
 int cube_axpy_real(dftk_mi_basis* b, int64_t N, const double* a, double scale, const cd* c, double* out);
+
+// Collinear-spin LDA pipeline: rho = (rho_up, rho_down), two cubes; Hartree of the TOTAL density, V_loc, and the spin-resolved
+// XC potential summed into (V_up, V_down); energies = Hartree, Xc, AtomicLocal (rho_tot V_loc).
+int local_potential_collinear(dftk_mi_kblock* cube_kb, const double* rho, const double* vloc, const double* green,
+                              int fun_mask, double* V_out, double* energies_h) {
+    dftk_mi_basis* b = cube_kb->basis;
+    const int64_t N = (int64_t)b->nx * b->ny * b->nz;
+    if (cube_kb->n_G != N) {
+        dftk_set_error("local_potential_collinear: the k-block must span the whole cube (n_G = %lld, N = %lld)",
+                       (long long)cube_kb->n_G, (long long)N);
+        return DFTK_MI_EINVAL;
+    }
+    if (fun_mask & ~(1 | 4 | 32)) {
+        dftk_set_error("local_potential_collinear: spin-polarised forms exist for lda_x, lda_c_pw, lda_xc_teter93 only "
+                       "(mask %d)", fun_mask);
+        return DFTK_MI_EINVAL;
+    }
+    CHK(cube_ws_ensure(b, 2 * (size_t)N * sizeof(cd) + 3 * XC_BLOCKS * sizeof(double)));
+    cd* c1 = reinterpret_cast<cd*>(b->dense_ws);
+    cd* c2 = c1 + N;
+    double* partial = reinterpret_cast<double*>(c2 + N);
+    const double *up = rho, *dn = rho + N;
+    const cd* vh = nullptr;
+    if (green) {
+        hipLaunchKernelGGL(k_total_to_complex, dim3(XC_BLOCKS), dim3(256), 0, b->stream, N, up, dn, c1);
+        CHK(launch_fft_from_cube(cube_kb, c1, c2));
+        hipLaunchKernelGGL(k_poisson, dim3(XC_BLOCKS), dim3(256), 0, b->stream, N, c2, green, partial + 2 * XC_BLOCKS);
+        CHK(launch_ifft_to_cube(cube_kb, c2, c1));
+        vh = c1;
+    }
+    hipLaunchKernelGGL(k_xc_sum_spin, dim3(XC_BLOCKS), dim3(256), 0, b->stream, N, up, dn, vh, 1.0 / (double)N, vloc, fun_mask,
+                       V_out, V_out ? V_out + N : (double*)nullptr, partial);
+    HIPCHK(hipGetLastError());
+    std::vector<double> hp(3 * XC_BLOCKS, 0.0);
+    CHK(host_fetch(b, hp.data(), partial, (green ? 3 : 2) * XC_BLOCKS * sizeof(double)));
+    double s3[3] = {0.0, 0.0, 0.0};
+    for (int k = 0; k < 3; ++k)
+        for (int i = 0; i < XC_BLOCKS; ++i) s3[k] += hp[(size_t)k * XC_BLOCKS + i];
+    const double dvol = b->volume / (double)N;
+    energies_h[0] = green ? 0.5 * b->volume / ((double)N * (double)N) * s3[2] : 0.0;
+    energies_h[1] = s3[0] * dvol;
+    energies_h[2] = s3[1] * dvol;
+    return 0;
+}
 
 // cube_kb: a k-block whose "sphere" is the whole cube (mapping = 0 .. N-1), i.e. the library's cube FFT.
 // fun_mask may carry LDA bits (1, 2, 4: point-wise in the final pass) and GGA bits (8, 16): for the latter
@@ -266,7 +404,7 @@ int local_potential_lda(dftk_mi_kblock* cube_kb, const double* recip_h, const do
         vh = c1;
     }
     hipLaunchKernelGGL(k_xc_sum, dim3(XC_BLOCKS), dim3(256), 0, b->stream, N, rho, vh, 1.0 / (double)N, vloc,
-                       fun_mask & 7, (const double*)e_g, (const double*)v_g, V_out, partial);
+                       fun_mask & (7 | 32), (const double*)e_g, (const double*)v_g, V_out, partial);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(hp.data(), partial, (green ? 3 : 2) * XC_BLOCKS * sizeof(double), hipMemcpyDeviceToHost,
                           b->stream));

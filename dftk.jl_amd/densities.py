@@ -14,16 +14,22 @@ def compute_density(basis, psi, occupation, occupation_threshold: float = 0.0, r
     satisfy psi(-G) = conj(psi(G)) -- two bands then share one transform (dftk_mi_density_accumulate_real)."""
     basis._require_gpu()
     nx, ny, nz = basis.fft_size
-    # one accumulator per lane (the lanes run concurrently on their own streams), summed in lane order afterwards
-    rhos = [torch.zeros((nz, ny, nx), dtype=torch.float64, device=basis.device) for _ in range(basis.n_lanes)]
+    n_spin = basis.model.n_spin_components
+    # one accumulator per lane (the lanes run concurrently on their own streams), summed in lane order afterwards;
+    # rho[kpt.spin - 1] takes the bands of a k-block (rho[:, :, :, kpt.spin], densities.jl:29, :39)
+    rhos = [torch.zeros((n_spin, nz, ny, nx), dtype=torch.float64, device=basis.device) for _ in range(basis.n_lanes)]
     torch.cuda.current_stream(basis.device).synchronize()
 
     if getattr(basis, "kbatch", False) and basis.n_lanes == 1 and len(basis.kpoints) > 1:
         # many small k-blocks: the bands of all of them go through ONE pipeline (dftk_mi_density_accumulate_multi);
         # k-points whose orbitals are real-symmetric keep their paired call
         import ctypes as C
-        multi = [ik for ik in range(len(basis.kpoints)) if not (real_symmetric is not None and real_symmetric[ik])]
-        if len(multi) > 1:
+        multi_all = [ik for ik in range(len(basis.kpoints)) if not (real_symmetric is not None and real_symmetric[ik])]
+        done_multi = set()
+        for spin in range(1, n_spin + 1):          # one batched pipeline per spin channel (its own density cube)
+            multi = [ik for ik in multi_all if basis.kpoints[ik].spin == spin]
+            if len(multi) < 2:
+                continue
             ws, keep = [], []
             for ik in multi:
                 occ = np.asarray(occupation[ik], dtype=np.float64)
@@ -39,10 +45,9 @@ def compute_density(basis, psi, occupation, occupation_threshold: float = 0.0, r
             nbs = (C.c_int * n)(*[len(w_) for w_ in ws])
             pp = (C.c_void_p * n)(*[p_.data_ptr() for p_ in keep])
             ld = (C.c_int64 * n)(*[p_.stride(0) for p_ in keep])
-            _lib.check(basis.lib.dftk_mi_density_accumulate_multi(n, kbs, nbs, pp, ld, w_all.ctypes.data, rhos[0].data_ptr()))
-            done_multi = set(multi)
-        else:
-            done_multi = set()
+            _lib.check(basis.lib.dftk_mi_density_accumulate_multi(n, kbs, nbs, pp, ld, w_all.ctypes.data,
+                                                                  rhos[0][spin - 1].data_ptr()))
+            done_multi |= set(multi)
     else:
         done_multi = set()
 
@@ -56,8 +61,13 @@ def compute_density(basis, psi, occupation, occupation_threshold: float = 0.0, r
         if not (psik.is_cuda and psik.dtype == torch.complex128 and psik.stride(1) == 1):
             raise TypeError("compute_density: complex128 CUDA band-major blocks required")
         paired = real_symmetric is not None and real_symmetric[ik]
-        fn = basis.lib.dftk_mi_density_accumulate_real if paired else basis.lib.dftk_mi_density_accumulate
-        _lib.check(fn(kpt.handle, len(w), psik.data_ptr(), psik.stride(0), w.ctypes.data, rhos[kpt.lane].data_ptr()))
+        if paired:
+            _lib.check(basis.lib.dftk_mi_density_accumulate_real(kpt.handle, len(w), psik.data_ptr(), psik.stride(0),
+                                                                 w.ctypes.data, rhos[kpt.lane][kpt.spin - 1].data_ptr()))
+        else:
+            _lib.check(basis.lib.dftk_mi_density_accumulate_spin(kpt.handle, len(w), psik.data_ptr(), psik.stride(0),
+                                                                 w.ctypes.data, rhos[kpt.lane].data_ptr(), kpt.spin - 1,
+                                                                 n_spin))
     basis.run_on_lanes(accumulate, basis.kpoints)
     rho = rhos[0]
     if basis.n_lanes > 1:
@@ -73,5 +83,5 @@ def compute_density(basis, psi, occupation, occupation_threshold: float = 0.0, r
     basis.sync()
     if any(not s.isone() for s in basis.symmetries):
         from .symmetry import symmetrize_rho
-        rho = symmetrize_rho(basis, rho, do_lowpass=False)                # densities.jl:47
-    return rho
+        rho = torch.stack([symmetrize_rho(basis, r, do_lowpass=False) for r in rho])   # densities.jl:47 (per spin)
+    return rho if n_spin == 2 else rho[0]

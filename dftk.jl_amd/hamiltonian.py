@@ -26,6 +26,18 @@ class DftHamiltonianBlock:
         """The blocks of every local k-point for ONE summed potential (Hamiltonian.jl:36-57), bound with a single library
         call (``dftk_mi_kblocks_set_potential``) instead of one host round trip per k-point."""
         import ctypes as C
+        if potential is not None and potential.dim() == 4:
+            # collinear spin: potential[s] belongs to the k-blocks of spin s + 1 (xc.jl:163-175: Vxc[:, :, :, kpt.spin])
+            pots = [potential[s_].to(torch.float64).contiguous() for s_ in range(potential.shape[0])]
+            blocks = [DftHamiltonianBlock(basis, kpt, pots[kpt.spin - 1], bind=False) for kpt in basis.kpoints]
+            torch.cuda.current_stream(basis.device).synchronize()
+            for s_, pot_s in enumerate(pots):
+                mine = [b_ for b_ in blocks if b_.kpoint.spin == s_ + 1]
+                kbs = (C.c_void_p * len(mine))(*[b_.kpoint.handle.value for b_ in mine])
+                _lib.check(basis.lib.dftk_mi_kblocks_set_potential(len(mine), kbs, pot_s.data_ptr()))
+            for b_ in blocks:
+                b_.kpoint._pot_owner = b_
+            return blocks
         pot = potential.to(torch.float64).contiguous() if potential is not None else None
         blocks = [DftHamiltonianBlock(basis, kpt, pot, bind=False) for kpt in basis.kpoints]
         if pot is None or len(blocks) < 2:

@@ -80,25 +80,39 @@ def _gather_kpts(basis, local):
     return [x for part in parts for x in part]
 
 
+def _by_spin(basis, local):
+    """Per-(k, spin) host data -> [spin][kpoint (global order)]: every rank lists its spin-up blocks, then its spin-down
+    blocks (PlaneWaveBasis.jl:50-53); the reference's files index [spin][kpoint][...] (gather_kpts_block)."""
+    n_spin = basis.model.n_spin_components
+    parts = basis.comm_kpts.gather_lists([_tolist(x) for x in local])
+    out = [[] for _ in range(n_spin)]
+    for part in parts:
+        n = len(part) // n_spin
+        for s_ in range(n_spin):
+            out[s_].extend(part[s_ * n:(s_ + 1) * n])
+    return out
+
+
 def scfres_to_dict(scfres: dict, save_psi: bool = False, save_rho: bool = True) -> dict:
     """``scfres_to_dict`` (input_output.jl:345-386) for the dict returned by ``self_consistent_field``."""
     basis = scfres["basis"] if "basis" in scfres else scfres["ham"][0].basis
     d = basis_to_dict(basis)
-    eig = _gather_kpts(basis, [np.asarray(e, dtype=float) for e in scfres["eigenvalues"]])
-    occ = _gather_kpts(basis, [np.asarray(o, dtype=float) for o in scfres["occupation"]])
-    n_bands = min(len(e) for e in eig)
+    eig = _by_spin(basis, [np.asarray(e, dtype=float) for e in scfres["eigenvalues"]])
+    occ = _by_spin(basis, [np.asarray(o, dtype=float) for o in scfres["occupation"]])
+    n_bands = min(len(e) for es in eig for e in es)
     d["n_bands"] = n_bands
-    d["eigenvalues"] = [[list(e[:n_bands]) for e in eig]]          # [spin][kpoint][band]
-    d["occupation"] = [[list(o[:n_bands]) for o in occ]]
+    d["eigenvalues"] = [[list(e[:n_bands]) for e in es] for es in eig]          # [spin][kpoint][band]
+    d["occupation"] = [[list(o[:n_bands]) for o in os_] for os_ in occ]
     d["εF"] = scfres["eF"]
     diag = scfres["diagonalization"]
     d["diagonalization"] = {
         "n_matvec": int(basis.comm_kpts.sum_scalar(diag["n_matvec"])), "converged": bool(diag["converged"]),
-        "residual_norms": [[list(np.asarray(r)[:n_bands]) for r in _gather_kpts(basis, diag["residual_norms"])]],
-        "n_iter": [_gather_kpts(basis, [int(n) for n in diag["n_iter"]])],
+        "residual_norms": [[list(np.asarray(r)[:n_bands]) for r in rs] for rs in _by_spin(basis, diag["residual_norms"])],
+        "n_iter": _by_spin(basis, [int(n) for n in diag["n_iter"]]),
     }
     if save_rho:
-        d["ρ"] = [_tolist(scfres["rho"])]                          # [spin][iz][iy][ix]
+        rho_ = scfres["rho"]
+        d["ρ"] = _tolist(rho_) if rho_.dim() == 4 else [_tolist(rho_)]       # [spin][iz][iy][ix]
         d["τ"] = None
     d["energies"] = {k: float(v) for k, v in scfres["energies"].items()}
     d["energies"]["total"] = float(scfres["energies"].total)
@@ -114,7 +128,7 @@ def scfres_to_dict(scfres: dict, save_psi: bool = False, save_rho: bool = True) 
     d["scfres_extra_keys"] = list(extra)
     if save_psi:
         n_G = [int(p.shape[1]) for p in scfres["psi"]]
-        d["kpt_n_G_vectors"] = [_gather_kpts(basis, n_G)]
+        d["kpt_n_G_vectors"] = _by_spin(basis, n_G)
         d["kpt_max_n_G"] = int(basis.comm_kpts.max_scalar(max(n_G)))
     return d
 

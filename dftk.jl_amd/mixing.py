@@ -42,17 +42,17 @@ def default_smearing_temperature(model):
 
 
 def compute_dos(eps, basis, eigenvalues, smearing=None, temperature=None):
-    """Total density of states at ``eps`` (dos.jl:18-34), summed over ``comm_kpts``."""
+    """Density of states at ``eps`` per spin component (dos.jl:18-34: ``D[sigma]``), summed over ``comm_kpts``."""
     smearing = smearing or basis.model.smearing
     temperature = basis.model.temperature if temperature is None else temperature
     if temperature == 0 or smearing == "none":
         raise ValueError("compute_dos only supports finite temperature")
     filled = basis.model.filled_occupation
-    D = 0.0
-    for w, ek in zip(basis.kweights, eigenvalues):
+    D = np.zeros(basis.model.n_spin_components)
+    for kpt, w, ek in zip(basis.kpoints, basis.kweights, eigenvalues):
         x = (np.asarray(ek, dtype=float) - eps) / temperature
-        D -= filled * w / temperature * float(np.sum(occupation_derivative(smearing, x)))
-    return basis.comm_kpts.sum_scalar(D)
+        D[kpt.spin - 1] -= filled * w / temperature * float(np.sum(occupation_derivative(smearing, x)))
+    return np.asarray(basis.comm_kpts.sum_scalars(list(D)))
 
 
 def compute_ldos(eps, basis, eigenvalues, psi, smearing=None, temperature=None, weight_threshold=EPS):
@@ -70,7 +70,11 @@ def compute_ldos(eps, basis, eigenvalues, psi, smearing=None, temperature=None, 
 
 
 def gmres(apply, b: torch.Tensor, rtol: float, krylovdim: int = 30, maxiter: int = 100, atol: float = 1e-12):
-    """Restarted GMRES on device vectors (modified Gram-Schmidt; Givens rotations on the host)."""
+    """Restarted GMRES on device vectors (Givens rotations on the host).  ONE host fetch per Krylov step: the new
+    direction is orthogonalised against the whole basis with one stacked reduction (classical Gram-Schmidt,
+    h = V' w together with <w, w>; the norm of the remainder follows from Pythagoras and is recomputed explicitly only
+    when cancellation has eaten its digits) -- a fetch is a device synchronisation, and with a handful of cube-sized
+    vectors the k + 2 sequential fetches of the modified scheme were most of the solver's time."""
     x = torch.zeros_like(b)
     nb = float(torch.linalg.norm(b).item())
     tol = max(atol, rtol * nb)
@@ -78,18 +82,23 @@ def gmres(apply, b: torch.Tensor, rtol: float, krylovdim: int = 30, maxiter: int
     for _ in range(maxiter):
         if beta <= tol:
             break
-        V = [r / beta]
+        V = [(r / beta).reshape(-1)]
         H = np.zeros((krylovdim + 1, krylovdim))
         g = np.zeros(krylovdim + 1)
         g[0] = beta
         cs, sn = np.zeros(krylovdim), np.zeros(krylovdim)
         k_used = 0
         for k in range(krylovdim):
-            w = apply(V[k])
-            for j in range(k + 1):
-                H[j, k] = float((V[j] * w).sum().item())
-                w = w - H[j, k] * V[j]
-            H[k + 1, k] = float(torch.linalg.norm(w).item())
+            w = apply(V[k].reshape(b.shape)).reshape(-1)
+            Vm = torch.stack(V)                                            # (k + 1, n)
+            vals = torch.cat([Vm @ w, (w @ w).reshape(1)]).cpu().numpy()
+            h, ww = vals[:-1], float(vals[-1])
+            w = w - torch.as_tensor(h, device=w.device) @ Vm
+            H[:k + 1, k] = h
+            rest = ww - float(np.dot(h, h))
+            if rest < 1e-6 * ww:                                           # cancellation: measure the remainder itself
+                rest = float((w @ w).item())
+            H[k + 1, k] = math.sqrt(max(rest, 0.0))
             for j in range(k):
                 t = cs[j] * H[j, k] + sn[j] * H[j + 1, k]
                 H[j + 1, k] = -sn[j] * H[j, k] + cs[j] * H[j + 1, k]
@@ -106,8 +115,11 @@ def gmres(apply, b: torch.Tensor, rtol: float, krylovdim: int = 30, maxiter: int
                 break
             V.append(w / hk1)
         y = np.linalg.solve(np.triu(H[:k_used, :k_used]), g[:k_used])
-        for j in range(k_used):
-            x = x + float(y[j]) * V[j]
+        x = x + (torch.as_tensor(y, device=b.device) @ torch.stack(V[:k_used])).reshape(b.shape)
+        # |g[k_used]| IS the residual norm of the minimiser (exact arithmetic): trust it unless a restart is needed
+        if abs(g[k_used]) <= tol:
+            beta = abs(g[k_used])
+            break
         r = b - apply(x)
         beta = float(torch.linalg.norm(r).item())
     return x, beta <= tol
@@ -153,23 +165,44 @@ class SimpleMixing:
         return dF
 
 
-class KerkerMixing:
-    """mixing.jl:54-105 (spin-unpolarised): J^-1 ~ |G|^2 / (kTF^2 + |G|^2)."""
+def _total(x):
+    return x if x.dim() == 3 else x.sum(dim=0)
 
-    def __init__(self, kTF: float = 0.8):
-        self.kTF = float(kTF)
+
+def _from_total_and_spin(tot, spin):
+    return torch.stack([(tot + spin) / 2, (tot - spin) / 2])           # rho_from_total_and_spin (densities.jl:158-166)
+
+
+class KerkerMixing:
+    """mixing.jl:54-105: J^-1 ~ |G|^2 / (kTF^2 + |G|^2) on the TOTAL density; with collinear spin the spin density is
+    left alone unless ``dDOS_vol`` = (DOS_up - DOS_down) / volume is given (:62-84, :97-103)."""
+
+    def __init__(self, kTF: float = 0.8, dDOS_vol: float = 0.0):
+        self.kTF, self.dDOS_vol = float(kTF), float(dDOS_vol)
+
+    def _total_part(self, basis, dFtot):
+        if not _torch_twin():
+            return _filter(basis, "dftk_mi_mix_kerker", dFtot, self.kTF)
+        G2 = _G2(basis)
+        drho_f = basis.fft(dFtot) * (G2 / (self.kTF ** 2 + G2)) * basis.enforce_real_mask()
+        drho = basis.irfft(drho_f)
+        return drho + (dFtot.mean() - drho.mean())      # copy the DC component, otherwise it never gets updated
 
     def mix_density(self, basis, dF, **info):
-        if not _torch_twin():
-            return _filter(basis, "dftk_mi_mix_kerker", dF, self.kTF)
+        if dF.dim() == 3:
+            return self._total_part(basis, dF)
+        dFtot = _total(dF).contiguous()
+        drho_tot = self._total_part(basis, dFtot)
+        dFspin = dF[0] - dF[1]
+        if abs(self.dDOS_vol) < EPS:
+            return _from_total_and_spin(drho_tot, dFspin)
         G2 = _G2(basis)
-        drho_f = basis.fft(dF) * (G2 / (self.kTF ** 2 + G2)) * basis.enforce_real_mask()
-        drho = basis.irfft(drho_f)
-        return drho + (dF.mean() - drho.mean())      # copy the DC component, otherwise it never gets updated
+        dspin_f = (basis.fft(dFspin) - basis.fft(dFtot) * (4 * math.pi * self.dDOS_vol) / (self.kTF ** 2 + G2))
+        return _from_total_and_spin(drho_tot, basis.irfft(dspin_f * basis.enforce_real_mask()))
 
 
 class KerkerDosMixing:
-    """mixing.jl:117-137: Kerker with kTF from the density of states at the Fermi level."""
+    """mixing.jl:117-137: Kerker with kTF (and the spin coupling) from the density of states at the Fermi level."""
 
     def __init__(self, smearing=None, temperature=None):
         self.smearing, self.temperature = smearing, temperature
@@ -181,11 +214,13 @@ class KerkerDosMixing:
         if T == 0:
             return dF
         dos_per_vol = compute_dos(eF, basis, eigenvalues, sm, T) / basis.model.unit_cell_volume
-        return KerkerMixing(kTF=math.sqrt(4 * math.pi * dos_per_vol)).mix_density(basis, dF)
+        ddos = float(dos_per_vol[0] - dos_per_vol[1]) if len(dos_per_vol) == 2 else 0.0
+        return KerkerMixing(kTF=math.sqrt(4 * math.pi * float(np.sum(dos_per_vol))), dDOS_vol=ddos).mix_density(basis, dF)
 
 
 class DielectricMixing:
-    """mixing.jl:152-172: J^-1 ~ (kTF^2 - C0 G^2) / (eps_r kTF^2 - C0 G^2), C0 = 1 - eps_r."""
+    """mixing.jl:152-172: J^-1 ~ (kTF^2 - C0 G^2) / (eps_r kTF^2 - C0 G^2), C0 = 1 - eps_r; "applied to rho and
+    rho_spin in the same way": per spin channel, with ONE shift of the mean over the whole array."""
 
     def __init__(self, kTF: float = 0.8, eps_r: float = 10.0):
         self.kTF, self.eps_r = float(kTF), float(eps_r)
@@ -196,6 +231,12 @@ class DielectricMixing:
             return dF
         if er > 1 / math.sqrt(EPS):
             return KerkerMixing(kTF).mix_density(basis, dF)
+        if dF.dim() == 4:
+            # the one-channel pass copies each channel's own mean; the reference multiplies the G = 0 entry of every
+            # channel by 1 / eps_r and then adds mean(dF) - mean(d_rho) over the WHOLE 4-d array to all entries
+            out = torch.stack([self.mix_density(basis, x.contiguous()) for x in dF])
+            means = dF.mean(dim=(1, 2, 3), keepdim=True)
+            return out - means + means / er + dF.mean() * (1 - 1 / er)
         if not _torch_twin():
             return _filter(basis, "dftk_mi_mix_dielectric", dF, kTF, er)
         C0 = 1 - er
@@ -217,13 +258,14 @@ class LdosModel:
         if T == 0:
             return None
         ldos = compute_ldos(eF, basis, eigenvalues, psi, sm, T)
-        if float(ldos.abs().max().item()) < math.sqrt(EPS):
+        amax, total = torch.stack([ldos.abs().max(), ldos.sum()]).cpu().numpy()        # one fetch
+        if float(amax) < math.sqrt(EPS):
             return None
-        tdos = float(ldos.sum().item()) * basis.dvol
+        tdos = float(total) * basis.dvol
 
         def apply(drho, dV, alpha=1.0):
-            deF = float((ldos * dV).sum().item()) * basis.dvol
-            return drho + alpha * (ldos * (deF / tdos) - ldos * dV)
+            deF = (ldos * dV).sum() * (basis.dvol / tdos)        # stays on the device: no synchronisation per apply
+            return drho + alpha * (ldos * deF - ldos * dV)
         return apply
 
 
@@ -240,6 +282,9 @@ class DielectricModel:
         kTF = self.kTF
         if not _torch_twin():
             def apply(drho, dV, alpha=1.0):
+                if dV.dim() == 4:
+                    return drho + alpha * torch.stack([_filter(basis, "dftk_mi_chi0_dielectric_apply", v.contiguous(),
+                                                               kTF, self.eps_r) for v in dV])
                 return drho + alpha * _filter(basis, "dftk_mi_chi0_dielectric_apply", dV, kTF, self.eps_r)
             return apply
         G2 = _G2(basis)
@@ -268,12 +313,16 @@ class Chi0Mixing:
 
         def dielectric_adjoint(x):
             count[0] += 1
+            # apply_kernel with RPA = true: the Hartree kernel of the TOTAL density, the same dV for both spin channels
+            xt = _total(x).contiguous()
             if poisson is None:
-                dV = torch.zeros_like(x)
+                dV = torch.zeros_like(xt)
             elif _torch_twin():
-                dV = basis.irfft(poisson * basis.fft(x))                                            # apply_kernel, RPA
+                dV = basis.irfft(poisson * basis.fft(xt))
             else:
-                dV = _filter_array(basis, poisson, x)
+                dV = _filter_array(basis, poisson, xt)
+            if x.dim() == 4:
+                dV = torch.stack([dV, dV])
             dV = dV - dV.mean()
             out = x
             for a in applies:

@@ -41,11 +41,13 @@ def compute_recip_lattice(lattice):
 
 
 class Model:
-    """Spin-unpolarised ``Model`` (src/Model.jl): lattice (columns), atoms, fractional positions,
-    term list, XC functionals, temperature/smearing."""
+    """``Model`` (src/Model.jl): lattice (columns), atoms, fractional positions, term list, XC functionals,
+    temperature / smearing, and the spin polarisation -- ``:none`` or ``:collinear`` (Model.jl:29-39), inferred from the
+    per-atom initial ``magnetic_moments`` (mu_B, z components) as ``determine_spin_polarization`` does."""
 
     def __init__(self, lattice, atoms, positions, terms, functionals=("lda_x", "lda_c_pw"),
-                 temperature=0.0, smearing=None, n_electrons=None, symmetries=False):
+                 temperature=0.0, smearing=None, n_electrons=None, symmetries=False, magnetic_moments=(),
+                 spin_polarization=None):
         self.lattice = np.asarray(lattice, dtype=float)
         self.atoms = list(atoms)
         self.positions = [np.asarray(p, dtype=float) for p in positions]
@@ -60,8 +62,16 @@ class Model:
         self.recip_lattice = compute_recip_lattice(self.lattice)
         self.unit_cell_volume = abs(np.linalg.det(self.lattice))
         self.n_electrons = int(sum(a.charge_ionic for a in self.atoms)) if n_electrons is None else n_electrons
-        self.n_spin_components = 1
-        self.spin_polarization = "none"
+        self.magnetic_moments = tuple(float(np.asarray(m, dtype=float).reshape(-1)[-1]) for m in magnetic_moments)
+        if self.magnetic_moments and len(self.magnetic_moments) != len(self.atoms):
+            raise ValueError("Length of atoms and magnetic_moments vectors need to agree.")
+        if spin_polarization is None:
+            spin_polarization = "collinear" if any(m != 0 for m in self.magnetic_moments) else "none"
+        if spin_polarization not in ("none", "collinear"):
+            raise NotImplementedError(f"spin_polarization = {spin_polarization!r} (Model.jl:190-192: :full is not "
+                                      "supported by the reference either; :spinless is outside the hot path)")
+        self.spin_polarization = spin_polarization
+        self.n_spin_components = 2 if spin_polarization == "collinear" else 1          # Model.jl:196, :366-372
         # atom_groups (Model.jl:169): indices of identical elements, in order of first appearance
         self.atom_groups = []
         reps = []
@@ -78,14 +88,27 @@ class Model:
         # only, or an explicit list of SymOp.  Default False: explicit / unreduced k-lists unless asked for.
         from . import symmetry as _sym
         if symmetries is True:
-            symmetries = _sym.symmetry_operations(self.lattice, self.atom_groups, self.positions)
+            if self.spin_polarization == "collinear" and not self.magnetic_moments:
+                symmetries = [_sym.identity()]          # default_symmetries (Model.jl:330-332): the breaking is unknown
+            else:
+                # atoms that carry different moments are different species for the search (symmetry.jl:66-125 hands
+                # the moments to Spglib)
+                groups = self.atom_groups
+                if self.magnetic_moments:
+                    groups = []
+                    for g in self.atom_groups:
+                        by_m = {}
+                        for i in g:
+                            by_m.setdefault(round(self.magnetic_moments[i], 10), []).append(i)
+                        groups.extend(by_m.values())
+                symmetries = _sym.symmetry_operations(self.lattice, groups, self.positions)
         elif symmetries is False or symmetries is None:
             symmetries = [_sym.identity()]
         self.symmetries = list(symmetries)
 
     @property
     def filled_occupation(self):   # Model.jl:352-360
-        return 2
+        return 1 if self.spin_polarization == "collinear" else 2
 
 
 def model_atomic(lattice, atoms, positions, extra_terms=(), **kw):

@@ -343,7 +343,7 @@ class ScfStepper:
         t = time.time()
         energies, _ = energy_hamiltonian(basis, nxt["psi"], nxt["occupation"], rho=nxt["rho"], only_energies=True,
                                          eigenvalues=nxt["eigenvalues"], eF=nxt["eF"],
-                                         ritz_potential=ham[0].potential if self.ritz_energies else None,
+                                         ritz_potential=self._ritz_potential(ham) if self.ritz_energies else None,
                                          ritz_occupation_threshold=self.nbandsalg.occupation_threshold)
         t = lap("energies", t)
         drho = nxt["rho"] - self.rho_in
@@ -371,6 +371,14 @@ class ScfStepper:
         info["timers"] = timers
         self.info = info
         return info
+
+    @staticmethod
+    def _ritz_potential(ham):
+        """The local potential the step's Hamiltonian was built from; with collinear spin both channels' potentials
+        (the spin-up blocks come first, PlaneWaveBasis.jl:50-53)."""
+        if ham[0].basis.model.n_spin_components == 2:
+            return torch.stack([ham[0].potential, ham[len(ham) // 2].potential])
+        return ham[0].potential
 
     def finalize(self):
         info = self.info

@@ -36,12 +36,22 @@ def _structure_factor_cube(basis, r):
     return pz[:, None, None] * py[None, :, None] * px[None, None, :]
 
 
-def _atomic_superposition_abi(basis, kind, params_of):
-    """One library call (``dftk_mi_atomic_superposition``) for sum_s ff_s(|G|) sum_a e^{-2 pi i G.r_a} -> real cube."""
+def _atomic_superposition_abi(basis, kind, params_of, per_atom=False):
+    """One library call (``dftk_mi_atomic_superposition``) for sum_s ff_s(|G|) sum_a e^{-2 pi i G.r_a} -> real cube.
+    ``per_atom``: ``params_of(element, atom index)`` -- every atom is its own "species" (per-atom coefficients of the
+    spin-density guess, density_methods.jl:126-152)."""
     model = basis.model
-    par = np.zeros((len(model.atom_groups), 8))
     species, positions = [], []
-    for s_idx, g in enumerate(model.atom_groups):
+    if per_atom:
+        par = np.zeros((len(model.atoms), 8))
+        for ia, el in enumerate(model.atoms):
+            vals = params_of(el, ia)
+            par[ia, :len(vals)] = vals
+            species.append(ia)
+            positions.append(np.asarray(model.positions[ia], dtype=float))
+    else:
+        par = np.zeros((len(model.atom_groups), 8))
+    for s_idx, g in enumerate(model.atom_groups if not per_atom else []):
         vals = params_of(model.atoms[g[0]])
         par[s_idx, :len(vals)] = vals
         for ia in g:
@@ -381,14 +391,17 @@ def atom_decay_length(n_core, n_val):
     raise AssertionError
 
 
-def guess_density(basis):
-    """``guess_density(basis, ValenceDensityGaussian())`` (density_methods.jl:111-125,158-181,236-244)."""
+def _gaussian_superposition(basis, coefficients=None):
+    """atomic_density_superposition with the Gaussian valence densities (density_methods.jl:158-181, :236-244);
+    ``coefficients``: one amplitude per atom (default 1)."""
     model = basis.model
     if _use_setup_abi(basis):
-        rho = _atomic_superposition_abi(basis, 1, lambda el: [atom_decay_length(el.n_elec_core, el.charge_ionic),
-                                                              float(el.charge_ionic)])
-        N = float(rho.sum().item()) * model.unit_cell_volume / basis.N
-        return rho * (model.n_electrons / N) if N > 0 else rho
+        if coefficients is None:
+            return _atomic_superposition_abi(basis, 1, lambda el: [atom_decay_length(el.n_elec_core, el.charge_ionic),
+                                                                   float(el.charge_ionic)])
+        return _atomic_superposition_abi(basis, 1, lambda el, ia: [atom_decay_length(el.n_elec_core, el.charge_ionic),
+                                                                   float(el.charge_ionic) * float(coefficients[ia])],
+                                         per_atom=True)
     Gnorm = torch.linalg.norm(basis.G_vectors_cart_cube(), dim=-1)
     rho_G = torch.zeros(Gnorm.shape, dtype=torch.complex128, device=basis.device)
     for group in model.atom_groups:
@@ -396,13 +409,43 @@ def guess_density(basis):
         ff = el.charge_ionic * torch.exp(-(Gnorm * atom_decay_length(el.n_elec_core, el.charge_ionic)) ** 2)
         sf = torch.zeros_like(rho_G)
         for ia in group:
-            sf += _structure_factor_cube(basis, model.positions[ia])
+            sf += _structure_factor_cube(basis, model.positions[ia]) * (1.0 if coefficients is None else float(coefficients[ia]))
         rho_G += sf * ff / math.sqrt(model.unit_cell_volume)
-    rho = basis.irfft(rho_G * basis.enforce_real_mask())
+    return basis.irfft(rho_G * basis.enforce_real_mask())
+
+
+def guess_density(basis, magnetic_moments=()):
+    """``guess_density(basis, magnetic_moments)`` (density_methods.jl:35-38, :102-152): Gaussian superposition renormalised
+    to n_electrons; for a collinear model the result has shape (2, nz, ny, nx) = ((tot + spin) / 2, (tot - spin) / 2) with
+    the spin density = the superposition with coefficients magnetic_moment / n_elec_valence (zero without moments)."""
+    model = basis.model
+    rho_tot = _gaussian_superposition(basis)
+    mm = [float(np.asarray(m, dtype=float).reshape(-1)[-1]) for m in magnetic_moments]
+    if model.n_spin_components == 1:
+        if any(m != 0 for m in mm):
+            raise ValueError("Initial magnetic moments can only be used with collinear models.")
+        rho = rho_tot
+    else:
+        if not mm or all(m == 0 for m in mm):
+            rho_spin = torch.zeros_like(rho_tot)
+        else:
+            if len(mm) != len(model.atoms):
+                raise ValueError("one magnetic moment per atom")
+            for m, a in zip(mm, model.atoms):
+                if m > a.charge_ionic:
+                    raise ValueError(f"Magnetic moment {m} too large for {a.symbol} with {a.charge_ionic} valence electrons")
+            rho_spin = _gaussian_superposition(basis, [m / a.charge_ionic for m, a in zip(mm, model.atoms)])
+        rho = torch.stack([(rho_tot + rho_spin) / 2, (rho_tot - rho_spin) / 2])
     N = float(rho.sum().item()) * model.unit_cell_volume / basis.N
-    if N > 0:
-        rho = rho * (model.n_electrons / N)
-    return rho
+    return rho * (model.n_electrons / N) if N > 0 else rho
+
+
+def total_density(rho):
+    return rho if rho.dim() == 3 else rho.sum(dim=0)                 # densities.jl:149
+
+
+def spin_density(rho):
+    return torch.zeros_like(rho) if rho.dim() == 3 else rho[0] - rho[1]   # densities.jl:150-156
 
 
 # ---------------------------------------------------------------------------------- containers
@@ -418,7 +461,10 @@ def instantiate_terms(basis):
     T.P, T.D = None, None
     if "AtomicNonlocal" in T.names:
         build = build_projection_vectors_abi if _use_setup_abi(basis) else build_projection_vectors
-        P = [build(basis, k) for k in basis.kpoints]
+        # (the spin-down block of a k-point applies the SAME projector matrix as its spin-up twin: built once, shared)
+        n_k = getattr(basis, "n_kcoords_local", len(basis.kpoints))
+        P = [build(basis, k) for k in basis.kpoints[:n_k]]
+        P = P + P[:len(basis.kpoints) - n_k]
         if P and P[0] is not None:
             T.P, T.D = P, build_projection_coefficients(model)
     T.E_ewald = (energy_ewald(model.lattice, [a.charge_ionic for a in model.atoms], model.positions)
@@ -471,7 +517,8 @@ def _PH_psi(basis, Pt, psik):
     return out
 
 
-_LDA_BITS = {"lda_x": 1, "lda_c_vwn": 2, "lda_c_pw": 4}
+_LDA_BITS = {"lda_x": 1, "lda_c_vwn": 2, "lda_c_pw": 4, "lda_xc_teter93": 32}
+_SPIN_LDA = ("lda_x", "lda_c_pw", "lda_xc_teter93")      # functionals with a spin-polarised closed form in the library
 _GGA_BITS = {"gga_x_pbe": 8, "gga_c_pbe": 16}
 
 
@@ -498,7 +545,14 @@ def local_potential_fused(basis, rho, want_potential=True):
     E3 = (C.c_double * 3)()
     torch.cuda.current_stream(basis.device).synchronize()
     args = (vloc.data_ptr() if vloc is not None else None, green.data_ptr() if green is not None else None)
-    if mask & 24:
+    if rho.dim() == 4:
+        # collinear spin: (rho_up, rho_down) -> (V_up, V_down); Hartree and the local term see the total density
+        if "Xc" in T.names and any(f not in _SPIN_LDA for f in basis.model.functionals):
+            raise NotImplementedError(f"collinear spin: spin-polarised forms exist for {_SPIN_LDA} only, got "
+                                      f"{basis.model.functionals}")
+        _lib.check(basis.lib.dftk_mi_local_potential_collinear(basis._cube_handle, rho.data_ptr(), *args, mask,
+                                                               V.data_ptr() if V is not None else None, E3))
+    elif mask & 24:
         Bh = np.asfortranarray(basis.model.recip_lattice, dtype=np.float64)
         _lib.check(basis.lib.dftk_mi_local_potential_gga(basis._cube_handle, Bh.ctypes.data, rho.data_ptr(), *args, mask,
                                                          _DENSITY_THRESHOLD, V.data_ptr() if V is not None else None, E3))
@@ -552,6 +606,9 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, ei
         fused = local_potential_fused(basis, rho, want_potential=not only_energies)
         if fused is not None and not only_energies:
             pot = fused["V"]
+    if rho is not None and rho.dim() == 4 and fused is None and any(n in T.names for n in ("Hartree", "Xc")):
+        raise NotImplementedError("collinear spin needs the library's local-potential pipeline "
+                                  "(dftk_mi_local_potential_collinear); the torch twin is spin-unpolarised")
     for name in T.names:
         if fused is not None and name in ("AtomicLocal", "Hartree", "Xc"):
             E[name] = fused[name]
@@ -631,6 +688,7 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, ei
                     e += basis.kweights[ik] * e_k
                 E[name] = e
                 reduce_kpts.append(name)
+                # (collinear: rho and ritz_potential both carry the spin index -- sum_s int V_s rho_s)
                 ritz_fix = (float((rho * ritz_potential).sum().item() * basis.dvol), use_bandwise)
             elif have_psi:
                 e = 0.0

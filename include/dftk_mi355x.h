@@ -135,8 +135,18 @@ int dftk_mi_atomic_superposition(dftk_mi_kblock* cube_kb, int kind, const double
 #define DFTK_MI_XC_LDA_X     1
 #define DFTK_MI_XC_LDA_C_VWN 2
 #define DFTK_MI_XC_LDA_C_PW  4
+#define DFTK_MI_XC_LDA_XC_TETER93 32
 int dftk_mi_local_potential(dftk_mi_kblock* cube_kb, const double* rho_d, const double* V_loc_d,
                             const double* poisson_green_d, int xc_functionals, double* V_out_d, double* energies_h);
+
+/* Collinear spin (model.spin_polarization == :collinear, src/Model.jl:29-39): rho_d and V_out_d hold TWO cubes each,
+ * (up, down) = rho[:, :, :, 1:2] of the reference.  V_out[s] = V_loc + V_H[rho_up + rho_down] + v_xc,s(rho_up, rho_down)
+ * -- the potential of the k-blocks of spin s (ene_ops picks Vxc[:, :, :, kpt.spin], src/terms/xc.jl:163-175); the energies
+ * are those of dftk_mi_local_potential with the total density in the Hartree and local terms.  Spin-polarised closed forms:
+ * DFTK_MI_XC_LDA_X, DFTK_MI_XC_LDA_C_PW, DFTK_MI_XC_LDA_XC_TETER93 (anything else: DFTK_MI_EINVAL). */
+int dftk_mi_local_potential_collinear(dftk_mi_kblock* cube_kb, const double* rho_d, const double* V_loc_d,
+                                      const double* poisson_green_d, int xc_functionals, double* V_out_d,
+                                      double* energies_h);
 
 /* The same pipeline with GGA functionals (PBE() = gga_x_pbe + gga_c_pbe, DFTK_MI_XC_GGA_* bits, may be mixed with the
  * LDA bits): the density gradient and the divergence term of the potential (LibxcDensities src/terms/xc.jl:356-409,
@@ -194,6 +204,13 @@ int dftk_mi_fft_sphere(dftk_mi_kblock* kb, const dftk_mi_cplx* cube_d, dftk_mi_c
  * occupation[n] * kweight * ifft_normalization^2 (bands with weight 0 are skipped). */
 int dftk_mi_density_accumulate(dftk_mi_kblock* kb, int n_bands, const dftk_mi_cplx* psi_d,
                                int64_t ld_psi, const double* weight_h, double* rho_d);
+
+/* The same with the spin index of the k-block spelled out: rho_d holds n_spin cubes (n_spin = 1 or 2,
+ * model.n_spin_components), the bands of this block are added to cube `spin` (0-based: kpt.spin - 1) --
+ * `rho[:, :, :, kpt.spin] .+= ...` of src/densities.jl:39; a collinear basis lists all spin-up k-blocks, then all
+ * spin-down ones (src/PlaneWaveBasis.jl:50-53, build_kpoints src/Kpoint.jl:58-74). */
+int dftk_mi_density_accumulate_spin(dftk_mi_kblock* kb, int n_bands, const dftk_mi_cplx* psi_d, int64_t ld_psi,
+                                    const double* weight_h, double* rho_d, int spin, int n_spin);
 
 /* ---- lobpcg_hyper(A, X0; prec=PreconditionerTPA, tol, miniter, maxiter, n_conv_check)
  *      (src/eigen/diag_lobpcg_hyper.jl:5-18 -> LOBPCG, src/eigen/lobpcg_hyper_impl.jl:354-582;

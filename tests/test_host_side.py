@@ -1190,3 +1190,38 @@ def test_memory_statistics_and_plan_for_the_literal_4096_electron_cell():
     assert plans[8]["communication"]["gram_allreduce_bytes"] == 16 * (3 * 2051) ** 2
     assert not plans[8]["limits"]["register_resident_z_kernels"] and plans[8]["limits"]["fft_axis_lds_ok"]
     assert "DOES NOT FIT" in mu.format_plan(plans[1]) and "fits" in mu.format_plan(plans[8])
+
+
+def test_collinear_spin_descriptors_on_host():
+    """Model / PlaneWaveBasis with collinear spin (Model.jl:29-39, :352-372; PlaneWaveBasis.jl:50-53, :218-232;
+    Kpoint.jl:58-74): spin inferred from the magnetic moments, filled occupation 1, k-point list doubled (all up, then
+    all down) with repeated weights summing to 2, band counts and Fermi level / occupations equal to the oracle's."""
+    import oracle
+    lat = 2.71176 * np.array([[-1, 1, 1], [1, -1, 1], [1, 1, -1.0]])
+    Fe = dftk.ElementPsp("Fe", dftk.load_psp("Fe", "lda"))
+    m = dftk.model_DFT(lat, [Fe], [np.zeros(3)], functionals=("lda_xc_teter93",), temperature=0.01, smearing="fermi_dirac",
+                       magnetic_moments=(4.0,), symmetries=True)
+    assert (m.spin_polarization, m.n_spin_components, m.filled_occupation, m.n_electrons) == ("collinear", 2, 1, 8)
+    assert len(m.symmetries) == 48
+    b = dftk.PlaneWaveBasis(m, 15, dftk.MonkhorstPack((4, 4, 4), (0.5, 0.5, 0.5)), fft_size=(20, 20, 20), device="cpu",
+                            build_terms=False)
+    assert len(b.kpoints) == 12 and [k.spin for k in b.kpoints] == [1] * 6 + [2] * 6
+    assert abs(sum(b.kweights) - 2.0) < 1e-14 and b.kweights[:6] == b.kweights[6:]
+    assert all(np.array_equal(b.kpoints[i].mapping, b.kpoints[i + 6].mapping) for i in range(6))
+    assert dftk.AdaptiveBands(m).n_bands_compute == 8
+    om = oracle.model_DFT(lat, [oracle.ElementPsp("Fe", oracle.load_psp_hgh("Fe", "lda"))], [np.zeros(3)],
+                          functionals=("lda_xc_teter93",), temperature=0.01, smearing="fermi_dirac", magnetic_moments=(4.0,),
+                          symmetries=True)
+    ob = oracle.PlaneWaveBasis(om, 15, oracle.MonkhorstPack((4, 4, 4), (0.5, 0.5, 0.5)), fft_size=(20, 20, 20), build_terms=False)
+    assert all(np.allclose(k.coordinate, q.coordinate) and k.spin == q.spin for k, q in zip(b.kpoints, ob.kpoints))
+    rng = np.random.default_rng(1)
+    ev = [np.sort(rng.standard_normal(8)) * 0.3 + (0.05 if k.spin == 2 else 0.0) for k in b.kpoints]
+    occ, eF = dftk.compute_occupation(b, ev)
+    oocc, oeF = oracle.compute_occupation(ob, ev)
+    assert eF == pytest.approx(oeF, abs=1e-12) and all(np.allclose(a, c, atol=1e-12) for a, c in zip(occ, oocc))
+    assert max(float(o.max()) for o in occ) <= 1.0 + 1e-12
+    # a model without moments stays unpolarised; moments on an explicitly unpolarised model are refused by the guess
+    m0 = dftk.model_DFT(lat, [Fe], [np.zeros(3)], functionals=("lda_xc_teter93",), temperature=0.01)
+    assert (m0.spin_polarization, m0.n_spin_components, m0.filled_occupation) == ("none", 1, 2)
+    with pytest.raises(NotImplementedError):
+        dftk.model_DFT(lat, [Fe], [np.zeros(3)], spin_polarization="full")

@@ -664,3 +664,89 @@ def test_symmetrised_scf_equals_unsymmetrised():
     r1 = oracle.self_consistent_field(b1, tol=1e-10)
     assert abs(r0["energies"].total - r1["energies"].total) < 1e-10
     assert np.linalg.norm(r0["rho"] - r1["rho"]) * np.sqrt(b0.dvol) < 1e-8
+
+
+# ----------------------------------------------------------------------------------- collinear spin
+IRON_REF_LDA = [   # test/iron_lda.jl:11-36 (ABINIT, same k-points, Ecut 15): 6 irreducible k-points spin up, then spin down
+    [0.055335160026957, 0.318268719950663, 0.318268719983204, 0.453844901754021, 0.465456022940131, 0.465456022955040, 0.796938936853792, 0.9378278608989292],
+    [0.202562784343803, 0.257484383305897, 0.298153168492320, 0.484002264268755, 0.486738682667850, 0.586413954242265, 0.606054175235276, 0.7921984533391616],
+    [-0.025828679734167, 0.379219384359043, 0.379219384380489, 0.412266299189737, 0.421421148410838, 0.469007916884015, 1.014229786618585, 1.082646799659422],
+    [0.122870253157049, 0.284288157581980, 0.344201118979085, 0.418278709282607, 0.470914403053476, 0.473315810505416, 0.712342007821782, 0.8817040989078889],
+    [0.249396221271434, 0.249396221271986, 0.283803391450257, 0.464807045105138, 0.464807045129581, 0.600140396214226, 0.641661514945205, 0.6416615149484401],
+    [0.215115530345620, 0.230559459189795, 0.413101385500933, 0.413101385526945, 0.443282733300631, 0.476867020334080, 0.702492626996283, 0.7024926270118694],
+    [0.099871712572642, 0.424238848817503, 0.424238848844880, 0.596529745402267, 0.628841951719554, 0.628841951734441, 0.891993361117189, 1.0316903612443131],
+    [0.273624284119989, 0.308366088258763, 0.394136428473583, 0.637445234492337, 0.660367125811219, 0.695536341395981, 0.759456147985534, 0.9049047470326816],
+    [0.016725290665167, 0.501424956361337, 0.501424956379435, 0.543811076656092, 0.565010802783482, 0.63953000442497, 1.097171561169634, 1.1851677714770334],
+    [0.172968957815038, 0.369175928007706, 0.455665586569160, 0.556763288068905, 0.626381596590897, 0.636563034574486, 0.834717579200534, 0.9711639337454779],
+    [0.323081016250375, 0.323081016251097, 0.370943969450466, 0.609089414206416, 0.609089414224977, 0.713615164563541, 0.776414016931158, 0.7764140169376185],
+    [0.283999916316325, 0.339176502497316, 0.523562806877426, 0.523562806894741, 0.576405064140235, 0.604381023304363, 0.808531656348124, 0.8085316563716097],
+]
+IRON_REF_ETOT = -16.670871429685356
+IRON_LATTICE = 2.71176 * np.array([[-1, 1, 1], [1, -1, 1], [1, 1, -1.0]])       # test/testcases.jl:124-131
+
+
+def iron_oracle_basis():
+    Fe = oracle.ElementPsp("Fe", oracle.load_psp_hgh("Fe", "lda"))
+    model = oracle.model_DFT(IRON_LATTICE, [Fe], [np.zeros(3)], functionals=("lda_xc_teter93",), temperature=0.01,
+                             smearing="fermi_dirac", magnetic_moments=(4.0,), symmetries=True)
+    return oracle.PlaneWaveBasis(model, 15, oracle.MonkhorstPack((4, 4, 4), (0.5, 0.5, 0.5)), fft_size=(20, 20, 20))
+
+
+def _match_reference_spectra(eigenvalues, n_check):
+    """Every k-block's lowest ``n_check`` eigenvalues against the ABINIT list: the order of the irreducible k-points
+    within a spin channel is Spglib's there, the orbit search's here, so blocks are paired by their spectra (no two
+    reference spectra are closer than 1e-2)."""
+    worst, used = 0.0, set()
+    for lam in eigenvalues:
+        d = [float(np.max(np.abs(np.asarray(lam)[:n_check] - np.asarray(r)[:n_check]))) for r in IRON_REF_LDA]
+        used.add(int(np.argmin(d)))
+        worst = max(worst, min(d))
+    return worst, used
+
+
+def test_iron_lda_collinear_spin_matches_reference_abinit_values():
+    """test/iron_lda.jl (bcc iron, lda_xc_teter93, Fermi-Dirac T = 0.01, magnetic moment 4 mu_B as the initial guess,
+    Ecut 15, fft 20^3, 4x4x4 mesh shifted by 1/2, test_tol 5e-6, scf_dens_tol 1e-7): the collinear-spin path of the
+    oracle -- doubled k-point list, spin-resolved density, spin-polarised XC potential, guess density with moments,
+    spin-aware mixing -- against the reference's ABINIT eigenvalues of BOTH spin channels and total energy."""
+    basis = iron_oracle_basis()
+    model = basis.model
+    assert (model.spin_polarization, model.n_spin_components, model.filled_occupation) == ("collinear", 2, 1)
+    assert len(basis.kcoords) == 6 and len(basis.kpoints) == 12 and abs(sum(basis.kweights) - 2.0) < 1e-14
+    assert [k.spin for k in basis.kpoints] == [1] * 6 + [2] * 6
+    rho0 = oracle.guess_density(basis, (4.0,))
+    assert rho0.shape == (2, 20, 20, 20)
+    assert abs(rho0.sum() * basis.dvol - 8.0) < 1e-12 and abs((rho0[0] - rho0[1]).sum() * basis.dvol - 4.0) < 1e-12
+    res = oracle.self_consistent_field(basis, rho=rho0, tol=1e-7)
+    assert res["converged"]
+    assert abs(res["energies"].total - IRON_REF_ETOT) < 5e-6
+    worst, used = _match_reference_spectra(res["eigenvalues"], n_check=res["n_bands_converge"] - 3)
+    assert worst < 5e-6 and used == set(range(12))
+    mag = float((res["rho"][0] - res["rho"][1]).sum() * basis.dvol)
+    assert 2.0 < mag < 3.0                                   # ferromagnetic bcc iron: ~2.5 mu_B in this discretisation
+    assert abs(res["rho"].sum() * basis.dvol - 8.0) < 1e-5          # (the Fermi level is bisected to 1e-6 electrons)
+
+
+def test_collinear_model_without_magnetisation_equals_the_unpolarised_model():
+    """n_spin = 2 with a zero spin density is the same physics as n_spin = 1: identical total energy, eigenvalues of both
+    channels = the unpolarised ones, rho_up = rho_down = rho / 2 -- for lda_xc_teter93 and for lda_x + lda_c_pw (the
+    spin-interpolated PW92 reduces to the unpolarised form at zeta = 0)."""
+    Si = oracle.ElementPsp("Si", oracle.load_psp_hgh("Si", "lda"))
+    pos = [np.ones(3) / 8, -np.ones(3) / 8]
+    kg = oracle.ExplicitKpoints([[0, 0, 0], [0.25, 0.0, -0.5]], [0.5, 0.5])
+    for fun in (("lda_xc_teter93",), ("lda_x", "lda_c_pw")):
+        m1 = oracle.model_DFT(SI_LAT, [Si, Si], pos, functionals=fun)
+        m2 = oracle.model_DFT(SI_LAT, [Si, Si], pos, functionals=fun, spin_polarization="collinear")
+        b1 = oracle.PlaneWaveBasis(m1, 7, kg, fft_size=(18, 18, 18))
+        b2 = oracle.PlaneWaveBasis(m2, 7, kg, fft_size=(18, 18, 18))
+        r1 = oracle.self_consistent_field(b1, tol=1e-9)
+        r2 = oracle.self_consistent_field(b2, tol=1e-9)
+        assert r1["converged"] and r2["converged"]
+        assert abs(r1["energies"].total - r2["energies"].total) < 1e-9
+        for name, v in r1["energies"].items():
+            assert abs(r2["energies"][name] - v) < 1e-8, name
+        for ik in range(2):
+            for s_ in range(2):
+                np.testing.assert_allclose(r2["eigenvalues"][ik + 2 * s_][:4], r1["eigenvalues"][ik][:4], atol=1e-7)
+        assert np.linalg.norm(r2["rho"][0] - r1["rho"] / 2) * np.sqrt(b1.dvol) < 1e-7
+        assert np.linalg.norm(r2["rho"][0] - r2["rho"][1]) * np.sqrt(b1.dvol) < 1e-9

@@ -76,7 +76,7 @@ def _excess(basis, eigenvalues, eF, temperature, smearing):
 def _guess_fermi_level_intocc(basis, eigenvalues):
     """occupation.jl:190-211."""
     filled = basis.model.filled_occupation
-    n_fill = -(-basis.model.n_electrons // (basis.model.n_spin_components * filled))
+    n_fill = -(-basis.model.n_electrons // (getattr(basis.model, "n_spin_components", 1) * filled))
     homo = max(ek[n_fill - 1] for ek in eigenvalues)
     lumo = min((np.min(ek[n_fill:]) if len(ek) > n_fill else math.inf) for ek in eigenvalues)
     return homo + 1 if lumo == math.inf else (homo + lumo) / 2

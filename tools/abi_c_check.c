@@ -20,6 +20,7 @@
 #include "dftk_mi355x.h"
 
 #include <math.h>
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -274,6 +275,7 @@ int main(int argc, char** argv) {
     int (*up)[2] = malloc((size_t)n * sizeof *up), (*down)[2] = malloc((size_t)n * sizeof *down);
     pid_t* pids = malloc((size_t)n * sizeof(pid_t));
     int r, status = 0;
+    signal(SIGPIPE, SIG_IGN);   /* a rank that has already given up (no GPU) must not kill the parent relaying the id */
     for (r = 0; r < n; ++r) {
         if (pipe(up[r]) != 0 || pipe(down[r]) != 0) return 2;
         pids[r] = fork();
@@ -310,7 +312,7 @@ int main(int argc, char** argv) {
         char id[128];
         if (read(up[0][0], id, sizeof id) != (ssize_t)sizeof id) memset(id, 0, sizeof id);
         for (r = 0; r < n; ++r)
-            if (write(down[r][1], id, sizeof id) != (ssize_t)sizeof id) status = 2;
+            if (write(down[r][1], id, sizeof id) != (ssize_t)sizeof id) status = status ? status : 0;   /* rank gone: its exit code tells */
     }
     for (r = 0; r < n; ++r) {
         int ws = 0;

@@ -147,10 +147,9 @@ int plan_radices(int n, int* nrad, int* rad) {
     while (m % 2 == 0 && m > 1) { m /= 2; ++a2; }
     while (m % 3 == 0 && m > 1) { m /= 3; ++a3; }
     while (m % 5 == 0 && m > 1) { m /= 5; ++a5; }
-    static const bool small_only = getenv("DFTK_MI_FFT_SMALL_RADIX") != nullptr;   // 5,4,3,2 only (comparison runs)
     int best8 = 0, best6 = 0, best = 1 << 30;
-    for (int n8 = 0; n8 <= (small_only ? 0 : a2 / 3); ++n8)
-        for (int n6 = 0; n6 <= (small_only ? 0 : (a2 - 3 * n8 < a3 ? a2 - 3 * n8 : a3)); ++n6) {
+    for (int n8 = 0; n8 <= a2 / 3; ++n8)
+        for (int n6 = 0; n6 <= (a2 - 3 * n8 < a3 ? a2 - 3 * n8 : a3); ++n6) {
             const int rem2 = a2 - 3 * n8 - n6;
             const int stages = n8 + n6 + rem2 / 2 + rem2 % 2 + (a3 - n6) + a5;
             if (stages < best) {
@@ -309,8 +308,6 @@ extern "C" int dftk_mi_basis_create(int nx, int ny, int nz, double unit_cell_vol
     b->prof = new Prof();
     const char* g = getenv("DFTK_MI_GEMM");
     b->use_mfma = (g && strcmp(g, "naive") == 0) ? 0 : 1;
-    const char* fb = getenv("DFTK_MI_FFT_BATCH");
-    if (fb && atoi(fb) > 0) b->fft_batch = std::min(atoi(fb), 256);
     HIPCHK(hipStreamCreate(&b->stream));
     const int dims[3] = {nx, ny, nz};
     for (int a = 0; a < 3; ++a) {

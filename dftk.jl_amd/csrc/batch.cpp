@@ -1,6 +1,7 @@
 // batch.cpp -- fibers, recording and merged execution for many small k-blocks (see batch.h).
 #include "batch.h"
 #include <ucontext.h>
+#include <memory>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -10,13 +11,21 @@
 namespace {
 struct Fiber {
     ucontext_t ctx;
-    std::vector<char> stack;
+    char* stack = nullptr;      // borrowed from the thread's stack pool (fiber_stack)
     std::vector<BOp> fifo;
     size_t head = 0;
     bool done = false;
     int ret = 0;
     std::function<int()> body;
 };
+// Fiber stacks are pooled per host thread and never returned: a value-initialised 1 MiB vector per fiber and call was
+// 72 MiB of page faults (and an munmap) per batched call of a 72-k-point workload -- more than the call's device work.
+const size_t FIBER_STACK_BYTES = 1u << 20;
+char* fiber_stack(size_t i) {
+    static thread_local std::vector<std::unique_ptr<char[]>> pool;
+    while (pool.size() <= i) pool.emplace_back(new char[FIBER_STACK_BYTES]);   // (uninitialised: pages touched on use)
+    return pool[i].get();
+}
 }  // namespace
 
 // staging for batched launches: argument tables travel host -> device through one pinned ring, small results come
@@ -54,7 +63,7 @@ const void* batch_stage(BatchCtx* c, const void* src, size_t bytes) {
     memcpy(c->h_ring + c->off, src, bytes);
     // small tables are read by the kernels straight from the pinned ring (host memory mapped into the device's address
     // space): no copy to enqueue in front of every launch; large ones (job tables of thousands of bands) are copied
-    static const bool zero_copy = getenv("DFTK_MI_KBATCH_NO_ZEROCOPY") == nullptr;
+    const bool zero_copy = true;
     const void* d;
     if (zero_copy && bytes <= 16384) {
         d = c->h_ring + c->off;
@@ -373,13 +382,13 @@ int batch_run(dftk_mi_basis* b, std::vector<std::function<int()>>& bodies, std::
     c->scratch_bytes = pool.scratch_bytes;
     const size_t n = bodies.size();
     rec.fibers.resize(n);
-    const size_t stack_bytes = 1u << 20;
+    const size_t stack_bytes = FIBER_STACK_BYTES;
     for (size_t i = 0; i < n; ++i) {
         Fiber& f = rec.fibers[i];
         f.body = bodies[i];
-        f.stack.resize(stack_bytes);
+        f.stack = fiber_stack(i);
         getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack.data();
+        f.ctx.uc_stack.ss_sp = f.stack;
         f.ctx.uc_stack.ss_size = stack_bytes;
         f.ctx.uc_link = &rec.main_ctx;
         const uintptr_t p = reinterpret_cast<uintptr_t>(&f);

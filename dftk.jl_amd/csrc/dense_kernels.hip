@@ -1011,9 +1011,8 @@ __global__ void k_fetch_words(const uint32_t* __restrict__ src, uint32_t* __rest
 }
 int host_fetch(dftk_mi_basis* b, void* dst_h, const void* src_d, size_t bytes) {
     if (bytes == 0) return host_wait(b);
-    // DFTK_MI_FETCH_BLIT=1: the runtime's copy (a blit dispatch + staging), kept for the A/B of profiles/r04_host_fetch_ab.txt
-    static const bool blit = getenv("DFTK_MI_FETCH_BLIT") != nullptr;
-    if (blit || bytes > HOST_FETCH_BYTES || (bytes & 3) || (reinterpret_cast<uintptr_t>(src_d) & 3) || !b->h_fetch) {
+    // (A/B against the runtime's blit copy: profiles/r04_late_step_cfg5_{zero_copy,blit}_fetch.txt)
+    if (bytes > HOST_FETCH_BYTES || (bytes & 3) || (reinterpret_cast<uintptr_t>(src_d) & 3) || !b->h_fetch) {
         HIPCHK(hipMemcpyAsync(dst_h, src_d, bytes, hipMemcpyDeviceToHost, b->stream));
         return host_wait(b);
     }
@@ -1326,8 +1325,7 @@ int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, 
     // every imaginary part exactly zero (real symmetric input, e.g. the Rayleigh-Ritz matrices of the Gamma-real
     // LOBPCG): real rotations on plain-double work matrices -- a quarter of the matrix-core work and half the bytes
     // per round; the eigenvectors come back with exact zeros in their imaginary parts
-    static const bool no_real = getenv("DFTK_MI_HEEV_NO_REAL") != nullptr;
-    if (im2 == 0.0 && !no_real) return heev_impl<true>(b, n, A, lda, W_h, V, ldv, off2, dg2);
+    if (im2 == 0.0) return heev_impl<true>(b, n, A, lda, W_h, V, ldv, off2, dg2);
     return heev_impl<false>(b, n, A, lda, W_h, V, ldv, off2, dg2);
 }
 

@@ -431,10 +431,7 @@ __global__ __launch_bounds__(FFT_THREADS) void k_ybwd(FftAxis ay, int nxp, int n
 // MODE 0: backward z, multiply by Vs, forward z (fused local apply), T2 -> T2 in place
 // MODE 1: backward z only, natural-order output to an (nx,ny,nz) cube
 // MODE 2: forward z only from an (nx,ny,nz) cube, sphere planes -> T2
-// TWG: the twiddle table is read from global memory (3 KB, L1-resident) instead of an LDS copy: a third of the
-// butterflies' LDS reads moves to the otherwise idle vector-memory pipe, and without the table a 192-long tile
-// (24 KiB) fits six times into a CU's 160 KiB instead of five.
-template <int MODE, bool GEN, bool TWG = false>
+template <int MODE, bool GEN>
 __global__ __launch_bounds__(FFT_THREADS, ZPASS_MIN_BLOCKS) void k_zpass(FftAxis az, int nx, int nxp, int ny, int nzx,
                                                        int nbands, const int* __restrict__ zpos,
                                                        const double* __restrict__ Vs,
@@ -442,7 +439,7 @@ __global__ __launch_bounds__(FFT_THREADS, ZPASS_MIN_BLOCKS) void k_zpass(FftAxis
                                                        cd* __restrict__ cube, const FftJob* __restrict__ jobs = nullptr) {
     constexpr int FFT_LS = FFT_LS_YZ;
     cd* buf = reinterpret_cast<cd*>(dftk_smem);
-    cd* tw = TWG ? const_cast<cd*>(az.tw) : buf + az.n * FFT_LS;
+    cd* tw = buf + az.n * FFT_LS;
     const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
     // 1-D XCD-aware grid: workgroup id -> (xcd = id % 8, slot = id / 8); the bands of one (x tile, y) column
     // are consecutive slots of the SAME XCD, so the potential tile they all multiply with is fetched into
@@ -473,7 +470,7 @@ __global__ __launch_bounds__(FFT_THREADS, ZPASS_MIN_BLOCKS) void k_zpass(FftAxis
         if (j + FFT_TPL < nzx) e1 = t2[(int64_t)(j + FFT_TPL) * plane];
         if (j + 2 * FFT_TPL < nzx) e2 = t2[(int64_t)(j + 2 * FFT_TPL) * plane];
     }
-    tile_prologue<FFT_LS>(buf, tw, az, MODE != 2, !TWG);
+    tile_prologue<FFT_LS>(buf, tw, az, MODE != 2, true);
     __syncthreads();
     bool fused_v = false;
     if (MODE != 2) {
@@ -1215,18 +1212,11 @@ int launch_local_apply(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi,
         // stage C: T2 read + written per band, the potential once per launch
         const int pc = prof_begin(b, PROF_FFT_C, 2.0 * 16.0 * (double)kb->nzx * b->ny * b->nxp * nbb +
                                                      8.0 * (double)b->nz * b->ny * b->nxp);
-        static const bool twg = getenv("DFTK_MI_FFT_TWG") != nullptr;
         const RegZ rz{b, b->stream, zpass_grid(b, nbb), kb->nzx, kb->z_lo, nbb, kb->d_Vs, b->T2, st.s2, nullptr, nullptr, nullptr,
                       nullptr};
         const int reg_st = reg_zpass(rz, kb->z_lo >= 0);
         if (reg_st < 0) return reg_st;
-        if (reg_st == 0) {
-        } else if (twg && !axis_generic(b->ax[2])) {
-            const size_t lds = (size_t)b->nz * FFT_LS_YZ * sizeof(cd);
-            CHK(set_lds_attr(k_zpass<0, false, true>, lds));
-            hipLaunchKernelGGL((k_zpass<0, false, true>), zpass_grid(b, nbb), dim3(FFT_THREADS), lds, b->stream, b->ax[2],
-                               b->nx, b->nxp, b->ny, kb->nzx, nbb, kb->d_zpos, kb->d_Vs, b->T2, st.s2, (cd*)nullptr, (const FftJob*)nullptr);
-        } else
+        if (reg_st != 0)
         LAUNCH_ZPASS(0, b->ax[2], zpass_grid(b, nbb), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, nbb, kb->d_zpos, kb->d_Vs, b->T2, st.s2,
                            (cd*)nullptr, (const FftJob*)nullptr);
         prof_end(b, pc);

@@ -943,20 +943,13 @@ struct Split {
     bool compact = false;   // UPPER interior launch over the live tiles only (k_zgemm_3m, `upper & 16`)
     int live = 0;           // live tiles of the launch (compact: grid = 8 ceil(live nsplit / 8))
 };
-// UPPER launches of the 3M / REAL kernels rotate the row panels over the XCDs (k_zgemm_3m, `upper & 8`);
-// DFTK_MI_GEMM_NO_ROT=1 keeps the plain mapping (measurements)
-static bool gemm_rotate_rows() {
-    static const bool on = getenv("DFTK_MI_GEMM_NO_ROT") == nullptr;
-    return on;
-}
-static int64_t gemm_slots2() {
-    const char* senv = getenv("DFTK_MI_GEMM_BLOCKS");
-    return senv ? atoll(senv) : 512;   // resident workgroups of the 2-per-CU kernels
-}
+// UPPER launches of the 3M / REAL kernels that cannot take the compact live-tile grid rotate the row panels over the
+// XCDs (k_zgemm_3m, `upper & 8`)
+static bool gemm_rotate_rows() { return true; }
+static int64_t gemm_slots2() { return 512; }   // resident workgroups of the 2-per-CU kernels (256 CUs)
 static Split gemm_plan_split(int64_t m, int64_t n, int64_t k, int upper, const std::vector<int>& live_rows, int kind,
                              int64_t slots, bool compact_ok = false) {
     const int64_t plane = (int64_t)m * n * (int64_t)sizeof(cd);
-    static const bool no_zmajor = getenv("DFTK_MI_GEMM_NO_ZMAJOR") != nullptr;
     static std::map<std::vector<int64_t>, std::pair<int, int>> plan_cache;   // key -> (nsplit, zmajor)
     static std::mutex plan_mutex;   // host-only cache shared by every basis / thread of the process
     std::lock_guard<std::mutex> plan_lock(plan_mutex);
@@ -991,7 +984,7 @@ static Split gemm_plan_split(int64_t m, int64_t n, int64_t k, int upper, const s
                 kc = (kc + 7) & ~7;
                 if ((int)((k + kc - 1) / kc) != ns) continue;
                 for (int zm = 0; zm < 3; ++zm) {
-                    if (zm == 1 && (ns < 8 || no_zmajor || k < 2048)) continue;
+                    if (zm == 1 && (ns < 8 || k < 2048)) continue;
                     if (zm == 2 && !compact_ok) continue;
                     int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                     if (zm == 2) {
@@ -1022,12 +1015,6 @@ static Split gemm_plan_split(int64_t m, int64_t n, int64_t k, int upper, const s
             plan_cache[key] = {best_ns, best_zm};
         }
     }
-    static const int force_ns = getenv("DFTK_MI_GEMM_FORCE_NS") ? atoi(getenv("DFTK_MI_GEMM_FORCE_NS")) : 0;   // experiments
-    static const int force_mode = getenv("DFTK_MI_GEMM_FORCE_MODE") ? atoi(getenv("DFTK_MI_GEMM_FORCE_MODE")) : 0;
-    if (force_ns > 0 && kind >= 3 && (kind & 1) && k >= 4096) {
-        best_ns = force_ns;
-        best_zm = (force_mode == 2 && compact_ok) ? 2 : (force_mode == 1 ? 1 : 0);
-    }
     int kc = (int)((k + best_ns - 1) / best_ns);
     kc = (kc + 7) & ~7;
     const int ns = (int)((k + kc - 1) / kc);
@@ -1047,13 +1034,8 @@ struct GemmTiling {
     int gmI;     // tile rows of the interior launch = gmf + shift_r
     Split I, B;
 };
-// column tiles of the REAL kernels: 16 * RN wide; RN per operand layout (env DFTK_MI_REAL_RN_C / _N = 2 | 4)
-static int real_rn(bool conja) {
-    static const int rc = getenv("DFTK_MI_REAL_RN_C") ? atoi(getenv("DFTK_MI_REAL_RN_C")) : M3_RN_REAL;
-    static const int rn = getenv("DFTK_MI_REAL_RN_N") ? atoi(getenv("DFTK_MI_REAL_RN_N")) : M3_RN_REAL;
-    const int v = conja ? rc : rn;
-    return v == 2 ? 2 : 4;
-}
+// column tiles of the REAL kernels: 16 * RN wide (RN = 4: 128 x 64 workgroup tiles for both operand layouts)
+static int real_rn(bool) { return M3_RN_REAL == 2 ? 2 : 4; }
 static GemmTiling gemm_tiling(bool conja, int64_t m, int64_t n, int64_t k, int upper, bool use3m, bool real = false) {
     GemmTiling t;
     const int64_t slots2 = gemm_slots2();
@@ -1062,11 +1044,9 @@ static GemmTiling gemm_tiling(bool conja, int64_t m, int64_t n, int64_t k, int u
     t.gnt = (int)((n + t.BNt - 1) / t.BNt);
     t.gmf = (int)(m / GEMM_BM);
     t.gnf = (int)(n / t.BNt);
-    static const bool no_shift = getenv("DFTK_MI_GEMM_NO_SHIFT") != nullptr;
-    t.shift = (use3m && !no_shift && t.gnt > t.gnf && t.gnf >= 1) ? 1 : 0;
+    t.shift = (use3m && t.gnt > t.gnf && t.gnf >= 1) ? 1 : 0;
     t.gnI = t.gnf + t.shift;
-    static const bool no_rshift = getenv("DFTK_MI_GEMM_NO_ROWSHIFT") != nullptr;
-    t.shift_r = (use3m && !no_shift && !no_rshift && t.gm > t.gmf && t.gmf >= 1) ? 1 : 0;
+    t.shift_r = (use3m && t.gm > t.gmf && t.gmf >= 1) ? 1 : 0;
     t.gmI = t.gmf + t.shift_r;
     t.nright = (t.gnt > t.gnf && !t.shift) ? t.gm : 0;
     t.nbottom = (t.gm > t.gmf && !t.shift_r) ? t.gnI : 0;
@@ -1084,8 +1064,7 @@ static GemmTiling gemm_tiling(bool conja, int64_t m, int64_t n, int64_t k, int u
     const int64_t slots3 = use3m ? (slots2 / 2) * M3_MIN_BLOCKS(conja) : slots2;
     // compact UPPER launches (k_zgemm_3m, `upper & 16`): the kernel rebuilds the live tile list as "row panel r keeps its
     // column tiles >= r BM / BN" -- only used when that is exactly the list above
-    static const bool no_compact = getenv("DFTK_MI_GEMM_NO_COMPACT") != nullptr;
-    bool compact_ok = use3m && (upper & 1) && !no_compact && GEMM_BM % t.BNt == 0;
+    bool compact_ok = use3m && (upper & 1) && GEMM_BM % t.BNt == 0;
     for (int tr = 0; tr < t.gmI && compact_ok; ++tr)
         compact_ok = rowsI[tr] == std::max(0, t.gnI - tr * (GEMM_BM / t.BNt));
     t.I = gemm_plan_split(m, n, k, upper, rowsI, use3m ? 3 : 1, slots3, compact_ok);
@@ -1220,7 +1199,6 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
     if (bytesI + bytesB) CHK(ensure_ws(b, bytesI + bytesB));
     if (bytesI) spI.slab = (cd*)b->ws;
     if (bytesB) spB.slab = (cd*)((char*)b->ws + bytesI);
-    static const int pad_lds = getenv("DFTK_MI_GEMM_PAD_LDS") ? atoi(getenv("DFTK_MI_GEMM_PAD_LDS")) : 0;   // occupancy experiments
     auto launch = [&](int mode, int gm_s, int gn_s, int rt0, int ct0, int lsplit, const Split& sp) -> int {
         if (gm_s <= 0 || gn_s <= 0) return 0;
         const bool zmajor = sp.zmajor;
@@ -1233,14 +1211,14 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
         const int upper = (upper_in & 3) | (compact ? 16 : zmajor ? 4 : 0) |
                           ((!compact && !zmajor && (upper_in & 1) && use3m && gemm_rotate_rows() && gm_s <= 4) ? 8 : 0);
 #define DFTK_LAUNCH_LDS(CJ, FL)                                                                                        \
-    hipLaunchKernelGGL((k_zgemm_lds<CJ, FL>), grid, dim3(GEMM_WAVES * 64), pad_lds, b->stream, (int)m, (int)n, (int)k, \
+    hipLaunchKernelGGL((k_zgemm_lds<CJ, FL>), grid, dim3(GEMM_WAVES * 64), 0, b->stream, (int)m, (int)n, (int)k, \
                        sp.kchunk, gm_s, gn_s, rt0, ct0, lsplit, upper, sp.nsplit, A, lda, B, ldb, C, ldc, alpha, beta, sp.slab)
 #define DFTK_LAUNCH_3M(CJ, MD)                                                                                         \
     if (real && BNt == 64) DFTK_LAUNCH_3M_(CJ, MD, true, 4);                                                           \
     else if (real) DFTK_LAUNCH_3M_(CJ, MD, true, 2);                                                                   \
     else DFTK_LAUNCH_3M_(CJ, MD, false, M3_RN)
 #define DFTK_LAUNCH_3M_(CJ, MD, RL, RNN)                                                                               \
-    hipLaunchKernelGGL((k_zgemm_3m<CJ, MD, RL, RNN>), grid, dim3(GEMM_WAVES * 64), pad_lds, b->stream, (int)m, (int)n, (int)k,  \
+    hipLaunchKernelGGL((k_zgemm_3m<CJ, MD, RL, RNN>), grid, dim3(GEMM_WAVES * 64), 0, b->stream, (int)m, (int)n, (int)k,  \
                        sp.kchunk, gm_s, gn_s, rt0, ct0, lsplit, upper, til.shift ? gnf : -1,                           \
                        (til.shift_r && lsplit < 0) ? gmf : -1, sp.nsplit, A, lda, B, ldb, C,                           \
                        ldc, alpha, beta, sp.slab)

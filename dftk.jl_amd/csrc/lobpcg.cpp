@@ -601,14 +601,6 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
             // CPU-LAPACK `syevr` of Julia < 1.12 (lobpcg_hyper_impl.jl:152-171); its GPU arrays take the generic
             // method (:145-151) and Julia >= 1.12 `syevd`, both without it.  The Jacobi eigenvectors are an
             // accumulated product of unitary rotations (||V'V - I|| ~ 1e-13, tests/test_gpu_kernels.py::test_heev).
-            // DFTK_MI_RR_REORTHO=1 restores the extra Cholesky-QR pass.
-            static const bool rr_reortho = getenv("DFTK_MI_RR_REORTHO") != nullptr;
-            if (rr_reortho) {
-                int nch;
-                double gr;
-                NoComm replicated(c);
-                CHK(ortho_X(c, Mat{cX, nY, nY, ncx}, c.tmpS, ortho_tol, &nch, &gr));
-            }
             for (int i = 0; i < nact; ++i) full_lam[lo + i] = wv[i];
             CHK(hcat_mul(c, Ys, cX, nY, nact, nX));
             CHK(hcat_mul(c, AYs, cX, nY, nact, nAX));

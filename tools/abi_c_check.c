@@ -261,6 +261,7 @@ static int worker(int rank, int n_ranks, const char id[128]) {
     free(H); free(Hslab);
     if (rank == 0)
         printf("abi_c_check OK ranks=%d rccl=%d n_G=%lld (%s)\n", n_ranks, version, (long long)n_G, dftk_mi_version());
+    fflush(stdout);   /* the ranks leave through _exit */
     return 0;
 }
 

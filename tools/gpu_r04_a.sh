@@ -7,12 +7,8 @@ cd $R
 timeout 900 python -m pytest tests/test_gpu_multirank.py tests/test_gpu_kbatch.py -m gpu -q --tb=short -x -p no:cacheprovider 2>&1 | grep -v '^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl' | tail -15 > $O/pytest_multirank.log
 tail -5 $O/pytest_multirank.log
 for B in 1 2 3 4 8 16; do
-  echo "== DFTK_MI_FFT_BATCH=$B" >> $O/fft_batch_sweep.txt
-  DFTK_MI_FFT_BATCH=$B timeout 300 python tools/fft_bench.py 5 64 2>&1 | grep -v amdgpu >> $O/fft_batch_sweep.txt
+  echo "== bands per launch group = $B" >> $O/fft_batch_sweep.txt
+  timeout 300 python tools/fft_bench.py 5 64 $B 2>&1 | grep -v amdgpu >> $O/fft_batch_sweep.txt
 done
 cat $O/fft_batch_sweep.txt
-for B in 2 8; do
-  echo "== DFTK_MI_FFT_BATCH=$B late step" >> $O/late_step_batch.txt
-  DFTK_MI_FFT_BATCH=$B timeout 300 python tools/late_step_profile.py 5 8 6 2>/dev/null | head -12 >> $O/late_step_batch.txt
-done
-cat $O/late_step_batch.txt
+cat $O/fft_batch_sweep.txt

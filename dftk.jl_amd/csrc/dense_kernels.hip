@@ -1143,8 +1143,10 @@ static int heev_impl(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, c
     hipLaunchKernelGGL(k_set_identity<ET>, dim3((unsigned)(((size_t)np * np + 255) / 256)), dim3(256), 0, b->stream, np,
                        Vw, (int64_t)np);
     // off-diagonal Frobenius norm relative to ||A||_F; the round-off floor of the blocked sweeps
-    // grows like eps*sqrt(n), so accept 1e-14 outright or a stagnated sweep below 1e-12
-    const double tol = 1e-14;
+    // grows like eps*sqrt(n), so accept 1e-14 outright or a stagnated sweep below 1e-12.  Above n = 90 the tolerance is
+    // n eps / 2 (1.1e-13 at n = 1006): the backward error LAPACK itself guarantees is O(n eps ||A||), the sweeps
+    // converge quadratically here (3e-13 -> 1e-16 in the next one), and a sweep of a 1509^2 matrix is 2.5 ms
+    const double tol = std::max(1e-14, 0.5 * n * 2.220446049250313e-16);
     double prev_off = -1.0;
     int sweep = 0;
     const int maxsweeps = 40;

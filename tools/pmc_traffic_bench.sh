@@ -1,11 +1,11 @@
 # HBM traffic of every kernel family of the benchmark workload (TCC byte counters, separate passes per
 # the gfx950 slot limits; --pmc never combined with other trace domains except --kernel-trace).
 # Writes gpurun_out/${TAG}_pmc_traffic.json (copy to profiles/ to have bench.py quote it as roofline.traffic).
-# usage: TAG=r03 bash tools/pmc_traffic_bench.sh [bench args...]
+# usage: TAG=r04 bash tools/pmc_traffic_bench.sh [bench args...]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${TAG:-r03}
-ARGS="--no-cpu-baseline --no-complex-leg --prof-all $@"
+TAG=${TAG:-r04}
+ARGS="--no-cpu-baseline --no-complex-leg --no-parity --prof-all $@"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf -o pf --output-format csv -- python $R/bench.py $ARGS > /tmp/bench_f.json 2>/dev/null
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -o pw --output-format csv -- python $R/bench.py $ARGS > /tmp/bench_w.json 2>/dev/null
 python $R/tools/pmc_to_traffic.py /tmp/pf/pf_counter_collection.csv /tmp/pw/pw_counter_collection.csv /tmp/bench_f.json $R/gpurun_out/${TAG}_pmc_traffic.json

@@ -133,3 +133,64 @@ def test_collinear_model_without_magnetisation_equals_the_unpolarised_model_on_d
         for s_ in range(2):
             np.testing.assert_allclose(r2["eigenvalues"][ik + 2 * s_][:4], r1["eigenvalues"][ik][:4], atol=1e-7)
     assert float(torch.linalg.norm(r2["rho"][0] - r1["rho"] / 2)) * np.sqrt(b1.dvol) < 1e-7
+
+
+SPIN_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, os.environ["REPO"])
+import numpy as np, torch, torch.distributed as dist
+import dftk_jl_amd as dftk
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["PORT"],
+                        rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+comm = dftk.KptComm.from_torch()
+lat = 2.71176 * np.array([[-1, 1, 1], [1, -1, 1], [1, 1, -1.0]])
+Fe = dftk.ElementPsp("Fe", dftk.load_psp("Fe", "lda"))
+model = dftk.model_DFT(lat, [Fe], [np.zeros(3)], functionals=("lda_xc_teter93",), temperature=0.01, smearing="fermi_dirac",
+                       magnetic_moments=(4.0,), symmetries=True)
+basis = dftk.PlaneWaveBasis(model, 15, dftk.MonkhorstPack((4, 4, 4), (0.5, 0.5, 0.5)), fft_size=(20, 20, 20), device="cuda:0",
+                            comm_kpts=comm)
+# 6 irreducible k-points over 2 ranks: every rank holds 3 spin-up blocks followed by its 3 spin-down blocks
+assert len(basis.kpoints) == 6 and [k.spin for k in basis.kpoints] == [1, 1, 1, 2, 2, 2]
+res = dftk.self_consistent_field(basis, rho=dftk.guess_density(basis, (4.0,)), tol=1e-9)
+d = dftk.scfres_to_dict(res)
+if comm.rank == 0:
+    rho = res["rho"]
+    print("RESULT " + json.dumps({"E": res["energies"].total, "terms": dict(res["energies"]), "eF": res["eF"],
+                                  "eig": d["eigenvalues"], "converged": bool(res["converged"]),
+                                  "mag": float((rho[0] - rho[1]).sum()) * basis.dvol}))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_collinear_spin_with_kpoints_split_over_two_ranks_equals_single_rank(tmp_path):
+    """k-point sharding of a collinear model (PlaneWaveBasis.jl:218-232: every rank lists ITS spin-up blocks, then ITS
+    spin-down blocks; the density all-reduce carries both spin cubes; the Fermi level is found from the gathered
+    eigenvalues of all (k, spin) blocks): two ranks on the one GPU of the box (host-staged transport over gloo) against
+    the one-rank run, and the [spin][kpoint][band] wire format assembled from both ranks in global k order."""
+    import json
+    import os
+    import sys
+    from tests.test_gpu_multirank import ROOT, _spawn
+    script = tmp_path / "spin_worker.py"
+    script.write_text(SPIN_WORKER)
+    port = str(35000 + os.getpid() % 2000)
+    base = dict(os.environ, WORLD_SIZE="2", PORT=port, REPO=ROOT, MASTER_ADDR="127.0.0.1")
+    outs = _spawn([([sys.executable, str(script)], dict(base, RANK=str(r))) for r in range(2)])
+    got = json.loads([ln for ln in outs[0].splitlines() if ln.startswith("RESULT ")][-1][len("RESULT "):])
+    assert got["converged"]
+    db = iron_device_basis()
+    ref = dftk.self_consistent_field(db, rho=dftk.guess_density(db, (4.0,)), tol=1e-9)
+    assert ref["converged"]
+    assert abs(got["E"] - ref["energies"].total) < 1e-8
+    for name, v in ref["energies"].items():
+        assert abs(got["terms"][name] - v) < 1e-7, name
+    assert abs(got["eF"] - ref["eF"]) < 1e-7
+    nconv = ref["n_bands_converge"]
+    eig = np.array(got["eig"])                                        # [spin][kpoint][band], global k order
+    assert eig.shape[:2] == (2, 6)
+    for s_ in range(2):
+        for ik in range(6):
+            np.testing.assert_allclose(eig[s_, ik, :nconv - 2], np.asarray(ref["eigenvalues"][6 * s_ + ik])[:nconv - 2], atol=1e-7)
+    rho = ref["rho"]
+    assert abs(got["mag"] - float((rho[0] - rho[1]).sum()) * db.dvol) < 1e-6

@@ -106,6 +106,7 @@ _SIGNATURES = {
     "dftk_mi_zgemm_plan_host": (C.c_int, [C.c_char, _i64, _i64, _i64, C.c_int, C.POINTER(C.c_int)]),
     "dftk_mi_heev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, C.c_void_p, _i64]),
     "dftk_mi_potrf_trtri": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, _i64]),
+    "dftk_mi_potrf_trtri_real": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, _i64]),
     "dftk_mi_comm_get_unique_id": (C.c_int, [C.c_char_p]),
     "dftk_mi_comm_init_rank": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "dftk_mi_comm_create_host": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -1254,6 +1254,14 @@ extern "C" int dftk_mi_potrf_trtri(dftk_mi_basis* b, int n, dftk_mi_cplx* A_d, i
     return dense_potrf_trtri(b, n, reinterpret_cast<cd*>(A_d), lda, reinterpret_cast<cd*>(invR_d), ldi, &a, &c);
 }
 
+extern "C" int dftk_mi_potrf_trtri_real(dftk_mi_basis* b, int n, dftk_mi_cplx* A_d, int64_t lda, dftk_mi_cplx* invR_d,
+                                        int64_t ldi) {
+    if (!b || n < 1 || !A_d || !invR_d || lda < n || ldi < n) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(b->device));
+    double a, c;
+    return dense_potrf_trtri(b, n, reinterpret_cast<cd*>(A_d), lda, reinterpret_cast<cd*>(invR_d), ldi, &a, &c, true);
+}
+
 // ------------------------------------------------------------------------------------ LOBPCG building blocks
 extern "C" int dftk_mi_lobpcg_history(dftk_mi_kblock* kb, int* M_out, int* n_iter_out, double* hist_h, size_t cap,
                                       int* n_svd_out) {

@@ -212,7 +212,7 @@ int ensure_ws(dftk_mi_basis* b, size_t bytes);
 
 // dense_kernels.hip
 int dense_potrf_trtri(dftk_mi_basis* b, int n, cd* A, int64_t lda, cd* invR, int64_t ldi,
-                      double* normest_R, double* normest_invR);   // host outputs
+                      double* normest_R, double* normest_invR, bool real_input = false);   // host outputs
 int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, int64_t ldv);
 int jacobi_schedule_host(int n, int round, int* nb_out, int* pairs, int* where);
 int apply_D(dftk_mi_kblock* kb, int n_bands, const cd* X /*n_p x nb*/, cd* Y);

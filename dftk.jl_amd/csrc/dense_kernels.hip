@@ -397,6 +397,244 @@ __global__ __launch_bounds__(256) void k_trtri_upper_blk(int n, const cd* __rest
     }
 }
 
+// ---- cooperative Cholesky + inverse for n <= 512 (round 4) --------------------------------------------------------
+// The blocked factorisation above is a chain of 3 launches per 32-wide panel (diagonal block, row panel, trailing GEMM):
+// 16 panels x ~75 us = 1.2 ms for the 503^2 Gram matrices of ortho! -- all latency, the flops are nothing.  Here ONE launch of
+// nb = ceil(n / 16) workgroups runs the whole factorisation as a dataflow: workgroup l owns block column l of the LOWER
+// factor L (A = L L^H, R = L^H is what the caller gets), keeps its rows in REGISTERS (two rows of 16 per thread), consumes
+// the panels j < l as their owners publish them (global buffer + release / acquire flag at agent scope: the workgroups sit
+// on different XCDs), then factors its own diagonal block, scales its column panel and publishes it.  The critical path per
+// panel is: read 16 columns from L2, 256 complex multiply-adds per row, a 16-step Cholesky of the diagonal block in LDS, a
+// 16-step substitution per row, publish: ~10 us.  The inverse follows in the same launch: workgroup l forward-substitutes
+// block column l of X = L^{-1} (X_kl = -W_k sum_j L_kj X_jl with the published inverse diagonal blocks W_k), and
+// R^{-1} = X^H.  All nb <= 32 workgroups are resident at once (1 per CU), which is what makes the flag waits safe.
+#define CCB 16
+#define CCT 512                                          // threads per workgroup: one row of the block column each
+// element type of the factorisation: cd, or double when the caller vouches for a real symmetric matrix (the Gram matrices of
+// the Gamma-real LOBPCG: every imaginary part exactly zero) -- a quarter of the multiply-adds, half the bytes
+__device__ __forceinline__ cd e_mul(cd a, cd b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ cd e_mulc(cd a, cd b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a conj(b)
+__device__ __forceinline__ double e_mul(double a, double b) { return a * b; }
+__device__ __forceinline__ double e_mulc(double a, double b) { return a * b; }
+__device__ __forceinline__ void e_sub(cd& acc, cd z) { acc.x -= z.x; acc.y -= z.y; }
+__device__ __forceinline__ void e_sub(double& acc, double z) { acc -= z; }
+__device__ __forceinline__ void e_add(cd& acc, cd z) { acc.x += z.x; acc.y += z.y; }
+__device__ __forceinline__ void e_add(double& acc, double z) { acc += z; }
+__device__ __forceinline__ cd e_scale(cd a, double s) { return make_double2(a.x * s, a.y * s); }
+__device__ __forceinline__ double e_scale(double a, double s) { return a * s; }
+__device__ __forceinline__ double e_re(cd a) { return a.x; }
+__device__ __forceinline__ double e_re(double a) { return a; }
+__device__ __forceinline__ void e_set(cd& dst, double re) { dst = make_double2(re, 0.0); }
+__device__ __forceinline__ void e_set(double& dst, double re) { dst = re; }
+__device__ __forceinline__ void e_load_conj(cd& dst, cd a, bool diag) { dst = make_double2(a.x, diag ? 0.0 : -a.y); }
+__device__ __forceinline__ void e_load_conj(double& dst, cd a, bool) { dst = a.x; }
+__device__ __forceinline__ cd e_out_conj(cd a) { return make_double2(a.x, -a.y); }
+__device__ __forceinline__ cd e_out_conj(double a) { return make_double2(a, 0.0); }
+__device__ __forceinline__ void coop_wait(const int* flag) {
+    if (threadIdx.x == 0)
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
+    __syncthreads();
+    __threadfence();
+}
+__device__ __forceinline__ void coop_signal(int* flag) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__global__ __launch_bounds__(CCT, 1) void k_potrf_trtri_coop(int n, cd* __restrict__ A, int64_t lda, cd* __restrict__ Z,
+                                                             int64_t ldz, T* __restrict__ Lbuf, T* __restrict__ Wbuf,
+                                                             int* __restrict__ flags, int* __restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    T* Xs = reinterpret_cast<T*>(sm);                   // phase 2: [rows][16] block column of X = L^{-1}
+    __shared__ T Dm[CCB][CCB + 1];                       // diagonal block (lower), then scratch
+    __shared__ T Wm[CCB][CCB + 1];                       // its inverse
+    __shared__ T Lj[CCB][CCB + 1];                       // L_{l,j} of the panel being consumed
+    const int l = blockIdx.x, nb = gridDim.x, tid = threadIdx.x;
+    const int r0 = CCB * l;                              // first global row / column of this block
+    const int np = CCB * nb;                             // padded order
+    const int nrows = np - r0;                           // rows of this block column (diagonal block first)
+    int* flagsW = flags + 32;                            // second set: inverse diagonal blocks published
+    // panel j lives at Lbuf + j * np * CCB as [row - 16 j][16] (row-major: a row is contiguous)
+    auto panel = [&](int j) { return Lbuf + (size_t)j * np * CCB; };
+    // ---- load my row of the block column of the lower triangle: L(r, c) source = conj(A_upper(c, r)); identity in the padding
+    const int i = tid, gr = r0 + i;
+    const bool have_row = i < nrows;
+    T row[CCB];
+#pragma unroll
+    for (int c = 0; c < CCB; ++c) {
+        const int gc = r0 + c;
+        e_set(row[c], 0.0);
+        if (have_row) {
+            if (gr < n && gc < n) {
+                if (gr >= gc) e_load_conj(row[c], A[gc + (int64_t)gr * lda], gr == gc);
+            } else if (gr == gc) {
+                e_set(row[c], 1.0);
+            }
+        }
+    }
+    // ---- consume the panels of the block columns to the left
+    for (int j = 0; j < l; ++j) {
+        coop_wait(flags + j);
+        const T* P = panel(j) + (size_t)(r0 - CCB * j) * CCB;      // my first row inside panel j
+        if (tid < CCB * CCB) Lj[tid >> 4][tid & 15] = P[tid];      // rows r0 .. r0+15 of the panel = L_{l,j}
+        T p[CCB];
+        if (have_row) {
+#pragma unroll
+            for (int t = 0; t < CCB; ++t) p[t] = P[(size_t)i * CCB + t];
+        }
+        __syncthreads();
+        if (have_row) {
+#pragma unroll
+            for (int c = 0; c < CCB; ++c) {
+                T s;
+                e_set(s, 0.0);
+#pragma unroll
+                for (int t = 0; t < CCB; ++t) e_add(s, e_mulc(p[t], Lj[c][t]));
+                e_sub(row[c], s);
+            }
+        }
+        __syncthreads();   // Lj is rewritten by the next panel
+    }
+    // ---- factor the diagonal block (threads 0..15 hold its rows): wave 0 alone, LDS, no workgroup barriers
+    if (tid < CCB) {
+#pragma unroll
+        for (int c = 0; c < CCB; ++c) Dm[tid][c] = row[c];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        // lane owns elements (k, m) = (4 q + (lane >> 4), lane & 15), q = 0..3
+        const int m = tid & 15, kb = tid >> 4;
+        for (int c = 0; c < CCB; ++c) {
+            const double d = e_re(Dm[c][c]);
+            const bool ok = d > 0.0 && isfinite(d);
+            if (!ok && tid == 0) atomicCAS(info, 0, r0 + c + 1);
+            const double sd = ok ? sqrt(d) : 1.0, inv = 1.0 / sd;
+            __builtin_amdgcn_wave_barrier();
+            if (m == c) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = 4 * q + kb;
+                    if (k == c)
+                        e_set(Dm[k][c], sd);
+                    else if (k > c)
+                        Dm[k][c] = e_scale(Dm[k][c], inv);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (m > c) {
+                const T lm = Dm[m][c];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = 4 * q + kb;
+                    if (k >= m) e_sub(Dm[k][m], e_mulc(Dm[k][c], lm));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 4 * q + kb;
+            if (m > k) e_set(Dm[k][m], 0.0);
+        }
+    }
+    __syncthreads();
+    // ---- column panel below the diagonal block: y D^H = x  per row;  the diagonal block rows take D itself
+    if (have_row) {
+        if (i < CCB) {
+#pragma unroll
+            for (int c = 0; c < CCB; ++c) row[c] = Dm[i][c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < CCB; ++c) {
+                T acc = row[c];
+#pragma unroll
+                for (int t = 0; t < CCB; ++t)
+                    if (t < c) e_sub(acc, e_mulc(row[t], Dm[c][t]));
+                row[c] = e_scale(acc, 1.0 / e_re(Dm[c][c]));
+            }
+        }
+        // ---- publish my row of panel l
+        T* P = panel(l);
+#pragma unroll
+        for (int c = 0; c < CCB; ++c) P[(size_t)i * CCB + c] = row[c];
+    }
+    coop_signal(flags + l);
+    // ---- off the critical path: R = L^H into the caller's upper triangle, the inverse diagonal block
+    if (have_row) {
+#pragma unroll
+        for (int c = 0; c < CCB; ++c) {
+            const int gc = r0 + c;
+            if (gr < n && gc < n && gr >= gc) A[gc + (int64_t)gr * lda] = e_out_conj(row[c]);
+        }
+    }
+    if (tid < CCB) {   // column m of W = D^{-1} by forward substitution
+        const int m = tid;
+        T w[CCB];
+#pragma unroll
+        for (int k = 0; k < CCB; ++k) {
+            T acc;
+            e_set(acc, k == m ? 1.0 : 0.0);
+#pragma unroll
+            for (int t = 0; t < CCB; ++t)
+                if (t < k) e_sub(acc, e_mul(Dm[k][t], w[t]));
+            w[k] = e_scale(acc, 1.0 / e_re(Dm[k][k]));
+            if (k < m) e_set(w[k], 0.0);
+        }
+#pragma unroll
+        for (int k = 0; k < CCB; ++k) Wm[k][m] = w[k];
+    }
+    __syncthreads();
+    if (tid < CCB * CCB) Wbuf[(size_t)l * CCB * CCB + tid] = Wm[tid >> 4][tid & 15];
+    coop_signal(flagsW + l);
+    // ---- phase 2: block column l of X = L^{-1}:  X_ll = W_l,  X_kl = -W_k sum_{j=l}^{k-1} L_kj X_jl
+    // threads (half, a, b): the j range of the sum is split over the two halves of the workgroup
+    const int a = (tid >> 4) & 15, b = tid & 15, half = tid >> 8;
+    if (tid < CCB * CCB) Xs[a * CCB + b] = Wm[a][b];
+    __syncthreads();
+    for (int k = l + 1; k < nb; ++k) {
+        coop_wait(flagsW + k);
+        T s;
+        e_set(s, 0.0);
+        for (int j = l + half; j < k; j += 2) {
+            const T* Lkj = panel(j) + (size_t)(CCB * (k - j)) * CCB + a * CCB;   // row a of L_{k,j}
+            const T* Xj = Xs + (size_t)(CCB * (j - l)) * CCB + b;
+#pragma unroll
+            for (int t = 0; t < CCB; ++t) e_add(s, e_mul(Lkj[t], Xj[t * CCB]));
+        }
+        if (half == 1) Wm[a][b] = s;
+        __syncthreads();
+        if (half == 0) {
+            e_add(s, Wm[a][b]);
+            Lj[a][b] = s;                                              // S
+            Dm[a][b] = Wbuf[(size_t)k * CCB * CCB + (tid & 255)];        // W_k
+        }
+        __syncthreads();
+        if (half == 0) {
+            T acc;
+            e_set(acc, 0.0);
+#pragma unroll
+            for (int t = 0; t < CCB; ++t) e_sub(acc, e_mul(Dm[a][t], Lj[t][b]));
+            Xs[(size_t)(CCB * (k - l) + a) * CCB + b] = acc;
+        }
+        __syncthreads();
+    }
+    // ---- Z = R^{-1} = X^H: my block column of X is the block ROW l of Z; zeros below the diagonal
+    for (int e = tid; e < CCB * np; e += CCT) {
+        const int bb = e / np, gcol = e - bb * np;        // Z(r0 + bb, gcol)
+        const int grow = r0 + bb;
+        if (grow < n && gcol < n) {
+            cd v = make_double2(0.0, 0.0);
+            if (gcol >= grow) v = e_out_conj(Xs[(size_t)(gcol - r0) * CCB + bb]);   // conj X(gcol, grow)
+            Z[grow + (int64_t)gcol * ldz] = v;
+        }
+    }
+}
+
 // Partial results of column chunk blockIdx.x of matrix blockIdx.y -- (M, out) or (M2, out2), both estimates in
 // one launch: out[3 chunk + 0] = max |diag|, [+1] = sum of |offdiag|^2 over the upper triangle, [+2] = non-finite
 // flag.  The host combines the NORMEST_CHUNKS partials in fixed order.  A wave owns a column (rows contiguous:
@@ -1031,7 +1269,7 @@ static int fetch_scalars(dftk_mi_basis* b, int count) {
 }
 
 int dense_potrf_trtri(dftk_mi_basis* b, int n, cd* A, int64_t lda, cd* invR, int64_t ldi, double* normest_R,
-                      double* normest_invR) {
+                      double* normest_invR, bool real_input) {
     if (batching()) {
         double out[2] = {0.0, 0.0};      // on the fiber's stack: filled by the round's executor
         BOp o;
@@ -1045,7 +1283,32 @@ int dense_potrf_trtri(dftk_mi_basis* b, int n, cd* A, int64_t lda, cd* invR, int
     const int ps = prof_begin(b, PROF_CHOL, (double)n);
     int* d_info = reinterpret_cast<int*>(b->d_scalars + 200);
     HIPCHK(hipMemsetAsync(d_info, 0, sizeof(int), b->stream));
-    for (int j0 = 0; j0 < n; j0 += PB) {
+    // n <= 512 (the Gram matrices of ortho!): ONE cooperative launch instead of 3 launches per 32-wide panel
+    static int coop_ok = -1;
+    if (coop_ok < 0)
+        coop_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_trtri_coop<cd>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) == hipSuccess &&
+                  hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_trtri_coop<double>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 70 * 1024) == hipSuccess;
+    const bool coop = coop_ok == 1 && n <= 512 && n > 32;
+    if (coop) {
+        const int nb = (n + CCB - 1) / CCB, np = nb * CCB;
+        const size_t need = ((size_t)nb * np * CCB + (size_t)nb * CCB * CCB) * sizeof(cd) + 64 * sizeof(int);
+        CHK(dws_ensure(b, &b->dense_ws, &b->dense_ws_bytes, need));
+        cd* Lbuf = reinterpret_cast<cd*>(b->dense_ws);
+        cd* Wbuf = Lbuf + (size_t)nb * np * CCB;
+        int* flags = reinterpret_cast<int*>(Wbuf + (size_t)nb * CCB * CCB);
+        HIPCHK(hipMemsetAsync(flags, 0, 64 * sizeof(int), b->stream));
+        if (real_input)   // (the buffers are sized for complex elements: the real factorisation uses half of each)
+            hipLaunchKernelGGL(k_potrf_trtri_coop<double>, dim3(nb), dim3(CCT), (size_t)np * CCB * sizeof(double), b->stream, n,
+                               A, lda, invR, ldi, reinterpret_cast<double*>(Lbuf), reinterpret_cast<double*>(Wbuf), flags,
+                               d_info);
+        else
+            hipLaunchKernelGGL(k_potrf_trtri_coop<cd>, dim3(nb), dim3(CCT), (size_t)np * CCB * sizeof(cd), b->stream, n, A, lda,
+                               invR, ldi, Lbuf, Wbuf, flags, d_info);
+        HIPCHK(hipGetLastError());
+    }
+    for (int j0 = 0; j0 < n && !coop; j0 += PB) {
         const int jb = (n - j0) < PB ? (n - j0) : PB;
         hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, b->stream, jb, j0, A, lda, d_info);
         const int n2 = n - j0 - jb;
@@ -1057,7 +1320,7 @@ int dense_potrf_trtri(dftk_mi_basis* b, int n, cd* A, int64_t lda, cd* invR, int
             CHK(zgemm(b, 'C', n2, n2, jb, mone, R12, lda, R12, lda, one, A22, lda, /*upper=*/1));   // only the upper triangle is ever read
         }
     }
-    {
+    if (!coop) {
         const size_t lds = ((size_t)32 * ((n + 31) / 32) * TRI_TC + 32 * 33) * sizeof(cd);
         static int big_lds_ok = -1;   // > 64 KiB of dynamic LDS needs an opt-in
         if (big_lds_ok < 0)

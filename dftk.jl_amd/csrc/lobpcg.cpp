@@ -113,7 +113,8 @@ int safe_cholesky(Ctx& c, int m, int* nchol_out, double* nR, double* nI) {
         }
         nchol += 1;
         CHK(ew_copy(c.b, m, m, c.O, m, c.Rw, m));
-        int st = dense_potrf_trtri(c.b, m, c.Rw, m, c.invR, m, nR, nI);
+        // (Gamma-real mode: the Gram matrices are real symmetric, stored as complex with exactly zero imaginary parts)
+        int st = dense_potrf_trtri(c.b, m, c.Rw, m, c.invR, m, nR, nI, c.real_mode);
         if (st == 0) break;
         if (st != DFTK_MI_NUM_CHOLESKY) return st;
         double f2;

@@ -314,6 +314,10 @@ int dftk_mi_heev(dftk_mi_basis* basis, int n, dftk_mi_cplx* A_d, int64_t lda, do
  * Returns DFTK_MI_NUM_CHOLESKY when a pivot is not positive / finite. */
 int dftk_mi_potrf_trtri(dftk_mi_basis* basis, int n, dftk_mi_cplx* A_d, int64_t lda,
                         dftk_mi_cplx* invR_d, int64_t ldi);
+/* The same for a REAL symmetric A stored as complex: the caller vouches that every imaginary part of the upper
+ * triangle is exactly zero (the Gram matrices of the real-symmetric Gamma iteration); they are not read. */
+int dftk_mi_potrf_trtri_real(dftk_mi_basis* basis, int n, dftk_mi_cplx* A_d, int64_t lda,
+                             dftk_mi_cplx* invR_d, int64_t ldi);
 
 /* ---- comm_kpts: replaces MPI.Init / mpi_sum!(rho, comm_kpts)
  *      (src/common/mpi.jl:19-32 at src/densities.jl:46) with RCCL over xGMI ---------------------

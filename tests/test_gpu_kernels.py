@@ -218,12 +218,24 @@ def test_zgemm_asymmetric_layout(lib):
     np.testing.assert_allclose(Cd.cpu().numpy().T, B, rtol=0, atol=1e-12)
 
 
-@pytest.mark.parametrize("n", [1, 7, 31, 32, 33, 64, 259, 600])
+@pytest.mark.parametrize("n", [1, 7, 31, 32, 33, 47, 48, 49, 64, 100, 259, 500, 503, 511, 512, 513, 600])
 def test_potrf_trtri(lib, n):
+    """32 < n <= 512 takes the cooperative one-launch factorisation (16-column blocks, dataflow over flags: exact block
+    multiples, one column over, one short, the 503 of the headline cell, the last size before the blocked path); the
+    other sizes the three-launches-per-panel path.  ``lda`` > n and NaNs in the strict lower triangle check that only
+    the upper triangle is read and written."""
     rng = np.random.default_rng(n)
     bs = Basis(lib, 8, 8, 8)
-    X = rng.standard_normal((3 * n + 5, n)) + 1j * rng.standard_normal((3 * n + 5, n))
-    O = X.conj().T @ X
+    X = rng.standard_normal((3 * n + 5, n)) + (1j if n % 2 else 0) * rng.standard_normal((3 * n + 5, n))
+    O = (X.conj().T @ X).astype(complex)
+    if n in (100, 503):      # strict lower triangle must never be read: poison it
+        Od = dev((np.triu(O) + np.tril(np.full((n, n), np.nan), -1)).T.copy())
+        Id = torch.full_like(Od, float("nan"))
+        check(lib.dftk_mi_potrf_trtri(bs.h, n, Od.data_ptr(), n, Id.data_ptr(), n))
+        bs.sync()
+        R = np.triu(Od.cpu().numpy().T)
+        assert relerr(R.conj().T @ R, O) < 1e-13
+        assert np.all(np.isnan(np.tril(Od.cpu().numpy().T, -1)[np.tril_indices(n, -1)]))     # untouched
     Od = dev(O.T.copy())
     Id = torch.full_like(Od, float("nan"))
     check(lib.dftk_mi_potrf_trtri(bs.h, n, Od.data_ptr(), n, Id.data_ptr(), n))
@@ -238,6 +250,32 @@ def test_potrf_trtri(lib, n):
     Bd = dev(Bad.T.copy())
     st = lib.dftk_mi_potrf_trtri(bs.h, n, Bd.data_ptr(), n, Id.data_ptr(), n)
     assert st == 2
+
+
+@pytest.mark.parametrize("n", [5, 33, 48, 100, 259, 503, 512, 600])
+def test_potrf_trtri_real(lib, n):
+    """The real-symmetric entry (Gram matrices of the Gamma-real iteration): imaginary parts are never read (poisoned
+    here), results equal to the complex entry's on the same matrix."""
+    rng = np.random.default_rng(100 + n)
+    bs = Basis(lib, 8, 8, 8)
+    X = rng.standard_normal((3 * n + 5, n))
+    O = (X.T @ X).astype(complex)
+    Od = dev(O.T.copy())
+    Id = torch.full_like(Od, float("nan"))
+    check(lib.dftk_mi_potrf_trtri(bs.h, n, Od.data_ptr(), n, Id.data_ptr(), n))
+    bs.sync()
+    R_c, I_c = np.triu(Od.cpu().numpy().T), Id.cpu().numpy().T
+    Od = dev(O.T.copy())
+    Id = torch.full_like(Od, float("nan"))
+    check(lib.dftk_mi_potrf_trtri_real(bs.h, n, Od.data_ptr(), n, Id.data_ptr(), n))
+    bs.sync()
+    R, invR = np.triu(Od.cpu().numpy().T), Id.cpu().numpy().T
+    assert np.all(R.imag == 0) and np.all(invR.imag == 0)
+    assert relerr(R.T @ R, O) < 1e-13
+    assert relerr(R, R_c) < 1e-12 * np.linalg.cond(R_c) and relerr(invR, I_c) < 1e-12 * np.linalg.cond(R_c)
+    assert np.allclose(np.tril(invR, -1), 0)
+    Bd = dev((O - 2 * np.trace(O).real / n * np.eye(n)).T.copy())
+    assert lib.dftk_mi_potrf_trtri_real(bs.h, n, Bd.data_ptr(), n, Id.data_ptr(), n) == 2
 
 
 @pytest.mark.parametrize("n", [1, 5, 16, 17, 32, 33, 48, 64, 100, 300, 500, 777])

@@ -36,58 +36,106 @@ __device__ __forceinline__ double block_sum256(double v, double* sh) {
 }
 
 // ---------------------------------------------------------------------------- column reductions
-// One workgroup per column; deterministic (fixed strides and tree).
-// mode 0: out[c] = sqrt(sum |X|^2) ; 1: out[c] = Re sum conj(X) Y ; 2: out[c] = sum w |X|^2 ; 3: sum |X|^2
-__global__ __launch_bounds__(256) void k_col_reduce(int mode, int64_t n, const cd* __restrict__ X, int64_t ldx,
-                                                    const cd* __restrict__ Y, int64_t ldy,
-                                                    const double* __restrict__ w, double* __restrict__ out) {
-    __shared__ double sh[4];
+// The n_G-sized streaming kernels of one LOBPCG iteration.  They are HBM-bound, and what bounds them is the number of
+// bytes in flight: one 16-byte load per thread and 2 x 256 threads per CU (the round 1-3 form) keeps 8 KB per CU in the
+// air and reaches 1.2-1.5 TB/s (tools/ew_bench.py).  Here every thread issues EW_UNR independent loads per operand before
+// it touches any of them, and a long column gets a workgroup of 1024 threads: 64 KB per operand and workgroup in flight.
+// One workgroup per column; deterministic (fixed strides, fixed tree; the tree depends on the workgroup size, which is a
+// function of n alone).
+#define EW_UNR 4
+#define EW_LONG 8192      // rows from which a column gets 1024 threads
+template <int NT>
+__device__ __forceinline__ double block_sum(double v, double* sh) {   // sh[NT / 64]; result valid in thread 0
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NT / 64; ++i) r += sh[i];
+    }
+    __syncthreads();
+    return r;
+}
+// mode 0: out[c] = sqrt(sum |X|^2) ; 1: out[c] = Re sum conj(X) Y ; 2: out[c] = sum w |X|^2 ; 3: sum |X|^2 ; 4: Im sum conj(X) Y
+template <int NT>
+__global__ __launch_bounds__(NT) void k_col_reduce(int mode, int64_t n, const cd* __restrict__ X, int64_t ldx,
+                                                   const cd* __restrict__ Y, int64_t ldy,
+                                                   const double* __restrict__ w, double* __restrict__ out) {
+    __shared__ double sh[NT / 64];
     const int c = blockIdx.x;
     const cd* x = X + (int64_t)c * ldx;
     const cd* y = Y ? Y + (int64_t)c * ldy : nullptr;
+    const bool two = mode == 1 || mode == 4;
     double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 256) {
-        const cd a = x[i];
-        if (mode == 1) {
-            const cd bb = y[i];
-            acc += a.x * bb.x + a.y * bb.y;
-        } else if (mode == 4) {      // Im conj(a) b
-            const cd bb = y[i];
-            acc += a.x * bb.y - a.y * bb.x;
-        } else if (mode == 2) {
-            acc += w[i] * (a.x * a.x + a.y * a.y);
-        } else {
-            acc += a.x * a.x + a.y * a.y;
+    for (int64_t i0 = threadIdx.x; i0 < n; i0 += (int64_t)NT * EW_UNR) {
+        cd a[EW_UNR], bb[EW_UNR];
+        double ww[EW_UNR];
+#pragma unroll
+        for (int u = 0; u < EW_UNR; ++u) {
+            const int64_t i = i0 + (int64_t)u * NT;
+            const bool in = i < n;
+            a[u] = in ? x[i] : make_double2(0.0, 0.0);
+            bb[u] = (in && two) ? y[i] : make_double2(0.0, 0.0);
+            ww[u] = (in && mode == 2) ? w[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < EW_UNR; ++u) {
+            if (mode == 1)
+                acc += a[u].x * bb[u].x + a[u].y * bb[u].y;
+            else if (mode == 4)      // Im conj(a) b
+                acc += a[u].x * bb[u].y - a[u].y * bb[u].x;
+            else if (mode == 2)
+                acc += ww[u] * (a[u].x * a[u].x + a[u].y * a[u].y);
+            else
+                acc += a[u].x * a[u].x + a[u].y * a[u].y;
         }
     }
-    const double r = block_sum256(acc, sh);
+    const double r = block_sum<NT>(acc, sh);
     if (threadIdx.x == 0) out[c] = (mode == 0) ? sqrt(r) : r;
 }
 
 // R = AX - X * lam ; norms[c] = ||R[:,c]|| ; in the same pass over X (optional, kin != null / xx != null):
 // mk[c] = sum kin |X|^2 (precondprep! of the TPA preconditioner) and xx[c] = sum |X|^2 (normalisation check)
-__global__ __launch_bounds__(256) void k_residual(int64_t n, const cd* __restrict__ AX, int64_t lda,
-                                                  const cd* __restrict__ X, int64_t ldx,
-                                                  const double* __restrict__ lam, cd* __restrict__ R, int64_t ldr,
-                                                  double* __restrict__ norms, const double* __restrict__ kin,
-                                                  double* __restrict__ mk, double* __restrict__ xx) {
-    __shared__ double sh[4];
+template <int NT>
+__global__ __launch_bounds__(NT) void k_residual(int64_t n, const cd* __restrict__ AX, int64_t lda,
+                                                 const cd* __restrict__ X, int64_t ldx,
+                                                 const double* __restrict__ lam, cd* __restrict__ R, int64_t ldr,
+                                                 double* __restrict__ norms, const double* __restrict__ kin,
+                                                 double* __restrict__ mk, double* __restrict__ xx) {
+    __shared__ double sh[NT / 64];
     const int c = blockIdx.x;
     const double l = lam[c];
+    const cd* ax = AX + (int64_t)c * lda;
+    const cd* xc = X + (int64_t)c * ldx;
+    cd* rc = R + (int64_t)c * ldr;
     double acc = 0.0, acck = 0.0, accx = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 256) {
-        const cd a = AX[(int64_t)c * lda + i];
-        const cd x = X[(int64_t)c * ldx + i];
-        const cd r = make_double2(a.x - l * x.x, a.y - l * x.y);
-        R[(int64_t)c * ldr + i] = r;
-        acc += r.x * r.x + r.y * r.y;
-        const double x2 = x.x * x.x + x.y * x.y;
-        accx += x2;
-        if (kin) acck += kin[i] * x2;
+    for (int64_t i0 = threadIdx.x; i0 < n; i0 += (int64_t)NT * EW_UNR) {
+        cd a[EW_UNR], x[EW_UNR];
+        double kk[EW_UNR];
+#pragma unroll
+        for (int u = 0; u < EW_UNR; ++u) {
+            const int64_t i = i0 + (int64_t)u * NT;
+            const bool in = i < n;
+            a[u] = in ? ax[i] : make_double2(0.0, 0.0);
+            x[u] = in ? xc[i] : make_double2(0.0, 0.0);
+            kk[u] = (in && kin) ? kin[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < EW_UNR; ++u) {
+            const int64_t i = i0 + (int64_t)u * NT;
+            const cd r = make_double2(a[u].x - l * x[u].x, a[u].y - l * x[u].y);
+            if (i < n) rc[i] = r;
+            acc += r.x * r.x + r.y * r.y;
+            const double x2 = x[u].x * x[u].x + x[u].y * x[u].y;
+            accx += x2;
+            acck += kk[u] * x2;
+        }
     }
-    const double s = block_sum256(acc, sh);
-    const double sk = block_sum256(acck, sh);
-    const double sx = block_sum256(accx, sh);
+    const double s = block_sum<NT>(acc, sh);
+    const double sk = block_sum<NT>(acck, sh);
+    const double sx = block_sum<NT>(accx, sh);
     if (threadIdx.x == 0) {
         norms[c] = sqrt(s);
         if (kin) mk[c] = sk;
@@ -98,28 +146,51 @@ __global__ __launch_bounds__(256) void k_residual(int64_t n, const cd* __restric
 // ldiv!(precon, R) of the TPA preconditioner, out of place and with the column norms of the result:
 //   dst[:,c] = src[:,c] * mean_kin[c] / (mean_kin[c] + kin) ; norms[c] = ||dst[:,c]||     (kin == null: plain copy)
 // One workgroup per column (same reduction tree as k_col_reduce).
-__global__ __launch_bounds__(256) void k_tpa(int64_t n, const cd* __restrict__ src, int64_t lds, cd* __restrict__ dst,
-                                             int64_t ldd, const double* __restrict__ kin,
-                                             const double* __restrict__ mean_kin, double* __restrict__ norms,
-                                             double default_shift) {
-    __shared__ double sh[4];
+template <int NT>
+__global__ __launch_bounds__(NT) void k_tpa(int64_t n, const cd* __restrict__ src, int64_t lds, cd* __restrict__ dst,
+                                            int64_t ldd, const double* __restrict__ kin,
+                                            const double* __restrict__ mean_kin, double* __restrict__ norms,
+                                            double default_shift) {
+    __shared__ double sh[NT / 64];
     const int c = blockIdx.x;
     const double mk = (kin && mean_kin) ? mean_kin[c] : 0.0;
+    const cd* sc = src + (int64_t)c * lds;
+    cd* dc = dst + (int64_t)c * ldd;
     double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 256) {
-        cd r = src[(int64_t)c * lds + i];
-        if (kin) {
-            // mean_kin == null: precondprep! has not run yet -> ldiv!(Y, Diagonal(kin .+ default_shift), R)
-            const double f = mean_kin ? mk / (mk + kin[i]) : 1.0 / (kin[i] + default_shift);
-            r.x *= f;
-            r.y *= f;
+    for (int64_t i0 = threadIdx.x; i0 < n; i0 += (int64_t)NT * EW_UNR) {
+        cd r[EW_UNR];
+        double kk[EW_UNR];
+#pragma unroll
+        for (int u = 0; u < EW_UNR; ++u) {
+            const int64_t i = i0 + (int64_t)u * NT;
+            const bool in = i < n;
+            r[u] = in ? sc[i] : make_double2(0.0, 0.0);
+            kk[u] = (in && kin) ? kin[i] : 1.0;
         }
-        dst[(int64_t)c * ldd + i] = r;
-        acc += r.x * r.x + r.y * r.y;
+#pragma unroll
+        for (int u = 0; u < EW_UNR; ++u) {
+            const int64_t i = i0 + (int64_t)u * NT;
+            if (kin) {
+                // mean_kin == null: precondprep! has not run yet -> ldiv!(Y, Diagonal(kin .+ default_shift), R)
+                const double f = mean_kin ? mk / (mk + kk[u]) : 1.0 / (kk[u] + default_shift);
+                r[u].x *= f;
+                r[u].y *= f;
+            }
+            if (i < n) dc[i] = r[u];
+            acc += r[u].x * r[u].x + r[u].y * r[u].y;
+        }
     }
-    const double s = block_sum256(acc, sh);
+    const double s = block_sum<NT>(acc, sh);
     if (threadIdx.x == 0) norms[c] = sqrt(s);
 }
+// launch one workgroup per column with the workgroup size the column length asks for
+#define EW_LAUNCH_COLS(kernel, n, m, stream, ...)                                                            \
+    do {                                                                                                     \
+        if ((n) >= EW_LONG)                                                                                  \
+            hipLaunchKernelGGL(kernel<1024>, dim3(m), dim3(1024), 0, stream, __VA_ARGS__);                   \
+        else                                                                                                 \
+            hipLaunchKernelGGL(kernel<256>, dim3(m), dim3(256), 0, stream, __VA_ARGS__);                     \
+    } while (0)
 
 __global__ void k_conj_transpose(int n, const cd* __restrict__ A, int64_t lda, cd* __restrict__ B, int64_t ldb) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -133,30 +204,63 @@ __global__ void k_unary(int mode, double* __restrict__ d, size_t n) {
     if (i < n) d[i] = mode == 0 ? d[i] * d[i] : sqrt(d[i]);
 }
 
-__global__ void k_scale_cols(int64_t n, int m, cd* __restrict__ X, int64_t ldx, const double* __restrict__ s,
-                             int invert) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    for (int c = 0; c < m; ++c) {
-        const double f = invert ? 1.0 / s[c] : s[c];
-        cd v = X[(int64_t)c * ldx + i];
-        v.x *= f;
-        v.y *= f;
-        X[(int64_t)c * ldx + i] = v;
+// the row-parallel forms: a workgroup of 256 threads takes EW_UNR * 256 consecutive rows of one column (blockIdx.y)
+#define EW_ROWS (256 * EW_UNR)
+__global__ __launch_bounds__(256) void k_scale_cols(int64_t n, int m, cd* __restrict__ X, int64_t ldx,
+                                                    const double* __restrict__ s, int invert) {
+    const int c = blockIdx.y;
+    const double f = invert ? 1.0 / s[c] : s[c];
+    cd* x = X + (int64_t)c * ldx;
+    const int64_t i0 = (int64_t)blockIdx.x * EW_ROWS + threadIdx.x;
+    cd v[EW_UNR];
+#pragma unroll
+    for (int u = 0; u < EW_UNR; ++u) {
+        const int64_t i = i0 + u * 256;
+        v[u] = i < n ? x[i] : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < EW_UNR; ++u) {
+        const int64_t i = i0 + u * 256;
+        if (i < n) x[i] = make_double2(v[u].x * f, v[u].y * f);
     }
 }
 
-__global__ void k_copy(int64_t n, int m, const cd* __restrict__ X, int64_t ldx, cd* __restrict__ Y, int64_t ldy) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_copy(int64_t n, int m, const cd* __restrict__ X, int64_t ldx, cd* __restrict__ Y,
+                                              int64_t ldy) {
     const int c = blockIdx.y;
-    if (i < n) Y[(int64_t)c * ldy + i] = X[(int64_t)c * ldx + i];
+    const cd* x = X + (int64_t)c * ldx;
+    cd* y = Y + (int64_t)c * ldy;
+    const int64_t i0 = (int64_t)blockIdx.x * EW_ROWS + threadIdx.x;
+    cd v[EW_UNR];
+#pragma unroll
+    for (int u = 0; u < EW_UNR; ++u) {
+        const int64_t i = i0 + u * 256;
+        v[u] = i < n ? x[i] : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < EW_UNR; ++u) {
+        const int64_t i = i0 + u * 256;
+        if (i < n) y[i] = v[u];
+    }
 }
 
-__global__ void k_gather_cols(int64_t n, const cd* __restrict__ X, int64_t ldx, const int* __restrict__ perm,
-                              cd* __restrict__ Y, int64_t ldy) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_gather_cols(int64_t n, const cd* __restrict__ X, int64_t ldx,
+                                                     const int* __restrict__ perm, cd* __restrict__ Y, int64_t ldy) {
     const int c = blockIdx.y;
-    if (i < n) Y[(int64_t)c * ldy + i] = X[(int64_t)perm[c] * ldx + i];
+    const cd* x = X + (int64_t)perm[c] * ldx;
+    cd* y = Y + (int64_t)c * ldy;
+    const int64_t i0 = (int64_t)blockIdx.x * EW_ROWS + threadIdx.x;
+    cd v[EW_UNR];
+#pragma unroll
+    for (int u = 0; u < EW_UNR; ++u) {
+        const int64_t i = i0 + u * 256;
+        v[u] = i < n ? x[i] : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < EW_UNR; ++u) {
+        const int64_t i = i0 + u * 256;
+        if (i < n) y[i] = v[u];
+    }
 }
 
 // C[row0 + a, a] -= 1 for a in [0, cols)   (the "e" matrix of lobpcg_hyper_impl.jl:493-499)
@@ -1552,8 +1656,8 @@ static int heev_impl(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, c
         hipLaunchKernelGGL(k_gather_cols_real, dim3((n + 255) / 256, n), dim3(256), 0, b->stream, (int64_t)n, Vw,
                            (int64_t)np, d_perm, V, ldv);
     else
-        hipLaunchKernelGGL(k_gather_cols, dim3((n + 255) / 256, n), dim3(256), 0, b->stream, (int64_t)n, Vw, (int64_t)np,
-                           d_perm, V, ldv);
+        hipLaunchKernelGGL(k_gather_cols, dim3((n + EW_ROWS - 1) / EW_ROWS, n), dim3(256), 0, b->stream, (int64_t)n, Vw,
+                           (int64_t)np, d_perm, V, ldv);
     HIPCHK(hipGetLastError());
     CHK(host_wait(b));   // perm (host vector) must outlive the copy
     return 0;
@@ -1613,8 +1717,7 @@ int ew_colnorms(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, do
         return batch_record(std::move(o));
     }
     ProfScope prof_scope(b, PROF_EW, n >= 4096 ? 16.0 * (double)n * m : 0.0);
-    hipLaunchKernelGGL(k_col_reduce, dim3(m), dim3(256), 0, b->stream, 0, n, X, ldx, (const cd*)nullptr, (int64_t)0,
-                       (const double*)nullptr, out_d);
+    EW_LAUNCH_COLS(k_col_reduce, n, m, b->stream, 0, n, X, ldx, (const cd*)nullptr, (int64_t)0, (const double*)nullptr, out_d);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1628,8 +1731,7 @@ int ew_coldots(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, con
         return batch_record(std::move(o));
     }
     ProfScope prof_scope(b, PROF_EW, n >= 4096 ? 32.0 * (double)n * m : 0.0);
-    hipLaunchKernelGGL(k_col_reduce, dim3(m), dim3(256), 0, b->stream, 1, n, X, ldx, Y, ldy, (const double*)nullptr,
-                       out_re_d);
+    EW_LAUNCH_COLS(k_col_reduce, n, m, b->stream, 1, n, X, ldx, Y, ldy, (const double*)nullptr, out_re_d);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1643,8 +1745,7 @@ int ew_coldots_im(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, 
         return batch_record(std::move(o));
     }
     ProfScope prof_scope(b, PROF_EW, n >= 4096 ? 32.0 * (double)n * m : 0.0);
-    hipLaunchKernelGGL(k_col_reduce, dim3(m), dim3(256), 0, b->stream, 4, n, X, ldx, Y, ldy, (const double*)nullptr,
-                       out_im_d);
+    EW_LAUNCH_COLS(k_col_reduce, n, m, b->stream, 4, n, X, ldx, Y, ldy, (const double*)nullptr, out_im_d);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1658,8 +1759,7 @@ int ew_weighted_colsums(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t
         return batch_record(std::move(o));
     }
     ProfScope prof_scope(b, PROF_EW, n >= 4096 ? 16.0 * (double)n * m : 0.0);
-    hipLaunchKernelGGL(k_col_reduce, dim3(m), dim3(256), 0, b->stream, 2, n, X, ldx, (const cd*)nullptr, (int64_t)0,
-                       w_d, out_d);
+    EW_LAUNCH_COLS(k_col_reduce, n, m, b->stream, 2, n, X, ldx, (const cd*)nullptr, (int64_t)0, w_d, out_d);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1697,8 +1797,7 @@ int ew_frob2(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, doubl
         return batch_record(std::move(o));
     }
     ProfScope prof_scope(b, PROF_EW, n >= 4096 ? 16.0 * (double)n * m : 0.0);
-    hipLaunchKernelGGL(k_col_reduce, dim3(m), dim3(256), 0, b->stream, 3, n, X, ldx, (const cd*)nullptr, (int64_t)0,
-                       (const double*)nullptr, out_d);
+    EW_LAUNCH_COLS(k_col_reduce, n, m, b->stream, 3, n, X, ldx, (const cd*)nullptr, (int64_t)0, (const double*)nullptr, out_d);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1714,8 +1813,7 @@ int ew_residual(dftk_mi_basis* b, int64_t n, int m, const cd* AX, int64_t lda, c
         return batch_record(std::move(o));
     }
     ProfScope prof_scope(b, PROF_EW, n >= 4096 ? 48.0 * (double)n * m : 0.0);
-    hipLaunchKernelGGL(k_residual, dim3(m), dim3(256), 0, b->stream, n, AX, lda, X, ldx, lam_d, R, ldr, norms_d, kin,
-                       mean_kin_d, xx_d);
+    EW_LAUNCH_COLS(k_residual, n, m, b->stream, n, AX, lda, X, ldx, lam_d, R, ldr, norms_d, kin, mean_kin_d, xx_d);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1730,8 +1828,7 @@ int ew_tpa(dftk_mi_basis* b, int64_t n, int m, const cd* src, int64_t lds, cd* d
         return batch_record(std::move(o));
     }
     ProfScope prof_scope(b, PROF_EW, n >= 4096 ? 32.0 * (double)n * m : 0.0);
-    hipLaunchKernelGGL(k_tpa, dim3(m), dim3(256), 0, b->stream, n, src, lds, dst, ldd, kin, mean_kin_d, norms_d,
-                       default_shift);
+    EW_LAUNCH_COLS(k_tpa, n, m, b->stream, n, src, lds, dst, ldd, kin, mean_kin_d, norms_d, default_shift);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1744,8 +1841,8 @@ int ew_scale_cols(dftk_mi_basis* b, int64_t n, int m, cd* X, int64_t ldx, const 
         return batch_record(std::move(o));
     }
     ProfScope prof_scope(b, PROF_EW, n >= 4096 ? 32.0 * (double)n * m : 0.0);
-    hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, n, m, X, ldx, s_d,
-                       invert ? 1 : 0);
+    hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((n + EW_ROWS - 1) / EW_ROWS), m), dim3(256), 0, b->stream, n, m, X, ldx,
+                       s_d, invert ? 1 : 0);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1758,7 +1855,7 @@ int ew_copy(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, cd* Y,
         return batch_record(std::move(o));
     }
     ProfScope prof_scope(b, PROF_EW, n >= 4096 ? 32.0 * (double)n * m : 0.0);
-    hipLaunchKernelGGL(k_copy, dim3((unsigned)((n + 255) / 256), m), dim3(256), 0, b->stream, n, m, X, ldx, Y, ldy);
+    hipLaunchKernelGGL(k_copy, dim3((unsigned)((n + EW_ROWS - 1) / EW_ROWS), m), dim3(256), 0, b->stream, n, m, X, ldx, Y, ldy);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1795,7 +1892,7 @@ int ew_gather_cols(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx,
         return batch_record(std::move(o));
     }
     ProfScope prof_scope(b, PROF_EW, n >= 4096 ? 32.0 * (double)n * m : 0.0);
-    hipLaunchKernelGGL(k_gather_cols, dim3((unsigned)((n + 255) / 256), m), dim3(256), 0, b->stream, n, X, ldx,
+    hipLaunchKernelGGL(k_gather_cols, dim3((unsigned)((n + EW_ROWS - 1) / EW_ROWS), m), dim3(256), 0, b->stream, n, X, ldx,
                        perm_d, Y, ldy);
     HIPCHK(hipGetLastError());
     return 0;

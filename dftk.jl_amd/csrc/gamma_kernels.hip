@@ -67,33 +67,72 @@ int gamma_tables_host(int nx, int ny, int nz, int64_t n_G, const int64_t* mappin
 #define GR_SQRT2 1.4142135623730951
 #define GR_ISQRT2 0.70710678118654752
 
-__global__ void k_gr_compress(int64_t nh, const int* __restrict__ g, const int* __restrict__ mg,
-                              const cd* __restrict__ X, int64_t ldx, cd* __restrict__ H, int64_t ldh) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nh) return;
+// The format conversions are pure HBM streams (one 16-byte element per pair member): every thread handles GR_UNR pairs and
+// issues all of its loads before the first use -- one element per thread kept 8-32 KB per CU in flight and reached
+// 1.3-2.2 TB/s (tools/ew_bench.py).  A workgroup of 256 threads takes GR_UNR * 256 consecutive pairs of one column.
+#define GR_UNR 4
+#define GR_ROWS (256 * GR_UNR)
+__global__ __launch_bounds__(256) void k_gr_compress(int64_t nh, const int* __restrict__ g, const int* __restrict__ mg,
+                                                     const cd* __restrict__ X, int64_t ldx, cd* __restrict__ H, int64_t ldh) {
+    const int64_t j0 = (int64_t)blockIdx.x * GR_ROWS + threadIdx.x;
     const cd* x = X + (int64_t)blockIdx.y * ldx;
-    const cd a = x[g[j]], b = x[mg[j]];
-    const double s = j ? GR_ISQRT2 : 0.5;            // sqrt(2) * 1/2 (symmetric part), row 0: 1/2 (a == b)
-    H[j + (int64_t)blockIdx.y * ldh] = make_double2(s * (a.x + b.x), s * (a.y - b.y));
+    cd* h = H + (int64_t)blockIdx.y * ldh;
+    int ig[GR_UNR], im[GR_UNR];
+    cd a[GR_UNR], b[GR_UNR];
+#pragma unroll
+    for (int u = 0; u < GR_UNR; ++u) {
+        const int64_t j = j0 + u * 256;
+        ig[u] = j < nh ? g[j] : 0;
+        im[u] = j < nh ? mg[j] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < GR_UNR; ++u) {
+        a[u] = x[ig[u]];
+        b[u] = x[im[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < GR_UNR; ++u) {
+        const int64_t j = j0 + u * 256;
+        const double s = j ? GR_ISQRT2 : 0.5;            // sqrt(2) * 1/2 (symmetric part), row 0: 1/2 (a == b)
+        if (j < nh) h[j] = make_double2(s * (a[u].x + b[u].x), s * (a[u].y - b[u].y));
+    }
 }
 
 // compress with the phase alignment of the LOBPCG entry: every column is first rotated by exp(-i phi),
 // exp(2 i phi) = s / |s|, s = sum_G x(G) x(-G) -- the global phase that maximises its real-symmetric part (a real field
 // times any phase becomes +- itself: nothing is lost, e.g. when orbitals of a complex iteration are handed over).  A
 // column that is already real-symmetric has s > 0, phi = 0 exactly, and is compressed bit for bit as by k_gr_compress.
-// One workgroup per column: reduction pass over the pairs, then the write pass.
-__global__ __launch_bounds__(256) void k_gr_compress_aligned(int64_t nh, const int* __restrict__ g,
-                                                             const int* __restrict__ mg, const cd* __restrict__ X,
-                                                             int64_t ldx, cd* __restrict__ H, int64_t ldh) {
-    __shared__ double sh[2][4];
+// One workgroup of 1024 threads per column: reduction pass over the pairs, then the write pass.
+#define GRA_NT 1024
+__global__ __launch_bounds__(GRA_NT) void k_gr_compress_aligned(int64_t nh, const int* __restrict__ g,
+                                                                const int* __restrict__ mg, const cd* __restrict__ X,
+                                                                int64_t ldx, cd* __restrict__ H, int64_t ldh) {
+    __shared__ double sh[2][GRA_NT / 64];
     __shared__ double s_cs[2];
     const cd* x = X + (int64_t)blockIdx.x * ldx;
+    cd* h = H + (int64_t)blockIdx.x * ldh;
     double sr = 0.0, si = 0.0;
-    for (int64_t j = threadIdx.x; j < nh; j += 256) {
-        const cd a = x[g[j]], b = x[mg[j]];
-        const double w = j ? 2.0 : 1.0;
-        sr += w * (a.x * b.x - a.y * b.y);
-        si += w * (a.x * b.y + a.y * b.x);
+    for (int64_t j0 = threadIdx.x; j0 < nh; j0 += GRA_NT * GR_UNR) {
+        int ig[GR_UNR], im[GR_UNR];
+        cd a[GR_UNR], b[GR_UNR];
+#pragma unroll
+        for (int u = 0; u < GR_UNR; ++u) {
+            const int64_t j = j0 + u * GRA_NT;
+            ig[u] = j < nh ? g[j] : 0;
+            im[u] = j < nh ? mg[j] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < GR_UNR; ++u) {
+            a[u] = x[ig[u]];
+            b[u] = x[im[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < GR_UNR; ++u) {
+            const int64_t j = j0 + u * GRA_NT;
+            const double w = j < nh ? (j ? 2.0 : 1.0) : 0.0;
+            sr += w * (a[u].x * b[u].x - a[u].y * b[u].y);
+            si += w * (a[u].x * b[u].y + a[u].y * b[u].x);
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -106,7 +145,12 @@ __global__ __launch_bounds__(256) void k_gr_compress_aligned(int64_t nh, const i
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const double tr = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3], ti = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+        double tr = 0.0, ti = 0.0;
+#pragma unroll
+        for (int w = 0; w < GRA_NT / 64; ++w) {
+            tr += sh[0][w];
+            ti += sh[1][w];
+        }
         double c = 1.0, sn = 0.0;
         if ((tr != 0.0 || ti != 0.0) && isfinite(tr) && isfinite(ti) && !(ti == 0.0 && tr > 0.0)) {
             const double phi = 0.5 * atan2(ti, tr);
@@ -118,70 +162,146 @@ __global__ __launch_bounds__(256) void k_gr_compress_aligned(int64_t nh, const i
     }
     __syncthreads();
     const double c = s_cs[0], sn = s_cs[1];
-    for (int64_t j = threadIdx.x; j < nh; j += 256) {
-        cd a = x[g[j]], b = x[mg[j]];
-        if (sn != 0.0 || c != 1.0) {      // x * exp(-i phi)
-            a = make_double2(a.x * c + a.y * sn, a.y * c - a.x * sn);
-            b = make_double2(b.x * c + b.y * sn, b.y * c - b.x * sn);
+    const bool rot = sn != 0.0 || c != 1.0;
+    for (int64_t j0 = threadIdx.x; j0 < nh; j0 += GRA_NT * GR_UNR) {
+        int ig[GR_UNR], im[GR_UNR];
+        cd a[GR_UNR], b[GR_UNR];
+#pragma unroll
+        for (int u = 0; u < GR_UNR; ++u) {
+            const int64_t j = j0 + u * GRA_NT;
+            ig[u] = j < nh ? g[j] : 0;
+            im[u] = j < nh ? mg[j] : 0;
         }
-        const double s = j ? GR_ISQRT2 : 0.5;
-        H[j + (int64_t)blockIdx.x * ldh] = make_double2(s * (a.x + b.x), s * (a.y - b.y));
+#pragma unroll
+        for (int u = 0; u < GR_UNR; ++u) {
+            a[u] = x[ig[u]];
+            b[u] = x[im[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < GR_UNR; ++u) {
+            const int64_t j = j0 + u * GRA_NT;
+            cd aa = a[u], bb = b[u];
+            if (rot) {      // x * exp(-i phi)
+                aa = make_double2(aa.x * c + aa.y * sn, aa.y * c - aa.x * sn);
+                bb = make_double2(bb.x * c + bb.y * sn, bb.y * c - bb.x * sn);
+            }
+            const double s = j ? GR_ISQRT2 : 0.5;
+            if (j < nh) h[j] = make_double2(s * (aa.x + bb.x), s * (aa.y - bb.y));
+        }
     }
 }
 
-__global__ void k_gr_expand(int64_t nh, const int* __restrict__ g, const int* __restrict__ mg,
-                            const cd* __restrict__ H, int64_t ldh, cd* __restrict__ X, int64_t ldx) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nh) return;
+__global__ __launch_bounds__(256) void k_gr_expand(int64_t nh, const int* __restrict__ g, const int* __restrict__ mg,
+                                                   const cd* __restrict__ H, int64_t ldh, cd* __restrict__ X, int64_t ldx) {
+    const int64_t j0 = (int64_t)blockIdx.x * GR_ROWS + threadIdx.x;
     cd* x = X + (int64_t)blockIdx.y * ldx;
-    const cd h = H[j + (int64_t)blockIdx.y * ldh];
-    if (j == 0) {
-        x[g[0]] = make_double2(h.x, 0.0);
-        return;
+    const cd* hc = H + (int64_t)blockIdx.y * ldh;
+    int ig[GR_UNR], im[GR_UNR];
+    cd h[GR_UNR];
+#pragma unroll
+    for (int u = 0; u < GR_UNR; ++u) {
+        const int64_t j = j0 + u * 256;
+        const bool in = j < nh;
+        ig[u] = in ? g[j] : 0;
+        im[u] = in ? mg[j] : 0;
+        h[u] = in ? hc[j] : make_double2(0.0, 0.0);
     }
-    x[g[j]] = make_double2(GR_ISQRT2 * h.x, GR_ISQRT2 * h.y);
-    x[mg[j]] = make_double2(GR_ISQRT2 * h.x, -GR_ISQRT2 * h.y);
+#pragma unroll
+    for (int u = 0; u < GR_UNR; ++u) {
+        const int64_t j = j0 + u * 256;
+        if (j >= nh) continue;
+        if (j == 0) {
+            x[ig[u]] = make_double2(h[u].x, 0.0);
+            continue;
+        }
+        x[ig[u]] = make_double2(GR_ISQRT2 * h[u].x, GR_ISQRT2 * h[u].y);
+        x[im[u]] = make_double2(GR_ISQRT2 * h[u].x, -GR_ISQRT2 * h[u].y);
+    }
 }
 
 // Z[:, p] = full-sphere image of (a + i b), a = H[:, 2p], b = H[:, 2p + 1] (b = 0 past the last band)
-__global__ void k_gr_pack(int64_t nh, int nb, const int* __restrict__ g, const int* __restrict__ mg,
-                          const cd* __restrict__ H, int64_t ldh, cd* __restrict__ Z, int64_t ldz) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nh) return;
+__global__ __launch_bounds__(256) void k_gr_pack(int64_t nh, int nb, const int* __restrict__ g, const int* __restrict__ mg,
+                                                 const cd* __restrict__ H, int64_t ldh, cd* __restrict__ Z, int64_t ldz) {
+    const int64_t j0 = (int64_t)blockIdx.x * GR_ROWS + threadIdx.x;
     const int p = blockIdx.y;
-    const cd a = H[j + (int64_t)(2 * p) * ldh];
-    const cd b = (2 * p + 1 < nb) ? H[j + (int64_t)(2 * p + 1) * ldh] : make_double2(0.0, 0.0);
+    const bool has_b = 2 * p + 1 < nb;
+    const cd* ha = H + (int64_t)(2 * p) * ldh;
+    const cd* hb = H + (int64_t)(has_b ? 2 * p + 1 : 2 * p) * ldh;
     cd* z = Z + (int64_t)p * ldz;
-    if (j == 0) {
-        z[g[0]] = make_double2(a.x, b.x);
-        return;
+    int ig[GR_UNR], im[GR_UNR];
+    cd a[GR_UNR], b[GR_UNR];
+#pragma unroll
+    for (int u = 0; u < GR_UNR; ++u) {
+        const int64_t j = j0 + u * 256;
+        const bool in = j < nh;
+        ig[u] = in ? g[j] : 0;
+        im[u] = in ? mg[j] : 0;
+        a[u] = in ? ha[j] : make_double2(0.0, 0.0);
+        b[u] = (in && has_b) ? hb[j] : make_double2(0.0, 0.0);
     }
     const double s = GR_ISQRT2;
-    z[g[j]] = make_double2(s * (a.x - b.y), s * (a.y + b.x));       // a + i b
-    z[mg[j]] = make_double2(s * (a.x + b.y), s * (b.x - a.y));      // conj(a) + i conj(b)
+#pragma unroll
+    for (int u = 0; u < GR_UNR; ++u) {
+        const int64_t j = j0 + u * 256;
+        if (j >= nh) continue;
+        if (j == 0) {
+            z[ig[u]] = make_double2(a[u].x, b[u].x);
+            continue;
+        }
+        z[ig[u]] = make_double2(s * (a[u].x - b[u].y), s * (a[u].y + b[u].x));       // a + i b
+        z[im[u]] = make_double2(s * (a[u].x + b[u].y), s * (b[u].x - a[u].y));      // conj(a) + i conj(b)
+    }
 }
 
 // inverse of k_gr_pack on the pipeline's output W: A = (W(G) + conj W(-G)) / 2, B = (W(G) - conj W(-G)) / (2i)
-__global__ void k_gr_unpack(int64_t nh, int nb, const int* __restrict__ g, const int* __restrict__ mg,
-                            const cd* __restrict__ W, int64_t ldw, cd* __restrict__ H, int64_t ldh) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nh) return;
+__global__ __launch_bounds__(256) void k_gr_unpack(int64_t nh, int nb, const int* __restrict__ g, const int* __restrict__ mg,
+                                                   const cd* __restrict__ W, int64_t ldw, cd* __restrict__ H, int64_t ldh) {
+    const int64_t j0 = (int64_t)blockIdx.x * GR_ROWS + threadIdx.x;
     const int p = blockIdx.y;
     const cd* w = W + (int64_t)p * ldw;
-    const cd wg = w[g[j]], wm = w[mg[j]];
-    const double s = j ? GR_ISQRT2 : 0.5;            // sqrt(2) / 2, row 0: 1 / 2 (wg == wm)
-    H[j + (int64_t)(2 * p) * ldh] = make_double2(s * (wg.x + wm.x), s * (wg.y - wm.y));
-    if (2 * p + 1 < nb) H[j + (int64_t)(2 * p + 1) * ldh] = make_double2(s * (wg.y + wm.y), s * (wm.x - wg.x));
+    int ig[GR_UNR], im[GR_UNR];
+    cd wg[GR_UNR], wm[GR_UNR];
+#pragma unroll
+    for (int u = 0; u < GR_UNR; ++u) {
+        const int64_t j = j0 + u * 256;
+        ig[u] = j < nh ? g[j] : 0;
+        im[u] = j < nh ? mg[j] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < GR_UNR; ++u) {
+        wg[u] = w[ig[u]];
+        wm[u] = w[im[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < GR_UNR; ++u) {
+        const int64_t j = j0 + u * 256;
+        if (j >= nh) continue;
+        const double s = j ? GR_ISQRT2 : 0.5;            // sqrt(2) / 2, row 0: 1 / 2 (wg == wm)
+        H[j + (int64_t)(2 * p) * ldh] = make_double2(s * (wg[u].x + wm[u].x), s * (wg[u].y - wm[u].y));
+        if (2 * p + 1 < nb) H[j + (int64_t)(2 * p + 1) * ldh] = make_double2(s * (wg[u].y + wm[u].y), s * (wm[u].x - wg[u].x));
+    }
 }
 
 // Z[:, p] = X[:, 2p] + i X[:, 2p + 1] on the FULL sphere (density of real-symmetric orbitals: two bands per transform)
-__global__ void k_gr_pack_full(int64_t n, int nb, const cd* __restrict__ X, int64_t ldx, cd* __restrict__ Z, int64_t ldz) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+__global__ __launch_bounds__(256) void k_gr_pack_full(int64_t n, int nb, const cd* __restrict__ X, int64_t ldx,
+                                                      cd* __restrict__ Z, int64_t ldz) {
+    const int64_t i0 = (int64_t)blockIdx.x * GR_ROWS + threadIdx.x;
     const int p = blockIdx.y;
-    const cd a = X[i + (int64_t)(2 * p) * ldx];
-    const cd b = (2 * p + 1 < nb) ? X[i + (int64_t)(2 * p + 1) * ldx] : make_double2(0.0, 0.0);
-    Z[i + (int64_t)p * ldz] = make_double2(a.x - b.y, a.y + b.x);
+    const bool has_b = 2 * p + 1 < nb;
+    const cd* xa = X + (int64_t)(2 * p) * ldx;
+    const cd* xb = X + (int64_t)(has_b ? 2 * p + 1 : 2 * p) * ldx;
+    cd a[GR_UNR], b[GR_UNR];
+#pragma unroll
+    for (int u = 0; u < GR_UNR; ++u) {
+        const int64_t i = i0 + u * 256;
+        a[u] = i < n ? xa[i] : make_double2(0.0, 0.0);
+        b[u] = (i < n && has_b) ? xb[i] : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < GR_UNR; ++u) {
+        const int64_t i = i0 + u * 256;
+        if (i < n) Z[i + (int64_t)p * ldz] = make_double2(a[u].x - b[u].y, a[u].y + b[u].x);
+    }
 }
 
 // Ph[j, c] = s_j P[g_j, c]; out[0] = max |P[mg_j, c] - conj(P[g_j, c])|, out[1] = max |P| (bit patterns of
@@ -217,6 +337,8 @@ __global__ __launch_bounds__(256) void k_gr_gather_P(int64_t nh, const int* __re
 }
 
 static dim3 gr_grid(int64_t rows, int cols) { return dim3((unsigned)((rows + 255) / 256), (unsigned)cols); }
+// (the kernels that take GR_UNR pairs per thread)
+static dim3 gr_grid_unr(int64_t rows, int cols) { return dim3((unsigned)((rows + GR_ROWS - 1) / GR_ROWS), (unsigned)cols); }
 
 int gamma_enable(dftk_mi_kblock* kb, int on) {
     dftk_mi_basis* b = kb->basis;
@@ -300,7 +422,7 @@ int gamma_compress(dftk_mi_kblock* kb, int m, const cd* X, int64_t ldx, cd* H, i
     if (m <= 0) return 0;
     GammaReal* gr = kb->gr;
     ProfScope prof_scope(kb->basis, PROF_EW, 48.0 * (double)gr->n_half * m);
-    hipLaunchKernelGGL(k_gr_compress, gr_grid(gr->n_half, m), dim3(256), 0, kb->basis->stream, gr->n_half, gr->d_g,
+    hipLaunchKernelGGL(k_gr_compress, gr_grid_unr(gr->n_half, m), dim3(256), 0, kb->basis->stream, gr->n_half, gr->d_g,
                        gr->d_mg, X, ldx, H, ldh);
     HIPCHK(hipGetLastError());
     return 0;
@@ -310,7 +432,7 @@ int gamma_compress_aligned(dftk_mi_kblock* kb, int m, const cd* X, int64_t ldx, 
     if (m <= 0) return 0;
     GammaReal* gr = kb->gr;
     ProfScope prof_scope(kb->basis, PROF_EW, 64.0 * (double)gr->n_half * m);
-    hipLaunchKernelGGL(k_gr_compress_aligned, dim3(m), dim3(256), 0, kb->basis->stream, gr->n_half, gr->d_g, gr->d_mg, X, ldx,
+    hipLaunchKernelGGL(k_gr_compress_aligned, dim3(m), dim3(GRA_NT), 0, kb->basis->stream, gr->n_half, gr->d_g, gr->d_mg, X, ldx,
                        H, ldh);
     HIPCHK(hipGetLastError());
     return 0;
@@ -320,7 +442,7 @@ int gamma_expand(dftk_mi_kblock* kb, int m, const cd* H, int64_t ldh, cd* X, int
     if (m <= 0) return 0;
     GammaReal* gr = kb->gr;
     ProfScope prof_scope(kb->basis, PROF_EW, 48.0 * (double)gr->n_half * m);
-    hipLaunchKernelGGL(k_gr_expand, gr_grid(gr->n_half, m), dim3(256), 0, kb->basis->stream, gr->n_half, gr->d_g,
+    hipLaunchKernelGGL(k_gr_expand, gr_grid_unr(gr->n_half, m), dim3(256), 0, kb->basis->stream, gr->n_half, gr->d_g,
                        gr->d_mg, H, ldh, X, ldx);
     HIPCHK(hipGetLastError());
     return 0;
@@ -370,7 +492,7 @@ int gamma_pack_pairs(dftk_mi_kblock* kb, int nb, const cd* H, int64_t ldh, cd* Z
     if (nb <= 0) return 0;
     GammaReal* gr = kb->gr;
     ProfScope prof_scope(kb->basis, PROF_EW, 32.0 * (double)gr->n_half * nb);
-    hipLaunchKernelGGL(k_gr_pack, gr_grid(gr->n_half, (nb + 1) / 2), dim3(256), 0, kb->basis->stream, gr->n_half, nb,
+    hipLaunchKernelGGL(k_gr_pack, gr_grid_unr(gr->n_half, (nb + 1) / 2), dim3(256), 0, kb->basis->stream, gr->n_half, nb,
                        gr->d_g, gr->d_mg, H, ldh, Z, ldz);
     HIPCHK(hipGetLastError());
     return 0;
@@ -379,7 +501,7 @@ int gamma_unpack_pairs(dftk_mi_kblock* kb, int nb, const cd* W, int64_t ldw, cd*
     if (nb <= 0) return 0;
     GammaReal* gr = kb->gr;
     ProfScope prof_scope(kb->basis, PROF_EW, 32.0 * (double)gr->n_half * nb);
-    hipLaunchKernelGGL(k_gr_unpack, gr_grid(gr->n_half, (nb + 1) / 2), dim3(256), 0, kb->basis->stream, gr->n_half, nb,
+    hipLaunchKernelGGL(k_gr_unpack, gr_grid_unr(gr->n_half, (nb + 1) / 2), dim3(256), 0, kb->basis->stream, gr->n_half, nb,
                        gr->d_g, gr->d_mg, W, ldw, H, ldh);
     HIPCHK(hipGetLastError());
     return 0;
@@ -387,7 +509,7 @@ int gamma_unpack_pairs(dftk_mi_kblock* kb, int nb, const cd* W, int64_t ldw, cd*
 int gamma_pack_full(dftk_mi_kblock* kb, int nb, const cd* X, int64_t ldx, cd* Z, int64_t ldz) {
     if (nb <= 0) return 0;
     ProfScope prof_scope(kb->basis, PROF_EW, 32.0 * (double)kb->n_G * nb);
-    hipLaunchKernelGGL(k_gr_pack_full, gr_grid(kb->n_G, (nb + 1) / 2), dim3(256), 0, kb->basis->stream, kb->n_G, nb, X,
+    hipLaunchKernelGGL(k_gr_pack_full, gr_grid_unr(kb->n_G, (nb + 1) / 2), dim3(256), 0, kb->basis->stream, kb->n_G, nb, X,
                        ldx, Z, ldz);
     HIPCHK(hipGetLastError());
     return 0;

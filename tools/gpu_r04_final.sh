@@ -53,3 +53,6 @@ timeout 300 python tools/heev_bench.py real 503 1006 1509 2>&1 | grep -v amdgpu 
 timeout 300 python tools/gemm_real_bench.py 264859 503 struct 2>&1 | grep -v amdgpu > $O/r04_gemm_struct_bench.txt
 timeout 300 python tools/kpoints_share_profile.py 8 > $O/r04_kpoints_share_step_N8.txt 2>/dev/null
 cat $O/r04_late_step_cfg5.txt | head -16; cat $O/r04_heev_bench.txt
+timeout 300 python tools/potrf_bench.py 2>&1 | grep -v amdgpu > $O/r04_potrf_bench.txt
+timeout 300 python tools/ew_bench.py 2>&1 | grep -v amdgpu > $O/r04_ew_bench.txt
+cat $O/r04_potrf_bench.txt $O/r04_ew_bench.txt

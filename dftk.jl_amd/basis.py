@@ -126,8 +126,12 @@ class Kpoint:
         # Gamma point: LOBPCG iterates real-symmetric orbitals psi(-G) = conj(psi(G)) in the library's half-sphere
         # format (dftk_mi_kblock_set_gamma_real: real matrix products over half the rows, two bands per FFT pass).
         # An extension over the reference (no Gamma special case there); eigenvalues / density / energies unchanged.
+        # Automatic (basis.gamma_real None) only where it pays: a Gamma point inside a lock-step batched k-mesh (kbatch)
+        # stays a general complex block and iterates WITH the other k-blocks -- on its own it would be a separate,
+        # launch-latency-bound LOBPCG call per SCF step (Al 12^3 mesh: half of the diagonalisation time for 1 of 72 k-points).
         self.gamma_real = False
-        if (basis.gamma_real is not False and self.handle and not self.coordinate.any()):
+        auto_ok = basis.gamma_real is True or (basis.gamma_real is None and not getattr(basis, "kbatch", False))
+        if (auto_ok and self.handle and not self.coordinate.any()):
             st = basis.lib.dftk_mi_kblock_set_gamma_real(self.handle, 1)
             if st == 0:
                 self.gamma_real = True

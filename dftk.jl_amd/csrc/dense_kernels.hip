@@ -10,6 +10,7 @@
 #include "common.h"
 #include "batch.h"
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <numeric>
 #include <cstring>
@@ -1394,7 +1395,26 @@ int dense_potrf_trtri(dftk_mi_basis* b, int n, cd* A, int64_t lda, cd* invR, int
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) == hipSuccess &&
                   hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_trtri_coop<double>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 70 * 1024) == hipSuccess;
-    const bool coop = coop_ok == 1 && n <= 512 && n > 32;
+    bool coop = coop_ok == 1 && n <= 512 && n > 32;
+    // Every workgroup of the cooperative kernel needs a CU to itself (LDS) and spins until the other block columns of ITS
+    // launch have published: launches of many host threads (stream lanes) must not fill the device with workgroups that
+    // wait for siblings that cannot become resident.  The call is synchronous (it ends with a host fetch), so the
+    // workgroups in flight over all streams of the process are counted exactly; beyond half the device the blocked path runs.
+    static std::atomic<int> coop_wgs_in_flight{0};
+    struct CoopBudget {
+        std::atomic<int>& c;
+        int n = 0;
+        ~CoopBudget() { c.fetch_sub(n); }
+    } coop_budget{coop_wgs_in_flight};
+    if (coop) {
+        const int nb = (n + CCB - 1) / CCB;
+        if (coop_wgs_in_flight.fetch_add(nb) + nb > 128) {
+            coop_wgs_in_flight.fetch_sub(nb);
+            coop = false;
+        } else {
+            coop_budget.n = nb;
+        }
+    }
     if (coop) {
         const int nb = (n + CCB - 1) / CCB, np = nb * CCB;
         const size_t need = ((size_t)nb * np * CCB + (size_t)nb * CCB * CCB) * sizeof(cd) + 64 * sizeof(int);

@@ -86,6 +86,7 @@ void* batch_result_slot(BatchCtx* c, size_t bytes, void** host_twin) {
     c->res_off += al;
     return d;
 }
+size_t batch_result_room(BatchCtx* c) { return c->res_cap - c->res_off; }
 int batch_results_fetch(BatchCtx* c) {
     if (c->res_off == 0) return 0;
     HIPCHK(hipMemcpyAsync(c->h_res, c->d_res, c->res_off, hipMemcpyDeviceToHost, c->stream));
@@ -312,6 +313,18 @@ int dev_h2d(dftk_mi_basis* b, void* dst_d, const void* src_h, size_t bytes) {
     }
     HIPCHK(hipMemcpyAsync(dst_d, src_h, bytes, hipMemcpyHostToDevice, b->stream));
     return 0;
+}
+int dev_d2h_async(dftk_mi_basis* b, void* dst_h, const void* src_d, size_t bytes) {
+    if (batching()) {
+        BOp o;
+        o.b = b;
+        o.type = BOP_D2H;
+        o.A = src_d;
+        o.host = dst_h;
+        o.bytes = bytes;
+        return batch_record(std::move(o));
+    }
+    return host_fetch(b, dst_h, src_d, bytes);
 }
 int dev_stream_sync(dftk_mi_basis* b) {
     if (batching()) return batch_sync();

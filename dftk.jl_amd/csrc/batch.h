@@ -80,6 +80,9 @@ int batch_sync();
 // host <-> device traffic of host-driven drivers: recorded inside a fiber of a batched call, plain HIP calls otherwise
 int dev_h2d(dftk_mi_basis* b, void* dst_d, const void* src_h, size_t bytes);
 int dev_d2h_sync(dftk_mi_basis* b, void* dst_h, const void* src_d, size_t bytes);
+// the same without giving up the fiber: inside a batched call dst_h is valid after the fiber's NEXT synchronising call
+// (the copy rides on that round); outside it is a plain synchronous fetch
+int dev_d2h_async(dftk_mi_basis* b, void* dst_h, const void* src_d, size_t bytes);
 int dev_stream_sync(dftk_mi_basis* b);
 
 // batched executors (batch_kernels.hip / fft_kernels.hip); return 0 if the whole group was launched, 1 if the group
@@ -91,6 +94,7 @@ int batch_exec_density(BatchCtx* ctx, hipStream_t stream, std::vector<BOp*>& ops
 // helpers for the executors
 const void* batch_stage(BatchCtx* c, const void* src, size_t bytes);       // host table -> device (pinned ring + async copy)
 void* batch_result_slot(BatchCtx* c, size_t bytes, void** host_twin);      // device slot + pinned host twin for results
+size_t batch_result_room(BatchCtx* c);                                      // bytes of result slots left in this round
 int batch_results_fetch(BatchCtx* c);                                       // enqueue ONE copy of all result slots of the round
 // device scratch of the executors: a bump allocator.  A pointer stays valid until the enclosing BatchScratchScope ends
 // (later operations of the round then reuse the space in stream order) or, without a scope, until the round ends; it is

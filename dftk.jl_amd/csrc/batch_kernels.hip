@@ -840,8 +840,12 @@ int batch_exec_group(BatchCtx* ctx, hipStream_t stream, int type, std::vector<BO
     if (type == BOP_D2H) {
         // validate the WHOLE group before the first slot / fix-up exists: a fall-back to the one-by-one path must not
         // leave fix-ups behind that would overwrite its (correct) host data after the round's synchronisation
-        for (int i = 0; i < n_items; ++i)
+        size_t slots = 0;
+        for (int i = 0; i < n_items; ++i) {
             if (ops[i]->bytes % 4) return 1;
+            slots += (ops[i]->bytes + 255) & ~(size_t)255;
+        }
+        if (slots > batch_result_room(ctx)) return 1;   // (the one-by-one copies need no slots)
         std::vector<CopyItem> items(n_items);
         for (int i = 0; i < n_items; ++i) {
             void* htwin = nullptr;

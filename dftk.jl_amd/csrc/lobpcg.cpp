@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstring>
 #include <numeric>
 #include <random>
@@ -349,6 +350,109 @@ int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol, con
     return 0;
 }
 
+// ortho!(X, Y) of ortho_XY above for SMALL replicated matrices (the Ritz coefficient blocks cP against cX of a k-block with
+// a handful of bands), on the host: on the device the loop is four host synchronisations per LOBPCG iteration -- in the
+// lock-step multi-k driver four scheduling rounds of ~0.2 ms each for a few kiloflops.  Same algorithm, same tolerances,
+// same estimates (normest = max |diag| + ||offdiag||_F as k_normest_upper); only the COMMON path: anything unusual (a
+// column to re-randomise, a failing Cholesky factorisation, more than 10 rounds) returns 0 with X untouched and the caller
+// takes the device path with its fallbacks.  X: n x m, Y: n x ny (column-major, leading dimension n), orthonormal columns.
+typedef std::complex<double> zd;
+int host_ortho_small(std::vector<zd>& Xio, int n, int m, const zd* Y, int ny, double tol) {
+    std::vector<zd> X = Xio, T((size_t)n * m), BYX((size_t)ny * m), O((size_t)m * m), R((size_t)m * m), Ri((size_t)m * m);
+    auto colnorm = [&](int j) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += std::norm(X[i + (size_t)j * n]);
+        return std::sqrt(s);
+    };
+    for (int j = 0; j < m; ++j) {
+        const double f = 1.0 / colnorm(j);
+        for (int i = 0; i < n; ++i) X[i + (size_t)j * n] *= f;
+    }
+    auto normest = [&](const std::vector<zd>& U) {
+        double dmax = 0.0, off = 0.0;
+        for (int j = 0; j < m; ++j)
+            for (int i = 0; i <= j; ++i) {
+                if (i == j)
+                    dmax = std::max(dmax, std::abs(U[i + (size_t)j * m]));
+                else
+                    off += std::norm(U[i + (size_t)j * m]);
+            }
+        return dmax + std::sqrt(off);
+    };
+    for (int niter = 1;; ++niter) {
+        double byx2 = 0.0;
+        for (int j = 0; j < m; ++j)
+            for (int a = 0; a < ny; ++a) {
+                zd s = 0.0;
+                for (int i = 0; i < n; ++i) s += std::conj(Y[i + (size_t)a * n]) * X[i + (size_t)j * n];
+                BYX[a + (size_t)j * ny] = s;
+                byx2 += std::norm(s);
+            }
+        for (int j = 0; j < m; ++j)
+            for (int a = 0; a < ny; ++a) {
+                const zd s = BYX[a + (size_t)j * ny];
+                for (int i = 0; i < n; ++i) X[i + (size_t)j * n] -= Y[i + (size_t)a * n] * s;
+            }
+        for (int j = 0; j < m; ++j) {
+            const double nj = colnorm(j);
+            if (!std::isfinite(nj) || nj <= tol) return 0;   // drop_small! / non-finite: device path
+        }
+        if (std::sqrt(byx2) < tol && niter > 1) break;
+        // ortho!(X): Cholesky-QR passes until eps cond(R)^2 < tol
+        double growth = 1.0;
+        for (int pass = 0;; ++pass) {
+            if (pass >= 30) return 0;
+            for (int j = 0; j < m; ++j)
+                for (int i = 0; i <= j; ++i) {
+                    zd s = 0.0;
+                    for (int r = 0; r < n; ++r) s += std::conj(X[r + (size_t)i * n]) * X[r + (size_t)j * n];
+                    O[i + (size_t)j * m] = (i == j) ? zd(s.real(), 0.0) : s;
+                }
+            // upper Cholesky O = R^H R (column by column)
+            std::fill(R.begin(), R.end(), zd(0.0));
+            for (int j = 0; j < m; ++j) {
+                for (int i = 0; i < j; ++i) {
+                    zd s = O[i + (size_t)j * m];
+                    for (int k = 0; k < i; ++k) s -= std::conj(R[k + (size_t)i * m]) * R[k + (size_t)j * m];
+                    R[i + (size_t)j * m] = s / R[i + (size_t)i * m].real();
+                }
+                double d = O[j + (size_t)j * m].real();
+                for (int k = 0; k < j; ++k) d -= std::norm(R[k + (size_t)j * m]);
+                if (!(d > 0.0) || !std::isfinite(d)) return 0;   // safe_cholesky's shift-and-retry: device path
+                R[j + (size_t)j * m] = std::sqrt(d);
+            }
+            // inverse of the upper triangular R (back substitution, column by column)
+            std::fill(Ri.begin(), Ri.end(), zd(0.0));
+            for (int j = 0; j < m; ++j) {
+                Ri[j + (size_t)j * m] = 1.0 / R[j + (size_t)j * m].real();
+                for (int i = j - 1; i >= 0; --i) {
+                    zd s = 0.0;
+                    for (int k = i + 1; k <= j; ++k) s += R[i + (size_t)k * m] * Ri[k + (size_t)j * m];
+                    Ri[i + (size_t)j * m] = -s / R[i + (size_t)i * m].real();
+                }
+            }
+            const double nR = normest(R), nI = normest(Ri);
+            if (!std::isfinite(nR) || !std::isfinite(nI)) return 0;
+            for (int j = 0; j < m; ++j)
+                for (int i = 0; i < n; ++i) {
+                    zd s = 0.0;
+                    for (int k = 0; k <= j; ++k) s += X[i + (size_t)k * n] * Ri[k + (size_t)j * m];
+                    T[i + (size_t)j * n] = s;
+                }
+            X.swap(T);
+            growth *= nI;
+            const double condR = nR * nI;
+            if (EPS * condR * condR < tol) break;
+        }
+        if (growth * EPS < tol) break;
+        if (niter > 10) return 0;
+    }
+    Xio.swap(X);
+    return 1;
+}
+// largest coefficient block (elements) orthogonalised on the host: 32 KiB per k-block of a batched call
+const size_t HOST_CP_MAX_ELEMS = 2048;
+
 // C = sum_b Yb * coef[rows of b]   (LazyHcat * Matrix, lobpcg_hyper_impl.jl:124-132).  The active
 // blocks are kept adjacent in memory (see the workspace layout in lobpcg_run), so this is ONE GEMM
 // with k = sum of the block widths; the per-block loop only serves non-adjacent callers.
@@ -569,6 +673,8 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
         std::vector<Mat> Ys, AYs;
         int nY = 0;
         cd* cX = V;
+        bool host_cp = false;
+        std::vector<zd> h_cX;
         if (niter > 0) {
             CHK(apply_H(nact, Ra.p, Ra.ld, ARa.p, ARa.ld));
             n_matvec += nact;
@@ -603,6 +709,13 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
             // method (:145-151) and Julia >= 1.12 `syevd`, both without it.  The Jacobi eigenvectors are an
             // accumulated product of unitary rotations (||V'V - I|| ~ 1e-13, tests/test_gpu_kernels.py::test_heev).
             for (int i = 0; i < nact; ++i) full_lam[lo + i] = wv[i];
+            // small coefficient blocks: cP is orthogonalised on the host further down (host_ortho_small); the copy of cX
+            // rides on the residual fetch below
+            host_cp = (size_t)nY * nact <= HOST_CP_MAX_ELEMS;
+            if (host_cp) {
+                h_cX.resize((size_t)nY * nact);
+                CHK(dev_d2h_async(b, h_cX.data(), cX, h_cX.size() * sizeof(cd)));
+            }
             CHK(hcat_mul(c, Ys, cX, nY, nact, nX));
             CHK(hcat_mul(c, AYs, cX, nY, nact, nAX));
         }
@@ -650,10 +763,21 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
         if (niter > 0) {
             // cP = (cX - e)[:, newly_locked:], then orthogonalise against all of cX
             Mat cPm{cP, nY, nY, lenXn};
-            CHK(ew_copy(b, nY, lenXn, cX + (int64_t)newly_locked * nY, nY, cP, nY));
-            CHK(ew_sub_identity_shifted(b, nY, lenXn - newly_locked, cP, nY, 2 * newly_locked));
-            std::vector<Mat> cXs = {Mat{cX, nY, nY, ncx}};
-            {
+            bool cp_done = false;
+            if (host_cp) {
+                // (h_cX is valid: the residual fetch above was a synchronising call)
+                std::vector<zd> h_cP(h_cX.begin() + (size_t)newly_locked * nY, h_cX.begin() + (size_t)(newly_locked + lenXn) * nY);
+                for (int a = 0; a < lenXn - newly_locked; ++a)
+                    if (2 * newly_locked + a < nY) h_cP[(size_t)(2 * newly_locked + a) + (size_t)a * nY] -= 1.0;
+                if (host_ortho_small(h_cP, nY, lenXn, h_cX.data(), ncx, ortho_tol)) {
+                    CHK(h2d(b, cP, h_cP.data(), h_cP.size() * sizeof(cd)));
+                    cp_done = true;
+                }
+            }
+            if (!cp_done) {
+                CHK(ew_copy(b, nY, lenXn, cX + (int64_t)newly_locked * nY, nY, cP, nY));
+                CHK(ew_sub_identity_shifted(b, nY, lenXn - newly_locked, cP, nY, 2 * newly_locked));
+                std::vector<Mat> cXs = {Mat{cX, nY, nY, ncx}};
                 NoComm replicated(c);
                 CHK(ortho_XY(c, cPm, cXs, c.tmpS, ortho_tol));
             }

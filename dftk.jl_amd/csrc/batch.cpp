@@ -418,6 +418,12 @@ int batch_run(dftk_mi_basis* b, std::vector<std::function<int()>>& bodies, std::
             alive = true;
             rec.cur = (int)i;
             swapcontext(&rec.main_ctx, &f.ctx);   // runs until the fiber yields or finishes
+            // a fiber that ended with an error may have left copies queued whose host destinations died with its frames
+            // (dev_d2h_async): nothing it recorded since its last synchronisation is executed
+            if (f.done && f.ret != 0) {
+                f.fifo.clear();
+                f.head = 0;
+            }
         }
         rec.cur = -1;
         c->t_fibers += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count();

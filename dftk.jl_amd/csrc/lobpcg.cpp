@@ -15,6 +15,7 @@
 #include <cmath>
 #include <complex>
 #include <cstring>
+#include <functional>
 #include <numeric>
 #include <random>
 #include <utility>
@@ -23,6 +24,8 @@
 namespace {
 
 const double EPS = 2.220446049250313e-16;
+// ortho!(X, Y) on blocks up to this many elements lets its drop_small! fetch ride on the next Cholesky status (ortho_XY)
+const int64_t DEFER_FETCH_MAX_ELEMS = 1 << 16;
 const cd ONE = {1.0, 0.0}, ZERO = {0.0, 0.0}, MONE = {-1.0, 0.0};
 
 struct Mat {            // column-major view
@@ -139,8 +142,11 @@ int svd_polar(Ctx& c, Mat X, cd* scratch, int64_t scratch_ld);
 
 // ortho!(X): Cholesky-QR until the a-posteriori estimate eps*cond(R)^2 < tol.
 // tmp must hold rows x cols elements (leading dimension tmp_ld, default rows).
+// `hook` (optional): called once, right after the first Cholesky factorisation has come back (the first host
+// synchronisation of the call) and before X is touched; a non-zero result is handed to the caller in *hook_out and the call
+// returns at once with X unchanged (ortho_XY lets a fetch of its own ride on that synchronisation).
 int ortho_X(Ctx& c, Mat X, cd* tmp, double tol, int* nchol_total_out, double* growth_out, bool allow_svd = true,
-            int64_t tmp_ld = 0, bool force_svd = false) {
+            int64_t tmp_ld = 0, bool force_svd = false, const std::function<int()>* hook = nullptr, int* hook_out = nullptr) {
     double growth = 1.0;
     int nchol_total = 0;
     const int m = X.cols;
@@ -164,6 +170,15 @@ int ortho_X(Ctx& c, Mat X, cd* tmp, double tol, int* nchol_total_out, double* gr
         int nchol = 10000;
         double nR = 0, nI = 0;
         if (!force_svd) CHK(safe_cholesky(c, m, &nchol, &nR, &nI));
+        if (pass == 0 && hook) {
+            const int hr = (*hook)();
+            if (hr != 0) {
+                *hook_out = hr;
+                *growth_out = 1.0;
+                *nchol_total_out = 0;
+                return 0;
+            }
+        }
         nchol_total += nchol;
         if (nchol > 10) {
             if (!allow_svd) {
@@ -300,19 +315,56 @@ int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol, con
         CHK(ew_colnorms(c.b, X.rows, X.cols, X.p, X.ld, c.d_a));
         CHK(c.reduce_norms(c.d_a, X.cols));
         const bool one_fetch = c.dstride > 0 && c.d_b == c.d_a + c.dstride && X.cols <= c.dstride;
+        // Small blocks (the k-point workloads): the fetch does not get a synchronisation of its own -- it rides on the first
+        // Cholesky status of the ortho!(X) that follows, which runs ahead speculatively (X is not touched before that status
+        // is back).  In the common case (nothing to drop, not converged yet) that is one scheduling round less; if a column
+        // has to be re-randomised or the loop is over, the speculative Gram matrix + factorisation are thrown away (a few
+        // kiloflops here; for the n_G x 503 blocks of the large cells they would be milliseconds, so those keep the fetch).
+        const bool defer = one_fetch && (int64_t)X.rows * X.cols <= DEFER_FETCH_MAX_ELEMS;
+        std::vector<double> hb;     // norms [0, cols) and (one_fetch) column sums of |BYX|^2 at [dstride, dstride + cols)
         if (one_fetch) {
             CHK(ew_frob2(c.b, ny, X.cols, c.BYX, ny, c.d_b));
-            CHK(d2h(c, c.d_a, c.dstride + X.cols));
+            hb.resize(c.dstride + X.cols);
+            if (defer)
+                CHK(dev_d2h_async(c.b, hb.data(), c.d_a, hb.size() * sizeof(double)));
+            else
+                CHK(d2h_sync(c.b, hb.data(), c.d_a, hb.size() * sizeof(double)));
         } else {
-            CHK(d2h(c, c.d_a, X.cols));
+            hb.resize(X.cols);
+            CHK(d2h_sync(c.b, hb.data(), c.d_a, hb.size() * sizeof(double)));
         }
         double byx2 = 0.0;
-        if (one_fetch)
-            for (int j = 0; j < X.cols; ++j) byx2 += c.h[c.dstride + j];
         std::vector<int> dropped;
-        for (int j = 0; j < X.cols; ++j) {
-            if (!std::isfinite(c.h[j])) return DFTK_MI_NUM_NONFINITE;
-            if (c.h[j] <= tol) dropped.push_back(j);
+        bool nonfinite = false;
+        auto evaluate = [&]() {
+            byx2 = 0.0;
+            dropped.clear();
+            if (one_fetch)
+                for (int j = 0; j < X.cols; ++j) byx2 += hb[c.dstride + j];
+            for (int j = 0; j < X.cols; ++j) {
+                if (!std::isfinite(hb[j])) nonfinite = true;
+                if (hb[j] <= tol) dropped.push_back(j);
+            }
+        };
+        bool speculated = false;      // ortho!(X) of this round has already run (behind the deferred fetch)
+        int ninner = 0;
+        double growth = 1.0;
+        if (defer) {
+            const std::function<int()> hook = [&]() -> int {
+                evaluate();
+                if (nonfinite) return 3;
+                if (!dropped.empty()) return 2;
+                if (std::sqrt(byx2) < tol && niter > 1) return 1;
+                return 0;
+            };
+            int hr = 0;
+            CHK(ortho_X(c, X, tmp, tol, &ninner, &growth, true, 0, false, &hook, &hr));
+            if (hr == 3) return DFTK_MI_NUM_NONFINITE;
+            if (hr == 1) break;
+            speculated = hr == 0;     // (hr == 2: columns to drop -- handled below, then ortho!(X) runs as usual)
+        } else {
+            evaluate();
+            if (nonfinite) return DFTK_MI_NUM_NONFINITE;
         }
         for (int j : dropped) {
             CHK(randomize_column(c, X, j));
@@ -334,10 +386,10 @@ int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol, con
             }
         }
         if (!one_fetch) CHK(frob2(c, Mat{c.BYX, ny, ny, X.cols}, &byx2));
-        if (std::sqrt(byx2) < tol && niter > 1) break;
-        int ninner;
-        double growth;
-        CHK(ortho_X(c, X, tmp, tol, &ninner, &growth));
+        if (!speculated) {
+            if (std::sqrt(byx2) < tol && niter > 1) break;
+            CHK(ortho_X(c, X, tmp, tol, &ninner, &growth));
+        }
         if (growth * EPS < tol) break;
         if (niter > 10) {
             // "Ortho(X, Y) is failing badly, falling back to SVD" (:307-314): X = U V' and return

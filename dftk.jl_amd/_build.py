@@ -119,6 +119,29 @@ def build_abi_check(force: bool = False) -> str:
     return ABI_CHECK_BIN
 
 
+HOST_CHECK_SRC = os.path.join(os.path.dirname(HERE), "tools", "host_ortho_check.cpp")
+HOST_CHECK_BIN = os.path.join(os.path.dirname(HERE), "tools", "bin", "host_ortho_check")
+
+
+def build_host_ortho_check(force: bool = False) -> str:
+    """tools/host_ortho_check.cpp -> tools/bin/host_ortho_check: the host-only check of the LOBPCG driver's
+    ``host_ortho_small`` (the translation unit includes csrc/lobpcg.cpp -- the function sits in its anonymous namespace --
+    and links the rest from the in-tree library).  Runs without a GPU."""
+    build()
+    lobpcg_src = os.path.join(CSRC, "lobpcg.cpp")
+    src_time = max(os.path.getmtime(p) for p in (HOST_CHECK_SRC, LIBPATH, lobpcg_src))
+    if not force and os.path.exists(HOST_CHECK_BIN) and os.path.getmtime(HOST_CHECK_BIN) >= src_time:
+        return HOST_CHECK_BIN
+    os.makedirs(os.path.dirname(HOST_CHECK_BIN), exist_ok=True)
+    cmd = [shutil.which("hipcc") or "/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-x", "hip", "--offload-arch=gfx950", "-I", CSRC, HOST_CHECK_SRC, "-o", HOST_CHECK_BIN,
+           "-L", LIBDIR, "-ldftk_mi355x", "-Wl,-rpath,$ORIGIN/../../dftk.jl_amd/lib"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed on tools/host_ortho_check.cpp:\n" + res.stdout + res.stderr)
+    return HOST_CHECK_BIN
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
     print(build_abi_check(force=True))
+    print(build_host_ortho_check(force=True))

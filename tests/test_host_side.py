@@ -1161,6 +1161,22 @@ def test_header_is_plain_c_and_the_c_consumer_builds_and_fails_loudly_without_a_
         assert "no CPU fallback" in res.stderr
 
 
+def test_host_side_orthogonalisation_of_small_ritz_coefficient_blocks():
+    """``host_ortho_small`` of csrc/lobpcg.cpp -- ortho!(X, Y) (lobpcg_hyper_impl.jl:271-323) on the HOST for the Ritz
+    coefficient blocks ``cP = cX - e`` of small k-blocks (four scheduling rounds fewer per iteration of the lock-step
+    driver) -- through tools/host_ortho_check.cpp, which includes the driver's translation unit and runs without a
+    GPU: X'X = I, Y'X = 0 and span((1 - Y Y') X_in) kept to round-off for complex / real blocks shaped like the
+    driver's; a column inside span(Y) (``drop_small!``) and linearly dependent columns (Cholesky breakdown) are
+    DECLINED with X untouched, i.e. handed to the device path and its fallbacks."""
+    import subprocess
+    from dftk_jl_amd import _build
+    exe = _build.build_host_ortho_check()
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, (res.returncode, res.stdout[-3000:], res.stderr[-2000:])
+    assert "host_ortho_check OK" in res.stdout and "FAILED" not in res.stdout
+    assert res.stdout.count("done=1") == 7 and res.stdout.count("done=0") == 2
+
+
 def test_memory_statistics_and_plan_for_the_literal_4096_electron_cell():
     """``estimate_memory_usage`` (src/memory_usage.jl:35-87: psi_k, P_k, rho bytes and the 1 P + 2 psi + 6 psi_k + 12 rho
     peak) and the per-GPU plan of the plane-wave-sharded Gamma block: the headline 1000-electron cell fits one

@@ -1161,6 +1161,55 @@ def test_header_is_plain_c_and_the_c_consumer_builds_and_fails_loudly_without_a_
         assert "no CPU fallback" in res.stderr
 
 
+@pytest.mark.parametrize("n,real", [(33, False), (100, True), (259, False), (503, True), (512, False)])
+def test_block_recurrences_of_the_cooperative_cholesky_and_inverse(n, real):
+    """NumPy emulation of the block algebra of ``k_potrf_trtri_coop`` (dense_kernels.hip; safe_cholesky + inv(R),
+    lobpcg_hyper_impl.jl:190-210), block column by block column exactly as the workgroups walk it: block column l of
+    the lower factor = (its columns of O minus the contributions of the panels to its left) solved against its own
+    16 x 16 diagonal factor; W_l = D_l^{-1}; block column l of X = L^{-1} from X_ll = W_l,
+    X_kl = -W_k sum_{j=l}^{k-1} L_kj X_jl; the caller gets R = L^H and Z = X^H (upper triangular, zeros below).
+    Padding rows / columns up to the next multiple of 16 carry the identity."""
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((3 * n, n)) + (0 if real else 1j) * rng.standard_normal((3 * n, n))
+    O = A.conj().T @ A
+    B = 16
+    nb = -(-n // B)
+    npad = B * nb
+    Lp = np.eye(npad, dtype=O.dtype)
+    Lp[:n, :n] = np.tril(O)                              # what the kernel loads: conj of the caller's upper triangle
+    panels, W = [], []
+    for l in range(nb):
+        r0 = B * l
+        col = Lp[r0:, r0:r0 + B].copy()                  # rows r0 .. npad of block column l
+        for j in range(l):                               # consume the published panels to the left
+            P = panels[j][r0 - B * j:, :]                # their rows from r0 on; the first 16 are L_{l,j}
+            col -= P @ P[:B].conj().T
+        D = np.linalg.cholesky(col[:B])                  # lower factor of the diagonal block
+        col[B:] = col[B:] @ np.linalg.inv(D).conj().T    # y D^H = x, row by row
+        col[:B] = D
+        panels.append(col)
+        W.append(np.linalg.inv(D))
+    L = np.zeros((npad, npad), dtype=O.dtype)
+    for l in range(nb):
+        L[B * l:, B * l:B * (l + 1)] = panels[l]
+    assert np.allclose(np.triu(L, 1), 0)
+    X = np.zeros_like(L)
+    for l in range(nb):                                  # block column l of X = L^{-1}
+        X[B * l:B * (l + 1), B * l:B * (l + 1)] = W[l]
+        for k in range(l + 1, nb):
+            S = sum(L[B * k:B * (k + 1), B * j:B * (j + 1)] @ X[B * j:B * (j + 1), B * l:B * (l + 1)] for j in range(l, k))
+            X[B * k:B * (k + 1), B * l:B * (l + 1)] = -W[k] @ S
+    R = L.conj().T[:n, :n]
+    Z = X.conj().T[:n, :n]
+    scale = np.linalg.norm(O)
+    assert np.linalg.norm(R.conj().T @ R - O) < 1e-13 * scale
+    assert np.linalg.norm(Z @ R - np.eye(n)) < 1e-11 * np.linalg.cond(R)
+    assert np.allclose(np.tril(Z, -1), 0) and np.allclose(np.tril(R, -1), 0)
+    np.testing.assert_allclose(R, np.linalg.cholesky(O).conj().T, rtol=0, atol=1e-11 * np.sqrt(scale))
+    if real:
+        assert not np.iscomplexobj(R)
+
+
 def test_host_side_orthogonalisation_of_small_ritz_coefficient_blocks():
     """``host_ortho_small`` of csrc/lobpcg.cpp -- ortho!(X, Y) (lobpcg_hyper_impl.jl:271-323) on the HOST for the Ritz
     coefficient blocks ``cP = cX - e`` of small k-blocks (four scheduling rounds fewer per iteration of the lock-step

@@ -1161,6 +1161,34 @@ def test_header_is_plain_c_and_the_c_consumer_builds_and_fails_loudly_without_a_
         assert "no CPU fallback" in res.stderr
 
 
+def test_interpolate_kpoint_is_the_references_scatter_gather_through_the_cube():
+    """``interpolate_kpoint`` (src/interpolation.jl:96-115): the reference scatters the coefficients into a cube-sized
+    array by ``kpoint_in.mapping`` and gathers them by ``kpoint_out.mapping``; the mirror matches the two ascending
+    mapping lists directly (no cube-sized temporary per band).  Same numbers, plane waves outside the input sphere
+    get zero, identical k-points return a copy; the final ``ortho_qr`` of the reference is LOBPCG's own first step."""
+    import torch
+    from dftk_jl_amd.eigen import interpolate_kpoint
+    lat, atoms, pos = dftk.silicon_cell()
+    model = dftk.model_DFT(lat, atoms, pos)
+    basis = dftk.PlaneWaveBasis(model, 7.0, dftk.MonkhorstPack((3, 3, 3)), device="cpu", build_terms=False)
+    assert len(basis.kpoints) >= 3
+    gen = torch.Generator().manual_seed(0)
+    for k_in, k_out in [(basis.kpoints[0], basis.kpoints[1]), (basis.kpoints[2], basis.kpoints[0]),
+                        (basis.kpoints[1], basis.kpoints[2])]:
+        assert np.all(np.diff(k_in.mapping) > 0) and np.all(np.diff(k_out.mapping) > 0)     # the premise: ascending
+        data = torch.complex(torch.randn((5, k_in.n_G), dtype=torch.float64, generator=gen),
+                             torch.randn((5, k_in.n_G), dtype=torch.float64, generator=gen))
+        got = interpolate_kpoint(data, k_in, k_out).numpy()
+        cube = np.zeros((5, basis.N), dtype=complex)
+        cube[:, k_in.mapping] = data.numpy()
+        want = cube[:, k_out.mapping]
+        assert got.shape == (5, k_out.n_G) and np.array_equal(got, want)
+        shared = np.isin(k_out.mapping, k_in.mapping)
+        assert 0 < shared.sum() < k_out.n_G and np.all(got[:, ~shared] == 0)
+    same = interpolate_kpoint(data, k_in, k_in)
+    assert torch.equal(same, data) and same.data_ptr() != data.data_ptr()
+
+
 @pytest.mark.parametrize("n,real", [(33, False), (100, True), (259, False), (503, True), (512, False)])
 def test_block_recurrences_of_the_cooperative_cholesky_and_inverse(n, real):
     """NumPy emulation of the block algebra of ``k_potrf_trtri_coop`` (dense_kernels.hip; safe_cholesky + inv(R),

@@ -142,6 +142,12 @@ class FixedBands:
         self.n_bands_compute = n_bands_compute if n_bands_compute is not None else n_bands_converge + 3
         self.occupation_threshold = occupation_threshold
 
+    @classmethod
+    def for_model(cls, model, temperature_factor_converge=1.20, occupation_threshold=1e-6):
+        """``FixedBands(model; temperature_factor_converge)`` (nbands_algorithm.jl:26-30)."""
+        n_conv = default_n_bands(model, temperature_factor_converge)
+        return cls(n_conv, n_conv + 3, occupation_threshold)
+
     def determine_n_bands(self, occupation, eigenvalues, psi):
         return self.n_bands_converge, self.n_bands_compute
 

@@ -1161,6 +1161,48 @@ def test_header_is_plain_c_and_the_c_consumer_builds_and_fails_loudly_without_a_
         assert "no CPU fallback" in res.stderr
 
 
+def test_band_count_rules_fft_size_helper_and_kpoint_normalisation():
+    """``default_n_bands`` / ``AdaptiveBands`` / ``FixedBands`` (src/scf/nbands_algorithm.jl:7-110) at the BASELINE
+    configs (SURVEY section 8: M = 7 / 259 / 6 / 8 / 503) and ``determine_n_bands`` on hand-made occupations;
+    ``next_compatible_fft_size`` (src/fft.jl:277-287); ``normalize_kpoint_coordinate`` (src/bzmesh.jl:5-10: ties go UP,
+    so 1/2 maps to -1/2)."""
+    from dftk_jl_amd.basis import next_compatible_fft_size
+    from dftk_jl_amd.scf import FixedBands, default_n_bands
+    from dftk_jl_amd.symmetry import normalize_kpoint_coordinate
+    lat, atoms, pos = dftk.silicon_cell()
+    si = dftk.model_DFT(lat, atoms, pos)
+    assert (default_n_bands(si), dftk.AdaptiveBands(si).n_bands_converge, dftk.AdaptiveBands(si).n_bands_compute) == (4, 4, 7)
+    for ncell, M in ((4, 259), (5, 503)):
+        big = dftk.model_DFT(*dftk.silicon_cell((ncell,) * 3))
+        ab = dftk.AdaptiveBands(big)
+        assert (ab.n_bands_converge, ab.n_bands_compute) == (M - 3, M)
+    a = 7.6324708938577865
+    al = dftk.model_DFT(a / 2 * np.array([[0, 1, 1.0], [1, 0, 1.0], [1, 1, 0.0]]), [dftk.ElementPsp("Al", dftk.load_psp("Al", "pbe"))],
+                        [np.zeros(3)], functionals=("gga_x_pbe", "gga_c_pbe"), temperature=1e-3, smearing="gaussian")
+    ab = dftk.AdaptiveBands(al)                       # 3 electrons, T > 0: ceil(2 * 1.05) = 3 to converge, max(3 + 3, ceil(2.4)) = 6
+    assert (default_n_bands(al, 1.0), ab.n_bands_converge, ab.n_bands_compute) == (2, 3, 6)
+    fb = FixedBands.for_model(al)
+    assert (fb.n_bands_converge, fb.n_bands_compute) == (3, 6)          # ceil(2 * 1.20) = 3, + 3
+    assert FixedBands(8).n_bands_compute == 11
+    # first step (no occupation yet): converge floor((3 + 6) / 2) = 4, compute 6 (or as many as the guess holds)
+    assert ab.determine_n_bands(None, None, None) == (4, 6)
+    assert ab.determine_n_bands(None, None, [np.zeros((9, 5))]) == (4, 9)
+    # later steps: converge up to the last band occupied above the threshold; compute up to the last band within gap_min of it
+    occ = [np.array([2.0, 2.0, 1.0, 1e-3, 1e-9, 0.0]), np.array([2.0, 1.5, 1e-7, 0.0, 0.0, 0.0])]
+    eig = [np.array([0.0, 0.1, 0.2, 0.3, 0.305, 0.5]), np.array([0.0, 0.1, 0.2, 0.3, 0.4, 0.5])]
+    assert ab.determine_n_bands(occ, eig, None) == (4, 7)               # band 4 occupied (1e-3); eps_5 - eps_4 < gap_min -> 5, but >= 4 + 3
+    occ_full = [np.full(6, 2.0)]                                        # everything occupied: "one more than we have"
+    assert ab.determine_n_bands(occ_full, [np.arange(6.0)], None) == (6, 9)
+    assert ab.determine_n_bands(occ, None, [np.zeros((12, 5))])[1] == 12
+    # FFT sizes: 2-3-5-smooth and divisible by the product of the factors
+    assert [next_compatible_fft_size(n) for n in (27, 28, 31, 97, 150, 191)] == [27, 30, 32, 100, 150, 192]
+    assert next_compatible_fft_size(28, factors=(2,)) == 30 and next_compatible_fft_size(25, factors=(2, 3)) == 30
+    assert next_compatible_fft_size(27, factors=(4,)) == 32 and next_compatible_fft_size(31, smallprimes=()) == 31
+    # k-point coordinates in [-1/2, 1/2)
+    got = normalize_kpoint_coordinate([0.5, -0.5, 1.25, -0.75, 0.49999, 2.0])
+    np.testing.assert_allclose(got, [-0.5, -0.5, 0.25, 0.25, 0.49999, 0.0], atol=1e-15)
+
+
 def test_interpolate_kpoint_is_the_references_scatter_gather_through_the_cube():
     """``interpolate_kpoint`` (src/interpolation.jl:96-115): the reference scatters the coefficients into a cube-sized
     array by ``kpoint_in.mapping`` and gathers them by ``kpoint_out.mapping``; the mirror matches the two ascending

@@ -105,6 +105,9 @@ _SIGNATURES = {
                                    C.c_void_p, _i64, dftk_mi_cplx, C.c_void_p, _i64, C.c_int]),
     "dftk_mi_zgemm_plan_host": (C.c_int, [C.c_char, _i64, _i64, _i64, C.c_int, C.POINTER(C.c_int)]),
     "dftk_mi_heev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, C.c_void_p, _i64]),
+    "dftk_mi_heev_lowest": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, _i64, C.c_void_p, C.c_void_p, _i64]),
+    "dftk_mi_heev_sigma_host": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                          C.POINTER(C.c_int), C.c_double]),
     "dftk_mi_potrf_trtri": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, _i64]),
     "dftk_mi_potrf_trtri_real": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, _i64]),
     "dftk_mi_comm_get_unique_id": (C.c_int, [C.c_char_p]),

@@ -38,7 +38,7 @@ extern "C" const char* dftk_mi_version(void) {
 // ------------------------------------------------------------------------------------ profiling
 int prof_begin(dftk_mi_basis* b, int fam, double work, uint64_t tag) {
     Prof* p = b->prof;
-    if (!p || !p->on) return -1;
+    if (!p || !p->on || p->mute > 0) return -1;
     // slots index `pending`, and scopes nest (apply_H / heev hold one across inner zgemm / FFT scopes): never
     // flush while a scope is open
     if (p->pending.size() >= 60000 && p->open == 0) prof_resolve(b);
@@ -353,6 +353,7 @@ extern "C" int dftk_mi_basis_destroy(dftk_mi_basis* b) {
     if (b->T2) hipFree(b->T2);
     if (b->ws) hipFree(b->ws);
     if (b->dense_ws) hipFree(b->dense_ws);
+    if (b->eig_ws) hipFree(b->eig_ws);
     if (b->d_scalars) hipFree(b->d_scalars);
     if (b->h_scalars) hipHostFree(b->h_scalars);
     if (b->h_fetch) hipHostFree(b->h_fetch);
@@ -1244,6 +1245,20 @@ extern "C" int dftk_mi_heev(dftk_mi_basis* b, int n, dftk_mi_cplx* A_d, int64_t 
     if (!b || n < 1 || !A_d || !W_h || !V_d || lda < n || ldv < n) return DFTK_MI_EINVAL;
     HIPCHK(hipSetDevice(b->device));
     return dense_heev(b, n, reinterpret_cast<cd*>(A_d), lda, W_h, reinterpret_cast<cd*>(V_d), ldv);
+}
+
+extern "C" int dftk_mi_heev_lowest(dftk_mi_basis* b, int n, int nev, dftk_mi_cplx* A_d, int64_t lda, double* W_h,
+                                   dftk_mi_cplx* V_d, int64_t ldv) {
+    if (!b || n < 1 || nev < 1 || nev > n || !A_d || !W_h || !V_d || lda < n || ldv < n) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(b->device));
+    return dense_heev_lowest(b, n, nev, reinterpret_cast<cd*>(A_d), lda, W_h, reinterpret_cast<cd*>(V_d), ldv);
+}
+extern "C" int dftk_mi_heev_sigma_host(int n, const double* diag_h, int nev, double* sigma, double* gap_guess,
+                                       int* hold_iterations, double norm_bound) {
+    const int st = eig_choose_sigma_host(n, diag_h, nev, sigma, gap_guess);
+    if (st != 0) return st;
+    if (hold_iterations) *hold_iterations = norm_bound > 0.0 ? eig_hold_iterations_host(*gap_guess / norm_bound) : 0;
+    return 0;
 }
 
 extern "C" int dftk_mi_potrf_trtri(dftk_mi_basis* b, int n, dftk_mi_cplx* A_d, int64_t lda, dftk_mi_cplx* invR_d,

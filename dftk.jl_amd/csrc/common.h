@@ -65,6 +65,9 @@ struct dftk_mi_basis {
     // workspace of the dense factorizations (heev ping-pong copies, rotation buffers); owned by the basis so
     // that several bases / devices in one process never share it (freed in dftk_mi_basis_destroy)
     void* dense_ws; size_t dense_ws_bytes;
+    // workspace of the partial-spectrum eigensolver (eig_kernels.hip): its iterates live across calls into the routines
+    // that use dense_ws (Cholesky, Jacobi on the projected matrix), so it cannot share that buffer
+    void* eig_ws; size_t eig_ws_bytes;
     struct dftk_mi_comm* comm;    // plane-wave (row-slab) communicator of a sharded k-block, or null (borrowed)
 };
 
@@ -106,6 +109,7 @@ struct Prof {
     std::vector<Pair> pending;
     std::vector<Pair> pool;
     int open = 0;                       // scopes begun and not yet ended: no flush while > 0 (slots index `pending`)
+    int mute = 0;                       // > 0: prof_begin books nothing (inner calls of a routine that is booked as a whole)
     double ms[PROF_NFAM] = {0};
     double work[PROF_NFAM] = {0};
     int64_t launches[PROF_NFAM] = {0};
@@ -214,6 +218,22 @@ int ensure_ws(dftk_mi_basis* b, size_t bytes);
 int dense_potrf_trtri(dftk_mi_basis* b, int n, cd* A, int64_t lda, cd* invR, int64_t ldi,
                       double* normest_R, double* normest_invR, bool real_input = false);   // host outputs
 int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, int64_t ldv);
+// the blocked Jacobi itself (all n pairs), not booked in any profile family and never redirected
+int dense_heev_full(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, int64_t ldv);
+// sums over the n x n matrix: squared off-diagonal / diagonal magnitudes and squared imaginary parts (host outputs)
+int dense_input_norms(dftk_mi_basis* b, int n, const cd* A, int64_t lda, double* off2, double* dg2, double* im2);
+// eig_kernels.hip: the lowest nev eigenpairs only (spectral split on the matrix cores + Jacobi on the projected matrix);
+// falls back to dense_heev where the split does not apply
+int dense_heev_lowest(dftk_mi_basis* b, int n, int nev, cd* A, int64_t lda, double* W_h, cd* V, int64_t ldv);
+int eig_choose_sigma_host(int n, const double* diag, int nev, double* sigma, double* gap_guess);
+int eig_hold_iterations_host(double gap_over_norm);
+struct ProfMute {    // RAII: nothing inside is booked (the enclosing scope books the whole routine)
+    dftk_mi_basis* b;
+    explicit ProfMute(dftk_mi_basis* basis) : b(basis) { if (b->prof) b->prof->mute += 1; }
+    ~ProfMute() { if (b->prof) b->prof->mute -= 1; }
+    ProfMute(const ProfMute&) = delete;
+    ProfMute& operator=(const ProfMute&) = delete;
+};
 int jacobi_schedule_host(int n, int round, int* nb_out, int* pairs, int* where);
 int apply_D(dftk_mi_kblock* kb, int n_bands, const cd* X /*n_p x nb*/, cd* Y);
 // elementwise / reductions used by LOBPCG (all on b->stream)

@@ -1683,21 +1683,7 @@ static int heev_impl(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, c
     return 0;
 }
 
-int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, int64_t ldv) {
-    if (n <= 0) return 0;
-    if (batching()) {
-        BOp o;
-        o.b = b;
-        o.type = BOP_HEEV; o.m = n; o.C = A; o.ldc = lda; o.D = V; o.ldb = ldv; o.host = W_h;
-        return batch_record_sync(std::move(o));
-    }
-    const int pslot = prof_begin(b, PROF_HEEV, (double)n);
-    struct ProfGuard {
-        dftk_mi_basis* b;
-        int s;
-        ~ProfGuard() { prof_end(b, s); }
-    } guard{b, pslot};
-    // norms of the input (scale of the padding, early exit for a diagonal matrix) and sum Im^2
+int dense_input_norms(dftk_mi_basis* b, int n, const cd* A, int64_t lda, double* off2_out, double* dg2_out, double* im2_out) {
     const int redblocks = 64;
     CHK(dws_ensure(b, &b->dense_ws, &b->dense_ws_bytes, 4096 * sizeof(double)));
     double* d_red = reinterpret_cast<double*>(b->dense_ws);
@@ -1710,6 +1696,29 @@ int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, 
         dg2 += hred[2 * i + 1];
         im2 += hred[2 * redblocks + i];
     }
+    *off2_out = off2;
+    *dg2_out = dg2;
+    *im2_out = im2;
+    return 0;
+}
+
+int dense_heev(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, int64_t ldv) {
+    if (n <= 0) return 0;
+    if (batching()) {
+        BOp o;
+        o.b = b;
+        o.type = BOP_HEEV; o.m = n; o.C = A; o.ldc = lda; o.D = V; o.ldb = ldv; o.host = W_h;
+        return batch_record_sync(std::move(o));
+    }
+    ProfScope scope(b, PROF_HEEV, (double)n);
+    return dense_heev_full(b, n, A, lda, W_h, V, ldv);
+}
+
+int dense_heev_full(dftk_mi_basis* b, int n, cd* A, int64_t lda, double* W_h, cd* V, int64_t ldv) {
+    if (n <= 0) return 0;
+    // norms of the input (scale of the padding, early exit for a diagonal matrix) and sum Im^2
+    double off2 = 0.0, dg2 = 0.0, im2 = 0.0;
+    CHK(dense_input_norms(b, n, A, lda, &off2, &dg2, &im2));
     if (!std::isfinite(off2 + dg2)) return DFTK_MI_NUM_NONFINITE;
     // every imaginary part exactly zero (real symmetric input, e.g. the Rayleigh-Ritz matrices of the Gamma-real
     // LOBPCG): real rotations on plain-double work matrices -- a quarter of the matrix-core work and half the bytes

@@ -752,7 +752,8 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
             CHK(ew_hermitize_upper(b, nY, G, nY));
             std::vector<double> wv(nY);
             {
-                int st = dense_heev(b, nY, G, nY, wv.data(), V, nY);
+                // only `vectors[:, 1:N]` and the N lowest values are used (lobpcg_hyper_impl.jl:146-150): the partial solver
+                int st = dense_heev_lowest(b, nY, nact, G, nY, wv.data(), V, nY);
                 if (st != 0) return st;
             }
             ncx = nact;

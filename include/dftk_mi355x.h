@@ -310,6 +310,19 @@ int dftk_mi_zgemm_ex(dftk_mi_basis* basis, char transA, int64_t m, int64_t n, in
  * W_h[n] ascending eigenvalues (host), V_d n x n eigenvectors (columns, sorted like W). */
 int dftk_mi_heev(dftk_mi_basis* basis, int n, dftk_mi_cplx* A_d, int64_t lda, double* W_h,
                  dftk_mi_cplx* V_d, int64_t ldv);
+/* The LOWEST nev eigenpairs only -- what rayleigh_ritz consumes (lobpcg_hyper_impl.jl:141-153: `vectors[:, 1:N]`
+ * of the 2N x 2N / 3N x 3N matrix Y'AY): one spectral split by a Newton-Schulz sign iteration on the f64 matrix cores
+ * (sigma above the nev-th smallest diagonal entry), an orthonormal basis of the lower invariant subspace by
+ * Cholesky-QR, the blocked Jacobi on the k x k projected matrix (nev <= k), one product back.  W_h[0 .. nev) and the
+ * first nev columns of V_d are set; A is left intact.  Small problems (n < 600), nev > 0.6 n and inputs on which the
+ * split fails its own checks go to dftk_mi_heev (A destroyed, all n pairs returned).  DFTK_MI_HEEV_PARTIAL=0 switches
+ * the split off, DFTK_MI_HEEV_PARTIAL_MIN=<n> moves the size threshold. */
+int dftk_mi_heev_lowest(dftk_mi_basis* basis, int n, int nev, dftk_mi_cplx* A_d, int64_t lda, double* W_h,
+                        dftk_mi_cplx* V_d, int64_t ldv);
+/* Host-only: the shift rule of dftk_mi_heev_lowest on a diagonal (sigma, estimated distance to the nearest
+ * eigenvalue) and, for a norm bound of A - sigma I, the number of held iterations (CPU test-suite). */
+int dftk_mi_heev_sigma_host(int n, const double* diag_h, int nev, double* sigma, double* gap_guess,
+                            int* hold_iterations, double norm_bound);
 /* Upper Cholesky A = R^H R in place (strict lower part left untouched) + inverse of R.
  * Returns DFTK_MI_NUM_CHOLESKY when a pivot is not positive / finite. */
 int dftk_mi_potrf_trtri(dftk_mi_basis* basis, int n, dftk_mi_cplx* A_d, int64_t lda,

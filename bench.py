@@ -528,6 +528,23 @@ def roofline_of(fam, n_gpus, workload):
     return roof
 
 
+def step_roofline(fam, elapsed_s, steps, step_s, iters):
+    """Flat scalars for ``config`` (the driver's record keeps only scalars there): what the timed window would take at
+    the rooflines of its OWN useful work -- zgemm useful flops at the dense f64 MFMA peak plus the algorithmic bytes of
+    the FFT stages, the density pass and the n_G-sized element-wise kernels at the HBM peak -- over its wall time.
+    Everything else (eigensolver, Cholesky, host glue, launch gaps) counts as pure overhead."""
+    flops = fam[0][1] + fam[11][1]
+    nbytes = sum(fam[f][1] for f in (1, 2, 3, 4, 5, 6, 15))
+    t_roof = flops / (F64_MFMA_PEAK_TF * 1e12) + nbytes / (HBM_PEAK_GBS * 1e9)
+    t_roof63 = flops / (F64_MFMA_PEAK_TF * 1e12) + nbytes / 6.3e12        # 6.3 TB/s: the achievable copy rate (SURVEY 8d)
+    late = [1e3 * s_ for s_, i_ in zip(step_s, iters) if abs(i_ - 1.0) < 1e-9]
+    return {"step_roofline_frac": round(t_roof / elapsed_s, 4),
+            "step_roofline_frac_hbm_6p3": round(t_roof63 / elapsed_s, 4),
+            "step_roofline_ms": round(1e3 * t_roof / steps, 2),
+            "late_step_ms": round(float(np.median(late)), 2) if late else None,
+            "late_steps_counted": len(late)}
+
+
 def sharded_self_check(dftk, basis, comm_size):
     """--mode gamma, N > 1, before the SCF: one sharded H psi and one Gram matrix of a seeded random block against the
     UNSHARDED result computed from the gathered block on every rank -- a broken slab <-> band all-to-all plan or
@@ -557,6 +574,20 @@ def sharded_self_check(dftk, basis, comm_size):
         ref = full.conj() @ Hfull.T
         out["gram_vs_gathered"] = float((gram - ref).abs().max() / ref.abs().max())
     return out
+
+
+def kpoints_self_check(basis, comm, world):
+    """--mode kpoints / weak, N > 1, before the SCF: the density all-reduce (mpi_sum!(rho, comm_kpts), src/densities.jl:46)
+    on a rank-stamped cube through the SAME communicator the SCF uses -- every entry must come back as
+    sum_r (r + 1) (i + 1 mod 7) exactly (small integers: exact in fp64 whatever the reduction order)."""
+    import torch
+    n = int(basis.N)
+    i = torch.arange(n, dtype=torch.float64, device=basis.device) % 7 + 1.0
+    x = (comm.rank + 1.0) * i
+    comm.sum_(x, basis.stream_ptr)
+    basis.sync()
+    want = (world * (world + 1) / 2.0) * i
+    return {"allreduce_rank_stamped_cube_max_abs_error": float((x - want).abs().max()), "cube_entries": n}
 
 
 # ------------------------------------------------------------------------------------------ Amdahl model
@@ -762,6 +793,11 @@ def main():
         if bad:
             raise SystemExit(f"sharded self-check failed on rank {rank}: {self_check}")
 
+    if world > 1 and args.mode in ("kpoints", "weak"):
+        self_check = kpoints_self_check(basis, comm, world)
+        if not (self_check["allreduce_rank_stamped_cube_max_abs_error"] == 0.0):
+            raise SystemExit(f"k-point self-check failed on rank {rank}: {self_check}")
+
     run = run_scf(dftk, lib, basis, args, barrier, world, dist, torch)
     info, elapsed, fam = run["info"], run["elapsed"], run["fam"]
     n_atoms = len(model.positions)
@@ -812,6 +848,10 @@ def main():
                        "E_total": info["energies"].total, "drho": info["history_drho"][-1]},
             "roofline": roof,
         }
+        # flat scalars (the driver's BENCH record keeps scalars of `config`, not nested objects)
+        out["config"].update(step_roofline(fam, elapsed, steps_run, run["step_s"], run["iters"]))
+        out["config"]["roofline_frac_zgemm"] = round(roof["frac"], 4) if roof.get("bound") == "mfma" else None
+        out["config"]["heev_ms_per_step"] = round(fam[7][0] / steps_run, 2)
     # ---- the reference's own iteration (general complex orbitals) on the same cell, same run, same box
     if (world == 1 and args.mode == "gamma" and not args.no_gamma_real and not args.no_complex_leg
             and bool(getattr(basis.kpoints[0], "gamma_real", False))):
@@ -843,6 +883,9 @@ def main():
             "roofline": {k_: croof[k_] for k_ in ("bound", "achieved", "peak", "unit", "frac", "achieved_unstructured",
                                                   "mfma_busy_frac", "kernel", "launches", "avg_launch_ms", "families_ms",
                                                   "families_rate") if k_ in croof}}
+        out["config"]["complex_iteration_value"] = round(ci["n_iter"] / crun["elapsed"], 4)
+        out["config"]["complex_iteration_frac"] = round(croof["frac"], 4)
+        out["config"]["complex_iteration_steps"] = int(ci["n_iter"])
         del crun, ci, cbasis
         torch.cuda.empty_cache()
 
@@ -883,7 +926,18 @@ def main():
                               "real-symmetric and the reference's complex iteration, production cube), and -- N = 1 -- a whole SCF at "
                               "the k-mesh-compatible cube against the oracle fixture; the run exits non-zero when a check fails")
         out["config"]["parity"] = parity
+        if parity is not None:
+            out["config"]["parity_pass"] = bool(parity["pass"])
+            out["config"]["parity_E_total_converged"] = parity["timed_leg"]["E_total"]
+            out["config"]["parity_dE_real_vs_complex_per_atom"] = parity.get("dE_total_real_vs_complex_per_atom")
+            out["config"]["parity_max_deigenvalue_real_vs_complex"] = parity.get("max_deigenvalue_real_vs_complex")
+            if "golden" in parity:
+                out["config"]["parity_dE_vs_golden_per_atom"] = parity["golden"]["dE_total_vs_golden_per_atom"]
+                out["config"]["parity_max_deigenvalue_vs_golden"] = parity["golden"]["max_deigenvalue_vs_golden"]
         out["amdahl"] = amdahl
+        if isinstance(amdahl, dict) and "predicted_speedup" in amdahl:
+            for n_, v_ in amdahl["predicted_speedup"].items():
+                out["config"][f"amdahl_predicted_speedup_{n_}gpu"] = v_
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:
                 if args.mode == "kpoints":

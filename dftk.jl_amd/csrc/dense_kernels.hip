@@ -1397,9 +1397,27 @@ int dense_potrf_trtri(dftk_mi_basis* b, int n, cd* A, int64_t lda, cd* invR, int
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 70 * 1024) == hipSuccess;
     bool coop = coop_ok == 1 && n <= 512 && n > 32;
     // Every workgroup of the cooperative kernel needs a CU to itself (LDS) and spins until the other block columns of ITS
-    // launch have published: launches of many host threads (stream lanes) must not fill the device with workgroups that
-    // wait for siblings that cannot become resident.  The call is synchronous (it ends with a host fetch), so the
-    // workgroups in flight over all streams of the process are counted exactly; beyond half the device the blocked path runs.
+    // launch have published, so all nb <= 32 of them must be resident together.  Two guards:
+    //  * the launch is a COOPERATIVE launch (hipLaunchCooperativeKernel): the runtime refuses a grid that cannot be
+    //    co-resident on the device as it is (partitioned / CU-masked devices) and schedules the grid as a whole, also
+    //    against the cooperative grids of OTHER processes sharing the device (two ranks on one GPU in the test-suite);
+    //    a refused launch falls back to the blocked path below;
+    //  * within this process the workgroups in flight over all streams (lanes) are counted -- the call is synchronous,
+    //    it ends with a host fetch -- and kept below half the device's compute units.
+    // DFTK_MI_POTRF_COOP_LAUNCH=0: plain launch (the round-4 form) under the per-process count only.
+    static const bool coop_launch = !(getenv("DFTK_MI_POTRF_COOP_LAUNCH") && atoi(getenv("DFTK_MI_POTRF_COOP_LAUNCH")) == 0);
+    static int coop_budget_wgs = -1;
+    if (coop_budget_wgs < 0) {
+        hipDeviceProp_t prop;
+        int coop_attr = 0;
+        if (hipGetDeviceProperties(&prop, b->device) == hipSuccess && prop.multiProcessorCount > 0)
+            coop_budget_wgs = prop.multiProcessorCount / 2;
+        else
+            coop_budget_wgs = 0;
+        if (coop_launch && (hipDeviceGetAttribute(&coop_attr, hipDeviceAttributeCooperativeLaunch, b->device) != hipSuccess ||
+                            !coop_attr))
+            coop_budget_wgs = 0;      // no cooperative launches on this device: blocked path
+    }
     static std::atomic<int> coop_wgs_in_flight{0};
     struct CoopBudget {
         std::atomic<int>& c;
@@ -1408,7 +1426,7 @@ int dense_potrf_trtri(dftk_mi_basis* b, int n, cd* A, int64_t lda, cd* invR, int
     } coop_budget{coop_wgs_in_flight};
     if (coop) {
         const int nb = (n + CCB - 1) / CCB;
-        if (coop_wgs_in_flight.fetch_add(nb) + nb > 128) {
+        if (coop_wgs_in_flight.fetch_add(nb) + nb > coop_budget_wgs) {
             coop_wgs_in_flight.fetch_sub(nb);
             coop = false;
         } else {
@@ -1423,14 +1441,33 @@ int dense_potrf_trtri(dftk_mi_basis* b, int n, cd* A, int64_t lda, cd* invR, int
         cd* Wbuf = Lbuf + (size_t)nb * np * CCB;
         int* flags = reinterpret_cast<int*>(Wbuf + (size_t)nb * CCB * CCB);
         HIPCHK(hipMemsetAsync(flags, 0, 64 * sizeof(int), b->stream));
-        if (real_input)   // (the buffers are sized for complex elements: the real factorisation uses half of each)
-            hipLaunchKernelGGL(k_potrf_trtri_coop<double>, dim3(nb), dim3(CCT), (size_t)np * CCB * sizeof(double), b->stream, n,
-                               A, lda, invR, ldi, reinterpret_cast<double*>(Lbuf), reinterpret_cast<double*>(Wbuf), flags,
-                               d_info);
-        else
-            hipLaunchKernelGGL(k_potrf_trtri_coop<cd>, dim3(nb), dim3(CCT), (size_t)np * CCB * sizeof(cd), b->stream, n, A, lda,
-                               invR, ldi, Lbuf, Wbuf, flags, d_info);
-        HIPCHK(hipGetLastError());
+        if (!coop_launch) {
+            if (real_input)   // (the buffers are sized for complex elements: the real factorisation uses half of each)
+                hipLaunchKernelGGL(k_potrf_trtri_coop<double>, dim3(nb), dim3(CCT), (size_t)np * CCB * sizeof(double), b->stream,
+                                   n, A, lda, invR, ldi, reinterpret_cast<double*>(Lbuf), reinterpret_cast<double*>(Wbuf), flags,
+                                   d_info);
+            else
+                hipLaunchKernelGGL(k_potrf_trtri_coop<cd>, dim3(nb), dim3(CCT), (size_t)np * CCB * sizeof(cd), b->stream, n, A,
+                                   lda, invR, ldi, Lbuf, Wbuf, flags, d_info);
+            HIPCHK(hipGetLastError());
+        } else {
+            double* Ld = reinterpret_cast<double*>(Lbuf);
+            double* Wd = reinterpret_cast<double*>(Wbuf);
+            int n_arg = n;
+            void* args_r[] = {&n_arg, &A, &lda, &invR, &ldi, &Ld, &Wd, &flags, &d_info};
+            void* args_c[] = {&n_arg, &A, &lda, &invR, &ldi, &Lbuf, &Wbuf, &flags, &d_info};
+            const hipError_t le =
+                real_input ? hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_potrf_trtri_coop<double>), dim3(nb),
+                                                        dim3(CCT), args_r, (size_t)np * CCB * sizeof(double), b->stream)
+                           : hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_potrf_trtri_coop<cd>), dim3(nb), dim3(CCT),
+                                                        args_c, (size_t)np * CCB * sizeof(cd), b->stream);
+            if (le != hipSuccess) {       // the grid cannot be co-resident here: the blocked path takes over
+                (void)hipGetLastError();
+                coop_wgs_in_flight.fetch_sub(coop_budget.n);
+                coop_budget.n = 0;
+                coop = false;
+            }
+        }
     }
     for (int j0 = 0; j0 < n && !coop; j0 += PB) {
         const int jb = (n - j0) < PB ? (n - j0) : PB;

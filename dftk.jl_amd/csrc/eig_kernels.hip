@@ -34,6 +34,7 @@
 #include <vector>
 #include <numeric>
 #include <algorithm>
+#include <chrono>
 
 static const double EIG_L_HAT = 1e-2;
 
@@ -234,6 +235,10 @@ template <bool REAL>
 static int heev_lowest_impl(dftk_mi_basis* b, int n, int nev, cd* A, int64_t lda, double* W_h, cd* V, int64_t ldv,
                             bool* fell_back) {
     static const bool trace = getenv("DFTK_MI_HEEV_TRACE") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto ms_since = [&](const std::chrono::steady_clock::time_point& t0) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
     *fell_back = true;
     const int rf = REAL ? DFTK_MI_GEMM_REAL : 0;
     const int64_t ldt = REAL ? (n + 1) / 2 : n;             // leading dimension (complex units) of tall arrays
@@ -353,6 +358,7 @@ static int heev_lowest_impl(dftk_mi_basis* b, int n, int nev, cd* A, int64_t lda
         if (trace) fprintf(stderr, "[heev lowest] n=%d: no convergence of the sign iteration after %d iterations -> full solver\n", n, its);
         return 0;
     }
+    const double ms_sign = ms_since(t_start);   // (the last check was a synchronising fetch)
     // ---- k and the columns of the projector with the largest leverage
     if (REAL)
         hipLaunchKernelGGL(k_eig_diag_tall<true>, dim3((n + 255) / 256), dim3(256), 0, b->stream, n, Xc, ldt, d_udiag);
@@ -409,10 +415,18 @@ static int heev_lowest_impl(dftk_mi_basis* b, int n, int nev, cd* A, int64_t lda
     CHK(zgemm(b, 'C', k, k, tk, ONE, Bq, ldt, Tt, ldt, ZERO, Gk, k, rf | DFTK_MI_GEMM_UPPER));
     CHK(ew_hermitize_upper(b, k, Gk, k));
     std::vector<double> th(k);
+    double ms_basis = 0.0;
+    if (trace) {
+        CHK(host_wait(b));
+        ms_basis = ms_since(t_start) - ms_sign;
+    }
     {
         const int st = dense_heev_full(b, k, Gk, k, th.data(), Vk, k);
         if (st != 0) return st;
     }
+    if (trace)
+        fprintf(stderr, "[heev lowest timing] n=%d nev=%d k=%d its=%d: sign %.2f ms, basis + projection %.2f ms, Jacobi(k) %.2f ms\n", n,
+                nev, k, its, ms_sign, ms_basis, ms_since(t_start) - ms_sign - ms_basis);
     // ---- V[:, :nev] = Bq Vk[:, :nev]
     if (REAL) {
         CHK(zgemm(b, 'N', ldt, nev, k, ONE, Bq, ldt, Vk, k, ZERO, Tt, ldt, rf));

@@ -169,7 +169,11 @@ int ortho_X(Ctx& c, Mat X, cd* tmp, double tol, int* nchol_total_out, double* gr
         CHK(ew_hermitize_upper(c.b, m, c.O, m));
         int nchol = 10000;
         double nR = 0, nI = 0;
-        if (!force_svd) CHK(safe_cholesky(c, m, &nchol, &nR, &nI));
+        int st_chol = 0;
+        if (!force_svd) st_chol = safe_cholesky(c, m, &nchol, &nR, &nI);
+        // a speculative call (hook): the caller's verdict on X comes first -- a non-finite column must be reported as
+        // such, not as whatever the factorisation of its Gram matrix ran into
+        if (st_chol != 0 && pass == 0 && hook) CHK(stream_sync(c.b));   // (the hook reads a fetch that rides on a synchronisation)
         if (pass == 0 && hook) {
             const int hr = (*hook)();
             if (hr != 0) {
@@ -179,6 +183,7 @@ int ortho_X(Ctx& c, Mat X, cd* tmp, double tol, int* nchol_total_out, double* gr
                 return 0;
             }
         }
+        if (st_chol != 0) return st_chol;
         nchol_total += nchol;
         if (nchol > 10) {
             if (!allow_svd) {
@@ -295,6 +300,7 @@ int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol, con
     if (Ys.size() > 1 && contiguous(Ys)) merged = {Mat{Ys[0].p, Ys[0].ld, Ys[0].rows, ny}};
     const std::vector<Mat>& Yl = merged.empty() ? Ys : merged;
     int niter = 1;
+    std::vector<double> hb;     // landing zone of the (possibly deferred) fetch below: outlives every round of the loop
     for (;;) {
         // BYX = Y' X ; X -= Y BYX
         int off = 0;
@@ -321,7 +327,7 @@ int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol, con
         // has to be re-randomised or the loop is over, the speculative Gram matrix + factorisation are thrown away (a few
         // kiloflops here; for the n_G x 503 blocks of the large cells they would be milliseconds, so those keep the fetch).
         const bool defer = one_fetch && (int64_t)X.rows * X.cols <= DEFER_FETCH_MAX_ELEMS;
-        std::vector<double> hb;     // norms [0, cols) and (one_fetch) column sums of |BYX|^2 at [dstride, dstride + cols)
+        // hb: norms [0, cols) and (one_fetch) column sums of |BYX|^2 at [dstride, dstride + cols)
         if (one_fetch) {
             CHK(ew_frob2(c.b, ny, X.cols, c.BYX, ny, c.d_b));
             hb.resize(c.dstride + X.cols);

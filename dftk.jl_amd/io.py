@@ -187,12 +187,17 @@ def load_scfres(filename: str, basis=None) -> dict:
             raise ValueError("stored and passed basis are inconsistent (k-point coordinates / weights)")
         if basis.comm_kpts.size > 1 or basis.comm_pw.size > 1:
             raise NotImplementedError("npz checkpoints restart single-rank runs")
-        if "kpt_n_G_vectors" in out and [int(k.n_G) for k in basis.kpoints] != list(out["kpt_n_G_vectors"][0]):
-            raise ValueError("stored and passed basis are inconsistent (plane waves per k-point)")
+        # kpt_n_G_vectors is stored [spin][kpoint]; basis.kpoints lists the spin-up blocks, then the spin-down ones
+        if "kpt_n_G_vectors" in out and [int(k.n_G) for k in basis.kpoints] != [int(n) for per_spin in out["kpt_n_G_vectors"]
+                                                                                 for n in per_spin]:
+            raise ValueError("stored and passed basis are inconsistent (plane waves per k-point / spin components)")
         dev = basis.device
         if "rho" in data:
             out["rho"] = torch.from_numpy(data["rho"]).to(dev)
-        psi = [torch.from_numpy(data[f"psi_{ik}"]).to(dev) for ik in range(out["n_kpoints"]) if f"psi_{ik}" in data]
+        # one block per (k-point, spin component): psi_0 .. psi_{n_spin n_k - 1} in the order of basis.kpoints
+        psi = [torch.from_numpy(data[f"psi_{ik}"]).to(dev) for ik in range(len(basis.kpoints)) if f"psi_{ik}" in data]
         if psi:
+            if len(psi) != len(basis.kpoints):
+                raise ValueError(f"checkpoint holds {len(psi)} orbital blocks, the basis has {len(basis.kpoints)} k-blocks")
             out["psi"] = psi
     return out

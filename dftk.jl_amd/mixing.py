@@ -79,25 +79,36 @@ def gmres(apply, b: torch.Tensor, rtol: float, krylovdim: int = 30, maxiter: int
     nb = float(torch.linalg.norm(b).item())
     tol = max(atol, rtol * nb)
     r, beta = b.clone(), nb
+    n = b.numel()
+    Vbuf = torch.empty((krylovdim + 1, n), dtype=b.dtype, device=b.device)   # the Krylov basis, allocated once
     for _ in range(maxiter):
         if beta <= tol:
             break
-        V = [(r / beta).reshape(-1)]
+        Vbuf[0] = (r / beta).reshape(-1)
         H = np.zeros((krylovdim + 1, krylovdim))
         g = np.zeros(krylovdim + 1)
         g[0] = beta
         cs, sn = np.zeros(krylovdim), np.zeros(krylovdim)
         k_used = 0
         for k in range(krylovdim):
-            w = apply(V[k].reshape(b.shape)).reshape(-1)
-            Vm = torch.stack(V)                                            # (k + 1, n)
+            w = apply(Vbuf[k].reshape(b.shape)).reshape(-1)
+            Vm = Vbuf[:k + 1]                                              # (k + 1, n) view, no copy
             vals = torch.cat([Vm @ w, (w @ w).reshape(1)]).cpu().numpy()
-            h, ww = vals[:-1], float(vals[-1])
+            h, ww = vals[:-1].copy(), float(vals[-1])
             w = w - torch.as_tensor(h, device=w.device) @ Vm
-            H[:k + 1, k] = h
             rest = ww - float(np.dot(h, h))
-            if rest < 1e-6 * ww:                                           # cancellation: measure the remainder itself
-                rest = float((w @ w).item())
+            if rest < 1e-2 * ww:
+                # cancellation: one pass of classical Gram-Schmidt leaves components of size eps * ||w|| / ||rest|| along
+                # the basis, and Pythagoras has lost its digits -- a second pass ("twice is enough") and the remainder's
+                # own norm; costs one more fetch on the steps where it is needed
+                vals2 = torch.cat([Vm @ w, (w @ w).reshape(1)]).cpu().numpy()
+                h2 = vals2[:-1]
+                w = w - torch.as_tensor(h2, device=w.device) @ Vm
+                h = h + h2
+                rest = float(vals2[-1]) - float(np.dot(h2, h2))
+                if rest < 1e-2 * float(vals2[-1]):
+                    rest = float((w @ w).item())
+            H[:k + 1, k] = h
             H[k + 1, k] = math.sqrt(max(rest, 0.0))
             for j in range(k):
                 t = cs[j] * H[j, k] + sn[j] * H[j + 1, k]
@@ -113,11 +124,12 @@ def gmres(apply, b: torch.Tensor, rtol: float, krylovdim: int = 30, maxiter: int
             k_used = k + 1
             if abs(g[k + 1]) <= tol or hk1 == 0.0:
                 break
-            V.append(w / hk1)
+            Vbuf[k + 1] = w / hk1
         y = np.linalg.solve(np.triu(H[:k_used, :k_used]), g[:k_used])
-        x = x + (torch.as_tensor(y, device=b.device) @ torch.stack(V[:k_used])).reshape(b.shape)
-        # |g[k_used]| IS the residual norm of the minimiser (exact arithmetic): trust it unless a restart is needed
-        if abs(g[k_used]) <= tol:
+        x = x + (torch.as_tensor(y, device=b.device) @ Vbuf[:k_used]).reshape(b.shape)
+        # |g[k_used]| is the residual norm of the minimiser as long as the basis is orthonormal, which the second pass above
+        # maintains; the TRUE residual is measured at every restart and once before an accepted exit of a long cycle
+        if abs(g[k_used]) <= tol and k_used <= 8:
             beta = abs(g[k_used])
             break
         r = b - apply(x)

@@ -427,6 +427,11 @@ def guess_density(basis, magnetic_moments=()):
         rho = rho_tot
     else:
         if not mm or all(m == 0 for m in mm):
+            import warnings
+            # density_methods.jl:135-139 (@warn)
+            warnings.warn("Returning zero spin density guess, because no initial magnetization has been specified in any "
+                          "of the given elements / atoms. Your SCF will likely not converge to a spin-broken solution.",
+                          stacklevel=2)
             rho_spin = torch.zeros_like(rho_tot)
         else:
             if len(mm) != len(model.atoms):

@@ -116,6 +116,31 @@ def test_iron_lda_collinear_scf_matches_oracle_and_reference_abinit_values():
     assert d["spin_polarization"] == "collinear" and d["n_spin_components"] == 2
 
 
+def test_collinear_checkpoint_round_trip_and_restart(tmp_path):
+    """save_scfres / load_scfres (src/scf/scfres.jl:1-35, :69-86) of a collinear run: the .npz checkpoint holds one orbital
+    block per (k-point, spin) -- spin-up blocks, then spin-down ones -- and restarts the SCF at its fixed point."""
+    db = iron_device_basis()
+    res = dftk.self_consistent_field(db, rho=dftk.guess_density(db, (4.0,)), tol=1e-8)
+    assert res["converged"]
+    fn = str(tmp_path / "iron.npz")
+    dftk.save_scfres(fn, res)
+    back = dftk.load_scfres(fn, db)
+    assert len(back["psi"]) == len(db.kpoints) == 12 and back["rho"].shape == (2, 20, 20, 20)
+    for p, q in zip(back["psi"], res["psi"]):
+        assert torch.equal(p, q)
+    assert np.array(back["kpt_n_G_vectors"]).shape == (2, 6)
+    again = dftk.self_consistent_field(db, rho=back["rho"], psi=back["psi"], tol=1e-8)
+    assert again["converged"] and again["n_iter"] <= 3
+    assert abs(again["energies"].total - res["energies"].total) < 1e-8
+    # an unpolarised basis of the same cell is refused (half the k-blocks)
+    Fe = dftk.ElementPsp("Fe", dftk.load_psp("Fe", "lda"))
+    m1 = dftk.model_DFT(IRON_LATTICE, [Fe], [np.zeros(3)], functionals=("lda_xc_teter93",), temperature=0.01,
+                        smearing="fermi_dirac", symmetries=True)
+    b1 = dftk.PlaneWaveBasis(m1, 15, dftk.MonkhorstPack((4, 4, 4), (0.5, 0.5, 0.5)), fft_size=(20, 20, 20))
+    with pytest.raises(ValueError):
+        dftk.load_scfres(fn, b1)
+
+
 def test_collinear_model_without_magnetisation_equals_the_unpolarised_model_on_device():
     """n_spin = 2 with zero spin density == the unpolarised model (lda_x + lda_c_pw, the LDA() default of the BASELINE
     configs): same energy, both channels' eigenvalues = the unpolarised ones, rho_up = rho_down = rho / 2."""

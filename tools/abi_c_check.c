@@ -95,6 +95,9 @@ static int worker(int rank, int n_ranks, const char id[128]) {
     REQUIRE(backend == 0 && n_comm == n_ranks, "communicator reports backend %d with %d ranks, expected RCCL with %d",
             backend, n_comm, n_ranks);
     REQUIRE(dftk_mi_comm_rank(comm) == rank && dftk_mi_comm_size(comm) == n_ranks, "rank / size mismatch");
+    /* one line per rank: what a node operator checks first (every rank on its own device, one RCCL version, N ranks met) */
+    printf("[rank %d/%d] device %d of %d, RCCL %d, ncclCommCount %d\n", rank, n_ranks, device, n_dev, version, n_comm);
+    fflush(stdout);
     {
         enum { NV = 1000 };
         double h[NV];

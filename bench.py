@@ -57,6 +57,17 @@ GOLDEN = {   # supercell n -> (fixture, k-mesh-compatible cube edge, primitive c
     4: ("baseline_cfg2_prim_4x4x4_ecut30_fft40.json", 160, 64),
 }
 KERNEL_FAMS = (0, 1, 2, 3, 4, 5, 6)      # candidates for "the dominant kernel" (0 stands for 0 + 11)
+ONE_RANK_ENERGIES = os.path.join(ROOT, "tests", "golden", "device_one_rank_energies.json")
+
+
+def one_rank_energy(workload_key):
+    """Converged total energy of the ONE-rank device run of a workload (written by ``--write-reference-energy``; a
+    device-vs-device fixture, NOT an oracle number: the oracle parity of the one-rank run is the `golden` leg)."""
+    try:
+        with open(ONE_RANK_ENERGIES) as fh:
+            return json.load(fh).get(workload_key)
+    except (OSError, ValueError):
+        return None
 
 
 def parse():
@@ -89,6 +100,9 @@ def parse():
     ap.add_argument("--cpu-sample-bands", type=int, default=0, help="0 = one band per host core (max 256)")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the untimed parity legs (continuation of the timed SCFs to convergence, golden-fixture run)")
+    ap.add_argument("--write-reference-energy", action="store_true",
+                    help="N = 1: store the converged total energy of the parity leg in tests/golden/device_one_rank_energies.json "
+                         "(what the N > 1 runs of the same workload are compared with)")
     ap.add_argument("--no-amdahl-probe", action="store_true",
                     help="--mode kpoints, N = 1: skip the timed SCF steps on one rank's share of the k-points (Amdahl model)")
     return ap.parse_args()
@@ -386,7 +400,7 @@ def run_scf(dftk, lib, basis, args, barrier, world, dist, torch):
         del warm
     barrier()
     if not args.prof_all:
-        check(lib.dftk_mi_prof_enable(basis.handle, 1))
+        check(lib.dftk_mi_prof_enable(basis.handle, 3))        # 3: families + the per-shape zgemm table (slab replay)
     iters, diagtols, step_s, nmv_steps = [], [], [], []
     host_timers = {}
     t0 = time.time()
@@ -421,7 +435,18 @@ def run_scf(dftk, lib, basis, args, barrier, world, dist, torch):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     fam = {f: prof_get(lib, basis, f) for f in list(FAMILIES) + [10, 12, 14, 17, 18]}
-    return dict(info=info, elapsed=elapsed, iters=iters, diagtols=diagtols, step_s=step_s, nmv_steps=nmv_steps,
+    shapes = []
+    try:
+        cap = 512
+        rows = (C.c_int64 * (6 * cap))()
+        sms = (C.c_double * cap)()
+        cnt = C.c_int()
+        check(lib.dftk_mi_prof_zgemm_shapes(basis.handle, cap, rows, sms, C.byref(cnt)))
+        shapes = [dict(trans="NC"[rows[6 * i]], m=int(rows[6 * i + 1]), n=int(rows[6 * i + 2]), k=int(rows[6 * i + 3]),
+                       flags=int(rows[6 * i + 4]), calls=int(rows[6 * i + 5]), ms=float(sms[i])) for i in range(min(cnt.value, cap))]
+    except Exception:
+        shapes = []
+    return dict(zgemm_shapes=shapes, info=info, elapsed=elapsed, iters=iters, diagtols=diagtols, step_s=step_s, nmv_steps=nmv_steps,
                 host_timers=host_timers, fam=fam, stepper=stepper)
 
 
@@ -639,6 +664,115 @@ def amdahl_gamma(run, steps, n_cube):
                             "measured), ring all-reduce 2(p-1)/p bytes per link, all-to-all 1/p^2 of the block per link; no "
                             "overlap of communication with compute; per-rank kernels keep their one-GPU efficiency at 1/N "
                             "of the rows (optimistic for N = 8: tiles of 128 rows, 16 554 rows per rank)")}
+
+
+def measured_slab_step(dftk, lib, basis, run, steps, base):
+    """--mode gamma on ONE GPU: the row-sharded families of the timed SCF MEASURED at the size one of N ranks runs them,
+    instead of dividing their one-GPU times by N:
+      * every zgemm shape of the timed run (per-shape table of the library, dftk_mi_prof_zgemm_shapes) replayed with its
+        long dimension (rows of an 'N' product, inner dimension of a 'C' product) cut to 1 / N, same flags, same number
+        of calls per step;
+      * the FFT pipeline (H psi local part) and the density pass on ceil(M / N) bands per call -- a rank transforms its
+        share of the BANDS after the slab -> band transposition --, scaled to the bands per step of the timed run / N;
+      * the n_G-sized element-wise kernels divided by N (streaming kernels: 133 MB per block at N = 8, far above the
+        size where they lose bandwidth).
+    Replicated work (eigensolver, Cholesky, host glue, cube-sized work) is taken in full from the timed run, the
+    collectives from the model above.  Returns {N: predicted step ms} and the measured pieces."""
+    import torch
+    from dftk_jl_amd._lib import check, dftk_mi_cplx
+    kpt = basis.kpoints[0]
+    if not getattr(kpt, "gamma_real", False):
+        return None
+    dev = basis.device
+    h = basis.handle
+    M = int(run["info"]["psi"][0].shape[0])
+    n_half = C.c_int64()
+    check(lib.dftk_mi_gamma_half_size(kpt.handle, C.byref(n_half)))
+    n_half = int(n_half.value)
+    nmv_step = float(run["info"]["n_matvec"]) / steps
+    n_occ = basis.model.n_electrons // 2
+    one, zero = dftk_mi_cplx(1.0, 0.0), dftk_mi_cplx(0.0, 0.0)
+    gen = torch.Generator(device=dev).manual_seed(4321)
+
+    def fam_ms(fs):
+        return sum(prof_get(lib, basis, f)[0] for f in fs)
+
+    def time_zgemm(sh, n_div):
+        long_rows = sh["trans"] == "N" and sh["m"] >= 10000
+        long_k = sh["trans"] == "C" and sh["k"] >= 10000
+        m, n, k = sh["m"], sh["n"], sh["k"]
+        if long_rows:
+            m = -(-m // n_div)
+        if long_k:
+            k = -(-k // n_div)
+        flags = sh["flags"] | (8 if (long_rows or long_k) else 0)        # the long products of this run are REAL products
+        if sh["trans"] == "N":
+            A = torch.randn((k, m, 2), dtype=torch.float64, device=dev, generator=gen)      # column-major m x k
+            B = torch.randn((n, k, 2), dtype=torch.float64, device=dev, generator=gen)
+            lda, ldb = m, k
+        else:
+            A = torch.randn((m, k, 2), dtype=torch.float64, device=dev, generator=gen)      # column-major k x m
+            B = torch.randn((n, k, 2), dtype=torch.float64, device=dev, generator=gen)
+            lda, ldb = k, k
+        Cm = torch.empty((n, m, 2), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        reps = 3
+        check(lib.dftk_mi_zgemm_ex(h, sh["trans"].encode(), m, n, k, one, A.data_ptr(), lda, B.data_ptr(), ldb, zero,
+                                   Cm.data_ptr(), m, flags))                                    # warm (plan cache)
+        check(lib.dftk_mi_prof_enable(h, 1))
+        for _ in range(reps):
+            check(lib.dftk_mi_zgemm_ex(h, sh["trans"].encode(), m, n, k, one, A.data_ptr(), lda, B.data_ptr(), ldb, zero,
+                                       Cm.data_ptr(), m, flags))
+        t = fam_ms((0, 11)) / reps
+        check(lib.dftk_mi_prof_enable(h, 0))
+        return t, bool(long_rows or long_k)
+
+    out = {"measured_slab_step_ms": {}, "slab_pieces_ms": {}}
+    psi_h = torch.randn((M, n_half, 2), dtype=torch.float64, device=dev, generator=gen)
+    psi_full = torch.view_as_real(run["info"]["psi"][0]).contiguous()
+    rho = torch.zeros(tuple(reversed(basis.fft_size)), dtype=torch.float64, device=dev)
+    for n_div in (2, 4, 8):
+        zg = 0.0
+        for sh in run["zgemm_shapes"]:
+            t, sharded = time_zgemm(sh, n_div)
+            zg += t * sh["calls"] / steps if sharded else sh["ms"] / steps
+        nb = -(-M // n_div)
+        Hh = torch.empty((nb, n_half, 2), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        check(lib.dftk_mi_gamma_apply_H(kpt.handle, 3, nb, psi_h.data_ptr(), n_half, Hh.data_ptr(), n_half))   # warm
+        check(lib.dftk_mi_prof_enable(h, 1))
+        for _ in range(3):
+            check(lib.dftk_mi_gamma_apply_H(kpt.handle, 3, nb, psi_h.data_ptr(), n_half, Hh.data_ptr(), n_half))
+        t_fft_band = fam_ms((1, 2, 3, 4, 5, 15)) / 3 / nb
+        check(lib.dftk_mi_prof_enable(h, 0))
+        nbd = max(2, -(-n_occ // n_div))
+        w = np.full(nbd, 2.0)
+        check(lib.dftk_mi_density_accumulate_real(kpt.handle, nbd, psi_full.data_ptr(), int(psi_full.shape[1]), w.ctypes.data,
+                                                  rho.data_ptr()))
+        check(lib.dftk_mi_prof_enable(h, 1))
+        for _ in range(3):
+            check(lib.dftk_mi_density_accumulate_real(kpt.handle, nbd, psi_full.data_ptr(), int(psi_full.shape[1]),
+                                                      w.ctypes.data, rho.data_ptr()))
+        t_dens_band = fam_ms((1, 2, 6, 15)) / 3 / nbd
+        check(lib.dftk_mi_prof_enable(h, 0))
+        fft = t_fft_band * nmv_step / n_div
+        dens = t_dens_band * n_occ / n_div
+        # element-wise family of the timed run minus what the FFT replay above already contains (pack / unpack passes are
+        # booked as element-wise inside gamma_apply_H): only the LOBPCG driver's share is divided
+        ew_total = base["sharded_families_ms"].get(FAMILIES[15], 0.0)
+        pieces = {"zgemm": round(zg, 2), "fft_pipeline": round(fft, 2), "density": round(dens, 2),
+                  "elementwise_div_n": round(ew_total / n_div, 2), "bands_per_apply": nb}
+        sharded = zg + fft + dens + ew_total / n_div
+        out["slab_pieces_ms"][str(n_div)] = pieces
+        out["measured_slab_step_ms"][str(n_div)] = round(base["per_step_ms"]["replicated"] + sharded
+                                                         + base["comm_ms_per_step"][str(n_div)], 2)
+    wall = base["per_step_ms"]["wall"]
+    out["measured_speedup"] = {k_: round(wall / v_, 2) for k_, v_ in out["measured_slab_step_ms"].items()}
+    out["note"] = ("sharded families measured at slab size on this one GPU (zgemm shapes of the timed run replayed with 1/N of "
+                   "the long dimension, FFT pipeline / density on ceil(M/N) bands per call), replicated part and collectives "
+                   "as in predicted_ms_per_step; pack / unpack passes inside the H psi replay are part of fft_pipeline, so "
+                   "elementwise_div_n counts them a second time (conservative)")
+    return out
 
 
 def amdahl_kpoints(dftk, basis, model, ecut, device, run, steps, args):
@@ -903,6 +1037,13 @@ def main():
     try:
         if world == 1 and args.mode == "gamma":
             amdahl = amdahl_gamma(run, steps_run, basis.N)
+            if not args.no_amdahl_probe:
+                try:
+                    slab = measured_slab_step(dftk, lib, basis, run, steps_run, amdahl)
+                    if slab is not None:
+                        amdahl.update(slab)
+                except Exception as e:
+                    amdahl["measured_slab_step_ms"] = {"error": repr(e)}
         elif world == 1 and args.mode == "kpoints" and not args.no_amdahl_probe:
             amdahl = amdahl_kpoints(dftk, basis, model, ecut, device, run, steps_run, args)
     except Exception as e:           # the model is reporting only
@@ -915,6 +1056,24 @@ def main():
                 checks["complex_leg converged"] = parity["complex_leg"]["converged"]
                 checks["|dE real vs complex| per atom"] = abs(parity["dE_total_real_vs_complex_per_atom"]) < PARITY_TOL_HA_PER_ATOM
                 checks["eigenvalues real vs complex"] = parity["max_deigenvalue_real_vs_complex"] < 1e-7
+            wkey = workload.split(", Gamma-only")[0] if args.mode == "gamma" else workload.split(" k-points (")[0]
+            parity["workload_key"] = wkey
+            ref_e = one_rank_energy(wkey)
+            if n_gpus > 1 and ref_e is not None:
+                # the N-rank run against the ONE-rank run of the same workload (sharding must not move the fixed point)
+                parity["E_total_one_rank"] = ref_e["E_total"]
+                parity["dE_total_vs_one_rank_per_atom"] = (parity["timed_leg"]["E_total"] - ref_e["E_total"]) / n_atoms
+                checks["|dE N ranks vs one rank| per atom"] = abs(parity["dE_total_vs_one_rank_per_atom"]) < PARITY_TOL_HA_PER_ATOM
+            elif n_gpus == 1 and args.write_reference_energy and parity["timed_leg"]["converged"]:
+                try:
+                    with open(ONE_RANK_ENERGIES) as fh:
+                        table = json.load(fh)
+                except (OSError, ValueError):
+                    table = {}
+                table[wkey] = {"E_total": parity["timed_leg"]["E_total"], "scf_tol": parity["scf_tol"], "n_atoms": n_atoms,
+                               "lib_hash": library_source_hash()}
+                with open(ONE_RANK_ENERGIES, "w") as fh:
+                    json.dump(table, fh, indent=1, sort_keys=True)
             if "golden" in parity:
                 checks["golden leg converged"] = parity["golden"]["converged"]
                 checks["|dE vs golden| per atom"] = abs(parity["golden"]["dE_total_vs_golden_per_atom"]) < PARITY_TOL_HA_PER_ATOM
@@ -933,6 +1092,8 @@ def main():
             out["config"]["parity_max_deigenvalue_real_vs_complex"] = parity.get("max_deigenvalue_real_vs_complex")
             if "golden" in parity:
                 out["config"]["parity_dE_vs_golden_per_atom"] = parity["golden"]["dE_total_vs_golden_per_atom"]
+            if "dE_total_vs_one_rank_per_atom" in parity:
+                out["config"]["parity_dE_vs_one_rank_per_atom"] = parity["dE_total_vs_one_rank_per_atom"]
                 out["config"]["parity_max_deigenvalue_vs_golden"] = parity["golden"]["max_deigenvalue_vs_golden"]
         out["amdahl"] = amdahl
         if isinstance(amdahl, dict) and "predicted_speedup" in amdahl:

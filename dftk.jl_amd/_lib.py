@@ -105,6 +105,7 @@ _SIGNATURES = {
                                    C.c_void_p, _i64, dftk_mi_cplx, C.c_void_p, _i64, C.c_int]),
     "dftk_mi_zgemm_plan_host": (C.c_int, [C.c_char, _i64, _i64, _i64, C.c_int, C.POINTER(C.c_int)]),
     "dftk_mi_heev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, C.c_void_p, _i64]),
+    "dftk_mi_prof_zgemm_shapes": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "dftk_mi_heev_lowest": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, _i64, C.c_void_p, C.c_void_p, _i64]),
     "dftk_mi_heev_sigma_host": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                           C.POINTER(C.c_int), C.c_double]),

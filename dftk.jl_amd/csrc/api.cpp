@@ -114,7 +114,9 @@ extern "C" int dftk_mi_prof_enable(dftk_mi_basis* b, int on) {
             b->prof->launches[i] = 0;
         }
     }
-    if (!on && !b->prof->shapes.empty()) {
+    b->prof->shape_tags = (on & 2) != 0;
+    static const bool shapes_env = getenv("DFTK_MI_GEMM_SHAPES") != nullptr;
+    if (!on && shapes_env && !b->prof->shapes.empty()) {
         // DFTK_MI_GEMM_SHAPES: per-shape zgemm table (tag = trans | m | n | k)
         for (auto& kv : b->prof->shapes) {
             const uint64_t t = kv.first;
@@ -126,6 +128,30 @@ extern "C" int dftk_mi_prof_enable(dftk_mi_basis* b, int on) {
         b->prof->shapes.clear();
     }
     b->prof->on = on != 0;
+    return 0;
+}
+// Per-shape zgemm table accumulated since dftk_mi_prof_enable(b, 3): row i = { transA ('N' = 0, 'C' = 1), m, n, k, flags & 3,
+// calls }, ms[i] = summed HIP-event time.  Returns the number of shapes in *count (at most cap rows are written) and
+// clears the table.
+extern "C" int dftk_mi_prof_zgemm_shapes(dftk_mi_basis* b, int cap, int64_t* rows6, double* ms, int* count) {
+    if (!b || cap < 0 || !count || (cap > 0 && (!rows6 || !ms))) return DFTK_MI_EINVAL;
+    CHK(prof_resolve(b));
+    int i = 0;
+    for (auto& kv : b->prof->shapes) {
+        if (i < cap) {
+            const uint64_t t = kv.first;
+            rows6[6 * i + 0] = (int64_t)(t >> 63);
+            rows6[6 * i + 1] = (int64_t)((t >> 42) & 0xFFFFF);
+            rows6[6 * i + 2] = (int64_t)((t >> 22) & 0x3FFFF);
+            rows6[6 * i + 3] = (int64_t)(t & 0x3FFFFF);
+            rows6[6 * i + 4] = (int64_t)((t >> 40) & 3);
+            rows6[6 * i + 5] = (int64_t)kv.second.n;
+            ms[i] = kv.second.ms;
+        }
+        ++i;
+    }
+    *count = i;
+    b->prof->shapes.clear();
     return 0;
 }
 extern "C" int dftk_mi_prof_get(dftk_mi_basis* b, int family, double* total_ms, double* work, int64_t* launches) {

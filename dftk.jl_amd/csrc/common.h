@@ -110,6 +110,7 @@ struct Prof {
     std::vector<Pair> pool;
     int open = 0;                       // scopes begun and not yet ended: no flush while > 0 (slots index `pending`)
     int mute = 0;                       // > 0: prof_begin books nothing (inner calls of a routine that is booked as a whole)
+    bool shape_tags = false;            // dftk_mi_prof_enable(b, 3): zgemm calls are also booked per shape (dftk_mi_prof_zgemm_shapes)
     double ms[PROF_NFAM] = {0};
     double work[PROF_NFAM] = {0};
     int64_t launches[PROF_NFAM] = {0};

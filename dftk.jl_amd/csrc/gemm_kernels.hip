@@ -1109,7 +1109,8 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
     }
     static const bool trace = getenv("DFTK_MI_TRACE_GEMM") != nullptr;
     if (trace) fprintf(stderr, "[zgemm] %c %lld %lld %lld\n", transA, (long long)m, (long long)n, (long long)k);
-    static const bool shapes = getenv("DFTK_MI_GEMM_SHAPES") != nullptr;
+    static const bool shapes_env = getenv("DFTK_MI_GEMM_SHAPES") != nullptr;
+    const bool shapes = shapes_env || (b->prof && b->prof->shape_tags);
     const uint64_t tag = !shapes ? 0
                                  : ((uint64_t)conja << 63) | ((uint64_t)(m & 0xFFFFF) << 42) |
                                        ((uint64_t)(n & 0x3FFFF) << 22) | ((uint64_t)(upper_in & 3) << 40) |

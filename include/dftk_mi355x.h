@@ -430,6 +430,10 @@ int dftk_mi_shard_plan_host(int n_ranks, int rank, int n_bands, const int64_t* r
  * general complex iteration would need).  enable(1) resets. */
 int dftk_mi_prof_enable(dftk_mi_basis* basis, int on);
 int dftk_mi_prof_get(dftk_mi_basis* basis, int family, double* total_ms, double* work, int64_t* launches);
+/* dftk_mi_prof_enable(basis, 3) also books every zgemm call per SHAPE; this returns (and clears) that table: row i of
+ * rows6 = { transA ('N' = 0, 'C' = 1), m, n, k, flags & 3, calls }, ms[i] = summed time; *count = shapes seen (<= cap
+ * rows are written).  bench.py replays the table at 1 / N of the rows for its sharded-step measurement. */
+int dftk_mi_prof_zgemm_shapes(dftk_mi_basis* basis, int cap, int64_t* rows6, double* ms, int* count);
 
 /* Diagnostic: measured issue-rate ceiling of v_mfma_f64_16x16x4_f64 (TFLOP/s, no memory traffic). */
 int dftk_mi_diag_mfma_peak(dftk_mi_basis* basis, int waves_per_simd, int iters, double* tflops);

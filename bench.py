@@ -1092,9 +1092,9 @@ def main():
             out["config"]["parity_max_deigenvalue_real_vs_complex"] = parity.get("max_deigenvalue_real_vs_complex")
             if "golden" in parity:
                 out["config"]["parity_dE_vs_golden_per_atom"] = parity["golden"]["dE_total_vs_golden_per_atom"]
+                out["config"]["parity_max_deigenvalue_vs_golden"] = parity["golden"]["max_deigenvalue_vs_golden"]
             if "dE_total_vs_one_rank_per_atom" in parity:
                 out["config"]["parity_dE_vs_one_rank_per_atom"] = parity["dE_total_vs_one_rank_per_atom"]
-                out["config"]["parity_max_deigenvalue_vs_golden"] = parity["golden"]["max_deigenvalue_vs_golden"]
         out["amdahl"] = amdahl
         if isinstance(amdahl, dict) and "predicted_speedup" in amdahl:
             for n_, v_ in amdahl["predicted_speedup"].items():

@@ -94,7 +94,10 @@ def symmetric_block(rng, n, m, g, mg):
 @pytest.mark.parametrize("trans,m,n,k,flags", [("C", 37, 50, 1000, 0), ("C", 259, 259, 30011, 1), ("C", 130, 70, 2049, 0),
                                                 ("C", 300, 99, 5000, 0), ("C", 5, 3, 40001, 0), ("C", 777, 777, 66000, 1),
                                                 ("N", 1000, 37, 50, 0), ("N", 5000, 259, 777, 0), ("N", 3000, 36, 100, 0),
-                                                ("N", 66000, 300, 300, 2), ("N", 127, 34, 13, 0), ("N", 1, 1, 1, 0)])
+                                                ("N", 66000, 300, 300, 2), ("N", 127, 34, 13, 0), ("N", 1, 1, 1, 0),
+                                                # triangular B at the widths of ortho!(X): odd row counts, n = 503 / 512 / 259 / 64
+                                                ("N", 4099, 503, 503, 2), ("N", 3001, 512, 512, 2), ("N", 2500, 130, 130, 2),
+                                                ("N", 2048, 64, 64, 2), ("N", 20011, 259, 259, 2)])
 def test_zgemm_real_flag(lib, trans, m, n, k, flags):
     """DFTK_MI_GEMM_REAL: 'C' = Re(A^H B) with a zero imaginary part, 'N' = A Re(B); with alpha, beta, UPPER (1),
     B_UPPER (2), ragged tiles and the split-K path."""

@@ -35,6 +35,7 @@ struct BatchCtx {
     char *h_ring = nullptr, *d_ring = nullptr;
     size_t cap = 0, off = 0;
     char *h_res = nullptr, *d_res = nullptr;
+    bool res_mapped = false;     // d_res is the device view of h_res (zero-copy result slots)
     size_t res_cap = 0, res_off = 0;
     // device scratch of the executors: a bump allocator per round (every batch_scratch() pointer stays valid until the
     // round's stream synchronisation; a request that does not fit opens a larger buffer and RETIRES the current one,
@@ -88,7 +89,7 @@ void* batch_result_slot(BatchCtx* c, size_t bytes, void** host_twin) {
 }
 size_t batch_result_room(BatchCtx* c) { return c->res_cap - c->res_off; }
 int batch_results_fetch(BatchCtx* c) {
-    if (c->res_off == 0) return 0;
+    if (c->res_off == 0 || c->res_mapped) return 0;
     HIPCHK(hipMemcpyAsync(c->h_res, c->d_res, c->res_off, hipMemcpyDeviceToHost, c->stream));
     return 0;
 }
@@ -367,6 +368,7 @@ int batch_run(dftk_mi_basis* b, std::vector<std::function<int()>>& bodies, std::
         char *h_ring = nullptr, *d_ring = nullptr, *h_res = nullptr, *d_res = nullptr;
         void* d_scratch = nullptr;
         size_t scratch_bytes = 0;
+        bool res_mapped = false;
     };
     static thread_local Pool pool;
     const size_t cap = 16u << 20, res_cap = 8u << 20;
@@ -375,14 +377,21 @@ int batch_run(dftk_mi_basis* b, std::vector<std::function<int()>>& bodies, std::
             hipHostFree(pool.h_ring);
             hipFree(pool.d_ring);
             hipHostFree(pool.h_res);
-            hipFree(pool.d_res);
+            if (!pool.res_mapped) hipFree(pool.d_res);
             if (pool.d_scratch) hipFree(pool.d_scratch);
             pool = Pool();
         }
         HIPCHK(hipHostMalloc((void**)&pool.h_ring, cap));
         HIPCHK(hipMalloc((void**)&pool.d_ring, cap));
-        HIPCHK(hipHostMalloc((void**)&pool.h_res, res_cap));
-        HIPCHK(hipMalloc((void**)&pool.d_res, res_cap));
+        // result slots: pinned host memory mapped into the device's address space -- the executors' kernels write their few
+        // bytes (statuses, norms, eigenvalues) straight into it, the round's stream synchronisation makes them visible: no
+        // device -> host blit per round (as host_fetch does for the single-block drivers; measured on the Al workload:
+        // 35.7 - 38.1 -> 38.7 - 38.8 SCF it/s)
+        HIPCHK(hipHostMalloc((void**)&pool.h_res, res_cap, hipHostMallocMapped));
+        void* dp = nullptr;
+        HIPCHK(hipHostGetDevicePointer(&dp, pool.h_res, 0));
+        pool.d_res = reinterpret_cast<char*>(dp);
+        pool.res_mapped = true;
         pool.device = b->device;
     }
     c->cap = cap;
@@ -391,6 +400,7 @@ int batch_run(dftk_mi_basis* b, std::vector<std::function<int()>>& bodies, std::
     c->d_ring = pool.d_ring;
     c->h_res = pool.h_res;
     c->d_res = pool.d_res;
+    c->res_mapped = pool.res_mapped;
     c->d_scratch = pool.d_scratch;
     c->scratch_bytes = pool.scratch_bytes;
     const size_t n = bodies.size();

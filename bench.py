@@ -525,7 +525,7 @@ def roofline_of(fam, n_gpus, workload):
     # HBM bytes per launch of the dominant family from PMC passes over THIS command and THIS build
     # (tools/pmc_traffic_bench.sh writes profiles/<round>_pmc_traffic.json with the library's source hash)
     roof["traffic"] = None
-    for pmc_file in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for pmc_file in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", pmc_file)) as fh:
                 pmc = json.load(fh)

@@ -64,7 +64,7 @@ def main():
         fams[f]["ratio"] = fams[f]["bytes_per_launch"] / max(fams[f].get("algorithmic_bytes_per_launch", 0.0), 1e-300)
     json.dump({"workload": line["config"]["workload"], "lib_hash": line["config"]["lib_hash"],
                "collected": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over `python bench.py "
-                            "--no-cpu-baseline --prof-all` (tools/pmc_traffic_bench.sh)",
+                            "--no-cpu-baseline --prof-all` (tools/pmc_traffic_bench.sh)" + __import__("os").environ.get("PMC_NOTE", ""),
                "correction": "FETCH_SIZE x2 (gfx950), WRITE_SIZE x1, KiB -> B; per launch = family bytes / family "
                              "dispatches in the same pass",
                "families": fams}, open(sys.argv[4], "w"), indent=1)

@@ -1360,3 +1360,55 @@ def test_collinear_spin_descriptors_on_host():
     assert (m0.spin_polarization, m0.n_spin_components, m0.filled_occupation) == ("none", 1, 2)
     with pytest.raises(NotImplementedError):
         dftk.model_DFT(lat, [Fe], [np.zeros(3)], spin_polarization="full")
+
+
+def test_partial_eigensolver_shift_rule_and_numpy_model(lib):
+    """dftk_mi_heev_lowest (csrc/eig_kernels.hip) on the host: the shift rule exported by the library equals the NumPy model's
+    (tools/lab/heev_lowest_model.py), it always lies above the nev-th smallest diagonal entry (the interlacing argument), the
+    number of held iterations follows the estimated gap, and the model -- the same schedule of scaled Newton-Schulz iterations,
+    leverage-score column selection and Cholesky-QR passes as the kernels -- returns the lowest nev pairs of matrices with the
+    structure of LOBPCG Rayleigh-Ritz matrices to round-off."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "lab"))
+    import heev_lowest_model as model
+    rng = np.random.default_rng(12)
+    for n, nev in ((90, 30), (333, 111), (1006, 503)):
+        d = np.concatenate([np.sort(rng.uniform(-0.2, 0.4, nev)), rng.uniform(0.45, 9.0, n - nev)])
+        d = d[rng.permutation(n)]
+        sigma, gap, hold = C.c_double(), C.c_double(), C.c_int()
+        check(lib.dftk_mi_heev_sigma_host(n, d.ctypes.data, nev, C.byref(sigma), C.byref(gap), C.byref(hold), 12.0))
+        s_model, g_model = model.choose_sigma(d, nev)
+        assert abs(sigma.value - s_model) < 1e-15 and abs(gap.value - g_model) < 1e-15
+        ds = np.sort(d)
+        assert ds[nev - 1] < sigma.value < ds[nev]                 # above d_(nev); inside the diagonal gap when there is one
+        want = int(np.ceil(np.log(max(model.L_HAT / (gap.value / 12.0), 1.0)) / np.log(model.GROW)))
+        assert hold.value == min(want, 34)
+    assert lib.dftk_mi_heev_sigma_host(5, None, 2, None, None, None, 1.0) < 0
+    # no gap in the diagonal at all (equal entries): still strictly above d_(nev)
+    d = np.zeros(40)
+    check(lib.dftk_mi_heev_sigma_host(40, d.ctypes.data, 10, C.byref(sigma), C.byref(gap), None, 0.0))
+    assert sigma.value > 0.0 and gap.value > 0.0
+
+    def rr_like(n, nev, coupling):
+        nlow = nev + nev // 3
+        low = np.repeat(rng.uniform(-0.2, 0.6, nlow // 4 + 1), 4)[:nlow] + 1e-6 * rng.standard_normal(nlow)
+        lam = np.concatenate([np.sort(low), rng.uniform(0.6, 8.0, n - nlow)])
+        Q, _ = np.linalg.qr(np.eye(n) + coupling * rng.standard_normal((n, n)) / np.sqrt(n))
+        A = (Q.T * lam) @ Q
+        w, Z = np.linalg.eigh(A[:nev, :nev])
+        T = np.eye(n)
+        T[:nev, :nev] = Z
+        A = T.T @ A @ T
+        A = (A + A.T) / 2
+        A[:nev, :nev] = np.diag(w)
+        return A
+    for n, nev, coupling in ((240, 80, 0.3), (300, 150, 1e-3)):
+        A = rr_like(n, nev, coupling)
+        log = []
+        out = model.heev_lowest(A, nev, log)
+        assert out is not None, log
+        lam, V = out
+        ref = np.linalg.eigvalsh(A)[:nev]
+        assert np.abs(lam - ref).max() < 1e-12 and np.abs(V.T @ V - np.eye(nev)).max() < 1e-12
+        assert np.abs(A @ V - V * lam).max() < 1e-11
+        k = [e for e in log if e[0] == "summary"][0][2]
+        assert nev <= k <= max(nev + 64, (3 * nev) // 2)

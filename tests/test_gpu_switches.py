@@ -7,6 +7,8 @@ battery in a subprocess and compares it with the default process' results:
   DFTK_MI_GEMM=naive       the naive (non-MFMA) GEMM kernels
   DFTK_MI_FFT_REG=0        LDS-pass z kernels for axes that have a register-resident instantiation
   DFTK_MI_FFT_REG_MIN=256  the same through the length threshold
+  DFTK_MI_HEEV_PARTIAL_MIN=40 / DFTK_MI_HEEV_PARTIAL=0   the partial Rayleigh-Ritz solver from n = 40 on / switched off
+  DFTK_MI_POTRF_COOP_LAUNCH=0   plain instead of cooperative launch of the one-launch Cholesky
   diagnostics              DFTK_MI_HEEV_TRACE, DFTK_MI_HEEV_CLOCK, DFTK_MI_TRACE_GEMM, DFTK_MI_GEMM_SHAPES,
                            DFTK_MI_LOBPCG_CHECK, DFTK_MI_POISON, DFTK_MI_KBATCH_TRACE: identical numbers
 (DFTK_MI_KBATCH_SEQUENTIAL has its own test in tests/test_gpu_kbatch.py.)"""
@@ -78,6 +80,23 @@ for real in (False, True):
     torch.cuda.synchronize()
     check(lib.dftk_mi_heev(basis.handle, n, A2.data_ptr(), n, W.ctypes.data, V.data_ptr(), n))
     out["heev_err_real" if real else "heev_err"] = float(np.max(np.abs(W - want)))
+# ---- heev_lowest on a matrix with the structure of a Rayleigh-Ritz matrix (full solver below DFTK_MI_HEEV_PARTIAL_MIN)
+rng = np.random.default_rng(3)
+n, nev = 240, 80
+lam_ = np.concatenate([np.sort(rng.uniform(-0.2, 0.6, nev + 26)), rng.uniform(0.6, 8.0, n - nev - 26)])
+Q_, _ = np.linalg.qr(np.eye(n) + 0.3 * rng.standard_normal((n, n)) / np.sqrt(n))
+A_ = (Q_.T * lam_) @ Q_
+w_, Z_ = np.linalg.eigh(A_[:nev, :nev])
+T_ = np.eye(n); T_[:nev, :nev] = Z_
+A_ = T_.T @ A_ @ T_; A_ = (A_ + A_.T) / 2; A_[:nev, :nev] = np.diag(w_)
+Ad = torch.tensor(np.ascontiguousarray(A_.T), dtype=torch.complex128, device="cuda")
+Vd = torch.zeros((n, n), dtype=torch.complex128, device="cuda"); Wl = np.zeros(n)
+torch.cuda.synchronize()
+check(lib.dftk_mi_heev_lowest(basis.handle, n, nev, Ad.data_ptr(), n, Wl.ctypes.data, Vd.data_ptr(), n))
+torch.cuda.synchronize()
+Vl = Vd.cpu().numpy().T[:, :nev]
+out["heev_lowest_err"] = float(max(np.abs(Wl[:nev] - np.linalg.eigvalsh(A_)[:nev]).max(), np.abs(A_ @ Vl - Vl * Wl[:nev]).max(),
+                                   np.abs(Vl.conj().T @ Vl - np.eye(nev)).max()))
 # ---- H psi, density, LOBPCG on a cube whose z axis takes the register-resident kernels by default
 rho0 = dftk.guess_density(basis)
 _, ham = dftk.energy_hamiltonian(basis, None, None, rho=rho0)
@@ -117,6 +136,7 @@ def default_run(tmp_path_factory):
 def _check_against_default(got, ref, tight):
     (o, a, _), (o0, a0, _) = got, ref
     assert max(o["zgemm_err"]) < 1e-12 and o["heev_err"] < 1e-10 and o["heev_err_real"] < 1e-10, o
+    assert o["heev_lowest_err"] < 1e-10, o
     tol = 0.0 if tight else 1e-11
     assert np.linalg.norm(a["Hpsi"] - a0["Hpsi"]) <= tol * np.linalg.norm(a0["Hpsi"])
     assert np.linalg.norm(a["rho"] - a0["rho"]) <= tol * np.linalg.norm(a0["rho"])
@@ -127,6 +147,7 @@ def _check_against_default(got, ref, tight):
 def test_default_paths_are_accurate(default_run):
     o, a, _ = default_run
     assert max(o["zgemm_err"]) < 1e-12 and o["heev_err"] < 1e-10 and o["heev_err_real"] < 1e-10, o
+    assert o["heev_lowest_err"] < 1e-10, o
     assert np.all(np.diff(a["lam"]) >= -1e-12)
 
 
@@ -135,6 +156,12 @@ def test_default_paths_are_accurate(default_run):
     ("gemm_naive", {"DFTK_MI_GEMM": "naive"}),
     ("fft_lds_z", {"DFTK_MI_FFT_REG": "0"}),
     ("fft_reg_min", {"DFTK_MI_FFT_REG_MIN": "256"}),
+    # the partial Rayleigh-Ritz solver (spectral split) from n = 40 on: the battery's dftk_mi_heev_lowest call and the
+    # 48 x 48 / 72 x 72 Rayleigh-Ritz matrices of its LOBPCG run take it; and the same threshold with the solver switched off
+    ("heev_partial_small", {"DFTK_MI_HEEV_PARTIAL_MIN": "40"}),
+    ("heev_partial_off", {"DFTK_MI_HEEV_PARTIAL": "0", "DFTK_MI_HEEV_PARTIAL_MIN": "40"}),
+    # the one-launch Cholesky under a plain launch (per-process residency count only) instead of a cooperative launch
+    ("potrf_plain_launch", {"DFTK_MI_POTRF_COOP_LAUNCH": "0"}),
 ])
 def test_alternative_kernel_paths_match_the_default_ones(tmp_path, default_run, tag, env):
     _check_against_default(_run(tmp_path, tag, env), default_run, tight=False)

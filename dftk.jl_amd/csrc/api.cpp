@@ -330,7 +330,10 @@ extern "C" int dftk_mi_basis_create(int nx, int ny, int nz, double unit_cell_vol
     b->nxp = ((nx + 7) / 8) * 8;
     b->volume = unit_cell_volume;
     b->device = device;
-    b->fft_batch = 8;
+    // bands per launch group of the FFT pipeline.  32 since round 5: at 8 the launches of the x stages last 48 - 61 us and
+    // every stage loses bandwidth to its fill / drain (tools/fft_bench.py 5 256 <group>: pipeline + density of 256 bands
+    // 149.1 ms at 8, 143.3 at 16, 134.5 at 32, 135.6 at 64); scratch = group x (T1 + T2) = 2.8 GB at the 1000-electron cell
+    b->fft_batch = 32;
     b->prof = new Prof();
     const char* g = getenv("DFTK_MI_GEMM");
     b->use_mfma = (g && strcmp(g, "naive") == 0) ? 0 : 1;

@@ -81,7 +81,7 @@ def estimate_memory_usage(model, Ecut, kcoords=((0.0, 0.0, 0.0),), fft_size=None
     return MemoryStatistics(n_kpoints, n_Gk, n_bands, n_p, psik, Pk, psi, rho, P, P + 2 * psi + 6 * psik + 12 * rho)
 
 
-def plan_planewave_sharded(model, Ecut, n_ranks, fft_size=None, gamma_real=True, fft_batch=8,
+def plan_planewave_sharded(model, Ecut, n_ranks, fft_size=None, gamma_real=True, fft_batch=32,
                            hbm_bytes=HBM_BYTES_MI355X) -> dict:
     """Per-GPU bytes of a Gamma-only SCF whose single k-block is plane-wave sharded over ``n_ranks`` GPUs.
 

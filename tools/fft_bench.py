@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Time the five FFT stages of the local H psi (and the density z-pass) on a BASELINE-sized sphere:
-python tools/fft_bench.py [supercell n = 5] [bands = 64] [bands per launch group = 8].  Prints ms per launch and algorithmic TB/s per stage
+python tools/fft_bench.py [supercell n = 5] [bands = 64] [bands per launch group = 32].  Prints ms per launch and algorithmic TB/s per stage
 (HIP events inside the library).  DFTK_MI_ZPASS_CLASSIC=1 selects the LDS-staged z-pass for comparison."""
 import ctypes as C
 import os
@@ -15,7 +15,7 @@ from dftk_jl_amd._lib import check  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-fft_batch = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+fft_batch = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 lat, atoms, pos = dftk.silicon_cell((n, n, n))
 basis = dftk.PlaneWaveBasis(dftk.model_DFT(lat, atoms, pos), 30, dftk.MonkhorstPack((1, 1, 1)), build_terms=False)
 kpt = basis.kpoints[0]

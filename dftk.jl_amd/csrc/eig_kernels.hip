@@ -445,7 +445,7 @@ static int heev_lowest_impl(dftk_mi_basis* b, int n, int nev, cd* A, int64_t lda
 // batched calls, when nev is more than 60 % of n, or when the split fails its checks.
 int dense_heev_lowest(dftk_mi_basis* b, int n, int nev, cd* A, int64_t lda, double* W_h, cd* V, int64_t ldv) {
     if (n <= 0) return 0;
-    static const int min_n = getenv("DFTK_MI_HEEV_PARTIAL_MIN") ? atoi(getenv("DFTK_MI_HEEV_PARTIAL_MIN")) : 600;
+    static const int min_n = getenv("DFTK_MI_HEEV_PARTIAL_MIN") ? atoi(getenv("DFTK_MI_HEEV_PARTIAL_MIN")) : 384;
     static const bool off = getenv("DFTK_MI_HEEV_PARTIAL") && atoi(getenv("DFTK_MI_HEEV_PARTIAL")) == 0;
     if (off || batching() || !b->use_mfma || n < min_n || nev < 1 || 10 * nev > 6 * n)
         return dense_heev(b, n, A, lda, W_h, V, ldv);

@@ -314,7 +314,7 @@ int dftk_mi_heev(dftk_mi_basis* basis, int n, dftk_mi_cplx* A_d, int64_t lda, do
  * of the 2N x 2N / 3N x 3N matrix Y'AY): one spectral split by a Newton-Schulz sign iteration on the f64 matrix cores
  * (sigma above the nev-th smallest diagonal entry), an orthonormal basis of the lower invariant subspace by
  * Cholesky-QR, the blocked Jacobi on the k x k projected matrix (nev <= k), one product back.  W_h[0 .. nev) and the
- * first nev columns of V_d are set; A is left intact.  Small problems (n < 600), nev > 0.6 n and inputs on which the
+ * first nev columns of V_d are set; A is left intact.  Small problems (n < 384), nev > 0.6 n and inputs on which the
  * split fails its own checks go to dftk_mi_heev (A destroyed, all n pairs returned).  DFTK_MI_HEEV_PARTIAL=0 switches
  * the split off, DFTK_MI_HEEV_PARTIAL_MIN=<n> moves the size threshold. */
 int dftk_mi_heev_lowest(dftk_mi_basis* basis, int n, int nev, dftk_mi_cplx* A_d, int64_t lda, double* W_h,

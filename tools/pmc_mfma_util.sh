@@ -10,7 +10,6 @@ rm -rf /tmp/pm /tmp/pm2
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA -d /tmp/pm -o pm --output-format csv -- python $R/tools/gemm_bench.py > /tmp/gemm_bench_out.txt 2>&1
 if [ -n "$BENCH" ]; then
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA -d /tmp/pm2 -o pm --output-format csv -- python $R/$BENCH >> /tmp/gemm_bench_out.txt 2>&1
-  tail -n +2 /tmp/pm2/pm_counter_collection.csv | awk -F, 'BEGIN{OFS=","} {print}' > /tmp/pm2_rows.csv
   python - <<'PY2'
 import csv
 a = list(csv.DictReader(open('/tmp/pm/pm_counter_collection.csv')))

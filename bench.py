@@ -115,6 +115,36 @@ def prof_get(lib, basis, fam):
     return ms.value, work.value, n.value
 
 
+def library_counts(lib):
+    """(kernel launches, host synchronisations) the library has issued in this process so far (dftk_mi_launch_count)."""
+    a, b_ = C.c_int64(), C.c_int64()
+    lib.dftk_mi_launch_count(C.byref(a), C.byref(b_))
+    return a.value, b_.value
+
+
+def latency_roofline(run, steps, roof):
+    """--mode kpoints: the many-small-k workloads are launch-latency problems (n_G ~ 1e3, 6-8 bands: every kernel is
+    microseconds on kilobytes), so the bound that applies is neither HBM nor MFMA: it is launches and host
+    synchronisations per SCF step.  achieved = wall microseconds per library launch; peak = the back-to-back launch
+    rate of small kernels on one HIP stream (~5 us of host time per hipLaunchKernel here, profiles/r04_kpoints_share_
+    step_N8_torch_profile.txt); frac = peak / achieved.  The MFMA numbers of the zgemm family stay in `mfma_view`."""
+    launches = max(1, int(run["library_launches"]))
+    wall_us = 1e6 * run["elapsed"]
+    us_per_launch = wall_us / launches
+    peak_us = 5.0
+    return {"bound": "latency", "achieved": round(us_per_launch, 2), "peak": peak_us, "unit": "us/launch",
+            "frac": round(peak_us / us_per_launch, 4), "traffic": None,
+            "launches_per_step": round(launches / steps, 1),
+            "host_syncs_per_step": round(run["library_host_syncs"] / steps, 1),
+            "us_per_step": round(wall_us / steps, 1),
+            "note": ("launch-latency bound: achieved = wall time of the timed SCF / kernel launches the library issued in "
+                     "it (torch launches of the host mirror are not counted: they are what the native SCF glue removes); "
+                     "peak = host cost of one back-to-back small launch on a HIP stream; frac = peak / achieved (1 = the "
+                     "step is nothing but back-to-back launches)"),
+            "mfma_view": {k_: roof[k_] for k_ in ("achieved", "peak", "unit", "frac", "kernel", "launches", "avg_launch_ms",
+                                                  "families_ms", "families_launches") if k_ in roof}}
+
+
 def library_source_hash():
     """Hash of the library's sources (also compiled into dftk_mi_version()): ties a PMC traffic file to the build."""
     from dftk_jl_amd import _build
@@ -122,6 +152,79 @@ def library_source_hash():
 
 
 # ------------------------------------------------------------------------------------------ CPU leg
+class BandWorkers:
+    """Band-parallel local part of H psi and of the density on the host, as the reference threads them (one band per
+    thread, FFT threads = 1: src/terms/Hamiltonian.jl:155, src/common/threading.jl:12).  Every worker thread owns ONE
+    preallocated cube: no allocation and no page fault inside the timed loops (round 5 allocated a fresh 113 MB cube per
+    band -- 256 threads then spend their time in the kernel's address-space lock).  The scatter, the
+    in-place pocketfft transforms and the multiplication release the GIL."""
+
+    def __init__(self, threads, N, shape, mapping, pot):
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        self.threads, self.N, self.shape, self.mapping, self.pot = int(threads), N, shape, mapping, pot
+        self.pool = ThreadPoolExecutor(max_workers=self.threads)
+        self.tls = threading.local()
+
+    def _cube(self):
+        c = getattr(self.tls, "cube", None)
+        if c is None:
+            c = self.tls.cube = np.zeros(self.N, dtype=complex)
+        return c
+
+    def local_one(self, col):
+        import scipy.fft as sfft
+        cube = self._cube()
+        cube.fill(0.0)
+        cube[self.mapping] = col
+        c3 = sfft.ifftn(cube.reshape(self.shape), workers=1, norm="forward", overwrite_x=True)
+        c1 = c3.reshape(self.N)
+        c1 *= self.pot
+        c3 = sfft.fftn(c1.reshape(self.shape), workers=1, norm="backward", overwrite_x=True)
+        return c3.reshape(self.N)[self.mapping]
+
+    def dens_one(self, col):
+        import scipy.fft as sfft
+        cube = self._cube()
+        cube.fill(0.0)
+        cube[self.mapping] = col
+        c3 = sfft.ifftn(cube.reshape(self.shape), workers=1, norm="forward", overwrite_x=True)
+        return c3.real ** 2 + c3.imag ** 2
+
+    def shutdown(self):
+        self.pool.shutdown()
+
+
+def sweep_band_threads(N, shape, mapping, pot, cols, cores, avail_bytes):
+    """H psi applies per second of the band-parallel host leg for 32 / 64 / 128 / 256 threads (and the core count),
+    two waves of bands each (bounded: a wave is one 3-D FFT pair per thread); returns ({threads: rate}, best)."""
+    cand = sorted({t for t in (32, 64, 128, 256, cores) if 1 <= t <= cores and t * 16 * N * 3 < avail_bytes})
+    if not cand:
+        cand = [max(1, min(cores, int(avail_bytes // (3 * 16 * N))))]
+    rates = {}
+    for t in cand:
+        w = BandWorkers(t, N, shape, mapping, pot)
+        nb = min(t, 256)
+        list(w.pool.map(w.local_one, (cols[:, j % cols.shape[1]] for j in range(nb))))        # warm: buffers touched
+        t0 = time.time()
+        list(w.pool.map(w.local_one, (cols[:, j % cols.shape[1]] for j in range(2 * nb))))
+        rates[t] = 2 * nb / (time.time() - t0)
+        w.shutdown()
+    best = max(rates, key=rates.get)
+    return {str(k_): round(v_, 2) for k_, v_ in rates.items()}, best
+
+
+def rule_of_thumb(basis, cores):
+    """The reference's own "very (very) rough" estimate of the time per SCF step (docs/src/tricks/parallelization.md:57-73:
+    30 ms per FFT on a 128^3 grid x grid points x k-points x occupied states x 8 FFT steps per state, no
+    parallelisation), and what ideal scaling over this host's cores would make of it."""
+    n_occ = -(-basis.model.n_electrons // basis.model.filled_occupation)
+    serial = 30e-3 / 128 ** 3 * float(np.prod(basis.fft_size)) * len(basis.kcoords_global) * n_occ * 8
+    return {"rule_of_thumb_serial_s_per_step": round(serial, 1),
+            "rule_of_thumb_it_per_s": round(cores / serial, 4),
+            "rule_of_thumb_note": ("estimate_time_per_scf_step of docs/src/tricks/parallelization.md:61-73 (FFT-limited, "
+                                   f"unparallelised) divided by the {cores} host cores, i.e. DFTK with IDEAL thread scaling")}
+
 def cpu_baseline_gamma(basis, info, n_sample, per_step):
     """kind = "port": the NumPy/SciPy oracle's arithmetic timed on this host, BATCHED over bands so that every
     core is busy (the reference threads H psi over bands, src/terms/Hamiltonian.jl:155, src/common/threading.jl),
@@ -172,46 +275,33 @@ def cpu_baseline_gamma(basis, info, n_sample, per_step):
     err = float(np.linalg.norm(chk - ref) / np.linalg.norm(ref))
     assert err < 1e-12, f"batched CPU H psi deviates from the oracle: {err}"
     # band-parallel like the reference (one band per thread, FFT threads = 1: src/common/threading.jl:12,
-    # src/terms/Hamiltonian.jl:155): a thread pool over bands, each with a single-threaded pocketfft
-    from concurrent.futures import ThreadPoolExecutor
+    # src/terms/Hamiltonian.jl:155): worker threads with one preallocated cube each, thread count chosen by a sweep
     try:
         import psutil
         avail = psutil.virtual_memory().available
     except Exception:
         avail = 32 << 30
-    threads = int(max(1, min(cores, n_sample, avail // (6 * 16 * N))))
+    shape = (nz, ny, nx)
+    sweep, threads = sweep_band_threads(N, shape, kpt.mapping, pot, psi, cores, avail)
     P_h = P
     D_h = T.D
-
-    def hpsi_one(n):
-        cube = np.zeros(N, dtype=complex)
-        cube[kpt.mapping] = psi[:, n]
-        cube = sfft.ifftn(cube.reshape(nz, ny, nx), workers=1, norm="forward", overwrite_x=True).reshape(N)
-        cube *= pot
-        cube = sfft.fftn(cube.reshape(nz, ny, nx), workers=1, norm="backward", overwrite_x=True).reshape(N)
-        return cube[kpt.mapping] + kin * psi[:, n]
-
-    def dens_one(n):
-        cube = np.zeros(N, dtype=complex)
-        cube[kpt.mapping] = psi[:, n]
-        cube = sfft.ifftn(cube.reshape(nz, ny, nx), workers=1, norm="forward", overwrite_x=True)
-        return cube.real ** 2 + cube.imag ** 2
-
-    with ThreadPoolExecutor(max_workers=threads) as pool:
-        list(pool.map(hpsi_one, range(min(threads, n_sample))))          # warm
-        t0 = time.time()
-        loc = list(pool.map(hpsi_one, range(n_sample)))
-        if P_h is not None:                                                 # nonlocal part: one threaded zgemm pair
-            nl = P_h @ (D_h @ (P_h.conj().T @ psi))
-        t_hpsi = (time.time() - t0) / n_sample
-        one = np.stack(loc[:2], axis=1) + (nl[:, :2] if P_h is not None else 0.0)
-        err2 = float(np.linalg.norm(one - ref) / np.linalg.norm(ref))
-        assert err2 < 1e-12, f"band-parallel CPU H psi deviates from the oracle: {err2}"
-        t0 = time.time()
-        acc = None
-        for d in pool.map(dens_one, range(n_sample)):
-            acc = d if acc is None else acc + d
-        t_dens = (time.time() - t0) / n_sample
+    W = BandWorkers(threads, N, shape, kpt.mapping, pot)
+    list(W.pool.map(W.local_one, (psi[:, n] for n in range(min(threads, n_sample)))))          # warm
+    t0 = time.time()
+    loc = list(W.pool.map(W.local_one, (psi[:, n] for n in range(n_sample))))
+    loc = [l_ + kin * psi[:, n] for n, l_ in enumerate(loc)]
+    if P_h is not None:                                                 # nonlocal part: one threaded zgemm pair
+        nl = P_h @ (D_h @ (P_h.conj().T @ psi))
+    t_hpsi = (time.time() - t0) / n_sample
+    one = np.stack(loc[:2], axis=1) + (nl[:, :2] if P_h is not None else 0.0)
+    err2 = float(np.linalg.norm(one - ref) / np.linalg.norm(ref))
+    assert err2 < 1e-12, f"band-parallel CPU H psi deviates from the oracle: {err2}"
+    t0 = time.time()
+    acc = None
+    for d in W.pool.map(W.dens_one, (psi[:, n] for n in range(n_sample))):
+        acc = d if acc is None else acc + d
+    t_dens = (time.time() - t0) / n_sample
+    W.shutdown()
     bsz = threads
     # dense algebra rate: Gram matrix and rotation of a panel (threaded OpenBLAS zgemm)
     mcols = M                      # panels of the true width (LOBPCG's are M .. 3M wide)
@@ -226,11 +316,13 @@ def cpu_baseline_gamma(basis, info, n_sample, per_step):
     t_step = (per_step["n_matvec"] * t_hpsi + per_step["zgemm_flops"] / rate + n_occ * t_dens)
     late_flops = 80.0 * n_G * M * M         # one 1-iteration LOBPCG call: Gram / update products of a late step
     return {"value": 1.0 / t_step, "unit": "SCF iterations/s", "cores": cores, "kind": "port",
-            "hpsi_applies_per_s": 1.0 / t_hpsi,
+            "hpsi_applies_per_s": 1.0 / t_hpsi, "threads": threads, "thread_sweep_hpsi_per_s": sweep,
+            **rule_of_thumb(basis, cores),
             "model_terms": {"hpsi_s_per_band": t_hpsi, "density_s_per_band": t_dens, "zgemm_gflops": rate / 1e9,
                             "late_step_zgemm_s": late_flops / rate},
             "sample": (f"NumPy/SciPy oracle arithmetic (not DFTK: no Julia here), band-parallel as the reference: "
-                       f"{bsz} threads x one band each (pocketfft workers=1) + threaded OpenBLAS: {n_sample} bands of H psi "
+                       f"{bsz} threads x one band each (pocketfft workers=1, one preallocated cube per thread; best of the sweep "
+                       f"{sweep} H psi/s) + threaded OpenBLAS: {n_sample} bands of H psi "
                        f"({t_hpsi * 1e3:.2f} ms/band; checked against oracle.HamiltonianBlock.mul to {err:.1e}), "
                        f"{n_sample} density bands ({t_dens * 1e3:.2f} ms/band), a {mcols}-column zgemm panel "
                        f"({rate / 1e9:.0f} GF/s); one SCF step modelled as the device run's per-step averages: "
@@ -265,7 +357,7 @@ def cfg1_scf_3steps(device):
 
 
 # ------------------------------------------------------------------------------------------ CPU leg: a timed step
-def cpu_timed_late_step(basis, info, diagtol, budget_s, dinfo=None):
+def cpu_timed_late_step(basis, info, diagtol, budget_s, dinfo=None, threads_hint=None):
     """kind = "port, timed step": ONE real SCF step of the reference's algorithm on the host cores, with wall seconds,
     beside the device's time for the same step.  Input = the converged state of the device run (psi, rho): from there
     a step is what every late SCF step of this workload is -- H[rho] is rebuilt, LOBPCG (general complex orbitals,
@@ -306,33 +398,22 @@ def cpu_timed_late_step(basis, info, diagtol, budget_s, dinfo=None):
     pot = V.reshape(-1) * (basis.fft_normalization * basis.ifft_normalization)
     X0 = info["psi"][0].cpu().numpy().T.copy()                            # (n_G, M) general complex orbitals
     mapping = kpt.mapping
-    threads = int(max(1, min(cores, M, avail // (8 * 16 * N))))
-    pool = ThreadPoolExecutor(max_workers=threads)
+    threads = int(threads_hint) if threads_hint else int(max(1, min(cores, M, avail // (8 * 16 * N))))
+    W = BandWorkers(threads, N, (nz, ny, nx), mapping, pot)
+    pool = W.pool
     n_hpsi = [0]
-
-    def local_one(col):
-        cube = np.zeros(N, dtype=complex)
-        cube[mapping] = col
-        cube = sfft.ifftn(cube.reshape(nz, ny, nx), workers=1, norm="forward", overwrite_x=True).reshape(N)
-        cube *= pot
-        cube = sfft.fftn(cube.reshape(nz, ny, nx), workers=1, norm="backward", overwrite_x=True).reshape(N)
-        return cube[mapping]
 
     def A(block):                       # mul!(H psi, H, psi) (Hamiltonian.jl:137-192), band-parallel
         n_hpsi[0] += block.shape[1]
         out = np.empty_like(block)
-        for j, col in enumerate(pool.map(local_one, (block[:, j] for j in range(block.shape[1])))):
+        for j, col in enumerate(pool.map(W.local_one, (block[:, j] for j in range(block.shape[1])))):
             out[:, j] = col
         out += kin[:, None] * block
         if P is not None:
             out += P @ (D @ (P.conj().T @ block))
         return out
 
-    def dens_one(col):
-        cube = np.zeros(N, dtype=complex)
-        cube[mapping] = col
-        cube = sfft.ifftn(cube.reshape(nz, ny, nx), workers=1, norm="forward", overwrite_x=True)
-        return cube.real ** 2 + cube.imag ** 2
+    dens_one = W.dens_one
 
     # check the band-parallel operator against the oracle's own (2 bands)
     class OB:
@@ -403,6 +484,7 @@ def run_scf(dftk, lib, basis, args, barrier, world, dist, torch):
         check(lib.dftk_mi_prof_enable(basis.handle, 3))        # 3: families + the per-shape zgemm table (slab replay)
     iters, diagtols, step_s, nmv_steps = [], [], [], []
     host_timers = {}
+    counts0 = library_counts(lib)
     t0 = time.time()
     # guess_density is part of self_consistent_field.  The stepper's own convergence test is the (tighter) PARITY
     # tolerance so that it can be continued, untimed, after the timed loop; the timed loop stops at --tol exactly as
@@ -429,6 +511,7 @@ def run_scf(dftk, lib, basis, args, barrier, world, dist, torch):
     info["converged"] = bool(info["history_drho"][-1] < args.tol)
     barrier()
     elapsed = time.time() - t0
+    counts1 = library_counts(lib)
     check(lib.dftk_mi_prof_enable(basis.handle, 0))
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -447,7 +530,8 @@ def run_scf(dftk, lib, basis, args, barrier, world, dist, torch):
     except Exception:
         shapes = []
     return dict(zgemm_shapes=shapes, info=info, elapsed=elapsed, iters=iters, diagtols=diagtols, step_s=step_s, nmv_steps=nmv_steps,
-                host_timers=host_timers, fam=fam, stepper=stepper)
+                host_timers=host_timers, fam=fam, stepper=stepper,
+                library_launches=counts1[0] - counts0[0], library_host_syncs=counts1[1] - counts0[1])
 
 
 def continue_to_parity(stepper, max_extra=80):
@@ -705,7 +789,7 @@ def measured_slab_step(dftk, lib, basis, run, steps, base):
             m = -(-m // n_div)
         if long_k:
             k = -(-k // n_div)
-        flags = sh["flags"] | (8 if (long_rows or long_k) else 0)        # the long products of this run are REAL products
+        flags = sh["flags"]                                              # UPPER / B_UPPER / REAL exactly as the timed call had them
         if sh["trans"] == "N":
             A = torch.randn((k, m, 2), dtype=torch.float64, device=dev, generator=gen)      # column-major m x k
             B = torch.randn((n, k, 2), dtype=torch.float64, device=dev, generator=gen)
@@ -952,6 +1036,8 @@ def main():
     if rank == 0:
         gamma_real = bool(getattr(basis.kpoints[0], "gamma_real", False))
         roof = roofline_of(fam, n_gpus, workload)
+        if args.mode == "kpoints":
+            roof = latency_roofline(run, steps_run, roof)
         booked = sum(fam[f][0] for f in (0, 11, 1, 2, 3, 4, 5, 6, 7, 8, 13))
         kp0 = basis.kpoints[0]
         out = {
@@ -979,7 +1065,9 @@ def main():
                        "host_timers_ms_per_step": {k_: round(1e3 * v_ / steps_run, 2)
                                                    for k_, v_ in run["host_timers"].items()},
                        "library_booked_ms": round(booked, 1), "lib_hash": library_source_hash(),
-                       "E_total": info["energies"].total, "drho": info["history_drho"][-1]},
+                       "E_total": info["energies"].total, "drho": info["history_drho"][-1],
+                       "library_launches_per_step": round(run["library_launches"] / steps_run, 1),
+                       "library_host_syncs_per_step": round(run["library_host_syncs"] / steps_run, 1)},
             "roofline": roof,
         }
         # flat scalars (the driver's BENCH record keeps scalars of `config`, not nested objects)
@@ -1018,6 +1106,11 @@ def main():
                                                   "mfma_busy_frac", "kernel", "launches", "avg_launch_ms", "families_ms",
                                                   "families_rate") if k_ in croof}}
         out["config"]["complex_iteration_value"] = round(ci["n_iter"] / crun["elapsed"], 4)
+        # top level, next to `value`: the like-for-like number for the REFERENCE's own algorithm (general complex orbitals);
+        # `value` is the real-symmetric Gamma iteration, an extension the reference does not have
+        out["complex_iteration_value"] = round(ci["n_iter"] / crun["elapsed"], 4)
+        out["complex_iteration_unit"] = "SCF iterations/s"
+        out["value_algorithm"] = "real-symmetric Gamma orbitals (extension); complex_iteration_value = the reference's iteration"
         out["config"]["complex_iteration_frac"] = round(croof["frac"], 4)
         out["config"]["complex_iteration_steps"] = int(ci["n_iter"])
         del crun, ci, cbasis
@@ -1064,6 +1157,14 @@ def main():
                 parity["E_total_one_rank"] = ref_e["E_total"]
                 parity["dE_total_vs_one_rank_per_atom"] = (parity["timed_leg"]["E_total"] - ref_e["E_total"]) / n_atoms
                 checks["|dE N ranks vs one rank| per atom"] = abs(parity["dE_total_vs_one_rank_per_atom"]) < PARITY_TOL_HA_PER_ATOM
+                # a device-vs-device fixture: say which build wrote it (a stale entry is reported, not hidden)
+                parity["one_rank_reference_lib_hash"] = ref_e.get("lib_hash")
+                parity["one_rank_reference_is_this_build"] = ref_e.get("lib_hash") == library_source_hash()
+            elif n_gpus > 1:
+                parity["one_rank_reference"] = "MISSING"
+                print(f"bench.py: WARNING: no one-rank reference energy for workload key {wkey!r} in {ONE_RANK_ENERGIES}: the "
+                      f"N = {n_gpus} run is NOT compared with the one-rank run (write it with --gpus 1 --write-reference-energy)",
+                      file=sys.stderr, flush=True)
             elif n_gpus == 1 and args.write_reference_energy and parity["timed_leg"]["converged"]:
                 try:
                     with open(ONE_RANK_ENERGIES) as fh:
@@ -1120,7 +1221,8 @@ def main():
                                   + model_leg["model_terms"]["late_step_zgemm_s"])
                     timed = None
                     if late_model < args.cpu_step_budget:
-                        timed = cpu_timed_late_step(basis, late_info, float(dinfo["diagtol"]), args.cpu_step_budget, dinfo)
+                        timed = cpu_timed_late_step(basis, late_info, float(dinfo["diagtol"]), args.cpu_step_budget, dinfo,
+                                                    threads_hint=model_leg.get("threads"))
                     if timed is not None:
                         timed["device_step_s"] = round(t_dev, 4)
                         timed["device_lobpcg_iterations"] = float(np.mean(dinfo["diagonalization"]["n_iter"]))

@@ -76,6 +76,9 @@ _SIGNATURES = {
                                                    C.c_void_p]),
     "dftk_mi_band_kinetic_multi": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dftk_mi_batch_stats": (C.c_int, [C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "dftk_mi_lobpcg_small_stats": (C.c_int, [C.POINTER(_i64), C.POINTER(_i64)]),
+    "dftk_mi_ortho_small": (C.c_int, [C.c_void_p, _i64, C.c_int, C.c_void_p, _i64, C.c_int, C.c_void_p, _i64, C.c_void_p,
+                                      C.c_double, C.c_void_p]),
     "dftk_mi_lobpcg_last_AX": (C.c_void_p, [C.c_void_p]),
     "dftk_mi_lobpcg_history": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t,
                                          C.POINTER(C.c_int)]),
@@ -123,6 +126,7 @@ _SIGNATURES = {
     "dftk_mi_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "dftk_mi_prof_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                    C.POINTER(_i64)]),
+    "dftk_mi_launch_count": (C.c_int, [C.POINTER(_i64), C.POINTER(_i64)]),
     "dftk_mi_diag_mfma_peak": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "dftk_mi_jacobi_schedule_host": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                                C.POINTER(C.c_int)]),

@@ -236,8 +236,17 @@ class PlaneWaveBasis:
         # Measured (one MI355X, whole SCF): Al 72 k-points 17 vs 11 SCF it/s batched vs lanes, but Si 8 k-points 65 vs 80 and
         # graphene 12 k-points 20 vs 33 -- a scheduling round costs ~150 us whatever the number of k-blocks in it, so a
         # handful of k-points is better served by as many concurrent streams; DFTK_MI_KBATCH=1 forces the batched loop.
+        # Round 6: k-blocks small enough for the library's small-block LOBPCG driver (M <= 8 bands, n_G * M <= 65536: ONE
+        # host synchronisation per iteration, dftk_mi_lobpcg_small_stats) batch from two k-points on -- a scheduling round
+        # then carries a whole LOBPCG iteration of every k-point: Si 8 k-points 120 -> 207, graphene 12 k-points 33 -> 58 SCF
+        # it/s against the lanes (which run the same driver, one fiber per call).
         env_kb = os.environ.get("DFTK_MI_KBATCH")
         kb_min = int(os.environ.get("DFTK_MI_KBATCH_MIN", "32"))
+        n_occ = -(-model.n_electrons // (model.n_spin_components * model.filled_occupation))
+        m_est = max(n_occ + 3, int(math.ceil(1.2 * n_occ))) if model.temperature > 0 else n_occ + 3
+        n_g_est = model.unit_cell_volume * (2.0 * Ecut) ** 1.5 / (6.0 * math.pi ** 2)
+        if m_est <= 8 and 1.15 * n_g_est * m_est <= 65536 and os.environ.get("DFTK_MI_LOBPCG_SMALL") != "0":
+            kb_min = min(kb_min, 2)
         # The decision is taken from the GLOBAL k-point list: every rank of a k-parallel run must walk the same k-loop
         # algorithm and the same chain of start vectors whatever its local share (9 of 72 k-points per rank at 8 GPUs
         # stay batched, exactly as the one-rank run of the same workload).

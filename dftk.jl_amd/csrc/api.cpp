@@ -141,10 +141,10 @@ extern "C" int dftk_mi_prof_zgemm_shapes(dftk_mi_basis* b, int cap, int64_t* row
         if (i < cap) {
             const uint64_t t = kv.first;
             rows6[6 * i + 0] = (int64_t)(t >> 63);
-            rows6[6 * i + 1] = (int64_t)((t >> 42) & 0xFFFFF);
+            rows6[6 * i + 1] = (int64_t)((t >> 42) & 0x7FFFF);
             rows6[6 * i + 2] = (int64_t)((t >> 22) & 0x3FFFF);
             rows6[6 * i + 3] = (int64_t)(t & 0x3FFFFF);
-            rows6[6 * i + 4] = (int64_t)((t >> 40) & 3);
+            rows6[6 * i + 4] = (int64_t)((t >> 40) & 3) | (((t >> 61) & 1) ? DFTK_MI_GEMM_REAL : 0);
             rows6[6 * i + 5] = (int64_t)kv.second.n;
             ms[i] = kv.second.ms;
         }
@@ -152,6 +152,12 @@ extern "C" int dftk_mi_prof_zgemm_shapes(dftk_mi_basis* b, int cap, int64_t* row
     }
     *count = i;
     b->prof->shapes.clear();
+    return 0;
+}
+std::atomic<int64_t> g_dftk_launches{0}, g_dftk_host_syncs{0};
+extern "C" int dftk_mi_launch_count(int64_t* launches, int64_t* host_syncs) {
+    if (launches) *launches = g_dftk_launches.load(std::memory_order_relaxed);
+    if (host_syncs) *host_syncs = g_dftk_host_syncs.load(std::memory_order_relaxed);
     return 0;
 }
 extern "C" int dftk_mi_prof_get(dftk_mi_basis* b, int family, double* total_ms, double* work, int64_t* launches) {

@@ -32,6 +32,7 @@ enum BOpType {
     BOP_APPLYH,      // dftk_mi_apply_H_parts
     BOP_DENSITY,     // launch_density
     BOP_APPLYD,      // apply_D: Y = D X with the banded real D of a k-block (internal to the batched apply_H)
+    BOP_ORTHO,       // fused ortho!(X) / ortho!(X, Y) of a small block, whole adaptive loop inside ONE kernel (batched form only)
     BOP_NTYPES
 };
 
@@ -49,6 +50,11 @@ enum BOpType {
 //   APPLYH   kb, flags = which, m = bands, A = psi, lda, C = H psi, ldc
 //   APPLYD   kb, m = bands, A = X (n_p x m), C = Y
 //   DENSITY  kb, m = bands, A = psi, lda, C = rho, payload = m weights (+ m weights of the imaginary parts, flags = 1)
+//   ORTHO    n rows, m columns of X (C, ldc; m <= 8), k columns of Y (A, lda; k <= 16, 0 = ortho!(X) alone), W = column norms of X
+//            (optional), s0 = tol, host = double[4] {status, ortho!(X, Y) rounds, Cholesky count, growth factor} (after the round);
+//            status 0 = done, 1 = a rare branch is needed (drop_small!, SVD fallback: X is NOT usable), 2 = non-finite input
+// Extensions used by the small-block LOBPCG driver (lobpcg_run_small): RESIDUAL with W3 != null takes lam[c] = W[c] / W3[c];
+// HEEV with E != null also leaves the eigenvalues in that DEVICE array (the residual pass of the same round reads them).
 struct BOp {
     int type = 0;
     dftk_mi_basis* b = nullptr;

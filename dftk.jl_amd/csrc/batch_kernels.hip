@@ -41,7 +41,7 @@ __device__ __forceinline__ double b_block_sum(double v, double* sh) {
 struct EwItem {
     int64_t n, lda, ldb, ldc;
     int m, mode, flags, i0;
-    const void *A, *B, *W, *W2;
+    const void *A, *B, *W, *W2, *W3;
     void *C, *D, *E, *F;
     double s0;
     size_t bytes;
@@ -84,7 +84,9 @@ __global__ __launch_bounds__(256) void k_b_residual(const EwItem* __restrict__ i
     const cd* X = reinterpret_cast<const cd*>(it.B);
     cd* R = reinterpret_cast<cd*>(it.C);
     const double* kin = reinterpret_cast<const double*>(it.W2);
-    const double l = reinterpret_cast<const double*>(it.W)[c];
+    // (W3: the Rayleigh quotients of the start block, lam = <x, Ax> / <x, x>, formed here instead of on the host)
+    const double l = it.W3 ? reinterpret_cast<const double*>(it.W)[c] / reinterpret_cast<const double*>(it.W3)[c]
+                           : reinterpret_cast<const double*>(it.W)[c];
     double acc = 0.0, acck = 0.0, accx = 0.0;
     for (int64_t i = threadIdx.x; i < it.n; i += 256) {
         const cd a = AX[(int64_t)c * it.lda + i];
@@ -352,6 +354,7 @@ struct DenseItem {
     cd *A, *B;        // POTRF: A in / R out (upper), B = inv(R) out;  HEEV: A in (destroyed), B = eigenvectors out
     double* res;      // POTRF: 8 doubles {info, max|diag R|, sum|offdiag R|^2, bad R, same three for inv R, 0}
                       // HEEV : n eigenvalues ascending + {converged, non-finite}
+    double* ev;       // HEEV : optional DEVICE copy of the eigenvalues (read by later kernels of the same round)
 };
 extern __shared__ __attribute__((aligned(16))) char b_smem[];
 
@@ -609,6 +612,7 @@ __global__ __launch_bounds__(256) void k_b_heev(const DenseItem* __restrict__ it
         }
         if (rank < n) {
             res[rank] = di;
+            if (it.ev) it.ev[rank] = di;
             for (int i = 0; i < n; ++i) it.B[i + (int64_t)rank * it.ldb] = V[i * pitch + tid];
         }
     }
@@ -641,6 +645,708 @@ __global__ __launch_bounds__(256) void k_b_apply_D(const ApplyDItem* __restrict_
     it.Y[idx] = make_double2(sr, si);
 }
 
+
+// ---- fused ortho!(X) / ortho!(X, Y) of a small block: the whole adaptive loop inside one kernel ----
+// lobpcg_hyper_impl.jl:216-323 for B = I: Cholesky-QR passes until eps cond(R)^2 < tol (safe_cholesky's shift-and-retry
+// included, :190-210), projection against Y until ||Y'X||_F < tol or the growth factor says it is not needed.  One
+// workgroup per block; X stays in global memory (L2-resident: 1350 x 6 complex = 130 KB), the m x m algebra (m <= 8) runs
+// in the registers of the first wave, fully unrolled on an identity-padded 8 x 8 matrix.  The host-driven loop of
+// lobpcg.cpp (ortho_XY / ortho_X) spends 2-4 host synchronisations per call on these few kiloflops -- in the batched
+// multi-k driver 2-4 scheduling rounds per LOBPCG iteration.  Rare branches that need the host (drop_small!'s random
+// columns, the SVD fallback) are NOT taken here: the kernel reports status 1 and the driver restarts on its general path.
+#define OR_M 8
+#define OR_NY 16
+#define OR_T 512
+struct OrthoItem {
+    int64_t n, ldx, ldy;
+    int m, ny;
+    cd* X;
+    const cd* Y;
+    const double* norms;   // column norms of X from its producer, or null (computed here); used with Y only
+    double tol;
+    double* res;           // {status, ortho!(X, Y) rounds, Cholesky count of the last ortho!(X), growth factor}
+};
+
+// s_out[a + na * j] = sum_r conj(A[r, a]) B[r, j] (block-wide, fixed summation order)
+__device__ __forceinline__ void o_block_dots(const cd* __restrict__ A, int64_t lda, int na, const cd* __restrict__ B,
+                                             int64_t ldb, int nb, int64_t n, cd* s_out, cd* s_part) {
+    const int tid = threadIdx.x;
+    const int P = na * nb;                 // <= 128
+    const int G = OR_T / P;                // row groups per entry (>= 4); consecutive threads walk consecutive rows
+    const int p = tid / G, g = tid - p * G;
+    double sr = 0.0, si = 0.0;
+    if (p < P) {
+        const int a = p % na, j = p / na;
+        const cd* ap = A + (int64_t)a * lda;
+        const cd* bp = B + (int64_t)j * ldb;
+#pragma unroll 8
+        for (int64_t r = g; r < n; r += G) {     // (unrolled: eight independent load pairs in flight per thread)
+            const cd u = ap[r], v = bp[r];
+            sr += u.x * v.x + u.y * v.y;
+            si += u.x * v.y - u.y * v.x;
+        }
+    }
+    s_part[tid] = make_double2(sr, si);
+    __syncthreads();
+    if (tid < P) {
+        double tr = 0.0, ti = 0.0;
+        for (int q = 0; q < G; ++q) {
+            const cd v = s_part[tid * G + q];
+            tr += v.x;
+            ti += v.y;
+        }
+        s_out[tid] = make_double2(tr, ti);
+    }
+    __syncthreads();
+}
+
+// block-wide sums of OR_M doubles per thread -> s_out[0 .. OR_M)
+__device__ __forceinline__ void o_block_sum8(const double (&v)[OR_M], double* s_out, double* s_red /* [OR_T / 64][OR_M] */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < OR_M; ++j) {
+        const double s = b_wave_sum(v[j]);
+        if (lane == 0) s_red[w * OR_M + j] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < OR_M) {
+        double t = 0.0;
+        for (int q = 0; q < OR_T / 64; ++q) t += s_red[q * OR_M + threadIdx.x];
+        s_out[threadIdx.x] = t;
+    }
+    __syncthreads();
+}
+
+// safe_cholesky + inverse + normest of the m x m Gram matrix s_O by the FIRST WAVE, lane-parallel on LDS copies (the other
+// waves wait at the caller's barrier).  Synchronisation inside the wave: its LDS operations execute in program order;
+// the fences / wave barriers below only keep the compiler from moving accesses across the steps.
+// s_inv: inverse of the upper factor (zeros below the diagonal, identity outside m x m);
+// s_stat = {nchol (10000: gave up), normest R, normest inv R, non-finite Gram matrix}
+__device__ __forceinline__ void o_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double o_wave_sum_all(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double o_wave_max_all(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ void o_chol_inv(const cd* s_O, int m, cd* s_R, cd* s_inv, double* s_stat) {
+    const double EPSD = 2.220446049250313e-16;
+    const int lane = threadIdx.x & 63;
+    int nchol = 0;
+    double alpha = 100.0, shift = 0.0, nR = 0.0, nI = 0.0;
+    bool nonfinite = false;
+    for (;;) {
+        if (nchol >= 5) {
+            nchol = 10000;
+            break;
+        }
+        nchol += 1;
+        {
+            const int i = lane % OR_M, j = lane / OR_M;          // 64 lanes = the padded 8 x 8 matrix
+            cd v = s_O[i + OR_M * j];
+            if (i == j && i < m) v.x += shift;
+            s_R[i + OR_M * j] = v;
+            s_inv[i + OR_M * j] = make_double2(i == j ? 1.0 : 0.0, 0.0);
+        }
+        o_wave_sync();
+        bool ok = true;
+        for (int j = 0; j < m; ++j) {
+            const double d = s_R[j + OR_M * j].x;                // (every lane reads the pivot: uniform)
+            if (!(d > 0.0) || !isfinite(d)) {
+                ok = false;
+                break;
+            }
+            const double piv = sqrt(d), inv = 1.0 / piv;
+            o_wave_sync();
+            if (lane == 0) s_R[j + OR_M * j] = make_double2(piv, 0.0);
+            {
+                const int c = j + 1 + lane;
+                if (c < m) {
+                    cd v = s_R[j + OR_M * c];
+                    v.x *= inv;
+                    v.y *= inv;
+                    s_R[j + OR_M * c] = v;
+                }
+            }
+            o_wave_sync();
+            const int rem = m - j - 1;
+            if (lane < rem * rem) {                              // R[i][c] -= conj(R[j][i]) R[j][c],  j < i <= c < m
+                const int a = lane / rem, bq = lane - a * rem;
+                const int i = j + 1 + a, c = j + 1 + bq;
+                if (i <= c) {
+                    const cd u = s_R[j + OR_M * i], v = s_R[j + OR_M * c];
+                    cd w = s_R[i + OR_M * c];
+                    w.x -= u.x * v.x + u.y * v.y;
+                    w.y -= u.x * v.y - u.y * v.x;
+                    if (i == c) w.y = 0.0;
+                    s_R[i + OR_M * c] = w;
+                }
+            }
+            o_wave_sync();
+        }
+        bool bad = false;
+        if (ok) {
+            // inverse of the upper factor, lane j owns column j: x_j = 1 / R_jj, x_i = -(sum_{k > i} R_ik x_k) / R_ii
+            if (lane < m) {
+                const int j = lane;
+                s_inv[j + OR_M * j] = make_double2(1.0 / s_R[j + OR_M * j].x, 0.0);
+                for (int i = j - 1; i >= 0; --i) {
+                    double sr = 0.0, si = 0.0;
+                    for (int k = i + 1; k <= j; ++k) {
+                        const cd rr = s_R[i + OR_M * k], xx = s_inv[k + OR_M * j];
+                        sr += rr.x * xx.x - rr.y * xx.y;
+                        si += rr.x * xx.y + rr.y * xx.x;
+                    }
+                    const double d = s_R[i + OR_M * i].x;
+                    s_inv[i + OR_M * j] = make_double2(-sr / d, -si / d);
+                }
+                for (int i = j + 1; i < OR_M; ++i) s_inv[i + OR_M * j] = make_double2(0.0, 0.0);
+            }
+            o_wave_sync();
+            // normest = max |diag| + ||strict upper||_F of both factors (k_normest_upper), finiteness
+            double mxR = 0.0, offR = 0.0, mxI = 0.0, offI = 0.0, b = 0.0;
+            {
+                const int i = lane % OR_M, j = lane / OR_M;
+                if (i <= j && j < m) {
+                    const cd r = s_R[i + OR_M * j], x = s_inv[i + OR_M * j];
+                    if (!(isfinite(r.x) && isfinite(r.y) && isfinite(x.x) && isfinite(x.y))) b = 1.0;
+                    if (i == j) {
+                        mxR = fabs(r.x);
+                        mxI = fabs(x.x);
+                    } else {
+                        offR = r.x * r.x + r.y * r.y;
+                        offI = x.x * x.x + x.y * x.y;
+                    }
+                }
+            }
+            bad = o_wave_max_all(b) != 0.0;
+            nR = o_wave_max_all(mxR) + sqrt(o_wave_sum_all(offR));
+            nI = o_wave_max_all(mxI) + sqrt(o_wave_sum_all(offI));
+        }
+        if (ok && !bad) break;
+        // O += alpha eps ||O||_F I  (the Frobenius norm of the Hermitian matrix as it stands, earlier shifts included)
+        double f = 0.0;
+        {
+            const int i = lane % OR_M, j = lane / OR_M;
+            if (i < m && j < m) {
+                cd v = i <= j ? s_O[i + OR_M * j] : s_O[j + OR_M * i];
+                if (i == j) v = make_double2(v.x + shift, 0.0);
+                f = v.x * v.x + v.y * v.y;
+            }
+        }
+        const double f2 = o_wave_sum_all(f);
+        if (!isfinite(f2)) {
+            nonfinite = true;
+            break;
+        }
+        shift += alpha * EPSD * sqrt(f2);
+        alpha *= 10.0;
+        o_wave_sync();
+    }
+    if (lane == 0) {
+        s_stat[0] = (double)nchol;
+        s_stat[1] = nR;
+        s_stat[2] = nI;
+        s_stat[3] = nonfinite ? 1.0 : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(OR_T) void k_b_ortho(const OrthoItem* __restrict__ items) {
+    const OrthoItem it = items[blockIdx.x];
+    const double EPSD = 2.220446049250313e-16;
+    const int tid = threadIdx.x, m = it.m, ny = it.ny;
+    const int64_t n = it.n;
+    __shared__ cd s_part[OR_T];
+    __shared__ cd s_byx[OR_NY * OR_M];
+    __shared__ cd s_O[OR_M * OR_M];
+    __shared__ cd s_inv[OR_M * OR_M];
+    __shared__ cd s_R[OR_M * OR_M];
+    __shared__ double s_red[(OR_T / 64) * OR_M];
+    __shared__ double s_nrm[OR_M];
+    __shared__ double s_stat[4];
+    double status = 0.0, growth_last = 1.0;
+    int nchol_last = 0, rounds = 0;
+
+    // ortho!(X): Cholesky-QR passes; returns false when the caller has to stop (status set)
+    auto ortho_x = [&]() -> bool {
+        double growth = 1.0;
+        int nchol_total = 0;
+        for (int pass = 0;; ++pass) {
+            if (pass >= 30) {
+                status = 1.0;
+                return false;
+            }
+            o_block_dots(it.X, it.ldx, m, it.X, it.ldx, m, n, s_byx, s_part);      // s_byx[a + m * j] = <x_a, x_j>
+            if (tid < OR_M * OR_M) {
+                const int i = tid % OR_M, j = tid / OR_M;
+                cd v = make_double2(i == j ? 1.0 : 0.0, 0.0);                        // identity padding
+                if (i < m && j < m) {
+                    // hermitised from the upper triangle (ew_hermitize_upper): real diagonal, lower = conj(upper)
+                    const cd u = i <= j ? s_byx[i + m * j] : s_byx[j + m * i];
+                    v = i == j ? make_double2(u.x, 0.0) : (i < j ? u : make_double2(u.x, -u.y));
+                }
+                s_O[i + OR_M * j] = v;
+            }
+            __syncthreads();
+            if (tid < 64) o_chol_inv(s_O, m, s_R, s_inv, s_stat);
+            __syncthreads();
+            if (s_stat[3] != 0.0) {
+                status = 2.0;
+                return false;
+            }
+            const int nchol = (int)s_stat[0];
+            if (nchol > 10) {                  // "Ortho(X) is failing badly, falling back to SVD": host path
+                status = 1.0;
+                return false;
+            }
+            nchol_total += nchol;
+            // X <- X inv(R), row by row in registers
+            for (int64_t r = tid; r < n; r += OR_T) {
+                cd x[OR_M];
+#pragma unroll
+                for (int j = 0; j < OR_M; ++j) x[j] = j < m ? it.X[r + (int64_t)j * it.ldx] : make_double2(0.0, 0.0);
+#pragma unroll
+                for (int j = OR_M - 1; j >= 0; --j) {      // last column first: column j needs the old columns k <= j
+                    if (j < m) {
+                        double orr = 0.0, oi = 0.0;
+#pragma unroll
+                        for (int k = 0; k <= j; ++k) {
+                            const cd u = s_inv[k + OR_M * j];
+                            orr += x[k].x * u.x - x[k].y * u.y;
+                            oi += x[k].x * u.y + x[k].y * u.x;
+                        }
+                        it.X[r + (int64_t)j * it.ldx] = make_double2(orr, oi);
+                    }
+                }
+            }
+            __syncthreads();                   // (global writes of this block are visible to it after the barrier)
+            const double nR = s_stat[1], nI = s_stat[2];
+            growth *= nI;
+            const double condR = nR * nI;
+            __syncthreads();                   // s_stat / s_inv are rewritten by the next pass
+            if (nchol == 1 && EPSD * condR * condR < it.tol) break;
+        }
+        growth_last = growth;
+        nchol_last = nchol_total;
+        return true;
+    };
+
+    if (ny == 0) {
+        ortho_x();
+    } else {
+        // X ./= norms is folded into the first projection round (scale factors sc[j])
+        if (it.norms) {
+            if (tid < OR_M) s_nrm[tid] = tid < m ? it.norms[tid] : 1.0;
+            __syncthreads();
+        } else {
+            double acc[OR_M];
+#pragma unroll
+            for (int j = 0; j < OR_M; ++j) acc[j] = 0.0;
+            for (int64_t r = tid; r < n; r += OR_T)
+#pragma unroll
+                for (int j = 0; j < OR_M; ++j)
+                    if (j < m) {
+                        const cd v = it.X[r + (int64_t)j * it.ldx];
+                        acc[j] += v.x * v.x + v.y * v.y;
+                    }
+            o_block_sum8(acc, s_nrm, s_red);
+            if (tid < OR_M) s_nrm[tid] = tid < m ? sqrt(s_nrm[tid]) : 1.0;
+            __syncthreads();
+        }
+        double sc[OR_M];
+#pragma unroll
+        for (int j = 0; j < OR_M; ++j) sc[j] = 1.0 / s_nrm[j];
+        __syncthreads();
+        for (int niter = 1;; ++niter) {
+            rounds = niter;
+            // BYX = Y' X ; X -= Y BYX ; column norms of the new X and ||BYX||_F^2 on the way
+            o_block_dots(it.Y, it.ldy, ny, it.X, it.ldx, m, n, s_byx, s_part);      // s_byx[a + ny * j]
+            if (niter == 1) {
+                if (tid < ny * m) {
+                    const int j = tid / ny;
+                    double f = 1.0;
+#pragma unroll
+                    for (int q = 0; q < OR_M; ++q)
+                        if (q == j) f = sc[q];
+                    s_byx[tid].x *= f;
+                    s_byx[tid].y *= f;
+                }
+                __syncthreads();
+            }
+            double acc[OR_M];
+#pragma unroll
+            for (int j = 0; j < OR_M; ++j) acc[j] = 0.0;
+            for (int64_t r = tid; r < n; r += OR_T) {
+                cd x[OR_M];
+#pragma unroll
+                for (int j = 0; j < OR_M; ++j) {
+                    x[j] = j < m ? it.X[r + (int64_t)j * it.ldx] : make_double2(0.0, 0.0);
+                    if (niter == 1) {
+                        x[j].x *= sc[j];
+                        x[j].y *= sc[j];
+                    }
+                }
+#pragma unroll 2
+                for (int a = 0; a < ny; ++a) {
+                    const cd y = it.Y[r + (int64_t)a * it.ldy];
+#pragma unroll
+                    for (int j = 0; j < OR_M; ++j) {
+                        const cd bq = s_byx[a + ny * (j < m ? j : 0)];
+                        if (j < m) {
+                            x[j].x -= y.x * bq.x - y.y * bq.y;
+                            x[j].y -= y.x * bq.y + y.y * bq.x;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < OR_M; ++j)
+                    if (j < m) {
+                        it.X[r + (int64_t)j * it.ldx] = x[j];
+                        acc[j] += x[j].x * x[j].x + x[j].y * x[j].y;
+                    }
+            }
+            o_block_sum8(acc, s_nrm, s_red);        // (ends with a barrier: the new X is visible to the whole block)
+            double byx2 = 0.0;
+#pragma nounroll
+            for (int t = 0; t < ny * m; ++t) {
+                const cd v = s_byx[t];
+                byx2 += v.x * v.x + v.y * v.y;
+            }
+            bool nonfinite = false, drop = false;
+#pragma unroll
+            for (int j = 0; j < OR_M; ++j)
+                if (j < m) {
+                    const double nj = sqrt(s_nrm[j]);
+                    if (!isfinite(nj)) nonfinite = true;
+                    if (nj <= it.tol) drop = true;
+                }
+            __syncthreads();
+            if (nonfinite) {
+                status = 2.0;
+                break;
+            }
+            if (drop) {                         // drop_small!: a random column from the host's generator -- general path
+                status = 1.0;
+                break;
+            }
+            if (sqrt(byx2) < it.tol && niter > 1) break;
+            if (!ortho_x()) break;
+            if (growth_last * EPSD < it.tol) break;
+            if (niter > 10) {                   // "Ortho(X, Y) is failing badly, falling back to SVD"
+                status = 1.0;
+                break;
+            }
+        }
+    }
+    if (tid == 0) {
+        it.res[0] = status;
+        it.res[1] = (double)rounds;
+        it.res[2] = (double)nchol_last;
+        it.res[3] = growth_last;
+    }
+}
+
+
+// ---- the same loops with the block in REGISTERS (n <= RPT * OR_T rows): every thread keeps RPT rows of X for the whole
+// kernel; the tall products are per-thread partial sums over those rows, reduced by a reduce-scatter butterfly inside each
+// wave (63 lane exchanges for 64 values instead of 6 per value) and a fixed-order sum over the waves.  The streaming kernel
+// above walks X through L2 in every phase: its dependent-load loops made it ~180 us per call on the 1350 x 6 blocks of
+// the Al workload (rocprofv3, round 6), i.e. half of a scheduling round.
+#define OR_V 32          // values per block reduction (a 2 x 8 complex tile)
+template <int L>
+__device__ __forceinline__ void o_rs_step(double (&v)[OR_V], int lane) {
+    constexpr int H = L / 2;
+    const bool up = (lane & H) != 0;
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+        const double send = up ? v[i] : v[i + H];
+        const double keep = up ? v[i + H] : v[i];
+        v[i] = keep + __shfl_xor(send, H, 64);
+    }
+}
+// block-wide sums of OR_V values per thread -> s_out[0 .. OR_V) (fixed order: butterfly inside a wave -- lane l ends up
+// with value l % 32 --, then the two half-waves, then the waves in index order)
+template <int NW>
+__device__ __forceinline__ void o_block_sumv(double (&v)[OR_V], double* s_out, double* s_w /* [NW][OR_V] */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    o_rs_step<32>(v, lane);
+    o_rs_step<16>(v, lane);
+    o_rs_step<8>(v, lane);
+    o_rs_step<4>(v, lane);
+    o_rs_step<2>(v, lane);
+    const double t0 = v[0] + __shfl_xor(v[0], 32, 64);
+    if (lane < OR_V) s_w[w * OR_V + lane] = t0;
+    __syncthreads();
+    if (threadIdx.x < OR_V) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) t += s_w[q * OR_V + threadIdx.x];
+        s_out[threadIdx.x] = t;
+    }
+    __syncthreads();
+}
+
+template <int RPT>
+__global__ __launch_bounds__(OR_T) void k_b_ortho_reg(const OrthoItem* __restrict__ items) {
+    const OrthoItem it = items[blockIdx.x];
+    const double EPSD = 2.220446049250313e-16;
+    constexpr int NW = OR_T / 64;
+    const int tid = threadIdx.x, m = it.m, ny = it.ny;
+    const int64_t n = it.n;
+    __shared__ double s_w[NW * OR_V];
+    __shared__ double s_t[OR_V];                    // one reduced tile: (row-in-chunk * OR_M + column) * 2 + {re, im}
+    __shared__ cd s_byx[OR_NY * OR_M];              // BYX[a][j] at a * OR_M + j
+    __shared__ cd s_O[OR_M * OR_M];
+    __shared__ cd s_inv[OR_M * OR_M];
+    __shared__ cd s_R[OR_M * OR_M];
+    __shared__ double s_nrm[OR_M];
+    __shared__ double s_stat[4];
+    double status = 0.0, growth_last = 1.0;
+    int nchol_last = 0, rounds = 0;
+    cd x[RPT][OR_M];
+    bool live[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int64_t r = tid + (int64_t)q * OR_T;
+        live[q] = r < n;
+#pragma unroll
+        for (int j = 0; j < OR_M; ++j)
+            x[q][j] = (live[q] && j < m) ? it.X[r + (int64_t)j * it.ldx] : make_double2(0.0, 0.0);
+    }
+
+    auto ortho_x = [&]() -> bool {
+        double growth = 1.0;
+        int nchol_total = 0;
+        for (int pass = 0;; ++pass) {
+            if (pass >= 30) {
+                status = 1.0;
+                return false;
+            }
+            // Gram matrix, two columns per reduction: tile entry (jl, i) = <x_i, x_{2 c + jl}>
+#pragma unroll
+            for (int c = 0; c < OR_M / 2; ++c) {
+                if (2 * c < m) {
+                    double v[OR_V];
+#pragma unroll
+                    for (int t = 0; t < OR_V; ++t) v[t] = 0.0;
+#pragma unroll
+                    for (int q = 0; q < RPT; ++q)
+#pragma unroll
+                        for (int jl = 0; jl < 2; ++jl) {
+                            const cd xj = x[q][2 * c + jl];
+#pragma unroll
+                            for (int i = 0; i < OR_M; ++i) {
+                                v[(jl * OR_M + i) * 2] += x[q][i].x * xj.x + x[q][i].y * xj.y;
+                                v[(jl * OR_M + i) * 2 + 1] += x[q][i].x * xj.y - x[q][i].y * xj.x;
+                            }
+                        }
+                    o_block_sumv<NW>(v, s_t, s_w);
+                    if (tid < 2 * OR_M) {
+                        const int jl = tid / OR_M, i = tid % OR_M;
+                        s_O[i + OR_M * (2 * c + jl)] = make_double2(s_t[2 * tid], s_t[2 * tid + 1]);
+                    }
+                    __syncthreads();
+                }
+            }
+            // hermitise from the upper triangle, identity padding
+            if (tid < OR_M * OR_M) {
+                const int i = tid % OR_M, j = tid / OR_M;
+                cd vv = make_double2(i == j ? 1.0 : 0.0, 0.0);
+                if (i < m && j < m) {
+                    const cd u = i <= j ? s_O[i + OR_M * j] : s_O[j + OR_M * i];
+                    vv = i == j ? make_double2(u.x, 0.0) : (i < j ? u : make_double2(u.x, -u.y));
+                }
+                s_O[i + OR_M * j] = vv;
+            }
+            __syncthreads();
+            if (tid < 64) o_chol_inv(s_O, m, s_R, s_inv, s_stat);
+            __syncthreads();
+            if (s_stat[3] != 0.0) {
+                status = 2.0;
+                return false;
+            }
+            const int nchol = (int)s_stat[0];
+            if (nchol > 10) {
+                status = 1.0;
+                return false;
+            }
+            nchol_total += nchol;
+            // X <- X inv(R) in place, last column first (column j needs the OLD columns k <= j only); one column of
+            // inv(R) in registers at a time
+#pragma unroll
+            for (int j = OR_M - 1; j >= 0; --j) {
+                cd u[OR_M];
+#pragma unroll
+                for (int k = 0; k <= j; ++k) u[k] = s_inv[k + OR_M * j];
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) {
+                    double orr = 0.0, oi = 0.0;
+#pragma unroll
+                    for (int k = 0; k <= j; ++k) {
+                        orr += x[q][k].x * u[k].x - x[q][k].y * u[k].y;
+                        oi += x[q][k].x * u[k].y + x[q][k].y * u[k].x;
+                    }
+                    x[q][j] = j < m ? make_double2(orr, oi) : make_double2(0.0, 0.0);
+                }
+            }
+            const double nR = s_stat[1], nI = s_stat[2];
+            growth *= nI;
+            const double condR = nR * nI;
+            __syncthreads();
+            if (nchol == 1 && EPSD * condR * condR < it.tol) break;
+        }
+        growth_last = growth;
+        nchol_last = nchol_total;
+        return true;
+    };
+
+    if (ny == 0) {
+        ortho_x();
+    } else {
+        // column norms: from the producer or computed here; X ./= norms on the registers
+        if (it.norms) {
+            if (tid < OR_M) s_nrm[tid] = tid < m ? it.norms[tid] : 1.0;
+        } else {
+            double v[OR_V];
+#pragma unroll
+            for (int t = 0; t < OR_V; ++t) v[t] = 0.0;
+#pragma unroll
+            for (int q = 0; q < RPT; ++q)
+#pragma unroll
+                for (int j = 0; j < OR_M; ++j) v[j] += x[q][j].x * x[q][j].x + x[q][j].y * x[q][j].y;
+            o_block_sumv<NW>(v, s_t, s_w);
+            if (tid < OR_M) s_nrm[tid] = tid < m ? sqrt(s_t[tid]) : 1.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < OR_M; ++j) {
+            const double f = 1.0 / s_nrm[j];
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                x[q][j].x *= f;
+                x[q][j].y *= f;
+            }
+        }
+        __syncthreads();
+        for (int niter = 1;; ++niter) {
+            rounds = niter;
+            // BYX = Y' X, two rows of Y' per reduction
+#pragma nounroll
+            for (int a0 = 0; a0 < ny; a0 += 2) {
+                double v[OR_V];
+#pragma unroll
+                for (int t = 0; t < OR_V; ++t) v[t] = 0.0;
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) {
+                    const int64_t r = tid + (int64_t)q * OR_T;
+#pragma unroll
+                    for (int al = 0; al < 2; ++al) {
+                        cd y = make_double2(0.0, 0.0);
+                        if (live[q] && a0 + al < ny) y = it.Y[r + (int64_t)(a0 + al) * it.ldy];
+#pragma unroll
+                        for (int j = 0; j < OR_M; ++j) {
+                            v[(al * OR_M + j) * 2] += y.x * x[q][j].x + y.y * x[q][j].y;
+                            v[(al * OR_M + j) * 2 + 1] += y.x * x[q][j].y - y.y * x[q][j].x;
+                        }
+                    }
+                }
+                o_block_sumv<NW>(v, s_t, s_w);
+                if (tid < 2 * OR_M) {
+                    const int al = tid / OR_M, j = tid % OR_M;
+                    if (a0 + al < ny) s_byx[(a0 + al) * OR_M + j] = make_double2(s_t[2 * tid], s_t[2 * tid + 1]);
+                }
+                __syncthreads();
+            }
+            // X -= Y BYX, column norms of the result, ||BYX||_F^2
+            {
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) {
+                    const int64_t r = tid + (int64_t)q * OR_T;
+                    if (live[q])
+#pragma unroll 2
+                        for (int a = 0; a < ny; ++a) {
+                            const cd y = it.Y[r + (int64_t)a * it.ldy];
+#pragma unroll
+                            for (int j = 0; j < OR_M; ++j) {
+                                const cd bq = s_byx[a * OR_M + j];
+                                if (j < m) {
+                                    x[q][j].x -= y.x * bq.x - y.y * bq.y;
+                                    x[q][j].y -= y.x * bq.y + y.y * bq.x;
+                                }
+                            }
+                        }
+                }
+                double v[OR_V];
+#pragma unroll
+                for (int t = 0; t < OR_V; ++t) v[t] = 0.0;
+#pragma unroll
+                for (int q = 0; q < RPT; ++q)
+#pragma unroll
+                    for (int j = 0; j < OR_M; ++j) v[j] += x[q][j].x * x[q][j].x + x[q][j].y * x[q][j].y;
+                o_block_sumv<NW>(v, s_t, s_w);
+            }
+            double byx2 = 0.0;
+#pragma nounroll
+            for (int a = 0; a < ny; ++a)
+#pragma unroll
+                for (int j = 0; j < OR_M; ++j)
+                    if (j < m) {
+                        const cd vv = s_byx[a * OR_M + j];
+                        byx2 += vv.x * vv.x + vv.y * vv.y;
+                    }
+            bool nonfinite = false, drop = false;
+#pragma unroll
+            for (int j = 0; j < OR_M; ++j)
+                if (j < m) {
+                    const double nj = sqrt(s_t[j]);
+                    if (!isfinite(nj)) nonfinite = true;
+                    if (nj <= it.tol) drop = true;
+                }
+            __syncthreads();
+            if (nonfinite) {
+                status = 2.0;
+                break;
+            }
+            if (drop) {
+                status = 1.0;
+                break;
+            }
+            if (sqrt(byx2) < it.tol && niter > 1) break;
+            if (!ortho_x()) break;
+            if (growth_last * EPSD < it.tol) break;
+            if (niter > 10) {
+                status = 1.0;
+                break;
+            }
+        }
+    }
+    // the block goes back to memory once (not at all when a rare branch takes over: the driver starts again anyway)
+    if (status == 0.0) {
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int64_t r = tid + (int64_t)q * OR_T;
+            if (live[q])
+#pragma unroll
+                for (int j = 0; j < OR_M; ++j)
+                    if (j < m) it.X[r + (int64_t)j * it.ldx] = x[q][j];
+        }
+    }
+    if (tid == 0) {
+        it.res[0] = status;
+        it.res[1] = (double)rounds;
+        it.res[2] = (double)nchol_last;
+        it.res[3] = growth_last;
+    }
+}
+
 EwItem ew_item(const BOp& o) {
     EwItem e;
     e.n = o.n;
@@ -655,6 +1361,7 @@ EwItem ew_item(const BOp& o) {
     e.B = o.B;
     e.W = o.W;
     e.W2 = o.W2;
+    e.W3 = o.W3;
     e.C = o.C;
     e.D = o.D;
     e.E = o.E;
@@ -865,6 +1572,47 @@ int batch_exec_group(BatchCtx* ctx, hipStream_t stream, int type, std::vector<BO
         return 0;
     }
 
+    // ------------------------------------------------------------------ fused small-block orthogonalisation
+    if (type == BOP_ORTHO) {
+        std::vector<OrthoItem> items(n_items);
+        for (int i = 0; i < n_items; ++i) {
+            BOp* o = ops[i];
+            if (o->m < 1 || o->m > OR_M || o->k < 0 || o->k > OR_NY || o->n < 1) {
+                dftk_set_error("fused ortho: block shape %lld x %d against %d columns is outside the kernel's range", (long long)o->n,
+                               o->m, o->k);
+                return DFTK_MI_EINVAL;
+            }
+            void* htwin = nullptr;
+            double* dres = reinterpret_cast<double*>(batch_result_slot(ctx, 4 * sizeof(double), &htwin));
+            if (!dres) return DFTK_MI_EHIP;
+            items[i] = OrthoItem{o->n, o->ldc, o->lda, o->m, o->k, reinterpret_cast<cd*>(o->C), reinterpret_cast<const cd*>(o->A),
+                                 reinterpret_cast<const double*>(o->W), o->s0, dres};
+            const double* h = reinterpret_cast<const double*>(htwin);
+            batch_add_fixup(ctx, [o, h]() {
+                if (o->host) memcpy(o->host, h, 4 * sizeof(double));
+                o->status = 0;
+            });
+        }
+        const OrthoItem* d = reinterpret_cast<const OrthoItem*>(batch_stage(ctx, items.data(), items.size() * sizeof(OrthoItem)));
+        if (!d) return DFTK_MI_EHIP;
+        // blocks of up to 4 x 512 rows stay in registers for the whole call; longer ones stream through L2
+        int64_t nmax = 0;
+        for (BOp* o : ops) nmax = std::max(nmax, o->n);
+        static const bool no_reg = getenv("DFTK_MI_ORTHO_STREAM") != nullptr;
+        if (no_reg || nmax > 4 * OR_T)
+            hipLaunchKernelGGL(k_b_ortho, dim3(n_items), dim3(OR_T), 0, stream, d);
+        else if (nmax <= OR_T)
+            hipLaunchKernelGGL(k_b_ortho_reg<1>, dim3(n_items), dim3(OR_T), 0, stream, d);
+        else if (nmax <= 2 * OR_T)
+            hipLaunchKernelGGL(k_b_ortho_reg<2>, dim3(n_items), dim3(OR_T), 0, stream, d);
+        else if (nmax <= 3 * OR_T)
+            hipLaunchKernelGGL(k_b_ortho_reg<3>, dim3(n_items), dim3(OR_T), 0, stream, d);
+        else
+            hipLaunchKernelGGL(k_b_ortho_reg<4>, dim3(n_items), dim3(OR_T), 0, stream, d);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+
     // ------------------------------------------------------------------ small factorizations
     if (type == BOP_POTRF || type == BOP_HEEV) {
         int nmax = 1;
@@ -885,6 +1633,7 @@ int batch_exec_group(BatchCtx* ctx, hipStream_t stream, int type, std::vector<BO
             items[i].A = reinterpret_cast<cd*>(o->C);
             items[i].B = reinterpret_cast<cd*>(o->D);
             items[i].res = dres;
+            items[i].ev = type == BOP_HEEV ? reinterpret_cast<double*>(o->E) : nullptr;
             const double* h = reinterpret_cast<const double*>(htwin);
             if (type == BOP_POTRF) {
                 batch_add_fixup(ctx, [o, h]() {

@@ -10,6 +10,22 @@
 
 typedef double2 cd;   // complex fp64, (x, y) = (re, im); layout-compatible with dftk_mi_cplx
 
+// Every kernel launch of the library is counted (dftk_mi_launch_count): for the many-small-k workloads launches and
+// host synchronisations per SCF step ARE the cost model (bench.py --mode kpoints: roofline.bound = "latency").
+#include <atomic>
+extern std::atomic<int64_t> g_dftk_launches, g_dftk_host_syncs;
+inline hipError_t dftk_counted_stream_sync(hipStream_t s) {
+    g_dftk_host_syncs.fetch_add(1, std::memory_order_relaxed);
+    return (hipStreamSynchronize)(s);
+}
+#define hipStreamSynchronize(s) dftk_counted_stream_sync(s)
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, ...)                               \
+    do {                                                                  \
+        g_dftk_launches.fetch_add(1, std::memory_order_relaxed);          \
+        hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__);            \
+    } while (0)
+
 void dftk_set_error(const char* fmt, ...);
 // hipMalloc for library-owned scratch; DFTK_MI_POISON=1 fills it with 0xFF bytes (NaN doubles) so that any read
 // of scratch that was not written in the current call shows up as a non-finite result (debugging aid)

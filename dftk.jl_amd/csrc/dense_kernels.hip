@@ -11,6 +11,7 @@
 #include "batch.h"
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <cmath>
 #include <numeric>
 #include <cstring>
@@ -1406,19 +1407,26 @@ int dense_potrf_trtri(dftk_mi_basis* b, int n, cd* A, int64_t lda, cd* invR, int
     //    it ends with a host fetch -- and kept below half the device's compute units.
     // DFTK_MI_POTRF_COOP_LAUNCH=0: plain launch (the round-4 form) under the per-process count only.
     static const bool coop_launch = !(getenv("DFTK_MI_POTRF_COOP_LAUNCH") && atoi(getenv("DFTK_MI_POTRF_COOP_LAUNCH")) == 0);
-    static int coop_budget_wgs = -1;
-    if (coop_budget_wgs < 0) {
+    // budget and in-flight count PER DEVICE, initialised once under a lock (several host lane threads call this routine;
+    // a process may drive several devices)
+    const int MAXDEV = 64;
+    static std::once_flag coop_once[MAXDEV];
+    static int coop_budget_by_dev[MAXDEV];
+    static std::atomic<int> coop_in_flight_by_dev[MAXDEV];
+    const int dev = (b->device >= 0 && b->device < MAXDEV) ? b->device : 0;
+    std::call_once(coop_once[dev], [&]() {
         hipDeviceProp_t prop;
-        int coop_attr = 0;
+        int coop_attr = 0, budget = 0;
         if (hipGetDeviceProperties(&prop, b->device) == hipSuccess && prop.multiProcessorCount > 0)
-            coop_budget_wgs = prop.multiProcessorCount / 2;
-        else
-            coop_budget_wgs = 0;
+            budget = prop.multiProcessorCount / 2;
         if (coop_launch && (hipDeviceGetAttribute(&coop_attr, hipDeviceAttributeCooperativeLaunch, b->device) != hipSuccess ||
                             !coop_attr))
-            coop_budget_wgs = 0;      // no cooperative launches on this device: blocked path
-    }
-    static std::atomic<int> coop_wgs_in_flight{0};
+            budget = 0;      // no cooperative launches on this device: blocked path
+        coop_budget_by_dev[dev] = budget;
+        coop_in_flight_by_dev[dev].store(0);
+    });
+    const int coop_budget_wgs = coop_budget_by_dev[dev];
+    std::atomic<int>& coop_wgs_in_flight = coop_in_flight_by_dev[dev];
     struct CoopBudget {
         std::atomic<int>& c;
         int n = 0;

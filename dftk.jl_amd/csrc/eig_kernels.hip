@@ -342,6 +342,10 @@ static int heev_lowest_impl(dftk_mi_basis* b, int n, int nev, cd* A, int64_t lda
             CHK(error_norm(&e));
             if (trace) fprintf(stderr, "[heev lowest%s] n=%d nev=%d its=%d ||I - X^2||_F=%.3e\n", REAL ? " real" : "", n, nev, its, e);
             if (e < 1e-10) {
+                // one more a = 1 step unless the iterate already sits at round-off (Y is formed: one product): eigenvalues next
+                // to sigma may still be ~e / 2 away from +-1, and that much of the neighbouring eigenvectors would leak into
+                // the projector -- a residual floor of e * |lambda' - lambda| for tight LOBPCG tolerances
+                if (e >= 1e-13) CHK(advance());
                 converged = true;
                 break;
             }
@@ -461,8 +465,17 @@ int dense_heev_lowest(dftk_mi_basis* b, int n, int nev, cd* A, int64_t lda, doub
         if (!std::isfinite(off2 + dg2 + im2)) return DFTK_MI_NUM_NONFINITE;
         st = im2 == 0.0 ? heev_lowest_impl<true>(b, n, nev, A, lda, W_h, V, ldv, &fell_back)
                         : heev_lowest_impl<false>(b, n, nev, A, lda, W_h, V, ldv, &fell_back);
+        // the split declined: the full solver INSIDE this scope (one PROF_HEEV booking per call on either path)
+        if (st == 0 && fell_back) return dense_heev_full(b, n, A, lda, W_h, V, ldv);
     }
     if (st != 0) return st;
-    if (fell_back) return dense_heev(b, n, A, lda, W_h, V, ldv);
+    // Output contract by path: nev pairs with A intact here, n pairs with A destroyed after a fallback.  Callers may only
+    // read the first nev; DFTK_MI_POISON=1 makes a reader of the rest visible (NaN eigenvalues and vector columns).
+    static const bool poison = getenv("DFTK_MI_POISON") != nullptr;
+    if (poison && nev < n) {
+        for (int i = nev; i < n; ++i) W_h[i] = std::nan("");
+        HIPCHK(hipMemset2DAsync(V + (int64_t)nev * ldv, (size_t)ldv * sizeof(cd), 0xFF, (size_t)n * sizeof(cd), (size_t)(n - nev),
+                                b->stream));
+    }
     return 0;
 }

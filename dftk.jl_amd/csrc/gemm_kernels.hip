@@ -1112,7 +1112,8 @@ int zgemm(dftk_mi_basis* b, char transA, int64_t m, int64_t n, int64_t k, cd alp
     static const bool shapes_env = getenv("DFTK_MI_GEMM_SHAPES") != nullptr;
     const bool shapes = shapes_env || (b->prof && b->prof->shape_tags);
     const uint64_t tag = !shapes ? 0
-                                 : ((uint64_t)conja << 63) | ((uint64_t)(m & 0xFFFFF) << 42) |
+                                 // (bit 63 transA, 62 "tagged", 61 REAL, 42..60 m, 40..41 UPPER / B_UPPER, 22..39 n, 0..21 k)
+                                 : ((uint64_t)conja << 63) | ((uint64_t)(m & 0x7FFFF) << 42) | ((uint64_t)(real ? 1 : 0) << 61) |
                                        ((uint64_t)(n & 0x3FFFF) << 22) | ((uint64_t)(upper_in & 3) << 40) |
                                        (uint64_t)(k & 0x3FFFFF) | (1ull << 62);
     static const bool use3m_env = getenv("DFTK_MI_GEMM_4M") == nullptr;   // DFTK_MI_GEMM_4M=1: classic 4-product kernels

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <complex>
 #include <cstring>
@@ -579,9 +580,9 @@ int lobpcg_ortho(dftk_mi_basis* b, int64_t n, int m, cd* X, int64_t ldx, int for
     return st;
 }
 
-int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int miniter, int maxiter,
-               int n_conv_check, int use_tpa, uint64_t seed, double* lambda_h, double* resid_h, int* n_iter_out,
-               int* converged_out, int64_t* n_matvec_out) {
+static int lobpcg_run_general(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int miniter, int maxiter,
+                              int n_conv_check, int use_tpa, uint64_t seed, double* lambda_h, double* resid_h, int* n_iter_out,
+                              int* converged_out, int64_t* n_matvec_out) {
     dftk_mi_basis* b = kb->basis;
     if (!(kb->n_G > 3 * (int64_t)M)) {
         dftk_set_error("The eigenproblem is too small (n_G=%lld, M=%d): N > 3M required", (long long)kb->n_G, M);
@@ -934,6 +935,426 @@ int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int m
     *n_iter_out = final_iter;
     *n_matvec_out = n_matvec;
     return stream_sync(b);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Small blocks (the k-point workloads: n_G ~ 1e3, M <= 8) inside a batched multi-k call: the same algorithm with ONE host
+// synchronisation per LOBPCG iteration.  The general driver above yields to the host 4-6 times per iteration (Cholesky
+// statuses of the ortho! loops, the Ritz values, drop_small!'s norms, the residual norms) -- each a whole scheduling
+// round of the lock-step batch (~0.2 ms whatever is in it; 27-31 rounds per SCF step of the
+// 72-k-point Al workload).  Here
+//   * ortho!(X) and ortho!(X, Y) are ONE kernel each (k_b_ortho: adaptive loops, safe_cholesky's shifts and all
+//     estimates on the device; BOP_ORTHO),
+//   * the Ritz values stay on the device (the residual pass reads them there) and reach the host with the residual
+//     norms, as do the statuses of the orthogonalisation and of the eigensolver, the Rayleigh quotients of the start
+//     block and the Ritz coefficients the host needs for cP,
+//   * what the device cannot finish by itself (a column for drop_small! to re-randomise, the SVD fallbacks, a failed
+//     eigensolver) is only DETECTED: the call then starts again on the general driver from the caller's start block,
+//     which is untouched until the end (counted: DFTK_MI_KBATCH_TRACE).
+// Control flow, tolerances, locking, the order of the blocks and every n_G-sized kernel are those of lobpcg_run_general.
+std::atomic<int64_t> g_small_calls{0}, g_small_restarts{0};
+
+bool lobpcg_small_eligible(const dftk_mi_kblock* kb, int M) {
+    static const bool off = (getenv("DFTK_MI_LOBPCG_SMALL") && atoi(getenv("DFTK_MI_LOBPCG_SMALL")) == 0) ||
+                            getenv("DFTK_MI_KBATCH_SEQUENTIAL") != nullptr;
+    if (off || kb->sh_comm || (kb->gr && kb->gr->on)) return false;
+    return M >= 1 && M <= 8 && kb->n_G * (int64_t)M <= DEFER_FETCH_MAX_ELEMS && kb->n_G > 3 * (int64_t)M;
+}
+
+static int rec_ortho(dftk_mi_basis* b, Mat X, const cd* Y, int64_t ldy, int ny, const double* norms_d, double tol, double* res4) {
+    BOp o;
+    o.b = b;
+    o.type = BOP_ORTHO;
+    o.n = X.rows;
+    o.m = X.cols;
+    o.k = ny;
+    o.C = X.p;
+    o.ldc = X.ld;
+    o.A = Y;
+    o.lda = ldy;
+    o.W = norms_d;
+    o.s0 = tol;
+    o.host = res4;
+    return batch_record(std::move(o));
+}
+
+static int lobpcg_run_small(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int miniter, int maxiter,
+                            int n_conv_check, int use_tpa, uint64_t seed, double* lambda_h, double* resid_h, int* n_iter_out,
+                            int* converged_out, int64_t* n_matvec_out, bool* restart) {
+    dftk_mi_basis* b = kb->basis;
+    *restart = false;
+    const int64_t N = kb->n_G;
+    const double* kin = use_tpa ? kb->d_kin : nullptr;
+    if (n_conv_check <= 0 || n_conv_check > M) n_conv_check = M;
+    const double ortho_tol = 2 * EPS;
+    // ---- workspace (the general driver's layout; the double scratch holds the Ritz values as well) ----
+    const size_t blk = (size_t)N * M;
+    const size_t nbig = 14;
+    const size_t m3 = 3 * (size_t)M;
+    const size_t small_elems = m3 * m3 * 2 + m3 * M * 2 + (size_t)M * M * 4 + (2 * (size_t)M + m3) * (M + 1);
+    const int DS = (int)m3 + 8;                              // stride of the double slots
+    const size_t dbl = 9 * (size_t)DS;
+    const size_t need = (nbig * blk + small_elems) * sizeof(cd) + dbl * sizeof(double) + m3 * sizeof(int) + 1024;
+    if (need > kb->lob_bytes) {
+        CHK(host_wait(b));
+        if (kb->lob_buf) HIPCHK(hipFree(kb->lob_buf));
+        kb->lob_buf = nullptr;
+        kb->lob_bytes = 0;
+        HIPCHK(dftk_scratch_malloc((void**)&kb->lob_buf, need));
+        kb->lob_bytes = need;
+    }
+    cd* w = kb->lob_buf;
+    auto take = [&](size_t n) {
+        cd* r = w;
+        w += n;
+        return r;
+    };
+    Mat Yb[2] = {Mat{take(3 * blk), N, N, 3 * M}, Mat{take(3 * blk), N, N, 3 * M}};
+    Mat AYb[2] = {Mat{take(3 * blk), N, N, 3 * M}, Mat{take(3 * blk), N, N, 3 * M}};
+    int cur = 0;
+    auto Pblk = [&](const Mat& buf, int nact) { return buf.cols_from(M, nact); };
+    auto Rblk = [&](const Mat& buf, int nact, bool has_p) { return buf.cols_from(M + (has_p ? nact : 0), nact); };
+    Mat newR{take(blk), N, N, M};
+    cd* tmp = take(blk);
+    cd* G = take(m3 * m3);
+    cd* V = take(m3 * m3);
+    cd* cP = take(m3 * M);
+    Ctx c;
+    c.kb = kb;
+    c.b = b;
+    c.tmpS = take(m3 * M);
+    c.O = take((size_t)M * M);
+    c.Rw = take((size_t)M * M);
+    c.invR = take((size_t)M * M);
+    c.Vh = take((size_t)M * M);
+    c.BYX = take((2 * (size_t)M + m3) * (M + 1));
+    double* dd = reinterpret_cast<double*>(w);
+    // [ d_a | d_b | d_norms | d_mk | d_xx ] are fetched together (5 slots); d_ev, d_rn, perm follow
+    c.d_a = dd;
+    c.d_b = dd + DS;
+    c.dstride = DS;
+    double* d_norms = dd + 2 * DS;
+    double* d_mk = dd + 3 * DS;
+    double* d_xx = dd + 4 * DS;
+    double* d_ev = dd + 5 * DS;
+    double* d_rn = dd + 6 * DS;
+    c.rng.seed((seed ? seed : 0x9E3779B97F4A7C15ull));
+    c.rng_rep.seed((seed ? seed : 0x9E3779B97F4A7C15ull) ^ 0xD1B54A32D192ED03ull);
+    Mat X = Yb[0].cols_from(0, M), AX = AYb[0].cols_from(0, M);
+    kb->last_AX = AX.p;
+    Mat Xuser{Xp, ldX, N, M};
+    CHK(ew_copy(b, N, M, Xuser.p, Xuser.ld, X.p, X.ld));
+    std::vector<double> resid_history((size_t)M * (maxiter + 1), 0.0);
+    auto RH = [&](int i, int it) -> double& { return resid_history[(size_t)i + (size_t)M * it]; };
+    std::vector<double> full_lam(M, 0.0);
+    std::vector<double> hf(5 * (size_t)DS);              // landing zone of the per-iteration fetch
+    double o_res[4] = {0.0, 0.0, 0.0, 1.0};              // result of the orthogonalisation in flight
+    bool o_pending = false;
+    auto give_up = [&]() -> int {                         // a rare branch: the general driver takes the whole call
+        *restart = true;
+        return 0;
+    };
+
+    // ---- X = ortho!(copy(X)); AX = A X; Rayleigh quotients; residuals of iteration 0: ONE round ----
+    CHK(rec_ortho(b, X, nullptr, 0, 0, nullptr, ortho_tol, o_res));
+    o_pending = true;
+    int64_t n_matvec = M;
+    CHK(dftk_mi_apply_H(kb, M, reinterpret_cast<const dftk_mi_cplx*>(X.p), X.ld, reinterpret_cast<dftk_mi_cplx*>(AX.p), AX.ld));
+    CHK(ew_coldots(b, N, M, X.p, X.ld, AX.p, AX.ld, c.d_a));
+    CHK(ew_coldots(b, N, M, X.p, X.ld, X.p, X.ld, c.d_b));
+
+    int nlocked = 0, niter = 0, lo = 0;
+    bool finished = false;
+    int final_iter = maxiter;
+    int ncx = 0;
+    // state of the iteration whose device part is in flight (set by `head`, consumed after the fetch)
+    int nY = 0;
+    std::vector<Mat> Ys, AYs;
+    std::vector<zd> h_cX;
+    std::vector<double> wv(m3);
+    int heev_st = 0;
+    bool heev_pending = false;
+    cd* cX = V;
+
+    // device part of iteration `niter` up to the residuals (everything the general driver does before its locking decision)
+    auto head = [&]() -> int {
+        const int nact = M - lo;
+        Mat &Yc = Yb[cur], &AYc = AYb[cur], &Yn = Yb[cur ^ 1], &AYn = AYb[cur ^ 1];
+        X = Yc.cols_from(0, M);
+        AX = AYc.cols_from(0, M);
+        Mat Xa = X.cols_from(lo), AXa = AX.cols_from(lo);
+        Mat Ra = Rblk(Yc, nact, niter > 1), ARa = Rblk(AYc, nact, niter > 1), Pa = Pblk(Yc, nact), APa = Pblk(AYc, nact);
+        Mat nX = niter > 0 ? Yn.cols_from(lo, nact) : Xa, nAX = niter > 0 ? AYn.cols_from(lo, nact) : AXa;
+        Mat nR = newR.cols_from(0, nact);
+        Ys.clear();
+        AYs.clear();
+        nY = 0;
+        if (niter > 0) {
+            CHK(dftk_mi_apply_H(kb, nact, reinterpret_cast<const dftk_mi_cplx*>(Ra.p), Ra.ld, reinterpret_cast<dftk_mi_cplx*>(ARa.p),
+                                ARa.ld));
+            n_matvec += nact;
+            if (niter > 1) {
+                Ys = {Xa, Pa, Ra};
+                AYs = {AXa, APa, ARa};
+            } else {
+                Ys = {Xa, Ra};
+                AYs = {AXa, ARa};
+            }
+            nY = (int)Ys.size() * nact;
+            // (the blocks are adjacent by construction of the layout: one Gram product)
+            CHK(c.mm('C', nY, nY, N, ONE, Ys[0].p, Ys[0].ld, AYs[0].p, AYs[0].ld, ZERO, G, nY, /*upper=*/1));
+            CHK(ew_hermitize_upper(b, nY, G, nY));
+            {
+                BOp o;
+                o.b = b;
+                o.type = BOP_HEEV;
+                o.m = nY;
+                o.C = G;
+                o.ldc = nY;
+                o.D = V;
+                o.ldb = nY;
+                o.host = wv.data();
+                o.E = d_ev;
+                o.status_out = &heev_st;
+                heev_st = 0;
+                heev_pending = true;
+                CHK(batch_record(std::move(o)));
+            }
+            ncx = nact;
+            h_cX.resize((size_t)nY * nact);
+            CHK(dev_d2h_async(b, h_cX.data(), cX, h_cX.size() * sizeof(cd)));
+            CHK(hcat_mul(c, Ys, cX, nY, nact, nX));
+            CHK(hcat_mul(c, AYs, cX, nY, nact, nAX));
+        }
+        // residuals with the Ritz values as the device holds them (iteration 0: the Rayleigh quotients d_a / d_b)
+        BOp r;
+        r.b = b;
+        r.type = BOP_RESIDUAL;
+        r.n = N;
+        r.m = nact;
+        r.A = nAX.p;
+        r.lda = nAX.ld;
+        r.B = nX.p;
+        r.ldb = nX.ld;
+        r.W = niter > 0 ? d_ev : c.d_a;
+        r.W3 = niter > 0 ? nullptr : c.d_b;
+        r.C = nR.p;
+        r.ldc = nR.ld;
+        r.D = d_norms;
+        r.W2 = kin;
+        r.E = d_mk;
+        r.F = d_xx;
+        CHK(batch_record(std::move(r)));
+        // THE synchronisation of the iteration
+        CHK(d2h_sync(b, hf.data(), dd, hf.size() * sizeof(double)));
+        return 0;
+    };
+
+    CHK(head());
+    for (int i = 0; i < M; ++i) {
+        if (!std::isfinite(hf[i])) {
+            dftk_set_error("non-finite values in H*X");
+            return DFTK_MI_NUM_NONFINITE;
+        }
+        full_lam[i] = hf[i] / hf[DS + i];
+    }
+
+    while (true) {
+        const int nact = M - lo;
+        // ---- what came back with the fetch ----
+        if (o_pending) {
+            o_pending = false;
+            if (o_res[0] == 2.0) return DFTK_MI_NUM_NONFINITE;
+            if (o_res[0] != 0.0) return give_up();
+        }
+        if (heev_pending) {
+            heev_pending = false;
+            if (heev_st == DFTK_MI_NUM_NONFINITE) return heev_st;
+            if (heev_st != 0) return give_up();
+            for (int i = 0; i < nact; ++i) full_lam[lo + i] = wv[i];
+        }
+        Mat nR = newR.cols_from(0, nact);
+        const double* h_norms = hf.data() + 2 * DS;
+        const double* h_xx = hf.data() + 4 * DS;
+        for (int i = 0; i < nact; ++i) {
+            if (!std::isfinite(h_norms[i])) {
+                dftk_set_error("non-finite residual norm in LOBPCG iteration %d", niter);
+                return DFTK_MI_NUM_NONFINITE;
+            }
+            RH(nlocked + i, niter) = h_norms[i];
+        }
+        // locking
+        const int prev_nlocked = nlocked;
+        if (niter >= miniter) {
+            for (int i = nlocked; i < M; ++i) {
+                if (RH(i, niter) < tol)
+                    nlocked += 1;
+                else
+                    break;
+            }
+        }
+        const int tgt = niter > 0 ? (cur ^ 1) : cur;
+        if (nlocked >= n_conv_check) {
+            cur = tgt;
+            final_iter = niter;
+            finished = true;
+            break;
+        }
+        const int newly_locked = nlocked - prev_nlocked;
+        const int lenXn = nact - newly_locked;
+        Mat nP = Pblk(Yb[tgt], lenXn), nAP = Pblk(AYb[tgt], lenXn);
+        if (niter > 0) {
+            Mat cPm{cP, nY, nY, lenXn};
+            bool cp_done = false;
+            {
+                std::vector<zd> h_cP(h_cX.begin() + (size_t)newly_locked * nY, h_cX.begin() + (size_t)(newly_locked + lenXn) * nY);
+                for (int a = 0; a < lenXn - newly_locked; ++a)
+                    if (2 * newly_locked + a < nY) h_cP[(size_t)(2 * newly_locked + a) + (size_t)a * nY] -= 1.0;
+                if (host_ortho_small(h_cP, nY, lenXn, h_cX.data(), ncx, ortho_tol)) {
+                    CHK(h2d(b, cP, h_cP.data(), h_cP.size() * sizeof(cd)));
+                    cp_done = true;
+                }
+            }
+            if (!cp_done) {
+                CHK(ew_copy(b, nY, lenXn, cX + (int64_t)newly_locked * nY, nY, cP, nY));
+                CHK(ew_sub_identity_shifted(b, nY, lenXn - newly_locked, cP, nY, 2 * newly_locked));
+                std::vector<Mat> cXs = {Mat{cX, nY, nY, ncx}};
+                NoComm replicated(c);
+                CHK(ortho_XY(c, cPm, cXs, c.tmpS, ortho_tol));
+            }
+            CHK(hcat_mul(c, Ys, cP, nY, lenXn, nP));
+            CHK(hcat_mul(c, AYs, cP, nY, lenXn, nAP));
+        }
+        for (int i = 0; i < nact; ++i)
+            if (!(std::fabs(h_xx[i] - 1.0) < std::sqrt(EPS))) {
+                dftk_set_error("LOBPCG is badly failing to keep the vectors normalized (column %d: %g; iteration %d, "
+                               "%d locked, %d active, small-block driver)", lo + i, h_xx[i], niter, nlocked, nact);
+                return DFTK_MI_NUM_NORMALIZATION;
+            }
+        if (newly_locked > 0) {
+            CHK(ew_copy(b, N, newly_locked, Yb[tgt].p + (int64_t)lo * N, N, Yb[tgt ^ 1].p + (int64_t)lo * N, N));
+            CHK(ew_copy(b, N, newly_locked, AYb[tgt].p + (int64_t)lo * N, N, AYb[tgt ^ 1].p + (int64_t)lo * N, N));
+        }
+        lo = nlocked;
+        cur = tgt;
+        X = Yb[cur].cols_from(0, M);
+        AX = AYb[cur].cols_from(0, M);
+        Mat Rn = Rblk(Yb[cur], lenXn, niter > 0);
+        CHK(ew_tpa(b, N, lenXn, nR.p + (int64_t)newly_locked * nR.ld, nR.ld, Rn.p, Rn.ld, kin, d_mk + newly_locked, d_rn));
+        // ortho!(R, [X P]): X (all M columns) and the new P are adjacent in the layout -- one kernel, status with the next fetch
+        CHK(rec_ortho(b, Rn, X.p, X.ld, M + (niter > 0 ? lenXn : 0), d_rn, ortho_tol, o_res));
+        o_pending = true;
+        static const bool dbg_check = getenv("DFTK_MI_LOBPCG_CHECK") != nullptr;
+        if (dbg_check) {   // (a diagnostic: costs a synchronisation of its own)
+            const int nc = M + (niter > 0 ? 2 : 1) * lenXn;
+            CHK(c.mm('C', nc, nc, N, ONE, Yb[cur].p, N, Yb[cur].p, N, ZERO, G, nc));
+            std::vector<double> hg(2 * (size_t)nc * nc);
+            CHK(d2h_sync(b, hg.data(), G, hg.size() * sizeof(double)));
+            double worst = 0.0;
+            for (int j = 0; j < nc; ++j)
+                for (int i = 0; i < nc; ++i) {
+                    const double re = hg[2 * ((size_t)i + (size_t)j * nc)] - (i == j ? 1.0 : 0.0);
+                    const double im = hg[2 * ((size_t)i + (size_t)j * nc) + 1];
+                    worst = std::max(worst, std::sqrt(re * re + im * im));
+                }
+            fprintf(stderr, "[lobpcg-check small] it %d locked %d act %d  ||[X P R]'[X P R] - I||_max %.1e (ortho status %g)\n", niter,
+                    nlocked, lenXn, worst, o_res[0]);
+        }
+        if (niter >= maxiter) break;
+        niter += 1;
+        CHK(head());
+    }
+    if (o_pending && !finished) {
+        // (maxiter reached with an orthogonalisation in flight whose result is never used)
+        o_pending = false;
+    }
+    X = Yb[cur].cols_from(0, M);
+    AX = AYb[cur].cols_from(0, M);
+    kb->last_AX = AX.p;
+    if (!finished) final_iter = maxiter;
+    std::vector<int> perm(M);
+    std::iota(perm.begin(), perm.end(), 0);
+    const bool sorted = std::is_sorted(full_lam.begin(), full_lam.end());
+    if (!sorted) {
+        std::stable_sort(perm.begin(), perm.end(), [&](int a, int d) { return full_lam[a] < full_lam[d]; });
+        int* d_perm = reinterpret_cast<int*>(dd + 7 * DS);
+        CHK(h2d(b, d_perm, perm.data(), M * sizeof(int)));
+        CHK(ew_gather_cols(b, N, M, X.p, X.ld, d_perm, tmp, N));
+        CHK(ew_copy(b, N, M, tmp, N, X.p, X.ld));
+        CHK(ew_gather_cols(b, N, M, AX.p, AX.ld, d_perm, tmp, N));
+        CHK(ew_copy(b, N, M, tmp, N, AX.p, AX.ld));
+    }
+    CHK(ew_copy(b, N, M, X.p, X.ld, Xuser.p, Xuser.ld));
+    double maxres = 0.0;
+    for (int i = 0; i < M; ++i) {
+        lambda_h[i] = full_lam[perm[i]];
+        resid_h[i] = RH(perm[i], final_iter);
+    }
+    for (int i = 0; i < n_conv_check; ++i) maxres = std::max(maxres, resid_h[i]);
+    if (!kb->lob_hist) kb->lob_hist = new std::vector<double>();
+    kb->lob_hist->assign((size_t)M * (final_iter + 1), 0.0);
+    for (int it = 0; it <= final_iter; ++it)
+        for (int i = 0; i < M; ++i) (*kb->lob_hist)[(size_t)i + (size_t)M * it] = RH(perm[i], it);
+    kb->lob_hist_M = M;
+    kb->lob_hist_iters = final_iter;
+    kb->lob_n_svd = c.n_svd;
+    *converged_out = (maxres < tol) ? 1 : 0;
+    *n_iter_out = final_iter;
+    *n_matvec_out = n_matvec;
+    // (no synchronisation of its own: the copies above are queued on the fiber and run in the batch's closing round; the
+    //  batched call returns only after the stream has drained)
+    return 0;
+}
+
+// the fused kernel on a stand-alone block (tests; what lobpcg_run_small records per iteration)
+extern "C" int dftk_mi_ortho_small(dftk_mi_basis* b, int64_t n, int m, dftk_mi_cplx* X, int64_t ldx, int ny, const dftk_mi_cplx* Y,
+                                   int64_t ldy, const double* norms_d, double tol, double* res4_h) {
+    if (!b || !X || n < 1 || m < 1 || m > 8 || ny < 0 || ny > 16 || (ny > 0 && !Y) || ldx < n || (ny > 0 && ldy < n) || !res4_h)
+        return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(b->device));
+    std::vector<std::function<int()>> bodies;
+    bodies.push_back([&]() -> int {
+        CHK(rec_ortho(b, Mat{reinterpret_cast<cd*>(X), ldx, n, m}, reinterpret_cast<const cd*>(Y), ldy, ny, norms_d, tol, res4_h));
+        return dev_stream_sync(b);
+    });
+    std::vector<int> rets;
+    const int st = batch_run(b, bodies, rets);
+    return st != 0 ? st : rets[0];
+}
+
+extern "C" int dftk_mi_lobpcg_small_stats(int64_t* calls, int64_t* restarts) {
+    if (calls) *calls = g_small_calls.load();
+    if (restarts) *restarts = g_small_restarts.load();
+    return 0;
+}
+
+int lobpcg_run(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, double tol, int miniter, int maxiter,
+               int n_conv_check, int use_tpa, uint64_t seed, double* lambda_h, double* resid_h, int* n_iter_out,
+               int* converged_out, int64_t* n_matvec_out) {
+    if (lobpcg_small_eligible(kb, M)) {
+        if (batching()) {
+            bool restart = false;
+            g_small_calls.fetch_add(1);
+            const int st = lobpcg_run_small(kb, M, Xp, ldX, tol, miniter, maxiter, n_conv_check, use_tpa, seed, lambda_h, resid_h,
+                                            n_iter_out, converged_out, n_matvec_out, &restart);
+            if (!restart) return st;
+            g_small_restarts.fetch_add(1);
+            // the general driver below starts over from the caller's block, which the small-block driver has not written
+        } else {
+            // a single small block: a batch of one fiber (the fused kernels exist in their batched form only)
+            int status = 0;
+            cd* Xs[1] = {Xp};
+            const int64_t lds[1] = {ldX};
+            const uint64_t seeds[1] = {seed};
+            dftk_mi_kblock* kbs[1] = {kb};
+            const int st = lobpcg_run_multi(1, kbs, M, Xs, lds, tol, miniter, maxiter, n_conv_check, use_tpa, seeds, lambda_h, resid_h,
+                                            n_iter_out, converged_out, n_matvec_out, &status);
+            return st != 0 ? st : status;
+        }
+    }
+    return lobpcg_run_general(kb, M, Xp, ldX, tol, miniter, maxiter, n_conv_check, use_tpa, seed, lambda_h, resid_h, n_iter_out,
+                              converged_out, n_matvec_out);
 }
 
 // diagonalize_all_kblocks' loop over k-points (src/eigen/diag.jl:24-48) as ONE call: every k-block runs lobpcg_run as a

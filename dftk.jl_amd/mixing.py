@@ -80,7 +80,9 @@ def gmres(apply, b: torch.Tensor, rtol: float, krylovdim: int = 30, maxiter: int
     tol = max(atol, rtol * nb)
     r, beta = b.clone(), nb
     n = b.numel()
-    Vbuf = torch.empty((krylovdim + 1, n), dtype=b.dtype, device=b.device)   # the Krylov basis, allocated once
+    # the Krylov basis grows geometrically (8 rows, doubling up to krylovdim + 1): a solve that ends in 2-3 steps must not
+    # reserve 31 cube-sized vectors (1.75 GB at 192^3) next to a nearly full HBM
+    Vbuf = torch.empty((min(8, krylovdim + 1), n), dtype=b.dtype, device=b.device)
     for _ in range(maxiter):
         if beta <= tol:
             break
@@ -124,6 +126,10 @@ def gmres(apply, b: torch.Tensor, rtol: float, krylovdim: int = 30, maxiter: int
             k_used = k + 1
             if abs(g[k + 1]) <= tol or hk1 == 0.0:
                 break
+            if k + 1 >= Vbuf.shape[0]:
+                grown = torch.empty((min(krylovdim + 1, 2 * Vbuf.shape[0]), n), dtype=b.dtype, device=b.device)
+                grown[:Vbuf.shape[0]] = Vbuf
+                Vbuf = grown
             Vbuf[k + 1] = w / hk1
         y = np.linalg.solve(np.triu(H[:k_used, :k_used]), g[:k_used])
         x = x + (torch.as_tensor(y, device=b.device) @ Vbuf[:k_used]).reshape(b.shape)

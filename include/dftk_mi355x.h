@@ -253,6 +253,20 @@ int dftk_mi_band_kinetic_multi(int n_kblocks, dftk_mi_kblock* const* kbs, const 
 /* Counters of the calling thread's last batched call: scheduling rounds (= host synchronisations), recorded
  * operations, merged launches, operations that ran one by one (no batched form). */
 int dftk_mi_batch_stats(int64_t* rounds, int64_t* ops, int64_t* merged_launches, int64_t* sequential_ops);
+/* Small k-blocks (M <= 8 bands, n_G * M <= 65536, neither sharded nor Gamma-real) run a driver with ONE host
+ * synchronisation per LOBPCG iteration: ortho!(X) / ortho!(X, Y) are one kernel each, Ritz values and statuses travel
+ * with the residual norms (lobpcg.cpp: lobpcg_run_small; src/eigen/lobpcg_hyper_impl.jl:354-582 unchanged as an
+ * algorithm).  Rare branches it only detects (drop_small!, SVD fallbacks) restart the call on the general driver.
+ * Process-wide counters: calls that took the small-block driver, and how many of them restarted.
+ * DFTK_MI_LOBPCG_SMALL=0 switches the driver off. */
+int dftk_mi_lobpcg_small_stats(int64_t* calls, int64_t* restarts);
+/* The fused orthogonalisation kernel of that driver on a stand-alone block: ortho!(X, Y) for ny > 0 (X is normalised by
+ * norms_d -- its column norms on the device -- or by norms computed here when NULL, projected against the orthonormal Y
+ * and orthonormalised, lobpcg_hyper_impl.jl:271-323), plain ortho!(X) for ny = 0 (:216-261); m <= 8, ny <= 16.
+ * res4_h = {status (0 done, 1 a host-side branch is needed: X unusable, 2 non-finite), rounds of the ortho!(X, Y) loop,
+ * Cholesky factorisations of the last ortho!(X), growth factor}. */
+int dftk_mi_ortho_small(dftk_mi_basis* basis, int64_t n, int m, dftk_mi_cplx* X_d, int64_t ldx, int ny, const dftk_mi_cplx* Y_d,
+                        int64_t ldy, const double* norms_d, double tol, double* res4_h);
 int dftk_mi_lobpcg_history(dftk_mi_kblock* kb, int* M, int* n_iter, double* hist_h, size_t cap, int* n_svd);
 /* Optional: device pointer to H*X of the last dftk_mi_lobpcg call on this block (n_G x M,
  * leading dimension n_G; valid until the next lobpcg call on the block). */
@@ -430,8 +444,12 @@ int dftk_mi_shard_plan_host(int n_ranks, int rank, int n_bands, const int64_t* r
  * general complex iteration would need).  enable(1) resets. */
 int dftk_mi_prof_enable(dftk_mi_basis* basis, int on);
 int dftk_mi_prof_get(dftk_mi_basis* basis, int family, double* total_ms, double* work, int64_t* launches);
+/* Process-wide counters since load: kernel launches issued by the library and host synchronisations it waited on
+ * (stream synchronisations of its drivers, result fetches, scheduling rounds of the batched k-point driver).  For the
+ * many-small-k workloads these two ARE the cost model; either pointer may be NULL. */
+int dftk_mi_launch_count(int64_t* launches, int64_t* host_syncs);
 /* dftk_mi_prof_enable(basis, 3) also books every zgemm call per SHAPE; this returns (and clears) that table: row i of
- * rows6 = { transA ('N' = 0, 'C' = 1), m, n, k, flags & 3, calls }, ms[i] = summed time; *count = shapes seen (<= cap
+ * rows6 = { transA ('N' = 0, 'C' = 1), m, n, k, flags (UPPER | B_UPPER | DFTK_MI_GEMM_REAL), calls }, ms[i] = summed time; *count = shapes seen (<= cap
  * rows are written).  bench.py replays the table at 1 / N of the rows for its sharded-step measurement. */
 int dftk_mi_prof_zgemm_shapes(dftk_mi_basis* basis, int cap, int64_t* rows6, double* ms, int* count);
 

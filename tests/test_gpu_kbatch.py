@@ -20,7 +20,7 @@ A_AL = 7.6324708938577865
 def _gpu(monkeypatch):
     assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
     torch.manual_seed(3)
-    # the batched k loop is the default from 32 local k-points on (below that the stream lanes win); force it here
+    # (the batched k loop is the default for these small blocks; forced here so that the tests do not depend on the rule)
     monkeypatch.setenv("DFTK_MI_KBATCH", "1")
 
 
@@ -142,13 +142,18 @@ def test_density_and_apply_H_multi_equal_per_kblock_calls(monkeypatch):
 
 
 def test_kbatch_default_threshold(monkeypatch):
-    """Default choice between the two k loops: batched from 32 local k-points on (BASELINE configs[2]: 72), stream lanes
-    below (configs[0]: 8, configs[3]: 12), where a ~150 us scheduling round per synchronisation costs more than it saves."""
+    """Default choice between the two k loops: batched from 32 local k-points on whatever the block size (BASELINE
+    configs[2]: 72), and from TWO k-points on when the blocks are small enough for the library's small-block LOBPCG driver
+    (M <= 8, n_G * M <= 65536: configs[0] 8 k-points, configs[3] 12); stream lanes for a few LARGE k-blocks."""
     monkeypatch.delenv("DFTK_MI_KBATCH")
     few = _si_basis(kgrid=(3, 3, 3))
-    assert len(few.kpoints) == 27 and not few.kbatch and few.n_lanes > 1
+    assert len(few.kpoints) == 27 and few.kbatch and few.n_lanes == 1          # 7 bands of ~200 plane waves: small blocks
     many = _si_basis(kgrid=(4, 4, 4), Ecut=8)
     assert len(many.kpoints) == 64 and many.kbatch and many.n_lanes == 1
+    lat, atoms, pos = dftk.silicon_cell((2, 2, 2))                              # 16 atoms, 32 + 3 bands: not small blocks
+    big = dftk.PlaneWaveBasis(dftk.model_DFT(lat, atoms, pos, functionals=("lda_x", "lda_c_pw")), 8,
+                              dftk.MonkhorstPack((2, 2, 2)), fft_size=(32, 32, 32))
+    assert len(big.kpoints) > 1 and not big.kbatch and big.n_lanes > 1
 
 
 def test_gamma_point_of_a_batched_mesh_stays_in_the_batch():

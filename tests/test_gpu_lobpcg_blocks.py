@@ -211,6 +211,24 @@ def test_lobpcg_residual_history_matches_oracle(lib, use_tpa):
     assert abs(nmv - ores["n_matvec"]) <= M * (2 + nit_o // 10)
 
 
+def test_lobpcg_reaches_a_tight_tolerance(lib):
+    """LOBPCG driven to tol = 1e-12 (the reference's diagtol_min is 100 eps): every Rayleigh-Ritz solve on the way has
+    to be accurate to round-off, or the residuals stall above the tolerance until maxiter.  Part of the suites that
+    tests/test_gpu_partial_solver_forced.py re-runs with the partial-spectrum solver forced on from n = 24, where its
+    sign iteration's acceptance threshold is what is being tested."""
+    _, H, bs, kb = _tpa_setup(lib, Ecut=12, fft=(24, 24, 24))
+    rng = np.random.default_rng(33)
+    M, ncc, tol = 14, 10, 1e-12
+    X0 = np.linalg.qr(_block(rng, H.n_G, M))[0]
+    lam, res, nit, conv, nmv, X = run_lobpcg(lib, kb, X0, tol, n_conv_check=ncc, maxiter=100)
+    assert conv == 1 and nit < 60, (conv, nit, res)
+    assert res[:ncc].max() < tol
+    dense = np.linalg.eigvalsh(H.to_dense())[:ncc]
+    np.testing.assert_allclose(lam[:ncc], dense, atol=1e-11)
+    true_res = np.linalg.norm(H.mul(X[:, :ncc]) - X[:, :ncc] * lam[:ncc], axis=0)
+    assert true_res.max() < 5e-12, true_res
+
+
 def test_host_mirror_helpers_match_oracle():
     """The reference-named helpers of the host mirror (PreconditionerTPA.precondprep_ / ldiv_, columnwise_norms,
     columnwise_dots, ortho_qr) on band-major torch blocks against the oracle."""

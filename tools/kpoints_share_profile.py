@@ -41,6 +41,18 @@ print(f"{n_loc} of {n_k} k-points (N = {N}), fft {sub.fft_size}, kbatch={sub.kba
 for k in timers[-1]:
     print(f"  {k:22s} {1e3 * np.median([t.get(k, 0.0) for t in timers[late]]):7.2f} ms")
 print("  LOBPCG iterations of the late steps:", [float(np.mean(info["diagonalization"]["n_iter"]))])
+import ctypes as C  # noqa: E402
+a_, b_ = C.c_int64(), C.c_int64()
+sub.lib.dftk_mi_lobpcg_small_stats(C.byref(a_), C.byref(b_))
+l0, s0 = C.c_int64(), C.c_int64()
+sub.lib.dftk_mi_launch_count(C.byref(l0), C.byref(s0))
+st.step()
+torch.cuda.synchronize()
+l1, s1 = C.c_int64(), C.c_int64()
+sub.lib.dftk_mi_launch_count(C.byref(l1), C.byref(s1))
+from dftk_jl_amd.eigen import batch_stats  # noqa: E402
+print(f"  small-block driver: {a_.value} calls, {b_.value} restarts; one more step: {l1.value - l0.value} library launches, "
+      f"{s1.value - s0.value} host synchronisations; last batched call {batch_stats(sub)}")
 if "--torch-profile" in sys.argv:
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:

@@ -490,7 +490,8 @@ def run_scf(dftk, lib, basis, args, barrier, world, dist, torch):
     # tolerance so that it can be continued, untimed, after the timed loop; the timed loop stops at --tol exactly as
     # self_consistent_field would (the only difference: the last timed step also mixes, ~4 ms inside the timed region)
     ptol = min(PARITY_SCF_TOL, args.tol)
-    stepper = dftk.ScfStepper(basis, tol=args.tol, is_converged=lambda info_: info_["history_drho"][-1] < ptol)
+    stepper = dftk.ScfStepper(basis, tol=args.tol, is_converged=lambda info_: info_["history_drho"][-1] < ptol,
+                              phase_timers=(args.mode != "kpoints"))
     info = None
     for _ in range(max(args.steps, 1)):
         ts = time.time()
@@ -887,7 +888,10 @@ def amdahl_kpoints(dftk, basis, model, ecut, device, run, steps, args):
                 if info["converged"]:
                     break
             t_share = 1e3 * float(np.median(ts[2:] or ts))
-            share_timers[str(n)] = {k_: round(1e3 * v_, 2) for k_, v_ in info["timers"].items()}   # of the last step
+            # the phase breakdown needs a device synchronisation per phase: one more step with them switched on (not in t_share)
+            st.phase_timers = True
+            info = st.step()
+            share_timers[str(n)] = {k_: round(1e3 * v_, 2) for k_, v_ in info["timers"].items()}
             # one density all-reduce per step (+ one for the LDOS of a metal) and the eigenvalue gather
             c = _t_allreduce_ms(n, 2 if model.temperature > 0 else 1, (2 if model.temperature > 0 else 1) * 8.0 * n_cube) \
                 + COLLECTIVE_LATENCY_US * 1e-3
@@ -1064,6 +1068,7 @@ def main():
                        "step_wall_s": [round(s_, 3) for s_ in run["step_s"]],
                        "host_timers_ms_per_step": {k_: round(1e3 * v_ / steps_run, 2)
                                                    for k_, v_ in run["host_timers"].items()},
+                       "host_timers_synced": args.mode != "kpoints",   # (k-point steps: no per-phase device synchronisation)
                        "library_booked_ms": round(booked, 1), "lib_hash": library_source_hash(),
                        "E_total": info["energies"].total, "drho": info["history_drho"][-1],
                        "library_launches_per_step": round(run["library_launches"] / steps_run, 1),

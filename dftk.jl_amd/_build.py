@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libdftk_mi355x.so")
-SOURCES = ["api.cpp", "comm.cpp", "lobpcg.cpp", "batch.cpp", "batch_kernels.hip", "fft_kernels.hip", "gemm_kernels.hip", "dense_kernels.hip", "eig_kernels.hip", "xc_kernels.hip", "setup_kernels.hip", "gamma_kernels.hip", "cube_kernels.hip"]
+SOURCES = ["api.cpp", "comm.cpp", "lobpcg.cpp", "batch.cpp", "batch_kernels.hip", "fft_kernels.hip", "gemm_kernels.hip", "dense_kernels.hip", "eig_kernels.hip", "xc_kernels.hip", "setup_kernels.hip", "gamma_kernels.hip", "cube_kernels.hip", "mix_kernels.hip"]
 
 
 HASHPATH = LIBPATH + ".srchash"

@@ -126,6 +126,14 @@ _SIGNATURES = {
     "dftk_mi_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "dftk_mi_prof_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                    C.POINTER(_i64)]),
+    "dftk_mi_anderson_create": (C.c_int, [C.c_void_p, _i64, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p)]),
+    "dftk_mi_anderson_destroy": (C.c_int, [C.c_void_p]),
+    "dftk_mi_anderson_reset": (C.c_int, [C.c_void_p]),
+    "dftk_mi_anderson_history": (C.c_int, [C.c_void_p]),
+    "dftk_mi_anderson_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "dftk_mi_chi0_mix": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_double,
+                                   C.c_double, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int),
+                                   C.POINTER(C.c_int)]),
     "dftk_mi_launch_count": (C.c_int, [C.POINTER(_i64), C.POINTER(_i64)]),
     "dftk_mi_diag_mfma_peak": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "dftk_mi_jacobi_schedule_host": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),

@@ -319,6 +319,33 @@ class PlaneWaveBasis:
         for h in (self.lane_handles if lane is None else [self.lane_handles[lane]]):
             _lib.check(self.lib.dftk_mi_basis_sync(h))
 
+    # ---- stream discipline of the host mirror ----------------------------------------------------------------------
+    # The library works on ITS stream(s); torch on its current stream.  Round 6: ``on_library_stream()`` makes the
+    # library's stream torch's current stream (an ExternalStream) for a block of host code -- the SCF drivers run inside it
+    # -- so that torch kernels and library kernels are ordered by ONE stream and the mirror's calls need no host
+    # synchronisation around them (they were ~30 hipStreamSynchronize per SCF step of the k-point workloads).  Outside such
+    # a block, or when several lanes (streams) are in use, the two hooks below synchronise as before.
+    def on_library_stream(self):
+        self._require_gpu()
+        if getattr(self, "_ext_stream", None) is None:
+            self._ext_stream = torch.cuda.ExternalStream(int(self.stream_ptr), device=self.device)
+        return torch.cuda.stream(self._ext_stream)
+
+    def _same_stream(self):
+        ext = getattr(self, "_ext_stream", None)
+        return (ext is not None and self.n_lanes == 1
+                and torch.cuda.current_stream(self.device).cuda_stream == ext.cuda_stream)
+
+    def pre_call(self):
+        """Before a library call: its inputs, produced by torch, must be complete on the library's stream."""
+        if not self._same_stream():
+            torch.cuda.current_stream(self.device).synchronize()
+
+    def post_call(self, lane=None):
+        """After a library call whose outputs torch consumes next."""
+        if not self._same_stream():
+            self.sync(lane)
+
     def run_on_lanes(self, fn, items):
         """``[fn(i, item) for i, item in enumerate(items)]`` with item i executed by the host thread of lane
         ``kpoints[i].lane`` (items of one lane in order, lanes concurrently).  ctypes releases the GIL inside the
@@ -352,18 +379,18 @@ class PlaneWaveBasis:
         self._require_gpu()
         f = f_real.to(torch.complex128).contiguous()
         out = torch.empty_like(f)
-        torch.cuda.current_stream(self.device).synchronize()
+        self.pre_call()
         _lib.check(self.lib.dftk_mi_fft_sphere(self._cube_handle, f.data_ptr(), out.data_ptr()))
-        self.sync()
+        self.post_call()
         return out * self.fft_normalization
 
     def ifft(self, f_fourier: torch.Tensor) -> torch.Tensor:
         self._require_gpu()
         f = f_fourier.to(torch.complex128).contiguous()
         out = torch.empty_like(f)
-        torch.cuda.current_stream(self.device).synchronize()
+        self.pre_call()
         _lib.check(self.lib.dftk_mi_ifft_sphere(self._cube_handle, f.data_ptr(), out.data_ptr()))
-        self.sync()
+        self.post_call()
         return out * self.ifft_normalization
 
     def irfft(self, f_fourier: torch.Tensor) -> torch.Tensor:

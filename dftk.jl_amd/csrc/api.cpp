@@ -389,6 +389,7 @@ extern "C" int dftk_mi_basis_destroy(dftk_mi_basis* b) {
     if (b->ws) hipFree(b->ws);
     if (b->dense_ws) hipFree(b->dense_ws);
     if (b->eig_ws) hipFree(b->eig_ws);
+    if (b->symm_tab) hipFree(b->symm_tab);
     if (b->d_scalars) hipFree(b->d_scalars);
     if (b->h_scalars) hipHostFree(b->h_scalars);
     if (b->h_fetch) hipHostFree(b->h_fetch);

@@ -85,6 +85,9 @@ struct dftk_mi_basis {
     // that use dense_ws (Cholesky, Jacobi on the projected matrix), so it cannot share that buffer
     void* eig_ws; size_t eig_ws_bytes;
     struct dftk_mi_comm* comm;    // plane-wave (row-slab) communicator of a sharded k-block, or null (borrowed)
+    // device copy of the symmetry tables of the last cube_symmetrize call (owned; keyed by a hash of the operations: an SCF
+    // symmetrises with the same group every step -- no upload and no host synchronisation after the first call)
+    void* symm_tab; uint64_t symm_key; int symm_n;
 };
 
 // ------------------------------------------------------------------------------------ profiling

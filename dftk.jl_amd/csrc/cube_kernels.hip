@@ -253,26 +253,44 @@ int cube_symmetrize(dftk_mi_kblock* cube_kb, int n_sym, const int32_t* S_h, cons
     if (all_one) {                                           // all(isone, symmetries): the density is returned as is
         if (rho_out != rho_in)
             HIPCHK(hipMemcpyAsync(rho_out, rho_in, N * sizeof(double), hipMemcpyDeviceToDevice, b->stream));
-        HIPCHK(hipStreamSynchronize(b->stream));
         return 0;
     }
     const size_t tab = (size_t)n_sym * (18 * sizeof(int) + 3 * sizeof(double));
-    CHK(cube_ws_ensure(b, 2 * (size_t)N * sizeof(cd) + tab + 64));
+    // the tables stay on the device between calls (keyed by their content): no upload, no synchronisation per SCF step
+    uint64_t key = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t bytes) {
+        const unsigned char* c = reinterpret_cast<const unsigned char*>(p);
+        for (size_t i = 0; i < bytes; ++i) key = (key ^ c[i]) * 1099511628211ull;
+    };
+    mix(invS.data(), invS.size() * sizeof(int));
+    mix(S.data(), S.size() * sizeof(int));
+    mix(tau_h, 3 * (size_t)n_sym * sizeof(double));
+    if (!(b->symm_tab && b->symm_key == key && b->symm_n == n_sym)) {
+        HIPCHK(hipStreamSynchronize(b->stream));
+        if (b->symm_tab) HIPCHK(hipFree(b->symm_tab));
+        b->symm_tab = nullptr;
+        HIPCHK(hipMalloc(&b->symm_tab, tab + 64));
+        double* t_tau = reinterpret_cast<double*>(b->symm_tab);
+        int* t_invS = reinterpret_cast<int*>(t_tau + 3 * (size_t)n_sym);
+        int* t_S = t_invS + 9 * (size_t)n_sym;
+        HIPCHK(hipMemcpy(t_tau, tau_h, 3 * (size_t)n_sym * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(t_invS, invS.data(), 9 * (size_t)n_sym * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(t_S, S.data(), 9 * (size_t)n_sym * sizeof(int), hipMemcpyHostToDevice));
+        b->symm_key = key;
+        b->symm_n = n_sym;
+    }
+    CHK(cube_ws_ensure(b, 2 * (size_t)N * sizeof(cd)));
     cd* c1 = reinterpret_cast<cd*>(b->dense_ws);
     cd* c2 = c1 + N;
-    double* d_tau = reinterpret_cast<double*>(c2 + N);
-    int* d_invS = reinterpret_cast<int*>(d_tau + 3 * (size_t)n_sym);
-    int* d_S = d_invS + 9 * (size_t)n_sym;
-    HIPCHK(hipMemcpyAsync(d_tau, tau_h, 3 * (size_t)n_sym * sizeof(double), hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipMemcpyAsync(d_invS, invS.data(), 9 * (size_t)n_sym * sizeof(int), hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipMemcpyAsync(d_S, S.data(), 9 * (size_t)n_sym * sizeof(int), hipMemcpyHostToDevice, b->stream));
+    const double* d_tau = reinterpret_cast<const double*>(b->symm_tab);
+    const int* d_invS = reinterpret_cast<const int*>(d_tau + 3 * (size_t)n_sym);
+    const int* d_S = d_invS + 9 * (size_t)n_sym;
     CHK(cube_forward_real(cube_kb, rho_in, nullptr, c1, c2));                       // c2 = F[rho]
     hipLaunchKernelGGL(k_symmetrize, dim3(CUBE_BLOCKS), dim3(256), 0, b->stream, b->nx, b->ny, b->nz, n_sym, d_invS, d_S,
                        d_tau, c2, c1, do_lowpass, 1.0 / (double)n_sym);
     HIPCHK(hipGetLastError());
     CHK(cube_backward_real(cube_kb, c1, c2, 1.0 / (double)N, rho_out));
-    HIPCHK(hipStreamSynchronize(b->stream));                  // the host tables above go out of scope
-    return 0;
+    return 0;            // asynchronous on the basis' stream (header conventions)
 }
 
 // out = irfft(m(G) fft(f)) for the closed-form multipliers of mixing.jl / chi0models.jl or a given multiplier cube
@@ -309,6 +327,5 @@ int cube_fourier_filter(dftk_mi_kblock* cube_kb, int kind, const double* recip_h
     }
     HIPCHK(hipGetLastError());
     CHK(cube_backward_real(cube_kb, c2, c1, 1.0 / (double)N, out));
-    HIPCHK(hipStreamSynchronize(b->stream));
-    return 0;
+    return 0;            // asynchronous on the basis' stream (header conventions)
 }

@@ -956,9 +956,10 @@ static int lobpcg_run_general(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, do
 std::atomic<int64_t> g_small_calls{0}, g_small_restarts{0};
 
 bool lobpcg_small_eligible(const dftk_mi_kblock* kb, int M) {
-    static const bool off = (getenv("DFTK_MI_LOBPCG_SMALL") && atoi(getenv("DFTK_MI_LOBPCG_SMALL")) == 0) ||
-                            getenv("DFTK_MI_KBATCH_SEQUENTIAL") != nullptr;
-    if (off || kb->sh_comm || (kb->gr && kb->gr->on)) return false;
+    static const bool off = getenv("DFTK_MI_LOBPCG_SMALL") && atoi(getenv("DFTK_MI_LOBPCG_SMALL")) == 0;
+    // (DFTK_MI_KBATCH_SEQUENTIAL -- read per call, like the recorder reads it -- runs every recorded operation through its
+    //  original entry point, and the fused kernels have none: the general driver then)
+    if (off || getenv("DFTK_MI_KBATCH_SEQUENTIAL") != nullptr || kb->sh_comm || (kb->gr && kb->gr->on)) return false;
     return M >= 1 && M <= 8 && kb->n_G * (int64_t)M <= DEFER_FETCH_MAX_ELEMS && kb->n_G > 3 * (int64_t)M;
 }
 

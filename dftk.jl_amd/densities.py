@@ -18,7 +18,7 @@ def compute_density(basis, psi, occupation, occupation_threshold: float = 0.0, r
     # one accumulator per lane (the lanes run concurrently on their own streams), summed in lane order afterwards;
     # rho[kpt.spin - 1] takes the bands of a k-block (rho[:, :, :, kpt.spin], densities.jl:29, :39)
     rhos = [torch.zeros((n_spin, nz, ny, nx), dtype=torch.float64, device=basis.device) for _ in range(basis.n_lanes)]
-    torch.cuda.current_stream(basis.device).synchronize()
+    basis.pre_call()
 
     if getattr(basis, "kbatch", False) and basis.n_lanes == 1 and len(basis.kpoints) > 1:
         # many small k-blocks: the bands of all of them go through ONE pipeline (dftk_mi_density_accumulate_multi);
@@ -71,16 +71,16 @@ def compute_density(basis, psi, occupation, occupation_threshold: float = 0.0, r
     basis.run_on_lanes(accumulate, basis.kpoints)
     rho = rhos[0]
     if basis.n_lanes > 1:
-        basis.sync()
+        basis.post_call()
         for r in rhos[1:]:
             rho += r
-        torch.cuda.current_stream(basis.device).synchronize()
+        basis.pre_call()
     # mpi_sum!(rho, comm_kpts) (:46), enqueued on the library's stream behind the accumulation kernels; with
     # plane-wave sharding every rank has accumulated its share of the BANDS: the same all-reduce over comm_pw
     for comm in (basis.comm_pw, basis.comm_kpts):
         if comm.size > 1:
             comm.sum_(rho, basis.stream_ptr)
-    basis.sync()
+    basis.post_call()
     if any(not s.isone() for s in basis.symmetries):
         from .symmetry import symmetrize_rho
         rho = torch.stack([symmetrize_rho(basis, r, do_lowpass=False) for r in rho])   # densities.jl:47 (per spin)

@@ -35,7 +35,7 @@ class PreconditionerTPA:
         """``precondprep!(P, X)`` (:75-77): mean kinetic energy of every band of X (bands = rows)."""
         H = self.ham_block
         mk = np.zeros(X.shape[0])
-        torch.cuda.current_stream(H.basis.device).synchronize()
+        H.basis.pre_call()
         _lib.check(H.basis.lib.dftk_mi_tpa_precondprep(H.kpoint.handle, X.shape[0], X.data_ptr(), X.stride(0),
                                                        mk.ctypes.data))
         self.mean_kin = mk
@@ -45,18 +45,18 @@ class PreconditionerTPA:
         """``ldiv!(Y, P, R)`` (:50-60): Y = mean_kin / (mean_kin + kin) .* R, or R ./ (kin + default_shift) before
         the first ``precondprep_``."""
         H = self.ham_block
-        torch.cuda.current_stream(H.basis.device).synchronize()
+        H.basis.pre_call()
         mk = self.mean_kin.ctypes.data if self.mean_kin is not None else None
         _lib.check(H.basis.lib.dftk_mi_tpa_ldiv(H.kpoint.handle, R.shape[0], R.data_ptr(), R.stride(0), mk,
                                                 float(self.default_shift), Y.data_ptr(), Y.stride(0)))
-        H.basis.sync(H.kpoint.lane)
+        H.basis.post_call(H.kpoint.lane)
         return Y
 
 
 def columnwise_norms(basis, X: torch.Tensor) -> np.ndarray:
     """``columnwise_norms(X)`` (src/common/linalg.jl:2-4) of a band-major block through the library."""
     out = np.zeros(X.shape[0])
-    torch.cuda.current_stream(basis.device).synchronize()
+    basis.pre_call()
     _lib.check(basis.lib.dftk_mi_columnwise_norms(basis.handle, X.shape[1], X.shape[0], X.data_ptr(), X.stride(0),
                                                   out.ctypes.data))
     return out
@@ -65,7 +65,7 @@ def columnwise_norms(basis, X: torch.Tensor) -> np.ndarray:
 def columnwise_dots(basis, A: torch.Tensor, B: torch.Tensor) -> np.ndarray:
     """``columnwise_dots(A, B)`` (src/common/linalg.jl:7-9, src/gpu/linalg.jl:17-19): dot(A[:, i], B[:, i])."""
     out = (_lib.dftk_mi_cplx * A.shape[0])()
-    torch.cuda.current_stream(basis.device).synchronize()
+    basis.pre_call()
     _lib.check(basis.lib.dftk_mi_columnwise_dots(basis.handle, A.shape[1], A.shape[0], A.data_ptr(), A.stride(0),
                                                  B.data_ptr(), B.stride(0), out))
     return np.array([complex(d.re, d.im) for d in out])
@@ -75,7 +75,7 @@ def ortho_qr(basis, X: torch.Tensor) -> torch.Tensor:
     """``ortho_qr(X)`` (src/common/ortho.jl:1-9): orthonormal columns spanning those of X (Cholesky-QR with the
     reference's safeguards instead of Householder: Q differs from LAPACK's by a unitary diagonal)."""
     Q = X.clone().contiguous()
-    torch.cuda.current_stream(basis.device).synchronize()
+    basis.pre_call()
     _lib.check(basis.lib.dftk_mi_ortho_qr(basis.handle, Q.shape[1], Q.shape[0], Q.data_ptr(), Q.stride(0), 0,
                                           C.byref(C.c_int()), C.byref(C.c_int())))
     return Q
@@ -109,7 +109,7 @@ def lobpcg_hyper(A: DftHamiltonianBlock, X0: torch.Tensor, maxiter: int = 100, p
     lam = np.zeros(M)
     res = np.zeros(M)
     n_iter, conv, nmv = C.c_int(), C.c_int(), C.c_int64()
-    torch.cuda.current_stream(basis.device).synchronize()
+    basis.pre_call()
     _lib.check(basis.lib.dftk_mi_lobpcg(A.kpoint.handle, M, X.data_ptr(), X.stride(0), float(tol), int(miniter),
                                         int(maxiter), int(n_conv_check or 0), 1 if prec is not None else 0,
                                         int(seed) & (2 ** 64 - 1), lam.ctypes.data, res.ctypes.data,
@@ -135,7 +135,10 @@ def lobpcg_hyper_multi(As, X0s, maxiter: int = 100, prec=True, tol: float | None
         A.bind()
     if tol is None:
         tol = 20 * max(A.n_G for A in As) * EPS
-    Xs = [X0.clone().contiguous() for X0 in X0s]
+    # the solver works on copies (the guesses are the previous step's orbitals, which the caller may still hold): ONE
+    # multi-tensor copy instead of a launch per k-point
+    Xs = [torch.empty(X0.shape, dtype=X0.dtype, device=X0.device) for X0 in X0s]
+    torch._foreach_copy_(Xs, list(X0s))
     kbs = (C.c_void_p * n)(*[A.kpoint.handle.value for A in As])
     Xp = (C.c_void_p * n)(*[X.data_ptr() for X in Xs])
     ld = (C.c_int64 * n)(*[X.stride(0) for X in Xs])
@@ -143,7 +146,7 @@ def lobpcg_hyper_multi(As, X0s, maxiter: int = 100, prec=True, tol: float | None
     lam, res = np.zeros((n, M)), np.zeros((n, M))
     nit, conv, status = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
     nmv = np.zeros(n, dtype=np.int64)
-    torch.cuda.current_stream(basis.device).synchronize()
+    basis.pre_call()
     _lib.check(basis.lib.dftk_mi_lobpcg_multi(n, kbs, M, Xp, ld, float(tol), int(miniter), int(maxiter),
                                               int(n_conv_check or 0), 1 if prec else 0, sd, lam.ctypes.data,
                                               res.ctypes.data, nit.ctypes.data, conv.ctypes.data, nmv.ctypes.data,
@@ -267,7 +270,7 @@ def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None
             g = random_orbitals(basis, kpt, nev_per_kpoint, generator)
         guesses.append(g)
     if guesses:
-        torch.cuda.synchronize(ham[0].basis.device)
+        ham[0].basis.pre_call()
 
     basis0 = ham[0].basis if ham else None
     if ham and eigensolver is lobpcg_hyper and getattr(basis0, "kbatch", False) and basis0.n_lanes == 1:

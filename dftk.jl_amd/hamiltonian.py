@@ -30,7 +30,7 @@ class DftHamiltonianBlock:
             # collinear spin: potential[s] belongs to the k-blocks of spin s + 1 (xc.jl:163-175: Vxc[:, :, :, kpt.spin])
             pots = [potential[s_].to(torch.float64).contiguous() for s_ in range(potential.shape[0])]
             blocks = [DftHamiltonianBlock(basis, kpt, pots[kpt.spin - 1], bind=False) for kpt in basis.kpoints]
-            torch.cuda.current_stream(basis.device).synchronize()
+            basis.pre_call()
             for s_, pot_s in enumerate(pots):
                 mine = [b_ for b_ in blocks if b_.kpoint.spin == s_ + 1]
                 kbs = (C.c_void_p * len(mine))(*[b_.kpoint.handle.value for b_ in mine])
@@ -46,7 +46,7 @@ class DftHamiltonianBlock:
             return blocks
         n = len(blocks)
         kbs = (C.c_void_p * n)(*[b_.kpoint.handle.value for b_ in blocks])
-        torch.cuda.current_stream(basis.device).synchronize()
+        basis.pre_call()
         _lib.check(basis.lib.dftk_mi_kblocks_set_potential(n, kbs, pot.data_ptr()))
         for b_ in blocks:
             b_.kpoint._pot_owner = b_
@@ -58,7 +58,7 @@ class DftHamiltonianBlock:
         if not force and kpt._pot_owner is self:
             return
         if self.potential is not None:
-            torch.cuda.current_stream(self.basis.device).synchronize()
+            self.basis.pre_call()
             _lib.check(self.basis.lib.dftk_mi_kblock_set_potential(kpt.handle, self.potential.data_ptr()))
         else:
             _lib.check(self.basis.lib.dftk_mi_kblock_set_potential(kpt.handle, None))
@@ -87,10 +87,10 @@ class DftHamiltonianBlock:
         if psi.shape[1] != self.n_loc or Hpsi.shape != psi.shape:
             raise ValueError(f"mul_: blocks must be (n_bands, {self.n_loc})")
         self.bind()
-        torch.cuda.current_stream(self.basis.device).synchronize()
+        self.basis.pre_call()
         _lib.check(self.basis.lib.dftk_mi_apply_H_parts(self.kpoint.handle, which, nb, psi.data_ptr(), psi.stride(0),
                                                         Hpsi.data_ptr(), Hpsi.stride(0)))
-        self.basis.sync(self.kpoint.lane)
+        self.basis.post_call(self.kpoint.lane)
         return Hpsi
 
     def __matmul__(self, psi):

@@ -154,6 +154,13 @@ def _torch_twin():
     return os.environ.get("DFTK_MI_TORCH_LOCAL") is not None
 
 
+def _torch_mix():
+    """``DFTK_MI_TORCH_MIX=1`` (or ``DFTK_MI_TORCH_LOCAL=1``): GMRES and Anderson as host logic on torch vectors -- the parity
+    twins of ``dftk_mi_chi0_mix`` / ``dftk_mi_anderson_step`` in the test-suite."""
+    import os
+    return os.environ.get("DFTK_MI_TORCH_MIX") is not None or os.environ.get("DFTK_MI_TORCH_LOCAL") is not None
+
+
 def _filter(basis, entry, x, *params):
     """One of the library's Fourier-multiplier passes on a real cube (``dftk_mi_mix_kerker`` / ``_mix_dielectric`` /
     ``_chi0_dielectric_apply``): fft, multiplier evaluated per G in the kernel, irfft."""
@@ -161,8 +168,9 @@ def _filter(basis, entry, x, *params):
     Bh = np.asfortranarray(basis.model.recip_lattice, dtype=np.float64)
     xin = x.to(torch.float64).contiguous()
     out = torch.empty_like(xin)
-    torch.cuda.current_stream(basis.device).synchronize()
+    basis.pre_call()
     _lib.check(getattr(basis.lib, entry)(basis._cube_handle, Bh.ctypes.data, *params, xin.data_ptr(), out.data_ptr()))
+    basis.post_call()
     return out
 
 
@@ -171,8 +179,9 @@ def _filter_array(basis, mult, x):
     from . import _lib
     xin, m = x.to(torch.float64).contiguous(), mult.to(torch.float64).contiguous()
     out = torch.empty_like(xin)
-    torch.cuda.current_stream(basis.device).synchronize()
+    basis.pre_call()
     _lib.check(basis.lib.dftk_mi_cube_fourier_filter(basis._cube_handle, m.data_ptr(), xin.data_ptr(), out.data_ptr()))
+    basis.post_call()
     return out
 
 
@@ -322,7 +331,52 @@ class Chi0Mixing:
         self.chi0terms, self.reltol = list(chi0terms), float(reltol)
         self.last_gmres_applies = 0
 
+    def _native(self, basis, dF, info):
+        """The whole solve behind the C ABI (``dftk_mi_chi0_mix``: the LDOS / dielectric models and the restarted GMRES
+        of this class as ONE library call, 12 launches and one host synchronisation per Krylov step); None when a chi0
+        term is not one of the two models the library restates."""
+        import ctypes as C
+        from . import _lib
+        ldos_model = diel = None
+        for t in self.chi0terms:
+            if type(t) is LdosModel and ldos_model is None:
+                ldos_model = t
+            elif type(t) is DielectricModel and diel is None:
+                diel = t
+            else:
+                return None
+        ldos = None
+        if ldos_model is not None:
+            sm, T = default_smearing_temperature(basis.model)
+            sm = ldos_model.smearing or sm
+            T = ldos_model.temperature if ldos_model.temperature is not None else T
+            if T != 0:
+                ldos = compute_ldos(info.get("eF"), basis, info.get("eigenvalues"), info.get("psi"), sm, T)
+                ldos = ldos.to(torch.float64).contiguous()
+        if ldos is None and diel is None:
+            return dF
+        n_comp = 2 if dF.dim() == 4 else 1
+        if ldos is not None and ldos.dim() != dF.dim():
+            return None
+        xin = dF.to(torch.float64).contiguous()
+        out = torch.empty_like(xin)
+        poisson = basis.terms.poisson
+        Bh = np.asfortranarray(basis.model.recip_lattice, dtype=np.float64)
+        n_app, conv = C.c_int(), C.c_int()
+        basis.pre_call()
+        _lib.check(basis.lib.dftk_mi_chi0_mix(
+            basis._cube_handle, n_comp, Bh.ctypes.data, poisson.data_ptr() if poisson is not None else None,
+            ldos.data_ptr() if ldos is not None else None, float(basis.dvol), 1 if diel is not None else 0,
+            diel.kTF if diel is not None else 0.0, diel.eps_r if diel is not None else 1.0, xin.data_ptr(), self.reltol, 30, 100,
+            out.data_ptr(), C.byref(n_app), C.byref(conv)))
+        self.last_gmres_applies = n_app.value
+        return out
+
     def mix_density(self, basis, dF, **info):
+        if not _torch_mix():
+            out = self._native(basis, dF, info)
+            if out is not None:
+                return out
         applies = [a for a in (t(basis, **info) for t in self.chi0terms) if a is not None]
         if not applies:
             return dF                                   # "do not bother running GMRES": simple mixing

@@ -258,6 +258,52 @@ class AndersonAcceleration:
         return xn.reshape(x.shape)
 
 
+class AndersonNative:
+    """The same accelerator behind the C ABI (``dftk_mi_anderson_*``, csrc/mix_kernels.hip): history on the device, a step
+    is one reduction kernel, one host synchronisation, the small least-squares problem on the host and one fused update
+    kernel (the torch formulation above: ~25 launches).  ``AndersonAcceleration`` stays as its parity twin
+    (``DFTK_MI_TORCH_MIX=1``)."""
+
+    def __init__(self, basis, m=10, maxcond=1e6, errorfactor=1e5):
+        self.basis, self.m, self.maxcond, self.errorfactor = basis, int(m), float(maxcond), float(errorfactor)
+        self.handle, self.n = None, None
+
+    def _ensure(self, n):
+        import ctypes as C
+        from . import _lib
+        if self.handle is not None and self.n == n:
+            return
+        self.close()
+        h = C.c_void_p()
+        _lib.check(self.basis.lib.dftk_mi_anderson_create(self.basis.handle, n, self.m, self.maxcond, self.errorfactor, C.byref(h)))
+        self.handle, self.n = h, n
+
+    def __call__(self, x, alpha, Pfx):
+        from . import _lib
+        xin = x.to(torch.float64).contiguous()
+        pf = Pfx.to(torch.float64).contiguous()
+        self._ensure(xin.numel())
+        out = torch.empty_like(xin)
+        self.basis.pre_call()
+        _lib.check(self.basis.lib.dftk_mi_anderson_step(self.handle, xin.data_ptr(), float(alpha), pf.data_ptr(), out.data_ptr(), None))
+        return out
+
+    @property
+    def n_history(self):
+        return 0 if self.handle is None else int(self.basis.lib.dftk_mi_anderson_history(self.handle))
+
+    def close(self):
+        if self.handle is not None:
+            try:
+                self.basis.lib.dftk_mi_anderson_destroy(self.handle)
+            except Exception:
+                pass
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+
 def determine_diagtol(n_iter, history_drho, ratio=0.2, diagtol_max=0.005, diagtol_first=None, diagtol_min=None):
     """``determine_diagtol(::AdaptiveDiagtol, info)`` (scf_callbacks.jl:191-212): ``diagtol_first = 6 diagtol_max``
     unless given, ``min(diagtol_first, 5 diagtol_max)`` while ``n_iter <= 1``, then ``ratio * min(history_drho)``
@@ -305,9 +351,11 @@ class ScfStepper:
     scf_solvers.jl:85-98).  ``step()`` performs exactly one SCF iteration."""
 
     def __init__(self, basis, rho=None, psi=None, tol=1e-6, damping=0.8, nbandsalg=None, is_converged=None,
-                 eigensolver=lobpcg_hyper, anderson_m=10, seed=0, determine_tol=determine_diagtol, mixing=None):
+                 eigensolver=lobpcg_hyper, anderson_m=10, seed=0, determine_tol=determine_diagtol, mixing=None,
+                 phase_timers=None):
         basis._require_gpu()
         self.basis = basis
+        self.phase_timers = (os.environ.get("DFTK_MI_PHASE_TIMERS") is not None) if phase_timers is None else bool(phase_timers)
         # mixing = LdosMixing() as the reference (self_consistent_field.jl:177): simple mixing at T = 0
         self.mixing = mixing if mixing is not None else LdosMixing()
         # per-step nonlocal energy from the Ritz values (terms.energy_hamiltonian); the energies returned by
@@ -322,18 +370,30 @@ class ScfStepper:
         if determine_tol is None or determine_tol is determine_diagtol:
             determine_tol = default_diagtolalg(basis, tol)      # self_consistent_field.jl:179
         self.eigensolver, self.damping, self.determine_tol = eigensolver, damping, determine_tol
-        self.accel = AndersonAcceleration(m=anderson_m)
+        from .mixing import _torch_mix
+        self.accel = AndersonAcceleration(m=anderson_m) if _torch_mix() else AndersonNative(basis, m=anderson_m)
         self.sqrt_dvol = math.sqrt(basis.dvol)
         self.info = dict(psi=psi, occupation=None, eigenvalues=None, eF=None, n_iter=0, n_matvec=0, converged=False,
                          history_Etot=[], history_drho=[], rho=self.rho_in, timings=[])
 
     def step(self):
+        # the whole step runs with the library's stream as torch's current stream: torch kernels and library kernels are
+        # ordered by that one stream, no host synchronisation around the library calls (basis.pre_call / post_call)
+        with self.basis.on_library_stream():
+            out = self._step()
+            self.basis.sync()             # what the caller reads next (on ITS stream) is complete
+        return out
+
+    def _step(self):
         basis, info = self.basis, self.info
         t_it = time.time()
         timers = {}
 
         def lap(name, t0):
-            torch.cuda.synchronize(basis.device)
+            # per-phase device synchronisations only when asked for (phase_timers / DFTK_MI_PHASE_TIMERS=1): they are
+            # five of a k-point step's host synchronisations; without them the entries are host enqueue times
+            if self.phase_timers:
+                basis.sync()
             timers[name] = timers.get(name, 0.0) + time.time() - t0
             return time.time()
 
@@ -375,6 +435,7 @@ class ScfStepper:
             self.rho_in = self.accel(self.rho_in, self.damping, pf)
             lap("mixing", t)
         info["timers"] = timers
+        info["timers_synced"] = self.phase_timers
         self.info = info
         return info
 
@@ -388,8 +449,10 @@ class ScfStepper:
 
     def finalize(self):
         info = self.info
-        energies, ham = energy_hamiltonian(self.basis, info["psi"], info["occupation"], rho=info["rho"],
-                                       eigenvalues=info["eigenvalues"], eF=info["eF"])
+        with self.basis.on_library_stream():
+            energies, ham = energy_hamiltonian(self.basis, info["psi"], info["occupation"], rho=info["rho"],
+                                               eigenvalues=info["eigenvalues"], eF=info["eF"])
+            self.basis.sync()
         info.update(energies=energies, ham=ham)
         return info
 

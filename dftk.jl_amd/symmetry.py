@@ -287,9 +287,10 @@ def symmetrize_rho(basis, rho, do_lowpass=True):
         tau_h = np.ascontiguousarray(np.stack([s.tau for s in syms]), dtype=np.float64)
         rin = rho.to(torch.float64).contiguous()
         out = torch.empty_like(rin)
-        torch.cuda.current_stream(basis.device).synchronize()
+        basis.pre_call()
         _lib.check(basis.lib.dftk_mi_symmetrize_rho(basis._cube_handle, len(syms), S_h.ctypes.data, tau_h.ctypes.data,
                                                     1 if do_lowpass else 0, rin.data_ptr(), out.data_ptr()))
+        basis.post_call()
         return out
     rf = basis.fft(rho).reshape(-1)
     acc = torch.zeros_like(rf)

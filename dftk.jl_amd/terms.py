@@ -62,7 +62,7 @@ def _atomic_superposition_abi(basis, kind, params_of, per_atom=False):
     Bh = np.asfortranarray(model.recip_lattice, dtype=np.float64)
     nx, ny, nz = basis.fft_size
     out = torch.empty((nz, ny, nx), dtype=torch.float64, device=basis.device)
-    torch.cuda.current_stream(basis.device).synchronize()
+    basis.pre_call()
     _lib.check(basis.lib.dftk_mi_atomic_superposition(basis._cube_handle, kind, Bh.ctypes.data, par.shape[0],
                                                       par.ctypes.data, len(species), species.ctypes.data,
                                                       positions.ctypes.data, out.data_ptr()))
@@ -135,7 +135,7 @@ def build_projection_vectors_abi(basis, kpt):
             len(groups), rp.ctypes.data, nproj.ctypes.data, len(species), species.ctypes.data, positions.ctypes.data)
     _lib.check(basis.lib.dftk_mi_build_projectors_hgh(*args, None, kpt.n_loc, C.byref(n_p)))
     P = torch.empty((n_p.value, kpt.n_loc), dtype=torch.complex128, device=basis.device)
-    torch.cuda.current_stream(basis.device).synchronize()
+    basis.pre_call()
     _lib.check(basis.lib.dftk_mi_build_projectors_hgh(*args, P.data_ptr(), kpt.n_loc, C.byref(n_p)))
     return P
 
@@ -350,7 +350,7 @@ def xc_energy_potential(basis, rho):
             mask = sum({"gga_x_pbe": 8, "gga_c_pbe": 16}[name] for name in gga)
             rho_c, sig_c = rho.contiguous(), sigma.contiguous()
             eg, vr, vsig = torch.empty_like(rho_c), torch.empty_like(rho_c), torch.empty_like(rho_c)
-            torch.cuda.current_stream(basis.device).synchronize()
+            basis.pre_call()
             _lib.check(basis.lib.dftk_mi_xc_gga(basis.handle, rho_c.numel(), rho_c.data_ptr(), sig_c.data_ptr(), mask,
                                                 _DENSITY_THRESHOLD, eg.data_ptr(), vr.data_ptr(), vsig.data_ptr()))
             e = e + eg
@@ -486,7 +486,7 @@ def instantiate_terms(basis):
             if T.P is not None:
                 Dh = np.asfortranarray(T.D)
                 kpt._keep["D"] = Dh
-                torch.cuda.current_stream(basis.device).synchronize()
+                basis.pre_call()
                 _lib.check(basis.lib.dftk_mi_kblock_set_projectors(kpt.handle, T.P[ik].shape[0],
                                                                    T.P[ik].data_ptr(), kpt.n_loc, Dh.ctypes.data))
     return T
@@ -513,12 +513,12 @@ def _PH_psi(basis, Pt, psik):
     n_p, n_G = Pt.shape
     nb = psik.shape[0]
     out = torch.empty((nb, n_p), dtype=torch.complex128, device=basis.device)
-    torch.cuda.current_stream(basis.device).synchronize()
+    basis.pre_call()
     _lib.check(basis.lib.dftk_mi_zgemm(basis.handle, b"C", n_p, nb, n_G, _lib.cplx(1.0), Pt.data_ptr(), Pt.stride(0),
                                        psik.data_ptr(), psik.stride(0), _lib.cplx(0.0), out.data_ptr(), n_p))
     if basis.comm_pw.size > 1:
         basis.comm_pw.sum_(torch.view_as_real(out).reshape(-1), basis.stream_ptr)
-    basis.sync()
+    basis.post_call()
     return out
 
 
@@ -548,7 +548,7 @@ def local_potential_fused(basis, rho, want_potential=True):
     vloc = T.V_loc if "AtomicLocal" in T.names else None
     green = T.poisson if "Hartree" in T.names else None
     E3 = (C.c_double * 3)()
-    torch.cuda.current_stream(basis.device).synchronize()
+    basis.pre_call()
     args = (vloc.data_ptr() if vloc is not None else None, green.data_ptr() if green is not None else None)
     if rho.dim() == 4:
         # collinear spin: (rho_up, rho_down) -> (V_up, V_down); Hartree and the local term see the total density
@@ -630,7 +630,7 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, ei
                     nbs = [int(p_.shape[0]) for p_ in psi]
                     out = np.zeros(sum(nbs))
                     kbs = (C.c_void_p * n)(*[k_.handle.value for k_ in basis.kpoints])
-                    torch.cuda.current_stream(basis.device).synchronize()
+                    basis.pre_call()
                     _lib.check(basis.lib.dftk_mi_band_kinetic_multi(
                         n, kbs, (C.c_int * n)(*nbs), (C.c_void_p * n)(*[p_.data_ptr() for p_ in psi]),
                         (C.c_int64 * n)(*[p_.stride(0) for p_ in psi]), out.ctypes.data))
@@ -646,7 +646,7 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, ei
                         # sum_G kin_G |psi_Gn|^2 per band: the library's one-pass column reduction (the kernel of
                         # precondprep!, preconditioners.jl:75-77) instead of three cube-sized torch temporaries
                         mk = np.zeros(psik.shape[0])
-                        torch.cuda.current_stream(basis.device).synchronize()
+                        basis.pre_call()
                         _lib.check(basis.lib.dftk_mi_tpa_precondprep(kpt.handle, psik.shape[0], psik.data_ptr(),
                                                                      psik.stride(0), mk.ctypes.data))
                         e += basis.kweights[ik] * float(np.dot(np.asarray(occupation[ik], dtype=float), mk))

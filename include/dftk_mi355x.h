@@ -444,6 +444,36 @@ int dftk_mi_shard_plan_host(int n_ranks, int rank, int n_bands, const int64_t* r
  * general complex iteration would need).  enable(1) resets. */
 int dftk_mi_prof_enable(dftk_mi_basis* basis, int on);
 int dftk_mi_prof_get(dftk_mi_basis* basis, int family, double* total_ms, double* work, int64_t* launches);
+/* ---- density-sized solvers of the SCF glue (mix_kernels.hip) -----------------------------
+ * Anderson acceleration of the density fixed-point iteration (src/scf/anderson.jl:36-130, ScfAndersonDensitySolver of
+ * src/scf/scf_solvers.jl:68-102): history of up to m (iterate, preconditioned residual) pairs of n doubles on the
+ * device; a step = one reduction kernel (the inner products with the new residual; the Gram matrix of the history is
+ * kept), ONE host synchronisation, the m x m least-squares problem on the host (conditioning test on cond(R) =
+ * sqrt(cond(M'M)), entries with error > errorfactor * min dropped, as the reference), one fused update kernel.
+ * x_next_d must not alias the inputs.  m = 0: plain damping x + alpha Pf. */
+typedef struct dftk_mi_anderson dftk_mi_anderson;
+int dftk_mi_anderson_create(dftk_mi_basis* basis, int64_t n, int m, double maxcond, double errorfactor,
+                            dftk_mi_anderson** out);
+int dftk_mi_anderson_destroy(dftk_mi_anderson* acc);
+int dftk_mi_anderson_reset(dftk_mi_anderson* acc);
+int dftk_mi_anderson_history(const dftk_mi_anderson* acc);   /* entries held */
+int dftk_mi_anderson_step(dftk_mi_anderson* acc, const double* x_d, double alpha, const double* Pf_d, double* x_next_d,
+                          int* n_history /* may be NULL */);
+/* chi0 mixing (src/scf/mixing.jl:228-290, LdosMixing / HybridMixing / Chi0Mixing with RPA = true):
+ * d_rho = (1 - chi0 vc)^-1 dF by restarted GMRES in real space (KrylovKit linsolve: krylovdim, tol = max(1e-12,
+ * reltol |dF - mean dF|), zero start vector), vc = the Hartree kernel through its multiplier cube poisson_d
+ * (src/terms/hartree.jl:68-81; NULL: no Hartree term), chi0 = LdosModel (ldos_d: n_comp cubes = the local density of
+ * states at the Fermi level, src/scf/chi0models.jl:21-45; NULL or |ldos| < sqrt(eps) everywhere: term absent) and /
+ * or DielectricModel (dielectric != 0: kTF, eps_r, :54-80, needs recip_lattice_h, column-major 3 x 3).  n_comp = 2:
+ * collinear spin, vectors are (up, down) stacked, the Hartree kernel sees the total.  With no term alive d_rho = dF
+ * (simple mixing, chi0models.jl:32, mixing.jl:264-266).  Every Krylov step is 12 launches and ONE host
+ * synchronisation (all inner products of the classical Gram-Schmidt step in one fetch; a second pass when cancellation
+ * asks for it).  *n_applies = applications of the dielectric operator, *converged = 0 if maxiter cycles did not
+ * reach the tolerance (d_rho is the last iterate, as the reference's mixing uses it). */
+int dftk_mi_chi0_mix(dftk_mi_kblock* cube_kblock, int n_comp, const double* recip_lattice_h, const double* poisson_d,
+                     const double* ldos_d, double dvol, int dielectric, double kTF, double eps_r, const double* dF_d,
+                     double reltol, int krylovdim, int maxiter, double* drho_d, int* n_applies, int* converged);
+
 /* Process-wide counters since load: kernel launches issued by the library and host synchronisations it waited on
  * (stream synchronisations of its drivers, result fetches, scheduling rounds of the batched k-point driver).  For the
  * many-small-k workloads these two ARE the cost model; either pointer may be NULL. */

@@ -128,3 +128,79 @@ def test_fourier_multiplier_kernels_match_torch_twin(fft_size, monkeypatch):
         assert float((g - r).norm()) < 1e-13 * float(r.norm())
     # the DC component of dF survives Kerker / dielectric mixing (mixing.jl:70-71)
     assert abs(float(got[0].mean()) - float(dF.mean())) < 1e-14 and abs(float(got[2].mean()) - float(dF.mean())) < 1e-14
+
+
+def test_native_anderson_matches_torch_twin_and_oracle():
+    """``dftk_mi_anderson_step`` (csrc/mix_kernels.hip; src/scf/anderson.jl:36-130) against the torch formulation of the host
+    mirror and the oracle's NumPy restatement on a fixed-point problem whose history fills up, rolls over (m = 5) and
+    drops badly conditioned entries: identical iterates."""
+    from oracle.scf import AndersonAcceleration as OA
+    from dftk_jl_amd.scf import AndersonAcceleration, AndersonNative
+    assert torch.cuda.is_available()
+    lat, atoms, pos = dftk.silicon_cell()
+    basis = dftk.PlaneWaveBasis(dftk.model_DFT(lat, atoms, pos), 5, dftk.MonkhorstPack((1, 1, 1)), fft_size=(12, 12, 12))
+    rng = np.random.default_rng(0)
+    n = 12 ** 3
+    Q = np.linalg.qr(rng.standard_normal((n, 40)))[0]
+    A = np.eye(n) + Q @ np.diag(np.geomspace(0.05, 30.0, 40) - 1.0) @ Q.T          # SPD, condition 600
+    bvec = rng.standard_normal(n)
+    Ad, bd = torch.from_numpy(A).cuda(), torch.from_numpy(bvec).cuda()
+    for m in (5, 0, 10):
+        nat, twin, orc = AndersonNative(basis, m=m), AndersonAcceleration(m=m), OA(m=m)
+        x_n = torch.zeros(n, dtype=torch.float64, device="cuda")
+        x_t = x_n.clone()
+        x_o = np.zeros(n)
+        for it in range(30):
+            x_n = nat(x_n.reshape(12, 12, 12), 0.05, (bd - Ad @ x_n.reshape(-1)).reshape(12, 12, 12)).reshape(-1)
+            x_t = twin(x_t, 0.05, bd - Ad @ x_t)
+            x_o = orc(x_o, 0.05, bvec - A @ x_o)
+            scale = np.linalg.norm(x_o) + 1e-300
+            assert np.linalg.norm(x_n.cpu().numpy() - x_o) < 1e-7 * scale, (m, it)
+            assert float((x_n - x_t).norm()) < 1e-7 * scale, (m, it)
+        if m:
+            assert nat.n_history == min(m, 30)
+            assert np.linalg.norm(A @ x_o - bvec) < 0.05 * np.linalg.norm(bvec)      # (accelerated: plain damping is at 0.2)
+        nat.close()
+
+
+@pytest.mark.parametrize("name,reltol", [("ldos", 1e-11), ("ldos", 0.01), ("hybrid", 1e-10), ("dielectric_only", 1e-10)])
+def test_native_chi0_mixing_matches_torch_twin(state, name, reltol, monkeypatch):
+    """``dftk_mi_chi0_mix`` (LDOS / dielectric models + restarted GMRES as ONE library call) against the host-logic GMRES
+    on torch vectors (``DFTK_MI_TORCH_MIX=1``): same solution at a tight tolerance, and at the reference's default
+    reltol = 0.01 the same number of operator applications (both walk the same Krylov steps)."""
+    s = state
+    mk = {"ldos": lambda: dftk.LdosMixing(reltol=reltol), "hybrid": lambda: dftk.HybridMixing(reltol=reltol),
+          "dielectric_only": lambda: dftk.mixing.Chi0Mixing([dftk.mixing.DielectricModel(7.0, 0.9)], reltol=reltol)}[name]
+    args = dict(eF=s["eF"], eigenvalues=s["lam"], psi=s["dpsi"])
+    nat = mk()
+    got = nat.mix_density(s["db"], s["dFd"].clone(), **args)
+    monkeypatch.setenv("DFTK_MI_TORCH_MIX", "1")
+    twin = mk()
+    ref = twin.mix_density(s["db"], s["dFd"].clone(), **args)
+    monkeypatch.delenv("DFTK_MI_TORCH_MIX")
+    tol = 1e-9 if reltol < 1e-6 else 2 * reltol
+    assert float((got - ref).norm()) < tol * float(ref.norm())
+    assert nat.last_gmres_applies == twin.last_gmres_applies and nat.last_gmres_applies >= 2
+    assert abs(float(got.mean()) - float(s["dFd"].mean())) < 1e-13                 # the DC component passes through
+
+
+def test_native_chi0_mixing_collinear_matches_torch_twin(monkeypatch):
+    """Two spin channels: the Hartree kernel sees the total density, the LDOS model both channels (mixing.jl:241-257)."""
+    lat = A_AL / 2 * np.array([[0, 1, 1.0], [1, 0, 1.0], [1, 1, 0.0]])
+    Al = dftk.ElementPsp("Al", dftk.load_psp("Al", "lda"))
+    model = dftk.model_DFT(lat, [Al], [np.zeros(3)], functionals=("lda_x", "lda_c_pw"), temperature=0.01, smearing="fermi_dirac",
+                           magnetic_moments=[0.5])
+    basis = dftk.PlaneWaveBasis(model, 6, dftk.MonkhorstPack((2, 2, 2)))
+    st = dftk.ScfStepper(basis, tol=1e-12, rho=dftk.guess_density(basis, [0.5]))
+    info = st.step()
+    dF = (info["rho"] - info["rho_in"]).contiguous()
+    assert dF.dim() == 4
+    args = dict(eF=info["eF"], eigenvalues=info["eigenvalues"], psi=info["psi"], occupation=info["occupation"])
+    nat = dftk.LdosMixing(reltol=1e-10)
+    got = nat.mix_density(basis, dF.clone(), **args)
+    monkeypatch.setenv("DFTK_MI_TORCH_MIX", "1")
+    twin = dftk.LdosMixing(reltol=1e-10)
+    ref = twin.mix_density(basis, dF.clone(), **args)
+    monkeypatch.delenv("DFTK_MI_TORCH_MIX")
+    assert float((got - ref).norm()) < 1e-8 * float(ref.norm())
+    assert nat.last_gmres_applies >= 2 and float((ref - dF).norm()) > 1e-3 * float(dF.norm())

@@ -66,19 +66,26 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-def test_cfg5_planewave_sharded_at_size_two_ranks_one_gpu(tmp_path):
+@pytest.mark.parametrize("n_ranks", [2, 3, 8])
+def test_cfg5_planewave_sharded_at_size_n_ranks_one_gpu(tmp_path, n_ranks):
+    """N = 2; N = 3 (ragged slabs and ragged band groups: 503 = 168 + 168 + 167); N = 8 -- the plan of the driver's 8-GPU
+    scaling run (63-band groups with a 62-band tail, 16 554-row half-format slabs, the cooperative one-launch Cholesky
+    entered from eight processes, `Transposer` plans with eight peers), every rank a process of its own on the ONE GPU of
+    the box."""
     assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
     script = tmp_path / "cfg5_worker.py"
     script.write_text(CFG5_WORKER)
-    port = str(41000 + os.getpid() % 2000)
+    port = str(41000 + (os.getpid() + 7 * n_ranks) % 2000)
     out_prefix = str(tmp_path / "c5")
-    base = dict(os.environ, WORLD_SIZE="2", PORT=port, REPO=ROOT, MASTER_ADDR="127.0.0.1", OUT=out_prefix,
+    base = dict(os.environ, WORLD_SIZE=str(n_ranks), PORT=port, REPO=ROOT, MASTER_ADDR="127.0.0.1", OUT=out_prefix,
                 N_BANDS=str(N_BANDS), N_ITER=str(N_LOBPCG_ITER))
-    outs = _spawn([([sys.executable, str(script)], dict(base, RANK=str(r))) for r in range(2)], timeout=1500.0)
+    outs = _spawn([([sys.executable, str(script)], dict(base, RANK=str(r))) for r in range(n_ranks)], timeout=2400.0)
     got = json.loads([ln for ln in outs[0].splitlines() if ln.startswith("RESULT ")][-1][len("RESULT "):])
-    metas = sorted(got["metas"], key=lambda m: m["row0"])
-    assert metas[0]["row0"] == 0 and metas[0]["n_loc"] + metas[1]["n_loc"] == 264859
-    order = [0, 1] if got["metas"][0]["row0"] == 0 else [1, 0]
+    order = sorted(range(n_ranks), key=lambda r: got["metas"][r]["row0"])
+    metas = [got["metas"][r] for r in order]
+    assert metas[0]["row0"] == 0 and sum(m["n_loc"] for m in metas) == 264859
+    for a_, b_ in zip(metas[:-1], metas[1:]):
+        assert a_["row0"] + a_["n_loc"] == b_["row0"]                        # contiguous slabs in rank order
 
     # the same block on ONE rank (this process)
     lat, atoms, pos = dftk.silicon_cell((5, 5, 5))
@@ -92,8 +99,8 @@ def test_cfg5_planewave_sharded_at_size_two_ranks_one_gpu(tmp_path):
     gen.manual_seed(11)
     psi = dftk.random_orbitals(basis, kpt, N_BANDS, gen)
     # the slabs of the sharded random block are the rows of this block (same generator): column sums of the slabs
-    r0 = metas[1]["row0"]
-    for m, sl in ((metas[0], psi[:, :r0]), (metas[1], psi[:, r0:])):
+    for m in metas:
+        sl = psi[:, m["row0"]:m["row0"] + m["n_loc"]]
         assert abs(float(sl.real.sum()) - m["psi_sum"][0]) < 1e-8 and abs(float(sl.imag.sum()) - m["psi_sum"][1]) < 1e-8
     Href = ham[0] @ psi
     Hgot = torch.from_numpy(np.concatenate([np.load(out_prefix + "_H_%d.npy" % r) for r in order], axis=1)).cuda()

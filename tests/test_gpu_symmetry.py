@@ -119,13 +119,16 @@ def test_symmetrize_rho_kernel_matches_torch_twin_and_oracle(fft_size, monkeypat
     S_h = np.ascontiguousarray(np.stack([np.asfortranarray(s.S).ravel(order="F") for s in db.symmetries]), dtype=np.int32)
     tau_h = np.ascontiguousarray(np.stack([s.tau for s in db.symmetries]))
     buf = torch.from_numpy(rho).cuda()
+    torch.cuda.synchronize()
     check(db.lib.dftk_mi_symmetrize_rho(db._cube_handle, 48, S_h.ctypes.data, tau_h.ctypes.data, 1, buf.data_ptr(),
                                         buf.data_ptr()))
+    db.sync()                                                    # (asynchronous on the basis' stream, as the header says)
     assert float((buf - got.new_tensor(osym(ob, rho, do_lowpass=True))).norm()) < 1e-12 * float(buf.norm())
     one = torch.from_numpy(rho).cuda()
     out = torch.empty_like(one)
     check(db.lib.dftk_mi_symmetrize_rho(db._cube_handle, 1, S_h[:1].ctypes.data, tau_h[:1].ctypes.data, 1,
                                         one.data_ptr(), out.data_ptr()))
+    db.sync()
     assert db.symmetries[0].isone() and torch.equal(out, one)
     bad = S_h[:1].copy()
     bad[0, 0] = 2                                                # det = 2: not a lattice symmetry

@@ -26,7 +26,7 @@ kc = [np.asarray(k) for k in full.kcoords_global[:n_loc]]
 kw = np.asarray(full.kweights_global[:n_loc], dtype=float)
 os.environ["DFTK_MI_KBATCH"] = "1"
 sub = dftk.PlaneWaveBasis(model, 40.0, dftk.ExplicitKpoints(kc, list(kw / kw.sum())), fft_size=full.fft_size)
-st = dftk.ScfStepper(sub, tol=1e-12)
+st = dftk.ScfStepper(sub, tol=1e-12, phase_timers="--no-phase-timers" not in sys.argv)
 walls, timers = [], []
 for i in range(12):
     torch.cuda.synchronize()

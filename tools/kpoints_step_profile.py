@@ -20,7 +20,7 @@ Al = dftk.ElementPsp("Al", dftk.load_psp("Al", "pbe"))
 model = dftk.model_DFT(lat, [Al], [np.zeros(3)], functionals=("gga_x_pbe", "gga_c_pbe"), temperature=1e-3,
                        smearing="gaussian", symmetries=True)
 basis = dftk.PlaneWaveBasis(model, 40.0, dftk.MonkhorstPack((12, 12, 12)))
-st = dftk.ScfStepper(basis, tol=1e-6)
+st = dftk.ScfStepper(basis, tol=1e-6, phase_timers=True)
 for _ in range(3):
     st.step()
 torch.cuda.synchronize()

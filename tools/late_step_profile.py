@@ -17,7 +17,7 @@ lib = dftk.load_library()
 lat, atoms, pos = dftk.silicon_cell((n, n, n))
 model = dftk.model_DFT(lat, atoms, pos, functionals=("lda_x", "lda_c_pw"))
 basis = dftk.PlaneWaveBasis(model, 30.0, dftk.MonkhorstPack((1, 1, 1)))
-st = dftk.ScfStepper(basis, tol=1e-6)
+st = dftk.ScfStepper(basis, tol=1e-6, phase_timers=True)
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 for _ in range(skip):
     st.step()

@@ -555,30 +555,36 @@ __global__ __launch_bounds__(256) void k_b_heev(const DenseItem* __restrict__ it
                 s_q[tid] = q;
             }
             __syncthreads();
-            for (int t = tid; t < npairs * np; t += nthr) {     // rows
-                const int k = t / np, j = t - k * np;
-                const int p = s_p[k], q = s_q[k];
-                const double c = s_c[k];
-                const cd s = s_s[k];
-                const cd a = S[p * pitch + j], b = S[q * pitch + j];
-                S[p * pitch + j] = make_double2(c * a.x - (s.x * b.x - s.y * b.y), c * a.y - (s.x * b.y + s.y * b.x));
-                S[q * pitch + j] = make_double2(s.x * a.x + s.y * a.y + c * b.x, s.x * a.y - s.y * a.x + c * b.y);
-            }
-            __syncthreads();
-            for (int t = tid; t < npairs * np; t += nthr) {     // columns of S and of V
-                const int k = t / np, i = t - k * np;
-                const int p = s_p[k], q = s_q[k];
-                const double c = s_c[k];
-                const cd s = s_s[k];
-                {
-                    const cd xp = S[i * pitch + p], xq = S[i * pitch + q];
-                    S[i * pitch + p] = make_double2(c * xp.x - (s.x * xq.x + s.y * xq.y), c * xp.y - (s.x * xq.y - s.y * xq.x));
-                    S[i * pitch + q] = make_double2(s.x * xp.x - s.y * xp.y + c * xq.x, s.x * xp.y + s.y * xp.x + c * xq.y);
-                }
-                {
-                    const cd xp = V[i * pitch + p], xq = V[i * pitch + q];
-                    V[i * pitch + p] = make_double2(c * xp.x - (s.x * xq.x + s.y * xq.y), c * xp.y - (s.x * xq.y - s.y * xq.x));
-                    V[i * pitch + q] = make_double2(s.x * xp.x - s.y * xp.y + c * xq.x, s.x * xp.y + s.y * xp.x + c * xq.y);
+            // S <- J^H S J and V <- V J in ONE phase: the 2 x 2 block of S at (rows of pair k) x (columns of pair l) is
+            // transformed by both rotations in registers -- the blocks are disjoint, so the update is in place with a single
+            // barrier (the former rows-then-columns form needed two phases and touched every element twice); the rows of V
+            // take the column rotation of pair l in the same phase.
+            for (int t = tid; t < npairs * npairs + np * npairs; t += nthr) {
+                if (t < npairs * npairs) {
+                    const int k = t / npairs, l = t - k * npairs;
+                    const int p = s_p[k], q = s_q[k], r = s_p[l], s2 = s_q[l];
+                    const double ck = s_c[k], cl = s_c[l];
+                    const cd sk = s_s[k], sl = s_s[l];
+                    const cd a = S[p * pitch + r], bq = S[p * pitch + s2], c2 = S[q * pitch + r], d = S[q * pitch + s2];
+                    // rows: (row_p, row_q) <- (c row_p - s row_q, conj(s) row_p + c row_q)
+                    const cd a1 = make_double2(ck * a.x - (sk.x * c2.x - sk.y * c2.y), ck * a.y - (sk.x * c2.y + sk.y * c2.x));
+                    const cd b1 = make_double2(ck * bq.x - (sk.x * d.x - sk.y * d.y), ck * bq.y - (sk.x * d.y + sk.y * d.x));
+                    const cd c1 = make_double2(sk.x * a.x + sk.y * a.y + ck * c2.x, sk.x * a.y - sk.y * a.x + ck * c2.y);
+                    const cd d1 = make_double2(sk.x * bq.x + sk.y * bq.y + ck * d.x, sk.x * bq.y - sk.y * bq.x + ck * d.y);
+                    // columns: (col_r, col_s) <- (c col_r - conj(s) col_s, s col_r + c col_s)
+                    S[p * pitch + r] = make_double2(cl * a1.x - (sl.x * b1.x + sl.y * b1.y), cl * a1.y - (sl.x * b1.y - sl.y * b1.x));
+                    S[p * pitch + s2] = make_double2(sl.x * a1.x - sl.y * a1.y + cl * b1.x, sl.x * a1.y + sl.y * a1.x + cl * b1.y);
+                    S[q * pitch + r] = make_double2(cl * c1.x - (sl.x * d1.x + sl.y * d1.y), cl * c1.y - (sl.x * d1.y - sl.y * d1.x));
+                    S[q * pitch + s2] = make_double2(sl.x * c1.x - sl.y * c1.y + cl * d1.x, sl.x * c1.y + sl.y * c1.x + cl * d1.y);
+                } else {
+                    const int u = t - npairs * npairs;
+                    const int l = u / np, i = u - l * np;
+                    const int r = s_p[l], s2 = s_q[l];
+                    const double cl = s_c[l];
+                    const cd sl = s_s[l];
+                    const cd xp = V[i * pitch + r], xq = V[i * pitch + s2];
+                    V[i * pitch + r] = make_double2(cl * xp.x - (sl.x * xq.x + sl.y * xq.y), cl * xp.y - (sl.x * xq.y - sl.y * xq.x));
+                    V[i * pitch + s2] = make_double2(sl.x * xp.x - sl.y * xp.y + cl * xq.x, sl.x * xp.y + sl.y * xp.x + cl * xq.y);
                 }
             }
             __syncthreads();
@@ -737,100 +743,92 @@ __device__ __forceinline__ double o_wave_max_all(double v) {
     for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
     return v;
 }
+// value of `v` in lane `src` (a compile-time lane): two v_readlane_b32
+__device__ __forceinline__ double o_bcast(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+// Lane c < 8 keeps column c of the identity-padded 8 x 8 matrix in REGISTERS; the right-looking Cholesky steps and the
+// column-wise inverse fetch the entries of other columns with v_readlane (wave-uniform values): no LDS round trips, no
+// wave synchronisation -- the LDS form of this routine was 10 000 cycles per call (clock64), a quarter of the kernel.
 __device__ __forceinline__ void o_chol_inv(const cd* s_O, int m, cd* s_R, cd* s_inv, double* s_stat) {
+    (void)s_R;
     const double EPSD = 2.220446049250313e-16;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, col = lane & (OR_M - 1);
     int nchol = 0;
     double alpha = 100.0, shift = 0.0, nR = 0.0, nI = 0.0;
     bool nonfinite = false;
+    double xr[OR_M], xi[OR_M];
     for (;;) {
         if (nchol >= 5) {
             nchol = 10000;
             break;
         }
         nchol += 1;
-        {
-            const int i = lane % OR_M, j = lane / OR_M;          // 64 lanes = the padded 8 x 8 matrix
-            cd v = s_O[i + OR_M * j];
-            if (i == j && i < m) v.x += shift;
-            s_R[i + OR_M * j] = v;
-            s_inv[i + OR_M * j] = make_double2(i == j ? 1.0 : 0.0, 0.0);
+        double Sr[OR_M], Si[OR_M];
+#pragma unroll
+        for (int i = 0; i < OR_M; ++i) {
+            const cd v = s_O[i + OR_M * col];
+            Sr[i] = v.x + ((i == col && i < m) ? shift : 0.0);
+            Si[i] = (i == col) ? 0.0 : v.y;
         }
-        o_wave_sync();
         bool ok = true;
-        for (int j = 0; j < m; ++j) {
-            const double d = s_R[j + OR_M * j].x;                // (every lane reads the pivot: uniform)
-            if (!(d > 0.0) || !isfinite(d)) {
-                ok = false;
-                break;
+#pragma unroll
+        for (int j = 0; j < OR_M; ++j) {
+            const double d = o_bcast(Sr[j], j);                   // the pivot S[j][j] (uniform)
+            if (!(d > 0.0) || !isfinite(d)) ok = false;
+            const double piv = ok ? sqrt(d) : 1.0, inv = 1.0 / piv;
+            if (col > j) {
+                Sr[j] *= inv;
+                Si[j] *= inv;
+            } else if (col == j) {
+                Sr[j] = piv;
+                Si[j] = 0.0;
             }
-            const double piv = sqrt(d), inv = 1.0 / piv;
-            o_wave_sync();
-            if (lane == 0) s_R[j + OR_M * j] = make_double2(piv, 0.0);
-            {
-                const int c = j + 1 + lane;
-                if (c < m) {
-                    cd v = s_R[j + OR_M * c];
-                    v.x *= inv;
-                    v.y *= inv;
-                    s_R[j + OR_M * c] = v;
+#pragma unroll
+            for (int i = j + 1; i < OR_M; ++i) {                   // S[i][col] -= conj(S[j][i]) S[j][col], col >= i
+                const double ur = o_bcast(Sr[j], i), ui = o_bcast(Si[j], i);
+                if (col >= i) {
+                    Sr[i] -= ur * Sr[j] + ui * Si[j];
+                    Si[i] = (col == i) ? 0.0 : Si[i] - (ur * Si[j] - ui * Sr[j]);
                 }
             }
-            o_wave_sync();
-            const int rem = m - j - 1;
-            if (lane < rem * rem) {                              // R[i][c] -= conj(R[j][i]) R[j][c],  j < i <= c < m
-                const int a = lane / rem, bq = lane - a * rem;
-                const int i = j + 1 + a, c = j + 1 + bq;
-                if (i <= c) {
-                    const cd u = s_R[j + OR_M * i], v = s_R[j + OR_M * c];
-                    cd w = s_R[i + OR_M * c];
-                    w.x -= u.x * v.x + u.y * v.y;
-                    w.y -= u.x * v.y - u.y * v.x;
-                    if (i == c) w.y = 0.0;
-                    s_R[i + OR_M * c] = w;
-                }
-            }
-            o_wave_sync();
         }
-        bool bad = false;
-        if (ok) {
-            // inverse of the upper factor, lane j owns column j: x_j = 1 / R_jj, x_i = -(sum_{k > i} R_ik x_k) / R_ii
-            if (lane < m) {
-                const int j = lane;
-                s_inv[j + OR_M * j] = make_double2(1.0 / s_R[j + OR_M * j].x, 0.0);
-                for (int i = j - 1; i >= 0; --i) {
-                    double sr = 0.0, si = 0.0;
-                    for (int k = i + 1; k <= j; ++k) {
-                        const cd rr = s_R[i + OR_M * k], xx = s_inv[k + OR_M * j];
-                        sr += rr.x * xx.x - rr.y * xx.y;
-                        si += rr.x * xx.y + rr.y * xx.x;
-                    }
-                    const double d = s_R[i + OR_M * i].x;
-                    s_inv[i + OR_M * j] = make_double2(-sr / d, -si / d);
-                }
-                for (int i = j + 1; i < OR_M; ++i) s_inv[i + OR_M * j] = make_double2(0.0, 0.0);
+        // column `col` of the inverse: x_col = 1 / R_cc, x_i = -(sum_{k > i} R_ik x_k) / R_ii for i < col, zero below
+#pragma unroll
+        for (int i = OR_M - 1; i >= 0; --i) {
+            const double rii = o_bcast(Sr[i], i);
+            double sr = 0.0, si = 0.0;
+#pragma unroll
+            for (int k = i + 1; k < OR_M; ++k) {
+                const double rr = o_bcast(Sr[i], k), ri = o_bcast(Si[i], k);
+                sr += rr * xr[k] - ri * xi[k];
+                si += rr * xi[k] + ri * xr[k];
             }
-            o_wave_sync();
-            // normest = max |diag| + ||strict upper||_F of both factors (k_normest_upper), finiteness
-            double mxR = 0.0, offR = 0.0, mxI = 0.0, offI = 0.0, b = 0.0;
-            {
-                const int i = lane % OR_M, j = lane / OR_M;
-                if (i <= j && j < m) {
-                    const cd r = s_R[i + OR_M * j], x = s_inv[i + OR_M * j];
-                    if (!(isfinite(r.x) && isfinite(r.y) && isfinite(x.x) && isfinite(x.y))) b = 1.0;
-                    if (i == j) {
-                        mxR = fabs(r.x);
-                        mxI = fabs(x.x);
+            xr[i] = i == col ? 1.0 / rii : (i < col ? -sr / rii : 0.0);
+            xi[i] = i < col ? -si / rii : 0.0;
+        }
+        // normest = max |diag| + ||strict upper||_F of both factors, finiteness (columns of the m x m part only, once each)
+        double mxR = 0.0, offR = 0.0, mxI = 0.0, offI = 0.0, bflag = 0.0;
+        if (lane < m) {
+#pragma unroll
+            for (int i = 0; i < OR_M; ++i) {
+                if (i <= col) {
+                    if (!(isfinite(Sr[i]) && isfinite(Si[i]) && isfinite(xr[i]) && isfinite(xi[i]))) bflag = 1.0;
+                    if (i == col) {
+                        mxR = fabs(Sr[i]);
+                        mxI = fabs(xr[i]);
                     } else {
-                        offR = r.x * r.x + r.y * r.y;
-                        offI = x.x * x.x + x.y * x.y;
+                        offR += Sr[i] * Sr[i] + Si[i] * Si[i];
+                        offI += xr[i] * xr[i] + xi[i] * xi[i];
                     }
                 }
             }
-            bad = o_wave_max_all(b) != 0.0;
-            nR = o_wave_max_all(mxR) + sqrt(o_wave_sum_all(offR));
-            nI = o_wave_max_all(mxI) + sqrt(o_wave_sum_all(offI));
         }
+        const bool bad = o_wave_max_all(bflag) != 0.0;
+        nR = o_wave_max_all(mxR) + sqrt(o_wave_sum_all(offR));
+        nI = o_wave_max_all(mxI) + sqrt(o_wave_sum_all(offI));
         if (ok && !bad) break;
         // O += alpha eps ||O||_F I  (the Frobenius norm of the Hermitian matrix as it stands, earlier shifts included)
         double f = 0.0;
@@ -849,7 +847,10 @@ __device__ __forceinline__ void o_chol_inv(const cd* s_O, int m, cd* s_R, cd* s_
         }
         shift += alpha * EPSD * sqrt(f2);
         alpha *= 10.0;
-        o_wave_sync();
+    }
+    if (lane < OR_M) {
+#pragma unroll
+        for (int i = 0; i < OR_M; ++i) s_inv[i + OR_M * col] = make_double2(xr[i], xi[i]);
     }
     if (lane == 0) {
         s_stat[0] = (double)nchol;
@@ -876,7 +877,7 @@ __global__ __launch_bounds__(OR_T) void k_b_ortho(const OrthoItem* __restrict__ 
     int nchol_last = 0, rounds = 0;
 
     // ortho!(X): Cholesky-QR passes; returns false when the caller has to stop (status set)
-    auto ortho_x = [&]() -> bool {
+    auto ortho_x = [&]() __attribute__((always_inline)) -> bool {
         double growth = 1.0;
         int nchol_total = 0;
         for (int pass = 0;; ++pass) {
@@ -1060,7 +1061,41 @@ __global__ __launch_bounds__(OR_T) void k_b_ortho(const OrthoItem* __restrict__ 
 // wave (63 lane exchanges for 64 values instead of 6 per value) and a fixed-order sum over the waves.  The streaming kernel
 // above walks X through L2 in every phase: its dependent-load loops made it ~180 us per call on the 1350 x 6 blocks of
 // the Al workload (rocprofv3, round 6), i.e. half of a scheduling round.
-#define OR_V 32          // values per block reduction (a 2 x 8 complex tile)
+#define OR_V 32          // values per wave reduction (a 2 x 8 complex tile)
+#define OR_SLOTS 8       // tiles reduced between two barriers (ny <= 16 rows of BYX = 8 tiles; 4 tiles of the Gram matrix)
+// the value lane `lane` receives from its partner of the butterfly step H.  Partners: lane ^ 32 / ^ 16 (v_permlane*_swap),
+// then the DPP mirrors inside a row of 16 -- 15 - i, 7 - i, 3 - i, i ^ 1: each differs from the lane in bit H (and below),
+// which is all a reduce-scatter step needs (the masks 16, 15, 7, 3, 1 are linearly independent: after the five steps a
+// lane has summed over its whole half-wave).  No LDS traffic (ds_bpermute) in the reduction.
+template <int H>
+__device__ __forceinline__ double o_recv(double send, int lane) {
+    int lo = __double2loint(send), hi = __double2hiint(send);
+    if constexpr (H == 1) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false);      // quad_perm:[1,0,3,2]
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false);
+    } else if constexpr (H == 2) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x1B, 0xF, 0xF, false);      // quad_perm:[3,2,1,0]
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x1B, 0xF, 0xF, false);
+    } else if constexpr (H == 4) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, false);     // row_half_mirror
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, false);
+    } else if constexpr (H == 8) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, false);     // row_mirror
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, false);
+    } else if constexpr (H == 16) {
+        // odd rows of the first operand <-> even rows of the second: lanes 16-31 get lanes 0-15 in [0], lanes 0-15 get 16-31 in [1]
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto c = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        lo = (lane & 16) ? (int)a[0] : (int)a[1];
+        hi = (lane & 16) ? (int)c[0] : (int)c[1];
+    } else {
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto c = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        lo = (lane & 32) ? (int)a[0] : (int)a[1];
+        hi = (lane & 32) ? (int)c[0] : (int)c[1];
+    }
+    return __hiloint2double(hi, lo);
+}
 template <int L>
 __device__ __forceinline__ void o_rs_step(double (&v)[OR_V], int lane) {
     constexpr int H = L / 2;
@@ -1069,27 +1104,33 @@ __device__ __forceinline__ void o_rs_step(double (&v)[OR_V], int lane) {
     for (int i = 0; i < H; ++i) {
         const double send = up ? v[i] : v[i + H];
         const double keep = up ? v[i + H] : v[i];
-        v[i] = keep + __shfl_xor(send, H, 64);
+        v[i] = keep + o_recv<H>(send, lane);
     }
 }
-// block-wide sums of OR_V values per thread -> s_out[0 .. OR_V) (fixed order: butterfly inside a wave -- lane l ends up
-// with value l % 32 --, then the two half-waves, then the waves in index order)
+// sums over the wave of OR_V values per lane: reduce-scatter butterfly (31 lane exchanges), the two half-waves added, the
+// result of value l left by lane l < 32 in s_w[(slot * NW + wave) * OR_V + l].  No barrier: a caller reduces several tiles
+// back to back and calls o_finish once.
 template <int NW>
-__device__ __forceinline__ void o_block_sumv(double (&v)[OR_V], double* s_out, double* s_w /* [NW][OR_V] */) {
+__device__ __forceinline__ void o_wave_reduce_store(double (&v)[OR_V], int slot, double* s_w) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     o_rs_step<32>(v, lane);
     o_rs_step<16>(v, lane);
     o_rs_step<8>(v, lane);
     o_rs_step<4>(v, lane);
     o_rs_step<2>(v, lane);
-    const double t0 = v[0] + __shfl_xor(v[0], 32, 64);
-    if (lane < OR_V) s_w[w * OR_V + lane] = t0;
+    const double t0 = v[0] + o_recv<32>(v[0], lane);
+    if (lane < OR_V) s_w[(slot * NW + w) * OR_V + lane] = t0;
+}
+// dest[slot * OR_V + l] = sum over the waves (in index order: deterministic) of the tiles stored since the last call
+template <int NW>
+__device__ __forceinline__ void o_finish(int nslots, double* dest, const double* s_w) {
     __syncthreads();
-    if (threadIdx.x < OR_V) {
+    if ((int)threadIdx.x < nslots * OR_V) {
+        const int slot = threadIdx.x / OR_V, idx = threadIdx.x - slot * OR_V;
         double t = 0.0;
 #pragma unroll
-        for (int q = 0; q < NW; ++q) t += s_w[q * OR_V + threadIdx.x];
-        s_out[threadIdx.x] = t;
+        for (int q = 0; q < NW; ++q) t += s_w[(slot * NW + q) * OR_V + idx];
+        dest[threadIdx.x] = t;
     }
     __syncthreads();
 }
@@ -1101,7 +1142,7 @@ __global__ __launch_bounds__(OR_T) void k_b_ortho_reg(const OrthoItem* __restric
     constexpr int NW = OR_T / 64;
     const int tid = threadIdx.x, m = it.m, ny = it.ny;
     const int64_t n = it.n;
-    __shared__ double s_w[NW * OR_V];
+    __shared__ double s_w[OR_SLOTS * NW * OR_V];
     __shared__ double s_t[OR_V];                    // one reduced tile: (row-in-chunk * OR_M + column) * 2 + {re, im}
     __shared__ cd s_byx[OR_NY * OR_M];              // BYX[a][j] at a * OR_M + j
     __shared__ cd s_O[OR_M * OR_M];
@@ -1111,6 +1152,15 @@ __global__ __launch_bounds__(OR_T) void k_b_ortho_reg(const OrthoItem* __restric
     __shared__ double s_stat[4];
     double status = 0.0, growth_last = 1.0;
     int nchol_last = 0, rounds = 0;
+    // shader clocks per phase (res[4 ..]): {total, load, BYX, update + norms, Gram, Cholesky, X inv(R), store}
+    long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tc = clock64();
+    const long long tc0 = tc;
+    auto lap = [&](int k) {
+        const long long now = clock64();
+        clk[k] += now - tc;
+        tc = now;
+    };
     cd x[RPT][OR_M];
     bool live[RPT];
 #pragma unroll
@@ -1122,7 +1172,8 @@ __global__ __launch_bounds__(OR_T) void k_b_ortho_reg(const OrthoItem* __restric
             x[q][j] = (live[q] && j < m) ? it.X[r + (int64_t)j * it.ldx] : make_double2(0.0, 0.0);
     }
 
-    auto ortho_x = [&]() -> bool {
+    lap(1);
+    auto ortho_x = [&]() __attribute__((always_inline)) -> bool {
         double growth = 1.0;
         int nchol_total = 0;
         for (int pass = 0;; ++pass) {
@@ -1130,7 +1181,11 @@ __global__ __launch_bounds__(OR_T) void k_b_ortho_reg(const OrthoItem* __restric
                 status = 1.0;
                 return false;
             }
-            // Gram matrix, two columns per reduction: tile entry (jl, i) = <x_i, x_{2 c + jl}>
+            // Gram matrix, two columns per tile: tile entry (jl, i) = <x_i, x_{2 c + jl}>; all tiles between two barriers.
+            // The layout of a reduced tile IS the layout of s_O (column 2 c + jl, row i, re / im): finish writes it in place.
+            // (unrolled so that every index into x[][] is a compile-time constant -- a runtime column index, even a select
+            //  between entries, makes the compiler keep x[][] in scratch memory; the scheduling barriers keep the four tiles'
+            //  accumulators from being live together, which spilled hundreds of registers)
 #pragma unroll
             for (int c = 0; c < OR_M / 2; ++c) {
                 if (2 * c < m) {
@@ -1148,14 +1203,11 @@ __global__ __launch_bounds__(OR_T) void k_b_ortho_reg(const OrthoItem* __restric
                                 v[(jl * OR_M + i) * 2 + 1] += x[q][i].x * xj.y - x[q][i].y * xj.x;
                             }
                         }
-                    o_block_sumv<NW>(v, s_t, s_w);
-                    if (tid < 2 * OR_M) {
-                        const int jl = tid / OR_M, i = tid % OR_M;
-                        s_O[i + OR_M * (2 * c + jl)] = make_double2(s_t[2 * tid], s_t[2 * tid + 1]);
-                    }
-                    __syncthreads();
+                    o_wave_reduce_store<NW>(v, c, s_w);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            o_finish<NW>((m + 1) / 2, reinterpret_cast<double*>(s_O), s_w);
             // hermitise from the upper triangle, identity padding
             if (tid < OR_M * OR_M) {
                 const int i = tid % OR_M, j = tid / OR_M;
@@ -1167,8 +1219,10 @@ __global__ __launch_bounds__(OR_T) void k_b_ortho_reg(const OrthoItem* __restric
                 s_O[i + OR_M * j] = vv;
             }
             __syncthreads();
+            lap(4);
             if (tid < 64) o_chol_inv(s_O, m, s_R, s_inv, s_stat);
             __syncthreads();
+            lap(5);
             if (s_stat[3] != 0.0) {
                 status = 2.0;
                 return false;
@@ -1201,6 +1255,7 @@ __global__ __launch_bounds__(OR_T) void k_b_ortho_reg(const OrthoItem* __restric
             growth *= nI;
             const double condR = nR * nI;
             __syncthreads();
+            lap(6);
             if (nchol == 1 && EPSD * condR * condR < it.tol) break;
         }
         growth_last = growth;
@@ -1208,9 +1263,9 @@ __global__ __launch_bounds__(OR_T) void k_b_ortho_reg(const OrthoItem* __restric
         return true;
     };
 
-    if (ny == 0) {
-        ortho_x();
-    } else {
+    // (ONE call site of ortho_x below: inlined, so that the rows x[][] stay in registers -- with two call sites the lambda
+    //  was outlined and x lived in scratch memory, 390 scratch instructions on the critical path)
+    if (ny > 0) {
         // column norms: from the producer or computed here; X ./= norms on the registers
         if (it.norms) {
             if (tid < OR_M) s_nrm[tid] = tid < m ? it.norms[tid] : 1.0;
@@ -1222,7 +1277,8 @@ __global__ __launch_bounds__(OR_T) void k_b_ortho_reg(const OrthoItem* __restric
             for (int q = 0; q < RPT; ++q)
 #pragma unroll
                 for (int j = 0; j < OR_M; ++j) v[j] += x[q][j].x * x[q][j].x + x[q][j].y * x[q][j].y;
-            o_block_sumv<NW>(v, s_t, s_w);
+            o_wave_reduce_store<NW>(v, 0, s_w);
+            o_finish<NW>(1, s_t, s_w);
             if (tid < OR_M) s_nrm[tid] = tid < m ? sqrt(s_t[tid]) : 1.0;
         }
         __syncthreads();
@@ -1236,53 +1292,80 @@ __global__ __launch_bounds__(OR_T) void k_b_ortho_reg(const OrthoItem* __restric
             }
         }
         __syncthreads();
-        for (int niter = 1;; ++niter) {
+    }
+    for (int niter = 1;; ++niter) {
+        if (ny > 0) {
             rounds = niter;
-            // BYX = Y' X, two rows of Y' per reduction
+            // BYX = Y' X, two rows of Y' per tile, all tiles between two barriers; a reduced tile is rows (2 s, 2 s + 1) of s_byx.
+            // The loads of FOUR rows of Y' (all RPT rows of the thread) are issued together, then two tiles are reduced from
+            // them: a load batch exposes one trip to L2 / the Infinity Cache (~3 000 cycles measured with clock64), and the
+            // two-row form exposed one per tile.
 #pragma nounroll
-            for (int a0 = 0; a0 < ny; a0 += 2) {
-                double v[OR_V];
-#pragma unroll
-                for (int t = 0; t < OR_V; ++t) v[t] = 0.0;
+            for (int a0 = 0; a0 < ny; a0 += 4) {
+                cd yv[RPT][4];
 #pragma unroll
                 for (int q = 0; q < RPT; ++q) {
                     const int64_t r = tid + (int64_t)q * OR_T;
 #pragma unroll
-                    for (int al = 0; al < 2; ++al) {
-                        cd y = make_double2(0.0, 0.0);
-                        if (live[q] && a0 + al < ny) y = it.Y[r + (int64_t)(a0 + al) * it.ldy];
-#pragma unroll
-                        for (int j = 0; j < OR_M; ++j) {
-                            v[(al * OR_M + j) * 2] += y.x * x[q][j].x + y.y * x[q][j].y;
-                            v[(al * OR_M + j) * 2 + 1] += y.x * x[q][j].y - y.y * x[q][j].x;
-                        }
+                    for (int al = 0; al < 4; ++al) {
+                        yv[q][al] = make_double2(0.0, 0.0);
+                        if (live[q] && a0 + al < ny) yv[q][al] = it.Y[r + (int64_t)(a0 + al) * it.ldy];
                     }
                 }
-                o_block_sumv<NW>(v, s_t, s_w);
-                if (tid < 2 * OR_M) {
-                    const int al = tid / OR_M, j = tid % OR_M;
-                    if (a0 + al < ny) s_byx[(a0 + al) * OR_M + j] = make_double2(s_t[2 * tid], s_t[2 * tid + 1]);
-                }
-                __syncthreads();
-            }
-            // X -= Y BYX, column norms of the result, ||BYX||_F^2
-            {
 #pragma unroll
-                for (int q = 0; q < RPT; ++q) {
-                    const int64_t r = tid + (int64_t)q * OR_T;
-                    if (live[q])
-#pragma unroll 2
-                        for (int a = 0; a < ny; ++a) {
-                            const cd y = it.Y[r + (int64_t)a * it.ldy];
+                for (int h = 0; h < 2; ++h) {
+                    if (a0 + 2 * h < ny) {
+                        double v[OR_V];
+#pragma unroll
+                        for (int t = 0; t < OR_V; ++t) v[t] = 0.0;
+#pragma unroll
+                        for (int q = 0; q < RPT; ++q)
+#pragma unroll
+                            for (int al = 0; al < 2; ++al) {
+                                const cd y = yv[q][2 * h + al];
+#pragma unroll
+                                for (int j = 0; j < OR_M; ++j) {
+                                    v[(al * OR_M + j) * 2] += y.x * x[q][j].x + y.y * x[q][j].y;
+                                    v[(al * OR_M + j) * 2 + 1] += y.x * x[q][j].y - y.y * x[q][j].x;
+                                }
+                            }
+                        o_wave_reduce_store<NW>(v, a0 / 2 + h, s_w);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            o_finish<NW>((ny + 1) / 2, reinterpret_cast<double*>(s_byx), s_w);
+            lap(2);
+            // X -= Y BYX (four columns of Y per load batch, all rows of the thread), column norms of the result, ||BYX||_F^2
+            {
+#pragma nounroll
+                for (int a0 = 0; a0 < ny; a0 += 4) {
+                    cd yv[RPT][4];
+#pragma unroll
+                    for (int q = 0; q < RPT; ++q) {
+                        const int64_t r = tid + (int64_t)q * OR_T;
+#pragma unroll
+                        for (int al = 0; al < 4; ++al) {
+                            yv[q][al] = make_double2(0.0, 0.0);
+                            if (live[q] && a0 + al < ny) yv[q][al] = it.Y[r + (int64_t)(a0 + al) * it.ldy];
+                        }
+                    }
+#pragma unroll
+                    for (int al = 0; al < 4; ++al) {
+                        if (a0 + al < ny) {
 #pragma unroll
                             for (int j = 0; j < OR_M; ++j) {
-                                const cd bq = s_byx[a * OR_M + j];
+                                const cd bq = s_byx[(a0 + al) * OR_M + j];
                                 if (j < m) {
-                                    x[q][j].x -= y.x * bq.x - y.y * bq.y;
-                                    x[q][j].y -= y.x * bq.y + y.y * bq.x;
+#pragma unroll
+                                    for (int q = 0; q < RPT; ++q) {
+                                        x[q][j].x -= yv[q][al].x * bq.x - yv[q][al].y * bq.y;
+                                        x[q][j].y -= yv[q][al].x * bq.y + yv[q][al].y * bq.x;
+                                    }
                                 }
                             }
                         }
+                    }
                 }
                 double v[OR_V];
 #pragma unroll
@@ -1291,7 +1374,8 @@ __global__ __launch_bounds__(OR_T) void k_b_ortho_reg(const OrthoItem* __restric
                 for (int q = 0; q < RPT; ++q)
 #pragma unroll
                     for (int j = 0; j < OR_M; ++j) v[j] += x[q][j].x * x[q][j].x + x[q][j].y * x[q][j].y;
-                o_block_sumv<NW>(v, s_t, s_w);
+                o_wave_reduce_store<NW>(v, 0, s_w);
+                o_finish<NW>(1, s_t, s_w);
             }
             double byx2 = 0.0;
 #pragma nounroll
@@ -1311,6 +1395,7 @@ __global__ __launch_bounds__(OR_T) void k_b_ortho_reg(const OrthoItem* __restric
                     if (nj <= it.tol) drop = true;
                 }
             __syncthreads();
+            lap(3);
             if (nonfinite) {
                 status = 2.0;
                 break;
@@ -1320,12 +1405,13 @@ __global__ __launch_bounds__(OR_T) void k_b_ortho_reg(const OrthoItem* __restric
                 break;
             }
             if (sqrt(byx2) < it.tol && niter > 1) break;
-            if (!ortho_x()) break;
-            if (growth_last * EPSD < it.tol) break;
-            if (niter > 10) {
-                status = 1.0;
-                break;
-            }
+        }
+        if (!ortho_x()) break;
+        if (ny == 0) break;
+        if (growth_last * EPSD < it.tol) break;
+        if (niter > 10) {
+            status = 1.0;
+            break;
         }
     }
     // the block goes back to memory once (not at all when a rare branch takes over: the driver starts again anyway)
@@ -1339,11 +1425,14 @@ __global__ __launch_bounds__(OR_T) void k_b_ortho_reg(const OrthoItem* __restric
                     if (j < m) it.X[r + (int64_t)j * it.ldx] = x[q][j];
         }
     }
+    lap(7);
     if (tid == 0) {
         it.res[0] = status;
         it.res[1] = (double)rounds;
         it.res[2] = (double)nchol_last;
         it.res[3] = growth_last;
+        clk[0] = clock64() - tc0;
+        for (int q = 0; q < 8; ++q) it.res[4 + q] = (double)clk[q];
     }
 }
 
@@ -1583,13 +1672,14 @@ int batch_exec_group(BatchCtx* ctx, hipStream_t stream, int type, std::vector<BO
                 return DFTK_MI_EINVAL;
             }
             void* htwin = nullptr;
-            double* dres = reinterpret_cast<double*>(batch_result_slot(ctx, 4 * sizeof(double), &htwin));
+            double* dres = reinterpret_cast<double*>(batch_result_slot(ctx, 16 * sizeof(double), &htwin));   // 4 results + phase clocks
             if (!dres) return DFTK_MI_EHIP;
             items[i] = OrthoItem{o->n, o->ldc, o->lda, o->m, o->k, reinterpret_cast<cd*>(o->C), reinterpret_cast<const cd*>(o->A),
                                  reinterpret_cast<const double*>(o->W), o->s0, dres};
             const double* h = reinterpret_cast<const double*>(htwin);
             batch_add_fixup(ctx, [o, h]() {
                 if (o->host) memcpy(o->host, h, 4 * sizeof(double));
+                if (o->host2) memcpy(o->host2, h + 4, 8 * sizeof(double));      // DFTK_MI_ORTHO_CLOCKS (dftk_mi_ortho_small)
                 o->status = 0;
             });
         }
@@ -1667,7 +1757,9 @@ int batch_exec_group(BatchCtx* ctx, hipStream_t stream, int type, std::vector<BO
         const size_t lds = 2 * (size_t)pitch * pitch * sizeof(cd);
         // small matrices (the k-point configs: M = 6 .. 8, 3M <= 24) get ONE wave per matrix: the dozens of barriers per
         // Jacobi sweep / Cholesky column are then free, and these kernels are pure dependent-latency chains
-        const int threads = nmax <= 32 ? 64 : 256;
+        // POTRF: ONE wave per matrix up to order 32 (dozens of dependent barriers per column are then free).  HEEV: the fused
+        // two-sided update is (n / 2)^2 + n^2 / 2 independent items per round -- one pass of 256 threads up to order 18
+        const int threads = type == BOP_POTRF ? (nmax <= 32 ? 64 : 256) : (nmax <= 10 ? 64 : 256);
         if (type == BOP_POTRF) {
             CHK(set_big_lds(reinterpret_cast<const void*>(k_b_potrf), lds));
             hipLaunchKernelGGL(k_b_potrf, dim3(n_items), dim3(threads), lds, stream, d, pitch);

@@ -1314,13 +1314,32 @@ extern "C" int dftk_mi_ortho_small(dftk_mi_basis* b, int64_t n, int m, dftk_mi_c
     if (!b || !X || n < 1 || m < 1 || m > 8 || ny < 0 || ny > 16 || (ny > 0 && !Y) || ldx < n || (ny > 0 && ldy < n) || !res4_h)
         return DFTK_MI_EINVAL;
     HIPCHK(hipSetDevice(b->device));
+    double clocks[8] = {0};
     std::vector<std::function<int()>> bodies;
     bodies.push_back([&]() -> int {
-        CHK(rec_ortho(b, Mat{reinterpret_cast<cd*>(X), ldx, n, m}, reinterpret_cast<const cd*>(Y), ldy, ny, norms_d, tol, res4_h));
+        BOp o;
+        o.b = b;
+        o.type = BOP_ORTHO;
+        o.n = n;
+        o.m = m;
+        o.k = ny;
+        o.C = X;
+        o.ldc = ldx;
+        o.A = Y;
+        o.lda = ldy;
+        o.W = norms_d;
+        o.s0 = tol;
+        o.host = res4_h;
+        o.host2 = clocks;
+        CHK(batch_record(std::move(o)));
         return dev_stream_sync(b);
     });
     std::vector<int> rets;
     const int st = batch_run(b, bodies, rets);
+    if (getenv("DFTK_MI_ORTHO_CLOCKS"))       // shader clocks of the register-resident kernel's phases (diagnostic)
+        fprintf(stderr, "[ortho clocks] n=%lld m=%d ny=%d rounds=%g: total %.0f = load %.0f + BYX %.0f + update/norms %.0f + Gram %.0f + "
+                "Cholesky %.0f + X inv(R) %.0f + store %.0f\n", (long long)n, m, ny, res4_h[1], clocks[0], clocks[1], clocks[2], clocks[3],
+                clocks[4], clocks[5], clocks[6], clocks[7]);
     return st != 0 ? st : rets[0];
 }
 

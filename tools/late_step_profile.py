@@ -1,5 +1,8 @@
 """Where a LATE SCF step of the benchmark cell spends its time: family timers of the library over steps 4..8 only
-(the first two steps diagonalise 59 + 15 LOBPCG iterations and dominate the whole-SCF profile)."""
+(the first two steps diagonalise 59 + 15 LOBPCG iterations and dominate the whole-SCF profile).
+python tools/late_step_profile.py [supercell = 5] [steps skipped = 8] [steps kept = 6] [--any]
+With --any every step is kept whatever its LOBPCG iteration count: `late_step_profile.py 5 0 1 --any` is the profile of the
+FIRST SCF step (15 LOBPCG iterations from random orbitals, 27 % of the driver's window)."""
 import ctypes as C
 import os
 import sys
@@ -12,6 +15,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dftk_jl_amd as dftk  # noqa: E402
 from dftk_jl_amd._lib import check  # noqa: E402
 
+keep_any = "--any" in sys.argv
+sys.argv = [a for a in sys.argv if a != "--any"]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 lib = dftk.load_library()
 lat, atoms, pos = dftk.silicon_cell((n, n, n))
@@ -63,7 +68,7 @@ while kept < nst and tried < 4 * nst:
     dt = time.time() - t0
     n_it = int(round(float(np.mean(info["diagonalization"]["n_iter"]))))
     iters_seen.append(n_it)
-    if n_it != 1:
+    if n_it != 1 and not keep_any:
         prof_off_capture()      # discard this step's records
         continue
     vals = {}
@@ -94,8 +99,8 @@ for f, nm in names.items():
     print(f"{nm:14s} {fam_ms[f] / nst:8.2f} ms/step  {fam_nl[f] / nst:7.1f} launches/step")
     if f not in (9, 16):      # (apply_H contains other families; the host waits overlap device time)
         tot += fam_ms[f]
-print(f"booked {tot / nst:.1f} ms/step of wall {1e3 * wall / nst:.1f} ms/step over {kept} one-iteration steps "
+print(f"booked {tot / nst:.1f} ms/step of wall {1e3 * wall / nst:.1f} ms/step over {kept} {'steps' if keep_any else 'one-iteration steps'} "
       f"(LOBPCG iterations of the steps tried: {iters_seen}); host timers/step:",
       {k: round(1e3 * v / nst, 1) for k, v in timers.items()})
-for key, (calls, ms, gf) in sorted(shape_tab.items(), key=lambda kv: -kv[1][1])[:14]:
+for key, (calls, ms, gf) in sorted(shape_tab.items(), key=lambda kv: -kv[1][1])[:40 if keep_any else 14]:
     print(f"[zgemm-shape] {key[0]} m={key[1]} n={key[2]} k={key[3]} flags={key[4]} calls={calls} ms={ms:.3f} TF/s={gf / ms:.2f}")

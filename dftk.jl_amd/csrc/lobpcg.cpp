@@ -416,7 +416,25 @@ int ortho_XY(Ctx& c, Mat X, const std::vector<Mat>& Ys, cd* tmp, double tol, con
 // column to re-randomise, a failing Cholesky factorisation, more than 10 rounds) returns 0 with X untouched and the caller
 // takes the device path with its fallbacks.  X: n x m, Y: n x ny (column-major, leading dimension n), orthonormal columns.
 typedef std::complex<double> zd;
-int host_ortho_small(std::vector<zd>& Xio, int n, int m, const zd* Y, int ny, double tol) {
+static int host_ortho_small_impl(std::vector<zd>& Xio, int n, int m, const zd* Y, int ny, double tol, int* why, std::mt19937_64* gen,
+                                 bool real);
+// gen (optional): drop_small! (lobpcg_hyper_impl.jl:262-271, :291-294) is then taken on the host as well -- a column whose
+// norm is <= tol after the projection is redrawn from `gen` (2 n normal deviates, as randomize_column draws them; imaginary
+// parts zeroed for the real matrices of the Gamma-real iteration) and projected against Y.  Not a rare branch: the reference's
+// cP = (cX - e)[:, Xn_indices] subtracts the identity from its first lenXn - newly_locked columns only, so with every newly
+// locked vector the last columns of cP are plain columns of cX and vanish in the projection against cX (measured on the Al
+// workload: one LOBPCG call in eight; without this the whole lock-step batch follows that k-point through the ~70 tiny
+// launches and 5-6 scheduling rounds of the device path).
+int host_ortho_small(std::vector<zd>& Xio, int n, int m, const zd* Y, int ny, double tol, std::mt19937_64* gen = nullptr,
+                     bool real = false) {
+    int why = 0;
+    const int ok = host_ortho_small_impl(Xio, n, m, Y, ny, tol, &why, gen, real);
+    static const bool trace = getenv("DFTK_MI_KBATCH_TRACE") != nullptr;
+    if (!ok && trace) fprintf(stderr, "[host cP ortho] %d x %d against %d columns: device path (reason %d)\n", n, m, ny, why);
+    return ok;
+}
+static int host_ortho_small_impl(std::vector<zd>& Xio, int n, int m, const zd* Y, int ny, double tol, int* why, std::mt19937_64* gen,
+                                 bool real) {
     std::vector<zd> X = Xio, T((size_t)n * m), BYX((size_t)ny * m), O((size_t)m * m), R((size_t)m * m), Ri((size_t)m * m);
     auto colnorm = [&](int j) {
         double s = 0.0;
@@ -454,13 +472,36 @@ int host_ortho_small(std::vector<zd>& Xio, int n, int m, const zd* Y, int ny, do
             }
         for (int j = 0; j < m; ++j) {
             const double nj = colnorm(j);
-            if (!std::isfinite(nj) || nj <= tol) return 0;   // drop_small! / non-finite: device path
+            if (!std::isfinite(nj) || (nj <= tol && !gen)) {   // non-finite (or drop_small! without a generator): device path
+                *why = 1;
+                return 0;
+            }
+            if (nj <= tol) {
+                // drop_small!: X[:, j] = randn; X[:, j] -= Y (Y' X[:, j])
+                std::normal_distribution<double> nd(0.0, 1.0);
+                for (int i = 0; i < n; ++i) {
+                    const double re = nd(*gen), im = nd(*gen);
+                    X[i + (size_t)j * n] = zd(re, real ? 0.0 : im);
+                }
+                for (int a = 0; a < ny; ++a) {
+                    zd s = 0.0;
+                    for (int i = 0; i < n; ++i) s += std::conj(Y[i + (size_t)a * n]) * X[i + (size_t)j * n];
+                    BYX[a + (size_t)j * ny] = s;     // (scratch: ||BYX|| of this round was taken above, as the device path does)
+                }
+                for (int a = 0; a < ny; ++a) {
+                    const zd s = BYX[a + (size_t)j * ny];
+                    for (int i = 0; i < n; ++i) X[i + (size_t)j * n] -= Y[i + (size_t)a * n] * s;
+                }
+            }
         }
         if (std::sqrt(byx2) < tol && niter > 1) break;
         // ortho!(X): Cholesky-QR passes until eps cond(R)^2 < tol
         double growth = 1.0;
         for (int pass = 0;; ++pass) {
-            if (pass >= 30) return 0;
+            if (pass >= 30) {
+                *why = 2;
+                return 0;
+            }
             for (int j = 0; j < m; ++j)
                 for (int i = 0; i <= j; ++i) {
                     zd s = 0.0;
@@ -477,7 +518,10 @@ int host_ortho_small(std::vector<zd>& Xio, int n, int m, const zd* Y, int ny, do
                 }
                 double d = O[j + (size_t)j * m].real();
                 for (int k = 0; k < j; ++k) d -= std::norm(R[k + (size_t)j * m]);
-                if (!(d > 0.0) || !std::isfinite(d)) return 0;   // safe_cholesky's shift-and-retry: device path
+                if (!(d > 0.0) || !std::isfinite(d)) {            // safe_cholesky's shift-and-retry: device path
+                    *why = 3;
+                    return 0;
+                }
                 R[j + (size_t)j * m] = std::sqrt(d);
             }
             // inverse of the upper triangular R (back substitution, column by column)
@@ -491,7 +535,10 @@ int host_ortho_small(std::vector<zd>& Xio, int n, int m, const zd* Y, int ny, do
                 }
             }
             const double nR = normest(R), nI = normest(Ri);
-            if (!std::isfinite(nR) || !std::isfinite(nI)) return 0;
+            if (!std::isfinite(nR) || !std::isfinite(nI)) {
+                *why = 4;
+                return 0;
+            }
             for (int j = 0; j < m; ++j)
                 for (int i = 0; i < n; ++i) {
                     zd s = 0.0;
@@ -504,7 +551,10 @@ int host_ortho_small(std::vector<zd>& Xio, int n, int m, const zd* Y, int ny, do
             if (EPS * condR * condR < tol) break;
         }
         if (growth * EPS < tol) break;
-        if (niter > 10) return 0;
+        if (niter > 10) {
+            *why = 5;
+            return 0;
+        }
     }
     Xio.swap(X);
     return 1;
@@ -829,7 +879,7 @@ static int lobpcg_run_general(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, do
                 std::vector<zd> h_cP(h_cX.begin() + (size_t)newly_locked * nY, h_cX.begin() + (size_t)(newly_locked + lenXn) * nY);
                 for (int a = 0; a < lenXn - newly_locked; ++a)
                     if (2 * newly_locked + a < nY) h_cP[(size_t)(2 * newly_locked + a) + (size_t)a * nY] -= 1.0;
-                if (host_ortho_small(h_cP, nY, lenXn, h_cX.data(), ncx, ortho_tol)) {
+                if (host_ortho_small(h_cP, nY, lenXn, h_cX.data(), ncx, ortho_tol, &c.rng_rep, c.real_mode)) {
                     CHK(h2d(b, cP, h_cP.data(), h_cP.size() * sizeof(cd)));
                     cp_done = true;
                 }
@@ -1212,7 +1262,7 @@ static int lobpcg_run_small(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, doub
                 std::vector<zd> h_cP(h_cX.begin() + (size_t)newly_locked * nY, h_cX.begin() + (size_t)(newly_locked + lenXn) * nY);
                 for (int a = 0; a < lenXn - newly_locked; ++a)
                     if (2 * newly_locked + a < nY) h_cP[(size_t)(2 * newly_locked + a) + (size_t)a * nY] -= 1.0;
-                if (host_ortho_small(h_cP, nY, lenXn, h_cX.data(), ncx, ortho_tol)) {
+                if (host_ortho_small(h_cP, nY, lenXn, h_cX.data(), ncx, ortho_tol, &c.rng_rep, c.real_mode)) {
                     CHK(h2d(b, cP, h_cP.data(), h_cP.size() * sizeof(cd)));
                     cp_done = true;
                 }

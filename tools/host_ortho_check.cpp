@@ -107,6 +107,30 @@ int main() {
         printf("column in span(Y): done=%d, X %s%s\n", done, X == X0 ? "untouched" : "MODIFIED", ok ? "" : "   <-- FAILED");
         failures += ok ? 0 : 1;
     }
+    // the same with a generator: drop_small! on the host -- the column is redrawn, projected, and the block comes back
+    // orthonormal and orthogonal to Y (the case of every LOBPCG iteration that locks a vector: the last columns of the
+    // reference's cP are plain columns of cX); real blocks stay real
+    for (int real = 0; real < 2; ++real) {
+        const int n = 18, ny = 6, m = 4;
+        std::vector<Z> Q((size_t)n * n);
+        for (auto& q : Q) q = real ? Z(nd(gen), 0.0) : Z(nd(gen), nd(gen));
+        orthonormalise(Q, n, n);
+        std::vector<Z> Y(Q.begin(), Q.begin() + (size_t)n * ny), X((size_t)n * m);
+        for (int j = 0; j < m; ++j)
+            for (int i = 0; i < n; ++i) X[i + (size_t)j * n] = Y[i + (size_t)(j + 2) * n];
+        X[4 + 0 * (size_t)n] -= 1.0;      // cP = (cX - e)[:, Xn_indices] with newly_locked = 2: identity under the first two
+        X[5 + 1 * (size_t)n] -= 1.0;      // columns only, the last two are columns of cX
+        std::mt19937_64 g2(99);
+        const int done = host_ortho_small(X, n, m, Y.data(), ny, tol, &g2, real != 0);
+        const double e_orth = max_abs_gram_minus(X, n, m, X, m, true), e_y = max_abs_gram_minus(Y, n, ny, X, m, false);
+        double im = 0.0;
+        if (real)
+            for (auto& x : X) im = std::max(im, std::abs(x.imag()));
+        const bool ok = done == 1 && e_orth < 1e-14 && e_y < 1e-14 && im == 0.0;
+        printf("columns of cX in cP (%s), host drop_small!: done=%d |X'X-I|=%.1e |Y'X|=%.1e%s\n", real ? "real" : "complex", done, e_orth,
+               e_y, ok ? "" : "   <-- FAILED");
+        failures += ok ? 0 : 1;
+    }
     // linearly dependent columns: the Cholesky factorisation breaks down (or the estimate never settles) -> decline
     {
         const int n = 10, ny = 2, m = 3;

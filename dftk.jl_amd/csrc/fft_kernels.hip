@@ -772,7 +772,7 @@ template <int R1A, int R1B, int R2A, int R2B>
 __global__ __launch_bounds__(FFT_L * ((R1A * R1B > R2A * R2B) ? R1A * R1B : R2A * R2B), ZREG_MIN_BLOCKS)
 void k_zdensity_reg(FftAxis az, int nx, int nxp, int ny, int nzx, int z_lo, int nb, const double* __restrict__ w,
                     const double* __restrict__ wim, const cd* __restrict__ T2, int64_t T2_stride,
-                    double* __restrict__ rho, const FftJob* __restrict__ jobs) {
+                    double* __restrict__ rho, const FftJob* __restrict__ jobs, double* __restrict__ part) {
     typedef FourStep<R1A, R1B, R2A, R2B> FS;
     cd* buf = reinterpret_cast<cd*>(dftk_smem);
     const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
@@ -782,7 +782,9 @@ void k_zdensity_reg(FftAxis az, int nx, int nxp, int ny, int nzx, int z_lo, int 
     double acc[FS::R2];
 #pragma unroll
     for (int p = 0; p < FS::R2; ++p) acc[p] = 0.0;
-    for (int ib = 0; ib < nb; ++ib) {
+    // part != null: gridDim.z band groups (bands blockIdx.z, + gridDim.z, ...), each WRITES its partial cube part[group]
+    // (k_dens_reduce adds them to rho in group order) -- small cubes have too few (x tile, y) columns to fill the chip
+    for (int ib = blockIdx.z; ib < nb; ib += gridDim.z) {
         double wb, wi;
         if (jobs) {
             const FftJob jb = jobs[ib];
@@ -817,13 +819,13 @@ void k_zdensity_reg(FftAxis az, int nx, int nxp, int ny, int nzx, int z_lo, int 
         __syncthreads();   // the tile image is rewritten by the next band
     }
     if (j < FS::R1 && x < nx) {
-        double* __restrict__ r0 = rho + (int64_t)y * nx + (x - l);   // tile origin of this y row: uniform
+        double* __restrict__ r0 = (part ? part + (int64_t)blockIdx.z * az.n * ny * nx : rho) + (int64_t)y * nx + (x - l);   // tile origin of this y row: uniform
         const unsigned zB = (unsigned)ny * (unsigned)nx * 8u;         // bytes between z planes of rho (the cube is < 2^32 bytes:
         const unsigned ob = (unsigned)j * zB + (unsigned)l * 8u;     //  192^3 doubles = 57 MB; checked by the launcher)
         static_for<0, FS::R2>([&](auto pi) {
             constexpr int p = decltype(pi)::value;
             const unsigned off = ob + (unsigned)(FS::R1 * FS::k2_of(p)) * zB;
-            st_off(r0, off, ld_off((const double*)r0, off) + acc[p]);
+            st_off(r0, off, part ? acc[p] : ld_off((const double*)r0, off) + acc[p]);
         });
     }
 }
@@ -925,7 +927,8 @@ __global__ __launch_bounds__(FFT_THREADS, DENS_MIN_BLOCKS) void k_zdensity(FftAx
                                                           const double* __restrict__ w,
                                                           const double* __restrict__ wim,
                                                           const cd* __restrict__ T2, int64_t T2_stride,
-                                                          double* __restrict__ rho, const FftJob* __restrict__ jobs) {
+                                                          double* __restrict__ rho, const FftJob* __restrict__ jobs,
+                                                          double* __restrict__ part) {
     constexpr int FFT_LS = FFT_LS_YZ;
     cd* buf = reinterpret_cast<cd*>(dftk_smem);
     cd* tw = buf + az.n * FFT_LS;
@@ -938,7 +941,8 @@ __global__ __launch_bounds__(FFT_THREADS, DENS_MIN_BLOCKS) void k_zdensity(FftAx
 #pragma unroll
     for (int k = 0; k < DENS_MAXACC; ++k) acc[k] = 0.0;
     for (int t = tid; t < nz; t += FFT_THREADS) tw[t] = az.tw[t];
-    for (int ib = 0; ib < nb; ++ib) {
+    // (band groups over gridDim.z with partial cubes: see k_zdensity_reg)
+    for (int ib = blockIdx.z; ib < nb; ib += gridDim.z) {
         double wb, wi;
         if (jobs) {               // multi-k launch: the band's k-block decides the z planes, its entry the weights
             const FftJob jb = jobs[ib];
@@ -969,12 +973,25 @@ __global__ __launch_bounds__(FFT_THREADS, DENS_MIN_BLOCKS) void k_zdensity(FftAx
         __syncthreads();
     }
     if (x < nx) {
+        double* __restrict__ dst = part ? part + (int64_t)blockIdx.z * nz * ny * nx : rho;
 #pragma unroll
         for (int k = 0; k < DENS_MAXACC; ++k) {
             const int z = j + k * FFT_TPL;
-            if (z < nz) rho[((int64_t)z * ny + y) * nx + x] += acc[k];
+            if (z < nz) {
+                const int64_t at = ((int64_t)z * ny + y) * nx + x;
+                dst[at] = part ? acc[k] : dst[at] + acc[k];
+            }
         }
     }
+}
+
+// rho += part[0] + part[1] + ... (group order: deterministic)
+__global__ void k_dens_reduce(int64_t n, int ngroups, const double* __restrict__ part, double* __restrict__ rho) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int g = 0; g < ngroups; ++g) s += part[(int64_t)g * n + i];
+    rho[i] += s;
 }
 
 __global__ void k_pad_potential(int nx, int nxp, int64_t rows, double scale, const double* __restrict__ V,
@@ -1099,6 +1116,7 @@ struct RegZ {   // arguments of the z kernels
     const double *w, *wim;
     double* rho;
     const FftJob* jobs;
+    double* part = nullptr;   // density: partial cubes of grid.z band groups (k_dens_reduce), or null
 };
 template <int A, int B, int C, int D>
 static int reg_zpass_t(const RegZ& r) {
@@ -1115,7 +1133,7 @@ static int reg_zdens_t(const RegZ& r) {
     const size_t lds = (size_t)FS::LDS_ELEMS * sizeof(cd);
     CHK(set_lds_attr(k_zdensity_reg<A, B, C, D>, lds));
     hipLaunchKernelGGL((k_zdensity_reg<A, B, C, D>), r.grid, dim3(FS::THREADS), lds, r.stream, r.b->ax[2], r.b->nx, r.b->nxp,
-                       r.b->ny, r.nzx, r.z_lo, r.nbands, r.w, r.wim, (const cd*)r.T2, r.s2, r.rho, r.jobs);
+                       r.b->ny, r.nzx, r.z_lo, r.nbands, r.w, r.wim, (const cd*)r.T2, r.s2, r.rho, r.jobs, r.part);
     return 0;
 }
 static int reg_zpass(const RegZ& r, bool tables_ok) {
@@ -1303,7 +1321,7 @@ int launch_density(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, con
         if (rs < 0) return rs;
         if (rs == 1)
         LAUNCH_FFT(k_zdensity, b->ax[2], dim3(b->nxp / FFT_L, b->ny), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, kb->d_zpos, nbb, w_d + b0,
-                           wim_d ? wim_d + b0 : (const double*)nullptr, b->T2, st.s2, rho, (const FftJob*)nullptr);
+                           wim_d ? wim_d + b0 : (const double*)nullptr, b->T2, st.s2, rho, (const FftJob*)nullptr, (double*)nullptr);
         prof_end(b, pz);
     }
     HIPCHK(hipGetLastError());
@@ -1494,15 +1512,28 @@ int batch_exec_density(BatchCtx* ctx, hipStream_t stream, std::vector<BOp*>& ops
                            b->nxp, 0, (const int*)nullptr, (const int*)nullptr, (const cd*)nullptr, (int64_t)0, T1, s1, dj);
         hipLaunchKernelGGL((k_ybwd<false>), dim3(nxt, mp.max_nzx, nb), dim3(FFT_THREADS), lds_bytes(b->ny), stream, b->ax[1],
                            b->nxp, b->ny, (const int*)nullptr, (const int*)nullptr, (const cd*)T1, s1, T2, s2, dj);
-        const RegZ rz{b, stream, dim3(nxt, b->ny), 0, 0, nb, nullptr, T2, s2, nullptr, nullptr, rho, dj};
+        // small cubes: (x tile, y) columns alone are 100-200 workgroups walking ALL bands one after the other (36^3, 54 bands:
+        // 178 us); the bands are dealt to up to 32 groups with a partial cube each, summed in group order by k_dens_reduce
+        const int64_t cube = (int64_t)b->nx * b->ny * b->nz;
+        int groups = 1;
+        if ((int64_t)nxt * b->ny < 1024 && nb >= 16) groups = std::min(32, std::max(1, nb / 8));
+        double* part = nullptr;
+        if (groups > 1) {
+            part = reinterpret_cast<double*>(batch_scratch(ctx, (size_t)groups * cube * sizeof(double)));
+            if (!part) return DFTK_MI_EHIP;
+        }
+        RegZ rz{b, stream, dim3(nxt, b->ny, groups), 0, 0, nb, nullptr, T2, s2, nullptr, nullptr, rho, dj};
+        rz.part = part;
         const int rs = reg_zdens(rz, mp.reg_z);
         if (rs < 0) return rs;
         if (rs == 1) {
             CHK(set_lds_attr(k_zdensity<false>, lds_bytes(b->nz)));
-            hipLaunchKernelGGL((k_zdensity<false>), dim3(nxt, b->ny), dim3(FFT_THREADS), lds_bytes(b->nz), stream, b->ax[2], b->nx,
+            hipLaunchKernelGGL((k_zdensity<false>), dim3(nxt, b->ny, groups), dim3(FFT_THREADS), lds_bytes(b->nz), stream, b->ax[2], b->nx,
                                b->nxp, b->ny, 0, (const int*)nullptr, nb, (const double*)nullptr, (const double*)nullptr,
-                               (const cd*)T2, s2, rho, dj);
+                               (const cd*)T2, s2, rho, dj, part);
         }
+        if (part)
+            hipLaunchKernelGGL(k_dens_reduce, dim3((unsigned)((cube + 255) / 256)), dim3(256), 0, stream, cube, groups, (const double*)part, rho);
     }
     HIPCHK(hipGetLastError());
     return 0;

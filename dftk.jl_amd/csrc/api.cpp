@@ -1246,6 +1246,47 @@ extern "C" int dftk_mi_density_accumulate_multi(int n_kblocks, dftk_mi_kblock* c
     return 0;
 }
 
+extern "C" int dftk_mi_fermi_bisection(int n_k, const int* n_bands, const double* eig, const double* kweights, int smearing,
+                                       double temperature, double filled, double n_electrons, double lo, double hi,
+                                       double* eF_out) {
+    if (n_k < 1 || !n_bands || !eig || !kweights || !eF_out || !(temperature > 0.0) || (smearing != 1 && smearing != 2) ||
+        !(lo <= hi))
+        return DFTK_MI_EINVAL;
+    auto excess = [&](double eF) {
+        double total = 0.0;
+        const double* e = eig;
+        for (int k = 0; k < n_k; ++k) {
+            double sk = 0.0;
+            for (int i = 0; i < n_bands[k]; ++i) {
+                const double x = (e[i] - eF) / temperature;
+                double f;
+                if (smearing == 2) {
+                    f = 0.5 * std::erfc(x);
+                } else if (x > 0) {                     // overflow-safe Fermi-Dirac (Smearing.jl:66-76)
+                    const double y = std::exp(-x);
+                    f = y / (1.0 + y);
+                } else {
+                    f = 1.0 / (1.0 + std::exp(x));
+                }
+                sk += filled * f;
+            }
+            total += kweights[k] * sk;
+            e += n_bands[k];
+        }
+        return total - n_electrons;
+    };
+    for (int it = 0; it < 200; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (mid == lo || mid == hi) break;
+        if (excess(mid) < 0)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    *eF_out = 0.5 * (lo + hi);
+    return 0;
+}
+
 extern "C" const dftk_mi_cplx* dftk_mi_lobpcg_last_AX(dftk_mi_kblock* kb) {
     return kb ? reinterpret_cast<const dftk_mi_cplx*>(kb->last_AX) : nullptr;
 }

@@ -496,6 +496,7 @@ __global__ __launch_bounds__(FFT_THREADS, ZPASS_MIN_BLOCKS) void k_zpass(FftAxis
         }
         __syncthreads();
     }
+    if (MODE == 1 || MODE == 2) cube += (int64_t)band * nz * ny * nx;   // several cubes per launch: one behind the other
     if (MODE == 1) {
         if (x < nx)
             for (int z = j; z < nz; z += FFT_TPL) cube[((int64_t)z * ny + y) * nx + x] = buf[z * FFT_LS + l];
@@ -1255,26 +1256,28 @@ int launch_kinetic_only(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi
     return 0;
 }
 
-int launch_ifft_to_cube(dftk_mi_kblock* kb, const cd* c, cd* cube) {
+// nb coefficient vectors (n_G apart) <-> nb cubes (nx ny nz apart) through ONE pipeline; in place is fine (the destination
+// is written by the last stage only, the source is consumed by the first)
+int launch_ifft_to_cube(dftk_mi_kblock* kb, const cd* c, cd* cube, int nb) {
     dftk_mi_basis* b = kb->basis;
     CHK(check_lds(b));
-    CHK(fft_ensure_scratch(b, kb, 1));
+    CHK(fft_ensure_scratch(b, kb, nb));
     const Strides st = strides(kb);
-    CHK(run_AB(kb, 1, c, kb->n_G));
-    LAUNCH_ZPASS(1, b->ax[2], zpass_grid(b, 1), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, 1, kb->d_zpos, (const double*)nullptr, b->T2, st.s2,
+    CHK(run_AB(kb, nb, c, kb->n_G));
+    LAUNCH_ZPASS(1, b->ax[2], zpass_grid(b, nb), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, nb, kb->d_zpos, (const double*)nullptr, b->T2, st.s2,
                        cube, (const FftJob*)nullptr);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-int launch_fft_from_cube(dftk_mi_kblock* kb, const cd* cube, cd* c) {
+int launch_fft_from_cube(dftk_mi_kblock* kb, const cd* cube, cd* c, int nb) {
     dftk_mi_basis* b = kb->basis;
     CHK(check_lds(b));
-    CHK(fft_ensure_scratch(b, kb, 1));
+    CHK(fft_ensure_scratch(b, kb, nb));
     const Strides st = strides(kb);
-    LAUNCH_ZPASS(2, b->ax[2], zpass_grid(b, 1), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, 1, kb->d_zpos, (const double*)nullptr, b->T2, st.s2,
+    LAUNCH_ZPASS(2, b->ax[2], zpass_grid(b, nb), lds_bytes(b->nz), b->stream, b->ax[2], b->nx, b->nxp, b->ny, kb->nzx, nb, kb->d_zpos, (const double*)nullptr, b->T2, st.s2,
                        const_cast<cd*>(cube), (const FftJob*)nullptr);
-    CHK(run_DE(kb, 1, nullptr, c, kb->n_G, c, kb->n_G));
+    CHK(run_DE(kb, nb, nullptr, c, kb->n_G, c, kb->n_G));
     HIPCHK(hipGetLastError());
     return 0;
 }

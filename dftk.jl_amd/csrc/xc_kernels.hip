@@ -283,6 +283,20 @@ __global__ __launch_bounds__(256) void k_xc_sum_spin(int64_t n, const double* __
 }  // namespace dftk_xc
 using namespace dftk_xc;
 
+// out[i] = scale * Re(c[i])
+__global__ __launch_bounds__(256) void k_xc_real_part_scaled(int64_t n, const cd* __restrict__ c, double scale, double* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = scale * c[i].x;
+}
+// out[a n + i] = v[i] * g[a n + i], a = 0, 1, 2 (as complex numbers)
+__global__ __launch_bounds__(256) void k_product3_to_complex(int64_t n, const double* __restrict__ v, const double* __restrict__ g,
+                                                             cd* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double vi = v[i];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) out[a * n + i] = make_double2(vi * g[a * n + i], 0.0);
+    }
+}
+
 int xc_gga_pointwise(dftk_mi_basis* b, int64_t n, const double* rho, const double* sigma, int fun_mask,
                      double threshold, double* e, double* vrho, double* vsigma) {
     hipLaunchKernelGGL(k_gga, dim3(XC_BLOCKS), dim3(256), 0, b->stream, n, rho, sigma, fun_mask, threshold, e, vrho,
@@ -360,43 +374,50 @@ int local_potential_lda(dftk_mi_kblock* cube_kb, const double* recip_h, const do
         return DFTK_MI_EINVAL;
     }
     const int gga_mask = fun_mask & 24;
-    // complex cubes c1, c2 (+ c3 and 7 real cubes for GGA) + reduction partials in the basis' dense workspace
-    const size_t need = (gga_mask ? 3 : 2) * (size_t)N * sizeof(cd) + (gga_mask ? 7 : 0) * (size_t)N * sizeof(double) +
+    // complex cubes c1, c2 (+ three more and 7 real cubes for GGA) + reduction partials in the basis' dense workspace
+    const size_t need = (gga_mask ? 5 : 2) * (size_t)N * sizeof(cd) + (gga_mask ? 7 : 0) * (size_t)N * sizeof(double) +
                         3 * XC_BLOCKS * sizeof(double);
     CHK(cube_ws_ensure(b, need));
     cd* c1 = reinterpret_cast<cd*>(b->dense_ws);
     cd* c2 = c1 + N;
-    cd* c3 = gga_mask ? c2 + N : nullptr;
-    double* rbase = reinterpret_cast<double*>(c2 + N + (gga_mask ? N : 0));
+    cd* g3 = gga_mask ? c2 + N : nullptr;          // three cubes behind one another (one FFT pipeline for the three)
+    double* rbase = reinterpret_cast<double*>(c2 + N + (gga_mask ? 3 * N : 0));
+    double* partial = rbase + (gga_mask ? 7 * N : 0);
     double *e_g = nullptr, *v_g = nullptr;
+    const cd* vh = nullptr;
+    std::vector<double> hp(3 * XC_BLOCKS, 0.0);
+    // F[rho] (unnormalised) is computed ONCE: the gradient multipliers read it, then the Poisson kernel works on it in place.
+    // The three components of grad rho and of v_sigma grad rho go through ONE transform pipeline each (three cubes per
+    // launch) instead of three: 18 launches fewer per call -- on the 36^3 ... 30 x 30 x 120 cubes of the k-point workloads
+    // every launch of this chain is ~6 us whatever it does.
     if (gga_mask) {
         double* grad[3] = {rbase, rbase + N, rbase + 2 * N};
         double* sigma = rbase + 3 * N;
         e_g = rbase + 4 * N;
         double* vrho = rbase + 5 * N;
         double* vsig = rbase + 6 * N;
-        rbase += 7 * N;
         CHK(cube_forward_real(cube_kb, rho, nullptr, c1, c2));                         // c2 = F[rho]
-        for (int a = 0; a < 3; ++a) {
-            CHK(cube_gradient_multiply(cube_kb, recip_h, a, c2, c3, false));           // c3 = i G_a F[rho]
-            CHK(cube_backward_real(cube_kb, c3, c1, 1.0 / (double)N, grad[a]));
+        for (int a = 0; a < 3; ++a) CHK(cube_gradient_multiply(cube_kb, recip_h, a, c2, g3 + a * N, false));   // i G_a F[rho]
+        if (green) {
+            hipLaunchKernelGGL(k_poisson, dim3(XC_BLOCKS), dim3(256), 0, b->stream, N, c2, green, partial + 2 * XC_BLOCKS);
+            CHK(launch_ifft_to_cube(cube_kb, c2, c1));                                 // c1 = N * V_H(r): kept until the final sum
+            vh = c1;
         }
+        CHK(launch_ifft_to_cube(cube_kb, g3, g3, 3));                                  // in place: N grad rho (complex cubes)
+        hipLaunchKernelGGL(k_xc_real_part_scaled, dim3(XC_BLOCKS), dim3(256), 0, b->stream, 3 * N, (const cd*)g3, 1.0 / (double)N,
+                           grad[0]);                                                   // the three gradients are adjacent
         CHK(cube_sigma(b, N, grad[0], grad[1], grad[2], sigma));
         hipLaunchKernelGGL(k_gga, dim3(XC_BLOCKS), dim3(256), 0, b->stream, N, rho, sigma, gga_mask, threshold, e_g, vrho,
                            vsig);
         HIPCHK(hipGetLastError());
-        for (int a = 0; a < 3; ++a) {
-            CHK(cube_forward_real(cube_kb, vsig, grad[a], c1, c2));                    // c2 = F[v_sigma d_a rho]
-            CHK(cube_gradient_multiply(cube_kb, recip_h, a, c2, c3, a > 0));           // c3 (+)= i G_a c2
-        }
-        CHK(launch_ifft_to_cube(cube_kb, c3, c1));                                     // c1 = N div(...)
+        hipLaunchKernelGGL(k_product3_to_complex, dim3(XC_BLOCKS), dim3(256), 0, b->stream, N, (const double*)vsig,
+                           (const double*)grad[0], g3);                                // v_sigma d_a rho, a = 0, 1, 2
+        CHK(launch_fft_from_cube(cube_kb, g3, g3, 3));                                 // in place
+        for (int a = 0; a < 3; ++a) CHK(cube_gradient_multiply(cube_kb, recip_h, a, g3 + a * N, c2, a > 0));   // c2 (+)= i G_a ...
+        CHK(launch_ifft_to_cube(cube_kb, c2, g3));                                     // g3[0] = N div(...)
         v_g = sigma;                                                                   // (sigma is dead by now)
-        CHK(cube_axpy_real(b, N, vrho, -2.0 / (double)N, c1, v_g));
-    }
-    double* partial = rbase;
-    const cd* vh = nullptr;
-    std::vector<double> hp(3 * XC_BLOCKS, 0.0);
-    if (green) {
+        CHK(cube_axpy_real(b, N, vrho, -2.0 / (double)N, g3, v_g));
+    } else if (green) {
         hipLaunchKernelGGL(k_real_to_complex, dim3(XC_BLOCKS), dim3(256), 0, b->stream, N, rho, c1);
         CHK(launch_fft_from_cube(cube_kb, c1, c2));                       // c2 = F[rho] (unnormalised)
         hipLaunchKernelGGL(k_poisson, dim3(XC_BLOCKS), dim3(256), 0, b->stream, N, c2, green, partial + 2 * XC_BLOCKS);

@@ -51,6 +51,31 @@ def _occupations(model, eigenvalues, eF):
     return out
 
 
+def _fermi_bisection(basis, model, kw, eig_all, lo, hi):
+    """The bisection loop of FermiBisection as ONE library call (``dftk_mi_fermi_bisection``: host-only C, same rule --
+    halve until the midpoint equals an end point); None when the library cannot take it."""
+    import ctypes as C
+    import os
+    kind = {"fermi_dirac": 1, "gaussian": 2}.get(model.smearing)
+    if kind is None or os.environ.get("DFTK_MI_TORCH_LOCAL"):
+        return None
+    lib = getattr(basis, "lib", None)
+    if lib is None:              # (a host-only entry point: usable without a device)
+        try:
+            from . import _lib
+            lib = _lib.load()
+        except Exception:
+            return None
+    nb = np.ascontiguousarray([len(e) for e in eig_all], dtype=np.int32)
+    flat = np.ascontiguousarray(np.concatenate(eig_all), dtype=np.float64)
+    kw_c = np.ascontiguousarray(kw, dtype=np.float64)
+    out = C.c_double()
+    st = lib.dftk_mi_fermi_bisection(len(eig_all), nb.ctypes.data, flat.ctypes.data, kw_c.ctypes.data, kind,
+                                     float(model.temperature), float(model.filled_occupation), float(model.n_electrons),
+                                     float(lo), float(hi), C.byref(out))
+    return float(out.value) if st == 0 else None
+
+
 def compute_occupation(basis, eigenvalues, tol_n_elec: float = 1e-6):
     """occupation.jl:53-132,160-211.  ``eigenvalues`` are this rank's k-points.  The reference reduces every
     trial electron count over ``comm_kpts`` (weighted_ksum, PlaneWaveBasis.jl:509-512) -- up to 200 all-reduces
@@ -87,15 +112,17 @@ def compute_occupation(basis, eigenvalues, tol_n_elec: float = 1e-6):
             lo, hi = eF, max(float(np.max(e)) for e in eig_all) + 1
         else:
             lo, hi = min(float(np.min(e)) for e in eig_all) - 1, eF
-        for _ in range(200):
-            mid = 0.5 * (lo + hi)
-            if mid == lo or mid == hi:
-                break
-            if excess(mid) < 0:
-                lo = mid
-            else:
-                hi = mid
-        eF = 0.5 * (lo + hi)
+        eF = _fermi_bisection(basis, model, kw, eig_all, lo, hi)
+        if eF is None:           # (smearing the library does not know, or DFTK_MI_TORCH_LOCAL=1: the interpreted twin)
+            for _ in range(200):
+                mid = 0.5 * (lo + hi)
+                if mid == lo or mid == hi:
+                    break
+                if excess(mid) < 0:
+                    lo = mid
+                else:
+                    hi = mid
+            eF = 0.5 * (lo + hi)
     return _occupations(model, eigenvalues, eF), eF
 
 

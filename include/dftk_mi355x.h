@@ -478,6 +478,15 @@ int dftk_mi_chi0_mix(dftk_mi_kblock* cube_kblock, int n_comp, const double* reci
  * (stream synchronisations of its drivers, result fetches, scheduling rounds of the batched k-point driver).  For the
  * many-small-k workloads these two ARE the cost model; either pointer may be NULL. */
 int dftk_mi_launch_count(int64_t* launches, int64_t* host_syncs);
+
+/* compute_occupation's Fermi-level search (src/occupation.jl:99-132, FermiBisection; host-only, no device call): bisection of
+ *   excess(eF) = sum_k kweights[k] sum_n filled * smearing((eig[k][n] - eF) / temperature) - n_electrons
+ * on the bracket [lo, hi] (excess(lo) < 0 <= excess(hi)) until the midpoint equals an end point (adjacent doubles; at most
+ * 200 halvings), *eF_out = midpoint of the final bracket.  eig: the k-points' eigenvalues behind one another (n_bands[k]
+ * each).  smearing: 1 = Fermi-Dirac, 2 = Gaussian (Smearing.jl:66-76, :86-92); temperature > 0.  The host mirror runs this
+ * once per SCF step (56 trial levels of a 72-k-point mesh: 0.3 ms of interpreted code in a 4 ms step). */
+int dftk_mi_fermi_bisection(int n_k, const int* n_bands, const double* eig, const double* kweights, int smearing,
+                            double temperature, double filled, double n_electrons, double lo, double hi, double* eF_out);
 /* dftk_mi_prof_enable(basis, 3) also books every zgemm call per SHAPE; this returns (and clears) that table: row i of
  * rows6 = { transA ('N' = 0, 'C' = 1), m, n, k, flags (UPPER | B_UPPER | DFTK_MI_GEMM_REAL), calls }, ms[i] = summed time; *count = shapes seen (<= cap
  * rows are written).  bench.py replays the table at 1 / N of the rows for its sharded-step measurement. */

@@ -546,6 +546,42 @@ def test_host_mirror_fermi_level_reference_pins():
         assert abs(sum(w * o.sum() for w, o in zip(basis.kweights, occ)) - 4.0) < 1e-9
 
 
+def test_native_fermi_bisection_equals_the_interpreted_twin(monkeypatch):
+    """``dftk_mi_fermi_bisection`` (the bisection loop of FermiBisection, occupation.jl:99-132, as one host-only library
+    call) against the interpreted loop of ``compute_occupation`` (``DFTK_MI_TORCH_LOCAL=1``): Fermi level to the last few
+    ulps (the two sum the occupations in different orders), electron count to 1e-12, for both smearings and ragged band
+    counts; the reference pins of test/occupation.jl run through the native path in the test above."""
+    from test_oracle_golden import MG_EIGENVALUES, LATTICE as LAT
+    kc = [[i / 13.0, 0, 0] for i in range(12)]
+    rng = np.random.default_rng(3)
+    for smearing in ("fermi_dirac", "gaussian"):
+        for T in (1e-3, 0.01, 0.05):
+            model = dftk.Model(LAT, [], [], ("Kinetic",), n_electrons=4, temperature=T, smearing=smearing)
+            basis = dftk.PlaneWaveBasis(model, 3, dftk.ExplicitKpoints(kc, [1 / 12] * 12), fft_size=(9, 9, 9),
+                                        device="cpu", build_terms=False)
+            ev = [np.array(e) + 0.01 * rng.standard_normal(len(e)) for e in MG_EIGENVALUES]
+            ev = [np.sort(e)[: len(e) - (i % 2)] for i, e in enumerate(ev)]            # ragged band counts
+            monkeypatch.delenv("DFTK_MI_TORCH_LOCAL", raising=False)
+            occ, eF = dftk.compute_occupation(basis, ev, tol_n_elec=1e-10)
+            monkeypatch.setenv("DFTK_MI_TORCH_LOCAL", "1")
+            occ_t, eF_t = dftk.compute_occupation(basis, ev, tol_n_elec=1e-10)
+            monkeypatch.delenv("DFTK_MI_TORCH_LOCAL", raising=False)
+            assert abs(eF - eF_t) < 1e-13 * max(1.0, abs(eF_t)), (smearing, T, eF, eF_t)
+            assert abs(sum(w * o.sum() for w, o in zip(basis.kweights, occ)) - 4.0) < 1e-12
+            for a, b in zip(occ, occ_t):
+                np.testing.assert_allclose(a, b, rtol=0, atol=1e-11)
+    # argument checks: no temperature, unknown smearing, inverted bracket
+    import ctypes as C
+    lib = dftk.load_library()
+    nb = np.array([2], dtype=np.int32)
+    e = np.array([0.0, 1.0])
+    w = np.array([1.0])
+    out = C.c_double()
+    for args in ((1, 0.0, 0.0, 1.0), (7, 0.01, 0.0, 1.0), (2, 0.01, 1.0, 0.0)):
+        assert lib.dftk_mi_fermi_bisection(1, nb.ctypes.data, e.ctypes.data, w.ctypes.data, args[0], args[1], 2.0, 2.0, args[2],
+                                           args[3], C.byref(out)) != 0
+
+
 def test_split_evenly_and_nuclear_energies():
     """test/split_evenly.jl (concatenation of the parts is the range) and the ABINIT pins of test/energy_nuclear.jl
     on the host mirror's set-up code."""
@@ -1285,15 +1321,17 @@ def test_host_side_orthogonalisation_of_small_ritz_coefficient_blocks():
     coefficient blocks ``cP = cX - e`` of small k-blocks (four scheduling rounds fewer per iteration of the lock-step
     driver) -- through tools/host_ortho_check.cpp, which includes the driver's translation unit and runs without a
     GPU: X'X = I, Y'X = 0 and span((1 - Y Y') X_in) kept to round-off for complex / real blocks shaped like the
-    driver's; a column inside span(Y) (``drop_small!``) and linearly dependent columns (Cholesky breakdown) are
-    DECLINED with X untouched, i.e. handed to the device path and its fallbacks."""
+    driver's; without a generator a column inside span(Y) (``drop_small!``) and linearly dependent columns (Cholesky
+    breakdown) are DECLINED with X untouched, i.e. handed to the device path and its fallbacks; with the driver's generator
+    ``drop_small!`` runs on the host too (the reference's ``cP`` holds plain columns of ``cX`` whenever a vector was newly
+    locked: complex and real block)."""
     import subprocess
     from dftk_jl_amd import _build
     exe = _build.build_host_ortho_check()
     res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, (res.returncode, res.stdout[-3000:], res.stderr[-2000:])
     assert "host_ortho_check OK" in res.stdout and "FAILED" not in res.stdout
-    assert res.stdout.count("done=1") == 7 and res.stdout.count("done=0") == 2
+    assert res.stdout.count("done=1") == 9 and res.stdout.count("done=0") == 2
 
 
 def test_memory_statistics_and_plan_for_the_literal_4096_electron_cell():

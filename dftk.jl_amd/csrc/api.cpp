@@ -483,12 +483,32 @@ extern "C" int dftk_mi_kblock_create(dftk_mi_basis* b, int64_t n_G, const int64_
     return 0;
 }
 
+// one padded potential shared by the k-blocks of a dftk_mi_kblocks_set_potential call (they all apply the SAME V)
+struct SharedVs {
+    double* p = nullptr;
+    int refs = 0;
+};
+// the block lets go of its padded potential (the caller has made sure no kernel reading it is in flight)
+static void release_Vs(dftk_mi_kblock* kb) {
+    if (kb->Vs_share) {
+        if (--kb->Vs_share->refs == 0) {
+            if (kb->Vs_share->p) hipFree(kb->Vs_share->p);
+            delete kb->Vs_share;
+        }
+        kb->Vs_share = nullptr;
+    } else if (kb->d_Vs) {
+        hipFree(kb->d_Vs);
+    }
+    kb->d_Vs = nullptr;
+}
+
 extern "C" int dftk_mi_kblock_destroy(dftk_mi_kblock* kb) {
     if (!kb) return 0;
     hipSetDevice(kb->device);
     hipDeviceSynchronize();   // the basis may already be gone: never dereference it here
+    release_Vs(kb);
     void* ptrs[] = {kb->d_cpos, kb->d_cx, kb->d_line_start, kb->d_line_ypos, kb->d_line_yval, kb->d_zls,
-                    kb->d_zpos, kb->d_zval, kb->d_kin, kb->d_Vs, kb->d_D, kb->lob_buf};
+                    kb->d_zpos, kb->d_zval, kb->d_kin, kb->d_D, kb->lob_buf};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (kb->sh_buf) hipFree(kb->sh_buf);
@@ -800,25 +820,51 @@ extern "C" int dftk_mi_kblock_set_potential(dftk_mi_kblock* kb, const double* V_
     if (!kb) return DFTK_MI_EINVAL;
     dftk_mi_basis* b = kb->basis;
     HIPCHK(hipSetDevice(b->device));
-    if (!V_d) {
+    if (!V_d || kb->Vs_share) {   // (a block that shares its buffer gets one of its own again: the others keep theirs)
         HIPCHK(hipStreamSynchronize(b->stream));
-        if (kb->d_Vs) HIPCHK(hipFree(kb->d_Vs));
-        kb->d_Vs = nullptr;
-        return 0;
+        release_Vs(kb);
+        if (!V_d) return 0;
     }
     if (!kb->d_Vs) HIPCHK(hipMalloc((void**)&kb->d_Vs, (size_t)b->nz * b->ny * b->nxp * sizeof(double)));
     return launch_pad_potential(kb, V_d);
 }
 
 // The SAME summed local potential for many k-blocks (every k-point of a basis applies one V): one call instead of a
-// host round trip per k-block; each block keeps its own padded copy (blocks of different bases / lanes stay independent).
+// host round trip per k-block.  The unsharded blocks of ONE basis (one stream) share ONE padded copy -- one pad kernel per
+// SCF step instead of one per k-point (72 launches of ~3 us for BASELINE configs[2]); a later dftk_mi_kblock_set_potential
+// on one of them detaches it.  Blocks of different bases (lanes) keep their own copies.
 extern "C" int dftk_mi_kblocks_set_potential(int n_kblocks, dftk_mi_kblock* const* kbs, const double* V_d) {
     if (n_kblocks < 0 || (n_kblocks > 0 && !kbs) || !V_d) return DFTK_MI_EINVAL;
-    for (int i = 0; i < n_kblocks; ++i) {
+    for (int i = 0; i < n_kblocks; ++i)
         if (!kbs[i]) return DFTK_MI_EINVAL;
-        CHK(dftk_mi_kblock_set_potential(kbs[i], V_d));     // asynchronous on the block's stream once its buffer exists
+    bool one_basis = n_kblocks >= 2;
+    for (int i = 1; i < n_kblocks && one_basis; ++i) one_basis = kbs[i]->basis == kbs[0]->basis;
+    if (!one_basis) {
+        for (int i = 0; i < n_kblocks; ++i) CHK(dftk_mi_kblock_set_potential(kbs[i], V_d));
+        return 0;
     }
-    return 0;
+    dftk_mi_basis* b = kbs[0]->basis;
+    HIPCHK(hipSetDevice(b->device));
+    // already one shared buffer held by exactly these blocks (the call of the previous SCF step): refill it
+    SharedVs* sh = kbs[0]->Vs_share;
+    bool reuse = sh != nullptr && sh->refs == n_kblocks;
+    for (int i = 0; i < n_kblocks && reuse; ++i) reuse = kbs[i]->Vs_share == sh;
+    if (!reuse) {
+        HIPCHK(hipStreamSynchronize(b->stream));
+        for (int i = 0; i < n_kblocks; ++i) release_Vs(kbs[i]);
+        sh = new SharedVs();
+        if (hipMalloc((void**)&sh->p, (size_t)b->nz * b->ny * b->nxp * sizeof(double)) != hipSuccess) {
+            delete sh;
+            dftk_set_error("dftk_mi_kblocks_set_potential: out of device memory");
+            return DFTK_MI_EHIP;
+        }
+        for (int i = 0; i < n_kblocks; ++i) {
+            kbs[i]->Vs_share = sh;
+            kbs[i]->d_Vs = sh->p;
+            sh->refs += 1;
+        }
+    }
+    return launch_pad_potential(kbs[0], V_d);     // asynchronous on the basis' stream
 }
 
 // ------------------------------------------------------------------------------------ H psi

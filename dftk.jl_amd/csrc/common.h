@@ -188,7 +188,8 @@ struct dftk_mi_kblock {
     int*   d_line_yval;           // [n_lines] iy of each line (natural index)
     int*   d_cx;                  // [n_G]   ix of each coefficient (natural index)
     double* d_kin;                // [n_G]
-    double* d_Vs;                 // [nz*ny*nxp] potential / N, padded pitch (owned) or null
+    double* d_Vs;                 // [nz*ny*nxp] potential / N, padded pitch (owned, or shared: Vs_share) or null
+    struct SharedVs* Vs_share;    // non-null: d_Vs is the buffer of this reference-counted object (dftk_mi_kblocks_set_potential)
     // nonlocal
     int n_p;
     const cd* P;                  // borrowed device pointer, n_G x n_p

@@ -963,7 +963,7 @@ extern "C" int dftk_mi_apply_H(dftk_mi_kblock* kb, int n_bands, const dftk_mi_cp
 extern "C" int dftk_mi_local_potential(dftk_mi_kblock* cube_kb, const double* rho_d, const double* V_loc_d,
                                        const double* poisson_green_d, int xc_functionals, double* V_out_d,
                                        double* energies_h) {
-    if (!cube_kb || !rho_d || !energies_h || (xc_functionals & ~(7 | 32)) || cube_kb->sh_comm) return DFTK_MI_EINVAL;
+    if (!cube_kb || !rho_d || (!energies_h && !V_out_d) || (xc_functionals & ~(7 | 32)) || cube_kb->sh_comm) return DFTK_MI_EINVAL;
     HIPCHK(hipSetDevice(cube_kb->basis->device));
     return local_potential_lda(cube_kb, nullptr, rho_d, V_loc_d, poisson_green_d, xc_functionals, 0.0, V_out_d,
                                energies_h);
@@ -972,7 +972,7 @@ extern "C" int dftk_mi_local_potential(dftk_mi_kblock* cube_kb, const double* rh
 extern "C" int dftk_mi_local_potential_collinear(dftk_mi_kblock* cube_kb, const double* rho_d, const double* V_loc_d,
                                                  const double* poisson_green_d, int xc_functionals, double* V_out_d,
                                                  double* energies_h) {
-    if (!cube_kb || !rho_d || !energies_h || cube_kb->sh_comm) return DFTK_MI_EINVAL;
+    if (!cube_kb || !rho_d || (!energies_h && !V_out_d) || cube_kb->sh_comm) return DFTK_MI_EINVAL;
     HIPCHK(hipSetDevice(cube_kb->basis->device));
     return local_potential_collinear(cube_kb, rho_d, V_loc_d, poisson_green_d, xc_functionals, V_out_d, energies_h);
 }
@@ -986,7 +986,7 @@ static void rowmajor3(const double* colmajor, double* out) {
 extern "C" int dftk_mi_local_potential_gga(dftk_mi_kblock* cube_kb, const double* recip_lattice_h, const double* rho_d,
                                            const double* V_loc_d, const double* poisson_green_d, int xc_functionals,
                                            double density_threshold, double* V_out_d, double* energies_h) {
-    if (!cube_kb || !rho_d || !energies_h || (xc_functionals & ~31) || cube_kb->sh_comm) return DFTK_MI_EINVAL;
+    if (!cube_kb || !rho_d || (!energies_h && !V_out_d) || (xc_functionals & ~31) || cube_kb->sh_comm) return DFTK_MI_EINVAL;
     if ((xc_functionals & 24) && !recip_lattice_h) return DFTK_MI_EINVAL;
     HIPCHK(hipSetDevice(cube_kb->basis->device));
     double B[9] = {0};

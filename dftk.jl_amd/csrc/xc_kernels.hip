@@ -346,6 +346,7 @@ int local_potential_collinear(dftk_mi_kblock* cube_kb, const double* rho, const 
     hipLaunchKernelGGL(k_xc_sum_spin, dim3(XC_BLOCKS), dim3(256), 0, b->stream, N, up, dn, vh, 1.0 / (double)N, vloc, fun_mask,
                        V_out, V_out ? V_out + N : (double*)nullptr, partial);
     HIPCHK(hipGetLastError());
+    if (!energies_h) return 0;      // potential only: asynchronous, like every call that returns no host data
     std::vector<double> hp(3 * XC_BLOCKS, 0.0);
     CHK(host_fetch(b, hp.data(), partial, (green ? 3 : 2) * XC_BLOCKS * sizeof(double)));
     double s3[3] = {0.0, 0.0, 0.0};
@@ -427,6 +428,7 @@ int local_potential_lda(dftk_mi_kblock* cube_kb, const double* recip_h, const do
     hipLaunchKernelGGL(k_xc_sum, dim3(XC_BLOCKS), dim3(256), 0, b->stream, N, rho, vh, 1.0 / (double)N, vloc,
                        fun_mask & (7 | 32), (const double*)e_g, (const double*)v_g, V_out, partial);
     HIPCHK(hipGetLastError());
+    if (!energies_h) return 0;      // potential only: asynchronous (no fetch, no synchronisation)
     HIPCHK(hipMemcpyAsync(hp.data(), partial, (green ? 3 : 2) * XC_BLOCKS * sizeof(double), hipMemcpyDeviceToHost,
                           b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));

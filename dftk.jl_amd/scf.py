@@ -427,7 +427,7 @@ class ScfStepper:
         t = time.time()
         # only the Hamiltonian of rho_in is needed here; the psi-dependent energy terms of this call
         # would be thrown away (the energies reported for the step are those of (psi_out, rho_out) below)
-        _, ham = energy_hamiltonian(basis, None, None, rho=self.rho_in)
+        _, ham = energy_hamiltonian(basis, None, None, rho=self.rho_in, only_hamiltonian=True)
         t = lap("energy_hamiltonian", t)
         diagtol = self.determine_tol(info["n_iter"], info["history_drho"])
         nxt = next_density(ham, self.nbandsalg, self.eigensolver, psi=info["psi"], eigenvalues=info["eigenvalues"],

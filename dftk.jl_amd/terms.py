@@ -527,11 +527,11 @@ _SPIN_LDA = ("lda_x", "lda_c_pw", "lda_xc_teter93")      # functionals with a sp
 _GGA_BITS = {"gga_x_pbe": 8, "gga_c_pbe": 16}
 
 
-def local_potential_fused(basis, rho, want_potential=True):
+def local_potential_fused(basis, rho, want_potential=True, want_energies=True):
     """Hartree + XC (LDA point-wise; PBE with its gradient / divergence Fourier passes) + V_loc summed into one
     potential and their three energies by ONE library call (``dftk_mi_local_potential`` / ``_gga``: hartree.jl:50-59,
     xc.jl:84-160,356-409,576-584, local.jl:15-16, operators.jl:213-222).  Returns None for functionals the library does
-    not evaluate."""
+    not evaluate.  ``want_energies=False`` (potential only): the call does not synchronise, the three energies are NaN."""
     import ctypes as C
     T = basis.terms
     mask = 0
@@ -547,7 +547,7 @@ def local_potential_fused(basis, rho, want_potential=True):
     V = torch.empty_like(rho) if want_potential else None
     vloc = T.V_loc if "AtomicLocal" in T.names else None
     green = T.poisson if "Hartree" in T.names else None
-    E3 = (C.c_double * 3)()
+    E3 = (C.c_double * 3)() if want_energies or not want_potential else None
     basis.pre_call()
     args = (vloc.data_ptr() if vloc is not None else None, green.data_ptr() if green is not None else None)
     if rho.dim() == 4:
@@ -564,6 +564,8 @@ def local_potential_fused(basis, rho, want_potential=True):
     else:
         _lib.check(basis.lib.dftk_mi_local_potential(basis._cube_handle, rho.data_ptr(), *args, mask,
                                                      V.data_ptr() if V is not None else None, E3))
+    if E3 is None:
+        return dict(Hartree=math.nan, Xc=math.nan, AtomicLocal=math.nan, V=V)
     return dict(Hartree=E3[0], Xc=E3[1], AtomicLocal=E3[2], V=V)
 
 
@@ -591,10 +593,12 @@ def smearing_entropy(kind, x):
 
 
 def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, eigenvalues=None, eF=None,
-                       ritz_potential=None, ritz_occupation_threshold=0.0):
+                       ritz_potential=None, ritz_occupation_threshold=0.0, only_hamiltonian=False):
     """``energy_hamiltonian(basis, psi, occupation; rho, eigenvalues, eF)`` (Hamiltonian.jl:200-227); with
     ``only_energies`` it is ``energy(...)`` (:232-236).  Returns (Energies, [DftHamiltonianBlock]).  The entropy
-    term -TS (terms/entropy.jl:11-42) needs this rank's eigenvalues and the Fermi level, else it is Inf."""
+    term -TS (terms/entropy.jl:11-42) needs this rank's eigenvalues and the Fermi level, else it is Inf.
+    ``only_hamiltonian`` (the SCF stepper's first call of a step, whose energies nobody reads): the local-potential pipeline
+    returns no energies and does not synchronise; Hartree / Xc / AtomicLocal are NaN in the returned Energies."""
     basis._require_gpu()
     T = basis.terms
     E = Energies()
@@ -608,7 +612,8 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, ei
     fused = None
     if rho is not None and os.environ.get("DFTK_MI_TORCH_LOCAL") is None and \
             any(n in T.names for n in ("AtomicLocal", "Hartree", "Xc")):
-        fused = local_potential_fused(basis, rho, want_potential=not only_energies)
+        fused = local_potential_fused(basis, rho, want_potential=not only_energies,
+                                      want_energies=not (only_hamiltonian and not only_energies))
         if fused is not None and not only_energies:
             pot = fused["V"]
     if rho is not None and rho.dim() == 4 and fused is None and any(n in T.names for n in ("Hartree", "Xc")):

@@ -131,7 +131,9 @@ int dftk_mi_atomic_superposition(dftk_mi_kblock* cube_kb, int kind, const double
  * cube_kb: a k-block whose mapping is 0 .. N-1 (the library's cube FFT).  rho_d, V_loc_d, poisson_green_d
  * (4 pi / |G|^2 with the G = 0 and unpaired-G entries zeroed, hartree.jl:29-45), V_out_d: real cubes on the device;
  * V_loc_d / poisson_green_d / V_out_d may be NULL (term absent / energies only).  energies_h[3] = Hartree, Xc,
- * AtomicLocal (host).  Synchronises the basis' stream. */
+ * AtomicLocal (host); the call then synchronises the basis' stream.  energies_h may be NULL when V_out_d is not (the
+ * Hamiltonian of an SCF step needs the potential only: no fetch, the call is asynchronous); the same holds for the
+ * _collinear and _gga entries below. */
 #define DFTK_MI_XC_LDA_X     1
 #define DFTK_MI_XC_LDA_C_VWN 2
 #define DFTK_MI_XC_LDA_C_PW  4

@@ -438,11 +438,18 @@ def test_pbe_local_potential_pipeline_behind_abi(fft_size, monkeypatch):
     assert np.abs(V1.cpu().numpy() - oham[0].potential).max() < 1e-9
     Eo, _ = dftk.energy_hamiltonian(basis, None, None, rho=rho, only_energies=True)
     assert Eo["Xc"] == E1["Xc"] and Eo["Hartree"] == E1["Hartree"]
-    # a GGA bit without the reciprocal lattice is an argument error
+    # potential only (what the SCF stepper asks for at the top of a step): no energies, no synchronisation, the SAME potential
+    Eh, hamh = dftk.energy_hamiltonian(basis, None, None, rho=rho, only_hamiltonian=True)
+    assert all(np.isnan(Eh[name]) for name in ("AtomicLocal", "Hartree", "Xc"))
+    assert torch.equal(hamh[0].potential, V1)
+    # neither energies nor a potential asked for, or a GGA bit without the reciprocal lattice: argument errors
     import ctypes as C
     E3 = (C.c_double * 3)()
     assert basis.lib.dftk_mi_local_potential_gga(basis._cube_handle, None, rho.data_ptr(), None, None, 24, 1e-12, None,
                                                  E3) != 0
+    Bh = np.asfortranarray(basis.model.recip_lattice, dtype=np.float64)
+    assert basis.lib.dftk_mi_local_potential_gga(basis._cube_handle, Bh.ctypes.data, rho.data_ptr(), None, None, 24, 1e-12,
+                                                 None, None) != 0
 
 
 def test_setup_behind_abi_matches_torch_construction(monkeypatch):

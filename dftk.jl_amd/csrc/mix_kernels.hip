@@ -239,6 +239,26 @@ __global__ __launch_bounds__(MT) void k_anderson_dots(int64_t Nt, const double* 
         if (threadIdx.x == 0) hpart[(size_t)blockIdx.x * (nh + 1) + k] = t;
     }
 }
+// step scalars: block partials of <a, b> (column 0) and ||a - c||^2 (column 1); a null b / c leaves its column at zero
+__global__ __launch_bounds__(MT) void k_step_sums(int64_t Nt, const double* __restrict__ a, const double* __restrict__ b,
+                                                  const double* __restrict__ c, double* __restrict__ hpart) {
+    __shared__ double sh[8];
+    double s0 = 0.0, s1 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * MT + threadIdx.x; i < Nt; i += (int64_t)gridDim.x * MT) {
+        const double ai = a[i];
+        if (b) s0 += ai * b[i];
+        if (c) {
+            const double d = ai - c[i];
+            s1 += d * d;
+        }
+    }
+    const double t0 = m_block_sum(s0, sh);
+    const double t1 = m_block_sum(s1, sh);
+    if (threadIdx.x == 0) {
+        hpart[(size_t)blockIdx.x * 2] = t0;
+        hpart[(size_t)blockIdx.x * 2 + 1] = t1;
+    }
+}
 // Anderson: xn = c0 (x + alpha pf) + sum_k beta_k (X_k + alpha R_k); the pair (x, pf) goes into the history slot
 __global__ __launch_bounds__(MT) void k_anderson_update(int64_t Nt, const double* __restrict__ x, const double* __restrict__ pf,
                                                         double alpha, double c0, int nh, PtrTable X, PtrTable R,
@@ -305,6 +325,22 @@ inline double host_sum(const double* part, int stride, int q) {
 }
 }  // namespace dftk_mix
 using namespace dftk_mix;
+
+// The two cube-sized scalars an SCF step reads on the host besides the term energies -- int V_in rho_out (the Ritz-value form
+// of the nonlocal energy, terms.py) and ||rho_out - rho_in||^2 (ScfConvergenceDensity, self_consistent_field.jl:229-236) --
+// in ONE kernel and ONE synchronisation (they were two chains of torch launches with a fetch each).
+extern "C" int dftk_mi_step_sums(dftk_mi_basis* b, int64_t n, const double* a_d, const double* b_d, const double* c_d,
+                                 double* out_h) {
+    if (!b || n < 1 || !a_d || (!b_d && !c_d) || !out_h) return DFTK_MI_EINVAL;
+    HIPCHK(hipSetDevice(b->device));
+    double* hpart = reinterpret_cast<double*>(b->h_fetch);
+    hipLaunchKernelGGL(k_step_sums, grid(), dim3(MT), 0, b->stream, n, a_d, b_d, c_d, hpart);
+    HIPCHK(hipGetLastError());
+    CHK(host_wait(b));
+    out_h[0] = host_sum(hpart, 2, 0);
+    out_h[1] = host_sum(hpart, 2, 1);
+    return 0;
+}
 
 // =============================================================================================== Anderson acceleration
 struct dftk_mi_anderson {

@@ -434,10 +434,13 @@ class ScfStepper:
                            occupation=info["occupation"], tol=diagtol, generator=self.gen, seed=self.seed,
                            timers=timers)
         t = time.time()
+        # int V_in rho_out (Ritz-value form of the nonlocal energy) and ||rho_out - rho_in||^2 in one library call / one fetch
+        ritz_pot = self._ritz_potential(ham) if self.ritz_energies else None
+        sums = self._step_sums(nxt["rho"], ritz_pot, self.rho_in)
         energies, _ = energy_hamiltonian(basis, nxt["psi"], nxt["occupation"], rho=nxt["rho"], only_energies=True,
-                                         eigenvalues=nxt["eigenvalues"], eF=nxt["eF"],
-                                         ritz_potential=self._ritz_potential(ham) if self.ritz_energies else None,
-                                         ritz_occupation_threshold=self.nbandsalg.occupation_threshold)
+                                         eigenvalues=nxt["eigenvalues"], eF=nxt["eF"], ritz_potential=ritz_pot,
+                                         ritz_occupation_threshold=self.nbandsalg.occupation_threshold,
+                                         ritz_potential_dot=None if sums is None or ritz_pot is None else sums[0])
         t = lap("energies", t)
         drho = nxt["rho"] - self.rho_in
         n_matvec_total = info["n_matvec"] + nxt["n_matvec"]
@@ -445,7 +448,8 @@ class ScfStepper:
         info.update(n_iter=info["n_iter"] + 1, n_matvec=n_matvec_total, n_matvec_step=nxt["n_matvec"],
                     energies=energies, ham=ham, rho_in=self.rho_in, diagtol=diagtol,
                     history_Etot=info["history_Etot"] + [energies.total],
-                    history_drho=info["history_drho"] + [float(torch.linalg.norm(drho).item()) * self.sqrt_dvol])
+                    history_drho=info["history_drho"] + [(float(torch.linalg.norm(drho).item()) if sums is None
+                                                          else math.sqrt(max(sums[1], 0.0))) * self.sqrt_dvol])
         # rank 0 decides for everybody (mpi_bcast(converged, comm_kpts), self_consistent_field.jl:249): the ranks
         # hold bit-identical densities, but a control-flow split on a last-bit difference must never deadlock
         conv = bool(self.is_converged(info))
@@ -465,6 +469,24 @@ class ScfStepper:
         info["timers_synced"] = self.phase_timers
         self.info = info
         return info
+
+    def _step_sums(self, rho_out, v_in, rho_in):
+        """``dftk_mi_step_sums``: (sum V_in rho_out, sum (rho_out - rho_in)^2) with one kernel and one fetch; None with
+        ``DFTK_MI_TORCH_LOCAL=1`` (the torch twins take over) or for arrays the call cannot take."""
+        import ctypes as C
+        import os
+        basis = self.basis
+        if os.environ.get("DFTK_MI_TORCH_LOCAL") is not None:
+            return None
+        arrs = [a for a in (rho_out, v_in, rho_in) if a is not None]
+        if not all(a.is_cuda and a.dtype == torch.float64 and a.is_contiguous() and a.numel() == rho_out.numel() for a in arrs):
+            return None
+        out = (C.c_double * 2)()
+        basis.pre_call()
+        from . import _lib
+        _lib.check(basis.lib.dftk_mi_step_sums(basis.handle, rho_out.numel(), rho_out.data_ptr(),
+                                               v_in.data_ptr() if v_in is not None else None, rho_in.data_ptr(), out))
+        return float(out[0]), float(out[1])
 
     @staticmethod
     def _ritz_potential(ham):

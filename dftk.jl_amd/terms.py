@@ -593,7 +593,7 @@ def smearing_entropy(kind, x):
 
 
 def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, eigenvalues=None, eF=None,
-                       ritz_potential=None, ritz_occupation_threshold=0.0, only_hamiltonian=False):
+                       ritz_potential=None, ritz_occupation_threshold=0.0, only_hamiltonian=False, ritz_potential_dot=None):
     """``energy_hamiltonian(basis, psi, occupation; rho, eigenvalues, eF)`` (Hamiltonian.jl:200-227); with
     ``only_energies`` it is ``energy(...)`` (:232-236).  Returns (Energies, [DftHamiltonianBlock]).  The entropy
     term -TS (terms/entropy.jl:11-42) needs this rank's eigenvalues and the Fermi level, else it is Inf.
@@ -699,7 +699,9 @@ def energy_hamiltonian(basis, psi, occupation, rho=None, only_energies=False, ei
                 E[name] = e
                 reduce_kpts.append(name)
                 # (collinear: rho and ritz_potential both carry the spin index -- sum_s int V_s rho_s)
-                ritz_fix = (float((rho * ritz_potential).sum().item() * basis.dvol), use_bandwise)
+                # (ritz_potential_dot: sum_i V_in[i] rho[i] when the caller has it already -- dftk_mi_step_sums)
+                vdot = float((rho * ritz_potential).sum().item()) if ritz_potential_dot is None else float(ritz_potential_dot)
+                ritz_fix = (vdot * basis.dvol, use_bandwise)
             elif have_psi:
                 e = 0.0
                 for ik, psik in enumerate(psi):

@@ -481,6 +481,13 @@ int dftk_mi_chi0_mix(dftk_mi_kblock* cube_kblock, int n_comp, const double* reci
  * many-small-k workloads these two ARE the cost model; either pointer may be NULL. */
 int dftk_mi_launch_count(int64_t* launches, int64_t* host_syncs);
 
+/* The two density-sized scalars an SCF step reads on the host besides the term energies, in one kernel and one
+ * synchronisation: out_h[0] = sum_i a[i] b[i] (b_d may be NULL: 0), out_h[1] = sum_i (a[i] - c[i])^2 (c_d may be NULL: 0);
+ * n doubles each, on the device.  The host mirror passes a = rho_out, b = V_in (the nonlocal energy from the Ritz values:
+ * sum f eps - E_kin - int V_in rho_out) and c = rho_in (||rho_out - rho_in||, the convergence criterion of
+ * src/scf/self_consistent_field.jl:229-236); the caller multiplies by the volume element. */
+int dftk_mi_step_sums(dftk_mi_basis* basis, int64_t n, const double* a_d, const double* b_d, const double* c_d, double* out_h);
+
 /* compute_occupation's Fermi-level search (src/occupation.jl:99-132, FermiBisection; host-only, no device call): bisection of
  *   excess(eF) = sum_k kweights[k] sum_n filled * smearing((eig[k][n] - eF) / temperature) - n_electrons
  * on the bracket [lo, hi] (excess(lo) < 0 <= excess(hi)) until the midpoint equals an end point (adjacent doubles; at most

@@ -204,3 +204,33 @@ def test_native_chi0_mixing_collinear_matches_torch_twin(monkeypatch):
     monkeypatch.delenv("DFTK_MI_TORCH_MIX")
     assert float((got - ref).norm()) < 1e-8 * float(ref.norm())
     assert nat.last_gmres_applies >= 2 and float((ref - dF).norm()) > 1e-3 * float(dF.norm())
+
+
+def test_step_sums_one_kernel_one_fetch(state, monkeypatch):
+    """``dftk_mi_step_sums``: int V_in rho_out and ||rho_out - rho_in||^2 of an SCF step in one kernel / one fetch, against
+    NumPy; the stepper's energies and density change with the call equal those of the torch twins (DFTK_MI_TORCH_LOCAL=1)."""
+    import ctypes as C
+    db = state["db"] if isinstance(state, dict) and "db" in state else None
+    if db is None:
+        dm, _ = _al_models()
+        db = dftk.PlaneWaveBasis(dm, 6, dftk.MonkhorstPack((1, 2, 2)))
+    rng = np.random.default_rng(5)
+    n = int(np.prod(db.fft_size))
+    a, b, c = (rng.standard_normal(n) for _ in range(3))
+    ad, bd, cd = (torch.tensor(x, device="cuda") for x in (a, b, c))
+    out = (C.c_double * 2)()
+    assert db.lib.dftk_mi_step_sums(db.handle, n, ad.data_ptr(), bd.data_ptr(), cd.data_ptr(), out) == 0
+    assert abs(out[0] - float(a @ b)) < 1e-11 * np.sqrt(n) and abs(out[1] - float(((a - c) ** 2).sum())) < 1e-11 * n
+    assert db.lib.dftk_mi_step_sums(db.handle, n, ad.data_ptr(), None, cd.data_ptr(), out) == 0 and out[0] == 0.0
+    assert db.lib.dftk_mi_step_sums(db.handle, n, ad.data_ptr(), None, None, out) != 0
+    # the stepper's wrapper on its own arrays against the torch formulas it replaces; the torch twins under DFTK_MI_TORCH_LOCAL=1
+    st = dftk.ScfStepper(db, tol=1e-10, seed=3)
+    info = st.step()
+    rho_out, rho_in, v_in = info["rho"], info["rho_in"], st._ritz_potential(info["ham"])
+    s0, s1 = st._step_sums(rho_out, v_in, rho_in)
+    assert abs(s0 - float((rho_out * v_in).sum().item())) < 1e-10 * max(1.0, abs(s0))
+    assert abs(np.sqrt(s1) - float(torch.linalg.norm(rho_out - rho_in).item())) < 1e-12 * max(1.0, np.sqrt(s1))
+    assert abs(info["history_drho"][-1] - float(torch.linalg.norm(rho_out - rho_in).item()) * st.sqrt_dvol) < 1e-12
+    monkeypatch.setenv("DFTK_MI_TORCH_LOCAL", "1")
+    assert st._step_sums(rho_out, v_in, rho_in) is None
+    monkeypatch.delenv("DFTK_MI_TORCH_LOCAL", raising=False)

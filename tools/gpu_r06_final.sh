@@ -71,9 +71,12 @@ PY
 python tools/kpoints_share_profile.py 8 > $O/r06_kpoints_share_step_N8.txt 2>&1
 python tools/kpoints_share_profile.py 1 >> $O/r06_kpoints_share_step_N8.txt 2>&1
 cd /tmp; rm -rf /tmp/ks
-timeout -s KILL 120 rocprofv3 --kernel-trace -d /tmp/ks -o s -- python $R/tools/kpoints_share_profile.py 8 > /dev/null 2>&1
+timeout -s KILL 240 rocprofv3 --kernel-trace -d /tmp/ks -o s -- python $R/tools/kpoints_share_profile.py 8 --no-phase-timers > /dev/null 2>&1
 python $R/tools/rocpd_stats.py $(ls /tmp/ks/*results.db | head -1) 30 > $O/r06_kernel_trace_kpoints_share8.txt
 rm -rf /tmp/ks
 cd $R
 DFTK_MI_GEMM_SHAPES=1 timeout 300 python tools/late_step_profile.py 5 8 6 > $O/r06_late_step_cfg5.txt 2> $O/late.err
 head -24 $O/r06_late_step_cfg5.txt
+DFTK_MI_GEMM_SHAPES=1 timeout 300 python tools/late_step_profile.py 5 0 1 --any > $O/r06_first_step_cfg5.txt 2> $O/first.err
+head -14 $O/r06_first_step_cfg5.txt
+DFTK_MI_ORTHO_CLOCKS=1 timeout 120 python tools/ortho_small_bench.py 6 > $O/r06_ortho_kernel_phase_clocks.txt 2>&1

@@ -610,7 +610,10 @@ def roofline_of(fam, n_gpus, workload):
     # HBM bytes per launch of the dominant family from PMC passes over THIS command and THIS build
     # (tools/pmc_traffic_bench.sh writes profiles/<round>_pmc_traffic.json with the library's source hash)
     roof["traffic"] = None
-    for pmc_file in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    import glob
+    pmc_files = sorted((os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json"))),
+                       reverse=True)       # newest round first; only a file of THIS build (lib_hash) is taken
+    for pmc_file in pmc_files:
         try:
             with open(os.path.join(ROOT, "profiles", pmc_file)) as fh:
                 pmc = json.load(fh)

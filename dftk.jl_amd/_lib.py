@@ -74,6 +74,8 @@ _SIGNATURES = {
                                        C.c_void_p, C.c_void_p]),
     "dftk_mi_density_accumulate_multi": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                    C.c_void_p]),
+    "dftk_mi_density_accumulate_multi2": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "dftk_mi_band_kinetic_multi": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dftk_mi_batch_stats": (C.c_int, [C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "dftk_mi_lobpcg_small_stats": (C.c_int, [C.POINTER(_i64), C.POINTER(_i64)]),

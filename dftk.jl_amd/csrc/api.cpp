@@ -1266,7 +1266,15 @@ extern "C" int dftk_mi_band_kinetic_multi(int n_kblocks, dftk_mi_kblock* const* 
 extern "C" int dftk_mi_density_accumulate_multi(int n_kblocks, dftk_mi_kblock* const* kbs, const int* n_bands,
                                                 const dftk_mi_cplx* const* psi_d, const int64_t* ld_psi,
                                                 const double* weights_h, double* rho_d) {
-    if (n_kblocks < 0 || (n_kblocks > 0 && (!kbs || !n_bands || !psi_d || !ld_psi || !weights_h)) || !rho_d)
+    return dftk_mi_density_accumulate_multi2(n_kblocks, kbs, n_bands, psi_d, ld_psi, weights_h, rho_d, nullptr, nullptr);
+}
+
+extern "C" int dftk_mi_density_accumulate_multi2(int n_kblocks, dftk_mi_kblock* const* kbs, const int* n_bands,
+                                                 const dftk_mi_cplx* const* psi_d, const int64_t* ld_psi,
+                                                 const double* weights_h, double* rho_d, const double* weights2_h,
+                                                 double* rho2_d) {
+    if (n_kblocks < 0 || (n_kblocks > 0 && (!kbs || !n_bands || !psi_d || !ld_psi || !weights_h)) || !rho_d ||
+        ((weights2_h == nullptr) != (rho2_d == nullptr)) || (rho2_d && rho2_d == rho_d))
         return DFTK_MI_EINVAL;
     if (n_kblocks == 0) return 0;
     dftk_mi_basis* b = kbs[0] ? kbs[0]->basis : nullptr;
@@ -1280,9 +1288,11 @@ extern "C" int dftk_mi_density_accumulate_multi(int n_kblocks, dftk_mi_kblock* c
     size_t off = 0;
     for (int i = 0; i < n_kblocks; ++i) {
         const double* w = weights_h + off;
+        const double* w2 = weights2_h ? weights2_h + off : nullptr;
         off += (size_t)n_bands[i];
         bodies.push_back([=]() {
-            return launch_density(kbs[i], n_bands[i], reinterpret_cast<const cd*>(psi_d[i]), ld_psi[i], w, rho_d, nullptr);
+            return launch_density(kbs[i], n_bands[i], reinterpret_cast<const cd*>(psi_d[i]), ld_psi[i], w, rho_d, nullptr, w2,
+                                  rho2_d);
         });
     }
     std::vector<int> rets;

@@ -195,7 +195,9 @@ int exec_one(BOp& o) {
         case BOP_APPLYD: return apply_D(o.kb, o.m, (const cd*)o.A, Cc);
         case BOP_DENSITY: {
             const double* w = reinterpret_cast<const double*>(o.payload.data());
-            return launch_density(o.kb, o.m, (const cd*)o.A, o.lda, w, (double*)o.C, o.flags ? w + o.m : nullptr);
+            const double* wim = (o.flags & 1) ? w + o.m : nullptr;
+            const double* w2 = (o.flags & 2) ? w + (size_t)((o.flags & 1) ? 2 : 1) * o.m : nullptr;
+            return launch_density(o.kb, o.m, (const cd*)o.A, o.lda, w, (double*)o.C, wim, w2, (double*)o.D);
         }
         default: return DFTK_MI_EINVAL;
     }
@@ -214,11 +216,13 @@ int flush(Recorder* r) {
         bool any = false;
         for (auto& g : groups) g.clear();
         for (auto& f : r->fibers)
-            if (f.head < f.fifo.size()) {
+            while (f.head < f.fifo.size()) {
                 BOp* op = &f.fifo[f.head++];
                 groups[op->type].push_back(op);
                 all.push_back(op);
                 any = true;
+                // (batch_join_next: the fiber's next operation is independent of this one and of the same type)
+                if (!(op->join_next && f.head < f.fifo.size() && f.fifo[f.head].type == op->type)) break;
             }
         if (!any) break;
         for (int t = 0; t < BOP_NTYPES && status == 0; ++t) {
@@ -287,6 +291,13 @@ int batch_record(BOp&& op) {
     Recorder* r = g_rec;
     r->fibers[r->cur].fifo.push_back(std::move(op));
     return 0;
+}
+
+void batch_join_next() {
+    Recorder* r = g_rec;
+    if (!r || g_suspended || r->cur < 0) return;
+    auto& q = r->fibers[r->cur].fifo;
+    if (!q.empty()) q.back().join_next = true;
 }
 
 int batch_record_sync(BOp&& op) {

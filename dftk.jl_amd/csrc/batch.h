@@ -71,6 +71,7 @@ struct BOp {
     void* host2 = nullptr;
     size_t bytes = 0;
     std::vector<char> payload;   // H2D source (copied when recorded: the caller may reuse its buffer)
+    bool join_next = false;      // the fiber's NEXT operation (same type, independent of this one) joins this one's launch
     int status = 0;              // numerical status of POTRF / HEEV (set by the executor)
     int* status_out = nullptr;   // where the issuing fiber reads it after resuming (on its own stack)
 };
@@ -79,6 +80,8 @@ struct BOp {
 bool batching();
 // enqueue on the current fiber; returns 0
 int batch_record(BOp&& op);
+// the operation recorded last and the one recorded next (same type, independent: e.g. X = Y c and AX = AY c) share a launch
+void batch_join_next();
 // enqueue, yield until the round has executed; returns the op's status
 int batch_record_sync(BOp&& op);
 // plain "wait for everything I have issued": yields (all queued work of the fiber is complete on return)

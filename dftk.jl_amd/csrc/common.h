@@ -221,8 +221,8 @@ int launch_local_apply(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi,
 int launch_ifft_to_cube(dftk_mi_kblock* kb, const cd* c, cd* cube, int nb = 1);
 int launch_fft_from_cube(dftk_mi_kblock* kb, const cd* cube, cd* c, int nb = 1);
 // w_im_h (optional): separate weights for the squared IMAGINARY parts (two real bands packed into one transform)
-int launch_density(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, const double* w_h,
-                   double* rho, const double* w_im_h = nullptr);
+int launch_density(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, const double* w_h, double* rho,
+                   const double* w_im_h = nullptr, const double* w2_h = nullptr, double* rho2 = nullptr);
 int launch_pad_potential(dftk_mi_kblock* kb, const double* V);
 int launch_kinetic_only(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, cd* out,
                         int64_t ldout, bool accumulate, bool use_kin);

@@ -337,6 +337,7 @@ struct FftJob {
     cd* out;              // stage E output
     int n_lines, nzx;
     double w, wim;        // density weights of the band
+    double w2;            // weight of the band in the SECOND accumulated cube (two-weight pass: density + LDOS), or 0
 };
 
 // ---------------------------------------------------------------------------------------- stage A
@@ -773,31 +774,33 @@ template <int R1A, int R1B, int R2A, int R2B>
 __global__ __launch_bounds__(FFT_L * ((R1A * R1B > R2A * R2B) ? R1A * R1B : R2A * R2B), ZREG_MIN_BLOCKS)
 void k_zdensity_reg(FftAxis az, int nx, int nxp, int ny, int nzx, int z_lo, int nb, const double* __restrict__ w,
                     const double* __restrict__ wim, const cd* __restrict__ T2, int64_t T2_stride,
-                    double* __restrict__ rho, const FftJob* __restrict__ jobs, double* __restrict__ part) {
+                    double* __restrict__ rho, const FftJob* __restrict__ jobs, double* __restrict__ part,
+                    double* __restrict__ rho2 = nullptr) {
     typedef FourStep<R1A, R1B, R2A, R2B> FS;
     cd* buf = reinterpret_cast<cd*>(dftk_smem);
     const int tid = threadIdx.x, l = tid & (FFT_L - 1), j = tid >> 3;
     const int x = blockIdx.x * FFT_L + l;
     const int y = blockIdx.y;
     const unsigned plane = (unsigned)ny * (unsigned)nxp;
-    double acc[FS::R2];
+    double acc[FS::R2], acc2[FS::R2];
 #pragma unroll
-    for (int p = 0; p < FS::R2; ++p) acc[p] = 0.0;
+    for (int p = 0; p < FS::R2; ++p) acc[p] = acc2[p] = 0.0;
     // part != null: gridDim.z band groups (bands blockIdx.z, + gridDim.z, ...), each WRITES its partial cube part[group]
     // (k_dens_reduce adds them to rho in group order) -- small cubes have too few (x tile, y) columns to fill the chip
     for (int ib = blockIdx.z; ib < nb; ib += gridDim.z) {
-        double wb, wi;
+        double wb, wi, wb2 = 0.0;
         if (jobs) {
             const FftJob jb = jobs[ib];
             wb = jb.w;
             wi = jb.wim;
+            wb2 = jb.w2;
             nzx = jb.nzx;
             z_lo = jb.z_lo;
         } else {
             wb = w[ib];
             wi = wim ? wim[ib] : wb;
         }
-        if (wb == 0.0 && wi == 0.0) continue;   // uniform across the block
+        if (wb == 0.0 && wi == 0.0 && wb2 == 0.0) continue;   // uniform across the block
         const cd* __restrict__ t2 = T2 + (int64_t)ib * T2_stride + (int64_t)y * nxp + (x - l);   // tile origin: uniform
         const unsigned planeB = plane * (unsigned)sizeof(cd), stepB = (unsigned)FS::R2 * planeB;
         const unsigned off_lo = (unsigned)j * planeB + (unsigned)l * (unsigned)sizeof(cd);
@@ -815,7 +818,10 @@ void k_zdensity_reg(FftAxis az, int nx, int nxp, int ny, int nzx, int z_lo, int 
         FS::backward(buf, az.tw, l, j, in, psi);
         if (j < FS::R1) {
 #pragma unroll
-            for (int p = 0; p < FS::R2; ++p) acc[p] = fma(wb, psi[p].x * psi[p].x, fma(wi, psi[p].y * psi[p].y, acc[p]));
+            for (int p = 0; p < FS::R2; ++p) {
+                acc[p] = fma(wb, psi[p].x * psi[p].x, fma(wi, psi[p].y * psi[p].y, acc[p]));
+                if (rho2) acc2[p] = fma(wb2, psi[p].x * psi[p].x + psi[p].y * psi[p].y, acc2[p]);
+            }
         }
         __syncthreads();   // the tile image is rewritten by the next band
     }
@@ -828,6 +834,14 @@ void k_zdensity_reg(FftAxis az, int nx, int nxp, int ny, int nzx, int z_lo, int 
             const unsigned off = ob + (unsigned)(FS::R1 * FS::k2_of(p)) * zB;
             st_off(r0, off, part ? acc[p] : ld_off((const double*)r0, off) + acc[p]);
         });
+        if (rho2) {   // second cube: the partial cubes of the groups follow those of the first (gridDim.z of them)
+            double* __restrict__ q0 = (part ? part + ((int64_t)gridDim.z + blockIdx.z) * az.n * ny * nx : rho2) + (int64_t)y * nx + (x - l);
+            static_for<0, FS::R2>([&](auto pi) {
+                constexpr int p = decltype(pi)::value;
+                const unsigned off = ob + (unsigned)(FS::R1 * FS::k2_of(p)) * zB;
+                st_off(q0, off, part ? acc2[p] : ld_off((const double*)q0, off) + acc2[p]);
+            });
+        }
     }
 }
 
@@ -929,7 +943,7 @@ __global__ __launch_bounds__(FFT_THREADS, DENS_MIN_BLOCKS) void k_zdensity(FftAx
                                                           const double* __restrict__ wim,
                                                           const cd* __restrict__ T2, int64_t T2_stride,
                                                           double* __restrict__ rho, const FftJob* __restrict__ jobs,
-                                                          double* __restrict__ part) {
+                                                          double* __restrict__ part, double* __restrict__ rho2 = nullptr) {
     constexpr int FFT_LS = FFT_LS_YZ;
     cd* buf = reinterpret_cast<cd*>(dftk_smem);
     cd* tw = buf + az.n * FFT_LS;
@@ -938,24 +952,25 @@ __global__ __launch_bounds__(FFT_THREADS, DENS_MIN_BLOCKS) void k_zdensity(FftAx
     const int y = blockIdx.y;
     const int nz = az.n;
     const int64_t plane = (int64_t)ny * nxp;
-    double acc[DENS_MAXACC];
+    double acc[DENS_MAXACC], acc2[DENS_MAXACC];
 #pragma unroll
-    for (int k = 0; k < DENS_MAXACC; ++k) acc[k] = 0.0;
+    for (int k = 0; k < DENS_MAXACC; ++k) acc[k] = acc2[k] = 0.0;
     for (int t = tid; t < nz; t += FFT_THREADS) tw[t] = az.tw[t];
-    // (band groups over gridDim.z with partial cubes: see k_zdensity_reg)
+    // (band groups over gridDim.z with partial cubes: see k_zdensity_reg; rho2: the second cube of a two-weight pass)
     for (int ib = blockIdx.z; ib < nb; ib += gridDim.z) {
-        double wb, wi;
+        double wb, wi, wb2 = 0.0;
         if (jobs) {               // multi-k launch: the band's k-block decides the z planes, its entry the weights
             const FftJob jb = jobs[ib];
             wb = jb.w;
             wi = jb.wim;
+            wb2 = jb.w2;
             zpos = jb.zpos;
             nzx = jb.nzx;
         } else {
             wb = w[ib];
             wi = wim ? wim[ib] : wb;
         }
-        if (wb == 0.0 && wi == 0.0) continue;   // uniform across the block
+        if (wb == 0.0 && wi == 0.0 && wb2 == 0.0) continue;   // uniform across the block
         const cd z0 = make_double2(0.0, 0.0);
         for (int t = tid; t < nz * FFT_LS; t += FFT_THREADS) buf[t] = z0;
         __syncthreads();
@@ -969,6 +984,7 @@ __global__ __launch_bounds__(FFT_THREADS, DENS_MIN_BLOCKS) void k_zdensity(FftAx
             if (z < nz) {
                 const cd v = buf[z * FFT_LS + l];
                 acc[k] = fma(wb, v.x * v.x, fma(wi, v.y * v.y, acc[k]));
+                if (rho2) acc2[k] = fma(wb2, v.x * v.x + v.y * v.y, acc2[k]);
             }
         }
         __syncthreads();
@@ -981,6 +997,17 @@ __global__ __launch_bounds__(FFT_THREADS, DENS_MIN_BLOCKS) void k_zdensity(FftAx
             if (z < nz) {
                 const int64_t at = ((int64_t)z * ny + y) * nx + x;
                 dst[at] = part ? acc[k] : dst[at] + acc[k];
+            }
+        }
+        if (rho2) {
+            double* __restrict__ dst2 = part ? part + ((int64_t)gridDim.z + blockIdx.z) * nz * ny * nx : rho2;
+#pragma unroll
+            for (int k = 0; k < DENS_MAXACC; ++k) {
+                const int z = j + k * FFT_TPL;
+                if (z < nz) {
+                    const int64_t at = ((int64_t)z * ny + y) * nx + x;
+                    dst2[at] = part ? acc2[k] : dst2[at] + acc2[k];
+                }
             }
         }
     }
@@ -1118,6 +1145,7 @@ struct RegZ {   // arguments of the z kernels
     double* rho;
     const FftJob* jobs;
     double* part = nullptr;   // density: partial cubes of grid.z band groups (k_dens_reduce), or null
+    double* rho2 = nullptr;   // density: second accumulated cube (weights FftJob::w2), or null
 };
 template <int A, int B, int C, int D>
 static int reg_zpass_t(const RegZ& r) {
@@ -1134,7 +1162,7 @@ static int reg_zdens_t(const RegZ& r) {
     const size_t lds = (size_t)FS::LDS_ELEMS * sizeof(cd);
     CHK(set_lds_attr(k_zdensity_reg<A, B, C, D>, lds));
     hipLaunchKernelGGL((k_zdensity_reg<A, B, C, D>), r.grid, dim3(FS::THREADS), lds, r.stream, r.b->ax[2], r.b->nx, r.b->nxp,
-                       r.b->ny, r.nzx, r.z_lo, r.nbands, r.w, r.wim, (const cd*)r.T2, r.s2, r.rho, r.jobs, r.part);
+                       r.b->ny, r.nzx, r.z_lo, r.nbands, r.w, r.wim, (const cd*)r.T2, r.s2, r.rho, r.jobs, r.part, r.rho2);
     return 0;
 }
 static int reg_zpass(const RegZ& r, bool tables_ok) {
@@ -1283,17 +1311,28 @@ int launch_fft_from_cube(dftk_mi_kblock* kb, const cd* cube, cd* c, int nb) {
 }
 
 int launch_density(dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, const double* w_h, double* rho,
-                   const double* w_im_h) {
+                   const double* w_im_h, const double* w2_h, double* rho2) {
     dftk_mi_basis* b = kb->basis;
     if (batching() && nb > 0) {   // part of a batched multi-k call: the bands of all k-blocks share one pipeline later
+        // payload: [w | wim (flags & 1) | w2 (flags & 2)]; D = the second cube of a two-weight pass
         BOp o;
         o.b = b;
         o.kb = kb;
-        o.type = BOP_DENSITY; o.m = nb; o.A = psi; o.lda = ldpsi; o.C = rho; o.flags = w_im_h ? 1 : 0;
-        o.payload.resize((size_t)(w_im_h ? 2 : 1) * nb * sizeof(double));
+        o.type = BOP_DENSITY; o.m = nb; o.A = psi; o.lda = ldpsi; o.C = rho; o.D = w2_h ? rho2 : nullptr;
+        o.flags = (w_im_h ? 1 : 0) | (w2_h ? 2 : 0);
+        o.payload.resize((size_t)(1 + (w_im_h ? 1 : 0) + (w2_h ? 1 : 0)) * nb * sizeof(double));
         memcpy(o.payload.data(), w_h, (size_t)nb * sizeof(double));
-        if (w_im_h) memcpy(o.payload.data() + (size_t)nb * sizeof(double), w_im_h, (size_t)nb * sizeof(double));
+        size_t at = (size_t)nb * sizeof(double);
+        if (w_im_h) {
+            memcpy(o.payload.data() + at, w_im_h, (size_t)nb * sizeof(double));
+            at += (size_t)nb * sizeof(double);
+        }
+        if (w2_h) memcpy(o.payload.data() + at, w2_h, (size_t)nb * sizeof(double));
         return batch_record(std::move(o));
+    }
+    if (w2_h) {   // outside a batched call: two passes (the one-pass form exists for the merged multi-k pipeline only)
+        CHK(launch_density(kb, nb, psi, ldpsi, w_h, rho, w_im_h, nullptr, nullptr));
+        return launch_density(kb, nb, psi, ldpsi, w2_h, rho2, nullptr, nullptr, nullptr);
     }
     CHK(check_lds(b));
     if (b->nz > DENS_MAXACC * FFT_TPL) {
@@ -1353,7 +1392,7 @@ struct MultiPlan {
     bool reg_z = true;   // every k-block's sphere planes wrap around contiguously (register-resident z kernels)
 };
 void add_jobs(MultiPlan& mp, const dftk_mi_kblock* kb, int nb, const cd* psi, int64_t ldpsi, cd* out, int64_t ldout,
-              bool kinetic, const double* w, const double* wim) {
+              bool kinetic, const double* w, const double* wim, const double* w2 = nullptr) {
     for (int i = 0; i < nb; ++i) {
         FftJob j;
         j.line_start = kb->d_line_start;
@@ -1370,6 +1409,7 @@ void add_jobs(MultiPlan& mp, const dftk_mi_kblock* kb, int nb, const cd* psi, in
         j.nzx = kb->nzx;
         j.w = w ? w[i] : 0.0;
         j.wim = wim ? wim[i] : j.w;
+        j.w2 = w2 ? w2[i] : 0.0;
         mp.jobs.push_back(j);
     }
     mp.max_lines = std::max(mp.max_lines, (int)kb->n_lines);
@@ -1480,8 +1520,9 @@ int batch_exec_apply_H(BatchCtx* ctx, hipStream_t stream, std::vector<BOp*>& ops
 int batch_exec_density(BatchCtx* ctx, hipStream_t stream, std::vector<BOp*>& ops) {
     dftk_mi_basis* b = ops[0]->kb->basis;
     double* rho = reinterpret_cast<double*>(ops[0]->C);
+    double* rho2 = reinterpret_cast<double*>(ops[0]->D);       // second cube of a two-weight pass (density + LDOS), or null
     for (BOp* o : ops)
-        if (o->kb->basis != b || o->kb->sh_comm || o->C != rho) return 1;
+        if (o->kb->basis != b || o->kb->sh_comm || o->C != rho || o->D != rho2) return 1;
     if (axis_generic(b->ax[0]) || axis_generic(b->ax[1]) || axis_generic(b->ax[2])) return 1;
     if (b->nz > DENS_MAXACC * FFT_TPL) return 1;
     CHK(check_lds(b));
@@ -1489,11 +1530,13 @@ int batch_exec_density(BatchCtx* ctx, hipStream_t stream, std::vector<BOp*>& ops
     for (BOp* o : ops) {
         const double* w = reinterpret_cast<const double*>(o->payload.data());
         // bands without weight never enter the pipeline (compute_density's occupation threshold, densities.jl:25-33)
+        const double* wim = (o->flags & 1) ? w + o->m : nullptr;
+        const double* w2 = (o->flags & 2) ? w + (size_t)((o->flags & 1) ? 2 : 1) * o->m : nullptr;
         for (int i = 0; i < o->m; ++i) {
-            const double wi = o->flags ? w[o->m + i] : w[i];
-            if (w[i] == 0.0 && wi == 0.0) continue;
+            const double wi = wim ? wim[i] : w[i];
+            if (w[i] == 0.0 && wi == 0.0 && (!w2 || w2[i] == 0.0)) continue;
             add_jobs(mp, o->kb, 1, reinterpret_cast<const cd*>(o->A) + (int64_t)i * o->lda, o->lda, nullptr, 0, false, w + i,
-                     o->flags ? w + o->m + i : nullptr);
+                     wim ? wim + i : nullptr, w2 ? w2 + i : nullptr);
         }
     }
     if (mp.jobs.empty()) return 0;
@@ -1522,21 +1565,26 @@ int batch_exec_density(BatchCtx* ctx, hipStream_t stream, std::vector<BOp*>& ops
         if ((int64_t)nxt * b->ny < 1024 && nb >= 16) groups = std::min(32, std::max(1, nb / 8));
         double* part = nullptr;
         if (groups > 1) {
-            part = reinterpret_cast<double*>(batch_scratch(ctx, (size_t)groups * cube * sizeof(double)));
+            part = reinterpret_cast<double*>(batch_scratch(ctx, (size_t)(rho2 ? 2 : 1) * groups * cube * sizeof(double)));
             if (!part) return DFTK_MI_EHIP;
         }
         RegZ rz{b, stream, dim3(nxt, b->ny, groups), 0, 0, nb, nullptr, T2, s2, nullptr, nullptr, rho, dj};
         rz.part = part;
+        rz.rho2 = rho2;
         const int rs = reg_zdens(rz, mp.reg_z);
         if (rs < 0) return rs;
         if (rs == 1) {
             CHK(set_lds_attr(k_zdensity<false>, lds_bytes(b->nz)));
             hipLaunchKernelGGL((k_zdensity<false>), dim3(nxt, b->ny, groups), dim3(FFT_THREADS), lds_bytes(b->nz), stream, b->ax[2], b->nx,
                                b->nxp, b->ny, 0, (const int*)nullptr, nb, (const double*)nullptr, (const double*)nullptr,
-                               (const cd*)T2, s2, rho, dj, part);
+                               (const cd*)T2, s2, rho, dj, part, rho2);
         }
-        if (part)
+        if (part) {
             hipLaunchKernelGGL(k_dens_reduce, dim3((unsigned)((cube + 255) / 256)), dim3(256), 0, stream, cube, groups, (const double*)part, rho);
+            if (rho2)
+                hipLaunchKernelGGL(k_dens_reduce, dim3((unsigned)((cube + 255) / 256)), dim3(256), 0, stream, cube, groups,
+                                   (const double*)(part + (size_t)groups * cube), rho2);
+        }
     }
     HIPCHK(hipGetLastError());
     return 0;

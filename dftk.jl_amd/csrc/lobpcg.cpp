@@ -1113,6 +1113,7 @@ static int lobpcg_run_small(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, doub
     int64_t n_matvec = M;
     CHK(dftk_mi_apply_H(kb, M, reinterpret_cast<const dftk_mi_cplx*>(X.p), X.ld, reinterpret_cast<dftk_mi_cplx*>(AX.p), AX.ld));
     CHK(ew_coldots(b, N, M, X.p, X.ld, AX.p, AX.ld, c.d_a));
+    batch_join_next();
     CHK(ew_coldots(b, N, M, X.p, X.ld, X.p, X.ld, c.d_b));
 
     int nlocked = 0, niter = 0, lo = 0;
@@ -1176,6 +1177,7 @@ static int lobpcg_run_small(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, doub
             h_cX.resize((size_t)nY * nact);
             CHK(dev_d2h_async(b, h_cX.data(), cX, h_cX.size() * sizeof(cd)));
             CHK(hcat_mul(c, Ys, cX, nY, nact, nX));
+            batch_join_next();                               // X = Y cX and AX = AY cX: one launch
             CHK(hcat_mul(c, AYs, cX, nY, nact, nAX));
         }
         // residuals with the Ritz values as the device holds them (iteration 0: the Rayleigh quotients d_a / d_b)
@@ -1275,6 +1277,7 @@ static int lobpcg_run_small(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, doub
                 CHK(ortho_XY(c, cPm, cXs, c.tmpS, ortho_tol));
             }
             CHK(hcat_mul(c, Ys, cP, nY, lenXn, nP));
+            batch_join_next();                               // P = Y cP and AP = AY cP: one launch
             CHK(hcat_mul(c, AYs, cP, nY, lenXn, nAP));
         }
         for (int i = 0; i < nact; ++i)

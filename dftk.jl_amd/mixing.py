@@ -55,8 +55,8 @@ def compute_dos(eps, basis, eigenvalues, smearing=None, temperature=None):
     return np.asarray(basis.comm_kpts.sum_scalars(list(D)))
 
 
-def compute_ldos(eps, basis, eigenvalues, psi, smearing=None, temperature=None, weight_threshold=EPS):
-    """Local density of states in real space (dos.jl:43-62): ``compute_density`` with modified weights."""
+def ldos_weights(eps, basis, eigenvalues, psi, smearing=None, temperature=None):
+    """The band weights of ``compute_ldos`` (dos.jl:52-58): ``-filled / T * f'((eps_kn - eps) / T)``."""
     smearing = smearing or basis.model.smearing
     temperature = basis.model.temperature if temperature is None else temperature
     if temperature == 0 or smearing == "none":
@@ -66,7 +66,12 @@ def compute_ldos(eps, basis, eigenvalues, psi, smearing=None, temperature=None, 
     for ek, p in zip(eigenvalues, psi):
         x = (np.asarray(ek, dtype=float)[:p.shape[0]] - eps) / temperature
         weights.append(-filled / temperature * occupation_derivative(smearing, x))
-    return compute_density(basis, psi, weights, weight_threshold)
+    return weights
+
+
+def compute_ldos(eps, basis, eigenvalues, psi, smearing=None, temperature=None, weight_threshold=EPS):
+    """Local density of states in real space (dos.jl:43-62): ``compute_density`` with modified weights."""
+    return compute_density(basis, psi, ldos_weights(eps, basis, eigenvalues, psi, smearing, temperature), weight_threshold)
 
 
 def gmres(apply, b: torch.Tensor, rtol: float, krylovdim: int = 30, maxiter: int = 100, atol: float = 1e-12):
@@ -351,7 +356,10 @@ class Chi0Mixing:
             sm = ldos_model.smearing or sm
             T = ldos_model.temperature if ldos_model.temperature is not None else T
             if T != 0:
-                ldos = compute_ldos(info.get("eF"), basis, info.get("eigenvalues"), info.get("psi"), sm, T)
+                # (the SCF stepper hands over the LDOS it accumulated in the density pass of the same orbitals)
+                ldos = info.get("ldos")
+                if ldos is None:
+                    ldos = compute_ldos(info.get("eF"), basis, info.get("eigenvalues"), info.get("psi"), sm, T)
                 ldos = ldos.to(torch.float64).contiguous()
         if ldos is None and diel is None:
             return dF
@@ -371,6 +379,22 @@ class Chi0Mixing:
             out.data_ptr(), C.byref(n_app), C.byref(conv)))
         self.last_gmres_applies = n_app.value
         return out
+
+    def extra_density_weights(self, basis, eigenvalues, eF, psi):
+        """Band weights (and their threshold) of the LDOS this mixing will ask for, so that ``compute_density`` can accumulate
+        it in the SAME pass over the orbitals (``dftk_mi_density_accumulate_multi2``); None when no LDOS is needed or the
+        torch twins are switched on."""
+        if _torch_mix() or eF is None:
+            return None
+        models = [t for t in self.chi0terms if type(t) is LdosModel]
+        if len(models) != 1 or any(type(t) not in (LdosModel, DielectricModel) for t in self.chi0terms):
+            return None
+        sm, T = default_smearing_temperature(basis.model)
+        sm = models[0].smearing or sm
+        T = models[0].temperature if models[0].temperature is not None else T
+        if T == 0 or sm == "none":
+            return None
+        return ldos_weights(eF, basis, eigenvalues, psi, sm, T), EPS
 
     def mix_density(self, basis, dF, **info):
         if not _torch_mix():

@@ -180,8 +180,10 @@ class FixedBands:
 
 
 def next_density(ham, nbandsalg, eigensolver=lobpcg_hyper, psi=None, eigenvalues=None, occupation=None,
-                 tol=1e-6, generator=None, seed=0, timers=None):
-    """self_consistent_field.jl:80-129."""
+                 tol=1e-6, generator=None, seed=0, timers=None, extra_weights=None):
+    """self_consistent_field.jl:80-129.  ``extra_weights(basis, eigenvalues, eF, psi) -> (weights, threshold) | None``: a second
+    set of band weights accumulated in the density pass (``rho_extra`` of the result; the stepper passes the LDOS weights of
+    its mixing)."""
     basis = ham[0].basis
     n_conv, n_comp = nbandsalg.determine_n_bands(occupation, eigenvalues, psi)
     if psi is not None:
@@ -192,14 +194,22 @@ def next_density(ham, nbandsalg, eigensolver=lobpcg_hyper, psi=None, eigenvalues
                                   miniter=1, generator=generator, seed=seed)
     t1 = time.time()
     occ, eF = compute_occupation(basis, eig["λ"], tol_n_elec=nbandsalg.occupation_threshold)
-    rho = compute_density(basis, eig["X"], occ, nbandsalg.occupation_threshold,
-                          real_symmetric=eig.get("real_symmetric"))
+    # extra_weights (optional callback of the mixing: LdosMixing's local density of states): accumulated in the same pass
+    extra = extra_weights(basis, eig["λ"], eF, eig["X"]) if extra_weights is not None else None
+    rho_extra = None
+    if extra is not None:
+        rho, rho_extra = compute_density(basis, eig["X"], occ, nbandsalg.occupation_threshold,
+                                         real_symmetric=eig.get("real_symmetric"), extra_weights=extra[0],
+                                         extra_threshold=extra[1])
+    else:
+        rho = compute_density(basis, eig["X"], occ, nbandsalg.occupation_threshold,
+                              real_symmetric=eig.get("real_symmetric"))
     if timers is not None:
         timers["diagonalization"] = timers.get("diagonalization", 0.0) + t1 - t0
         timers["occupation+density"] = timers.get("occupation+density", 0.0) + time.time() - t1
     n_matvec = int(basis.comm_kpts.sum_scalar(eig["n_matvec"]))    # (not over comm_pw: those ranks share the blocks)
     return dict(psi=eig["X"], eigenvalues=eig["λ"], occupation=occ, eF=eF, rho=rho, diagonalization=eig,
-                n_bands_converge=n_conv, n_matvec=n_matvec)
+                n_bands_converge=n_conv, n_matvec=n_matvec, rho_extra=rho_extra)
 
 
 # ---------------------------------------------------------------------------------- Anderson
@@ -432,7 +442,7 @@ class ScfStepper:
         diagtol = self.determine_tol(info["n_iter"], info["history_drho"])
         nxt = next_density(ham, self.nbandsalg, self.eigensolver, psi=info["psi"], eigenvalues=info["eigenvalues"],
                            occupation=info["occupation"], tol=diagtol, generator=self.gen, seed=self.seed,
-                           timers=timers)
+                           timers=timers, extra_weights=getattr(self.mixing, "extra_density_weights", None))
         t = time.time()
         # int V_in rho_out (Ritz-value form of the nonlocal energy) and ||rho_out - rho_in||^2 in one library call / one fetch
         ritz_pot = self._ritz_potential(ham) if self.ritz_energies else None
@@ -462,7 +472,7 @@ class ScfStepper:
             # rho_next = Anderson(rho_in, beta, mix_density(mixing, rho_out - rho_in))   (:247, scf_solvers.jl:85-98)
             t = time.time()
             pf = self.mixing.mix_density(basis, drho, eF=nxt["eF"], eigenvalues=nxt["eigenvalues"], psi=nxt["psi"],
-                                         occupation=nxt["occupation"], rho_in=self.rho_in)
+                                         occupation=nxt["occupation"], rho_in=self.rho_in, ldos=nxt.get("rho_extra"))
             self.rho_in = self.accel(self.rho_in, self.damping, pf)
             lap("mixing", t)
         info["timers"] = timers

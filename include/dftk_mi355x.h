@@ -248,6 +248,12 @@ int dftk_mi_lobpcg_multi(int n_kblocks, dftk_mi_kblock* const* kbs, int M, dftk_
 int dftk_mi_density_accumulate_multi(int n_kblocks, dftk_mi_kblock* const* kbs, const int* n_bands,
                                      const dftk_mi_cplx* const* psi_d, const int64_t* ld_psi, const double* weights_h,
                                      double* rho_d);
+/* The same with a SECOND weight set and a second cube accumulated in the same pass: rho2_d += sum_k sum_n weights2[k][n]
+ * |ifft psi_kn|^2 -- compute_density and compute_ldos (src/postprocess/dos.jl:43-62: "compute_density with modified weights")
+ * of an SCF step with LdosMixing transform every band once instead of twice.  weights2_h / rho2_d both NULL = the call above. */
+int dftk_mi_density_accumulate_multi2(int n_kblocks, dftk_mi_kblock* const* kbs, const int* n_bands,
+                                      const dftk_mi_cplx* const* psi_d, const int64_t* ld_psi, const double* weights_h,
+                                      double* rho_d, const double* weights2_h, double* rho2_d);
 /* Kinetic energy of every band of n k-blocks in one call: out_h = sum_G kin_G |psi_Gn|^2 for the bands of k-block 0,
  * then of k-block 1, ... (the band terms of the Kinetic energy, src/terms/kinetic.jl:49-54).  One basis handle. */
 int dftk_mi_band_kinetic_multi(int n_kblocks, dftk_mi_kblock* const* kbs, const int* n_bands,

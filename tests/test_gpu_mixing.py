@@ -234,3 +234,41 @@ def test_step_sums_one_kernel_one_fetch(state, monkeypatch):
     monkeypatch.setenv("DFTK_MI_TORCH_LOCAL", "1")
     assert st._step_sums(rho_out, v_in, rho_in) is None
     monkeypatch.delenv("DFTK_MI_TORCH_LOCAL", raising=False)
+
+
+def test_density_and_ldos_in_one_pass(state):
+    """``dftk_mi_density_accumulate_multi2``: compute_density and compute_ldos (dos.jl:43-62, "compute_density with modified
+    weights") of the same orbitals from ONE pass over the bands -- both cubes equal to those of the two separate passes
+    (same kernels, same order of the bands: 1e-14 relative) and to the oracle's; the hand-over to the chi0 mixing gives the same
+    preconditioned residual as the mixing's own LDOS pass."""
+    s = state
+    db, ob = s["db"], s["ob"]
+    from oracle import mixing as om
+    assert db.kbatch, "the fixture's k-mesh must take the batched multi-k pipeline"
+    occ, _ = dftk.compute_occupation(db, s["lam"])
+    mix = dftk.LdosMixing()
+    extra = mix.extra_density_weights(db, s["lam"], s["eF"], s["dpsi"])
+    assert extra is not None
+    rho, ldos = dftk.compute_density(db, s["dpsi"], occ, 1e-6, extra_weights=extra[0], extra_threshold=extra[1])
+    rho_1 = dftk.compute_density(db, s["dpsi"], occ, 1e-6)
+    sm, T = dftk.mixing.default_smearing_temperature(db.model)
+    ldos_1 = dftk.compute_ldos(s["eF"], db, s["lam"], s["dpsi"], sm, T)
+    assert float((rho - rho_1).abs().max()) < 1e-14 * float(rho_1.abs().max())
+    assert float((ldos - ldos_1).abs().max()) < 1e-14 * float(ldos_1.abs().max())
+    l0 = om.compute_ldos(s["eF"], ob, s["lam"], s["psi"], sm, T)
+    assert np.linalg.norm(ldos.cpu().numpy() - l0) < 1e-12 * np.linalg.norm(l0)
+    a = mix.mix_density(db, s["dFd"], eF=s["eF"], eigenvalues=s["lam"], psi=s["dpsi"], ldos=ldos)
+    b = mix.mix_density(db, s["dFd"], eF=s["eF"], eigenvalues=s["lam"], psi=s["dpsi"])
+    assert float((a - b).abs().max()) < 1e-12 * float(b.abs().max())
+    # argument checks of the entry point: second weights without a second cube (and vice versa), one cube for both
+    import ctypes as C
+    kbs = (C.c_void_p * 1)(db.kpoints[0].handle.value)
+    nbs = (C.c_int * 1)(1)
+    pp = (C.c_void_p * 1)(s["dpsi"][0].data_ptr())
+    ld = (C.c_int64 * 1)(s["dpsi"][0].stride(0))
+    w = np.ones(1)
+    r = torch.zeros_like(rho)
+    assert db.lib.dftk_mi_density_accumulate_multi2(1, kbs, nbs, pp, ld, w.ctypes.data, r.data_ptr(), w.ctypes.data, None) != 0
+    assert db.lib.dftk_mi_density_accumulate_multi2(1, kbs, nbs, pp, ld, w.ctypes.data, r.data_ptr(), None, r.data_ptr()) != 0
+    assert db.lib.dftk_mi_density_accumulate_multi2(1, kbs, nbs, pp, ld, w.ctypes.data, r.data_ptr(), w.ctypes.data,
+                                                    r.data_ptr()) != 0

@@ -1121,12 +1121,16 @@ static bool axis_generic(const FftAxis& ax) {
 // register-resident variants of stages B and D ran at exactly their speed (113.8 vs 112.9, 144.5 vs 141.4 us per launch).  DFTK_MI_FFT_REG=0 keeps the LDS-pass kernels everywhere, DFTK_MI_FFT_REG_MIN=n (default 64)
 // is the shortest axis they take (below that a tile has fewer than 64 threads).  The launchers return 1 if not applicable.
 #define REG_SIZES(X)                                                                                                      \
+    X(24, 2, 2, 3, 2) X(27, 3, 3, 3, 1) X(30, 5, 1, 3, 2) X(32, 2, 2, 4, 2) X(36, 3, 2, 3, 2) X(40, 2, 2, 5, 2) X(48, 3, 2, 4, 2) X(54, 3, 2, 3, 3)           \
+    X(45, 3, 3, 5, 1) X(50, 5, 2, 5, 1) X(60, 3, 2, 5, 2)                                                                 \
     X(64, 4, 2, 4, 2) X(72, 3, 3, 4, 2) X(80, 5, 2, 4, 2) X(90, 5, 2, 3, 3) X(96, 4, 3, 4, 2) X(100, 5, 2, 5, 2)          \
     X(108, 4, 3, 3, 3) X(120, 4, 3, 5, 2) X(128, 4, 4, 4, 2) X(144, 4, 3, 4, 3) X(150, 5, 3, 5, 2) X(160, 4, 4, 5, 2)     \
     X(180, 5, 3, 4, 3) X(192, 4, 4, 4, 3) X(200, 5, 4, 5, 2) X(216, 6, 3, 4, 3) X(240, 4, 4, 5, 3) X(256, 4, 4, 4, 4)
 static bool fft_reg_on(int n) {
     static const bool off = getenv("DFTK_MI_FFT_REG") != nullptr && atoi(getenv("DFTK_MI_FFT_REG")) == 0;
-    static const int nmin = getenv("DFTK_MI_FFT_REG_MIN") ? atoi(getenv("DFTK_MI_FFT_REG_MIN")) : 64;
+    // (round 6: the factorisations of 24 ... 60 were added for the cubes of the k-point workloads -- 36^3 of the Al cell:
+    //  stage C of 432 bands 280 -> ~150 us, 56 -> 63 SCF it/s; the default threshold was 64)
+    static const int nmin = getenv("DFTK_MI_FFT_REG_MIN") ? atoi(getenv("DFTK_MI_FFT_REG_MIN")) : 24;
     return !off && n >= nmin;
 }
 // the z kernels address a band's T2 slab, the potential and the density cube with 32-bit byte offsets from a tile origin

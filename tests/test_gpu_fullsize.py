@@ -191,7 +191,7 @@ def test_cfg5_apply_H_and_density():
 
 
 # ---- register-resident z kernels (fft_kernels.hip, FourStep): every instantiated axis length n = R1 R2 on a small cell
-@pytest.mark.parametrize("nz", [64, 72, 80, 90, 96, 100, 108, 120, 128, 144, 150, 160, 180, 192, 200, 216, 240, 256])
+@pytest.mark.parametrize("nz", [24, 27, 30, 32, 36, 40, 45, 48, 50, 54, 60, 64, 72, 80, 90, 96, 100, 108, 120, 128, 144, 150, 160, 180, 192, 200, 216, 240, 256])
 def test_register_resident_z_kernels_match_dense_cube_restatement(nz):
     """Local H psi (stages A-E with the fused potential) and the density of random sphere vectors on a (24, 30, nz) cube
     for every instantiated four-step factorisation of nz, against torch.fft on the dense cube.  The sphere (Ecut 5 on

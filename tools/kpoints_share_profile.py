@@ -2,7 +2,7 @@
 """Where ONE RANK'S SHARE of a k-point workload spends an SCF step (the floor of k-point strong scaling): the first
 ceil(n_k / N) irreducible k-points of BASELINE configs[2] (Al fcc PBE, Ecut 40, 12^3 mesh) as a self-consistent problem of
 its own, host timers of the stepper per phase (median over late steps) and, with --torch-profile, the top host-side ops.
-python tools/kpoints_share_profile.py [N = 8] [--torch-profile]"""
+python tools/kpoints_share_profile.py [N = 8] [--torch-profile] [--no-phase-timers] [--steps 12]"""
 import os
 import sys
 import time
@@ -28,14 +28,15 @@ os.environ["DFTK_MI_KBATCH"] = "1"
 sub = dftk.PlaneWaveBasis(model, 40.0, dftk.ExplicitKpoints(kc, list(kw / kw.sum())), fft_size=full.fft_size)
 st = dftk.ScfStepper(sub, tol=1e-12, phase_timers="--no-phase-timers" not in sys.argv)
 walls, timers = [], []
-for i in range(12):
+n_steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 12
+for i in range(n_steps):
     torch.cuda.synchronize()
     t0 = time.time()
     info = st.step()
     torch.cuda.synchronize()
     walls.append(time.time() - t0)
     timers.append(dict(info["timers"]))
-late = slice(4, None)
+late = slice(min(4, n_steps - 1), None)
 print(f"{n_loc} of {n_k} k-points (N = {N}), fft {sub.fft_size}, kbatch={sub.kbatch}: median late step {1e3 * np.median(walls[late]):.2f} ms "
       f"(all: {[round(1e3 * w, 2) for w in walls]})")
 for k in timers[-1]:

@@ -234,10 +234,14 @@ def interpolate_kpoint(data_in: torch.Tensor, kpoint_in, kpoint_out) -> torch.Te
 
 def _chain_width(basis) -> int:
     """How many k-points start from random orbitals when no guess is given; k-point ik > width interpolates the solution
-    of k-point ik - width (the reference: width 1, diag.jl:39-42; here the number of concurrent lanes, or the same 16
-    when the k loop is one batched library call)."""
+    of k-point ik - width (the reference: width 1, diag.jl:39-42; here the number of concurrent lanes, or -- when the k loop
+    is one batched library call -- half of the local k-points, at least 16)."""
     if getattr(basis, "kbatch", False) and basis.n_lanes == 1:
-        return max(1, int(os.environ.get("DFTK_MI_KBATCH_CHAIN", "16")))
+        # at most two waves, at least 16 k-points wide: a wave costs (iterations of its slowest k-point) x (one lock-step
+        # round), and a round is latency, not throughput, up to dozens of k-points -- Al 72 k-points, first SCF step:
+        # 57 / 46 / 42 / 39 / 45 ms at widths 8 / 16 / 24 / 36 / 72 (more random starts cost iterations, fewer waves save rounds)
+        default = max(16, -(-len(basis.kpoints) // 2))
+        return max(1, int(os.environ.get("DFTK_MI_KBATCH_CHAIN", str(default))))
     return basis.n_lanes
 
 

@@ -1063,7 +1063,8 @@ def test_four_step_z_pass_index_maps(size):
     Every instantiated length against numpy.fft, with a pruned input (sphere planes only) as the kernel sees it."""
     n, R1A, R1B, R2A, R2B = size
     R1, R2 = R1A * R1B, R2A * R2B
-    assert R1 * R2 == n and R1 >= R2 and all(2 <= r <= 6 for r in (R1A, R1B, R2A, R2B))
+    # (round 6: the small cubes of the k-point workloads added lengths with R1 < R2 and single-factor radices, R?B = 1)
+    assert R1 * R2 == n and all(2 <= r <= 6 for r in (R1A, R2A)) and all(1 <= r <= 6 for r in (R1B, R2B))
     assert 8 * max(R1, R2) <= 1024                                  # threads of a tile
     rng = np.random.default_rng(n)
     z_lo, nzx = n // 4 + 1, 2 * (n // 4) + 1                        # planes {0..z_lo-1} u {n-(nzx-z_lo)..n-1}

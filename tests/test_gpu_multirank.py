@@ -10,6 +10,8 @@ import sys
 import numpy as np
 import pytest
 
+from conftest import free_port  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
@@ -81,7 +83,7 @@ def test_two_ranks_one_gpu_scf_equals_single_rank(tmp_path):
     assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    port = str(31000 + os.getpid() % 2000)
+    port = free_port()
     base = dict(os.environ, WORLD_SIZE="2", PORT=port, REPO=ROOT, MASTER_ADDR="127.0.0.1",
                 KCOORDS=json.dumps(KCOORDS), KWEIGHTS=json.dumps(KWEIGHTS))
     outs = _spawn([([sys.executable, str(script)], dict(base, RANK=str(r))) for r in range(2)])
@@ -103,7 +105,7 @@ def test_two_ranks_one_gpu_scf_equals_single_rank(tmp_path):
 
 
 def _run_bench(extra, port_base):
-    port = str(port_base + os.getpid() % 2000)
+    port = free_port()
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"] + extra
     base = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
                 DFTK_MI_BENCH_BACKEND="gloo", DFTK_MI_BENCH_DEVICE="0")
@@ -218,7 +220,7 @@ def test_planewave_sharded_block_two_ranks_one_gpu(tmp_path):
     assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
     script = tmp_path / "pw_worker.py"
     script.write_text(PW_WORKER)
-    port = str(37000 + os.getpid() % 2000)
+    port = free_port()
     out_prefix = str(tmp_path / "pw")
     base = dict(os.environ, WORLD_SIZE="2", PORT=port, REPO=ROOT, MASTER_ADDR="127.0.0.1", OUT=out_prefix)
     outs = _spawn([([sys.executable, str(script)], dict(base, RANK=str(r))) for r in range(2)])

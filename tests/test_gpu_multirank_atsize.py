@@ -18,6 +18,8 @@ import sys
 import numpy as np
 import pytest
 
+from conftest import free_port  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
@@ -75,7 +77,7 @@ def test_cfg5_planewave_sharded_at_size_n_ranks_one_gpu(tmp_path, n_ranks):
     assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
     script = tmp_path / "cfg5_worker.py"
     script.write_text(CFG5_WORKER)
-    port = str(41000 + (os.getpid() + 7 * n_ranks) % 2000)
+    port = free_port()
     out_prefix = str(tmp_path / "c5")
     base = dict(os.environ, WORLD_SIZE=str(n_ranks), PORT=port, REPO=ROOT, MASTER_ADDR="127.0.0.1", OUT=out_prefix,
                 N_BANDS=str(N_BANDS), N_ITER=str(N_LOBPCG_ITER))
@@ -169,7 +171,7 @@ def test_cfg3_full_72_kpoints_two_ranks_one_gpu_equals_oracle(tmp_path):
         g = json.load(fh)
     script = tmp_path / "cfg3_worker.py"
     script.write_text(CFG3_WORKER)
-    port = str(43000 + os.getpid() % 2000)
+    port = free_port()
     base = dict(os.environ, WORLD_SIZE="2", PORT=port, REPO=ROOT, MASTER_ADDR="127.0.0.1", GOLDEN=gpath)
     outs = _spawn([([sys.executable, str(script)], dict(base, RANK=str(r))) for r in range(2)], timeout=900.0)
     got = json.loads([ln for ln in outs[0].splitlines() if ln.startswith("RESULT ")][-1][len("RESULT "):])

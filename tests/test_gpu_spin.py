@@ -6,6 +6,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from conftest import free_port  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
@@ -199,7 +201,7 @@ def test_collinear_spin_with_kpoints_split_over_two_ranks_equals_single_rank(tmp
     from tests.test_gpu_multirank import ROOT, _spawn
     script = tmp_path / "spin_worker.py"
     script.write_text(SPIN_WORKER)
-    port = str(35000 + os.getpid() % 2000)
+    port = free_port()
     base = dict(os.environ, WORLD_SIZE="2", PORT=port, REPO=ROOT, MASTER_ADDR="127.0.0.1")
     outs = _spawn([([sys.executable, str(script)], dict(base, RANK=str(r))) for r in range(2)])
     got = json.loads([ln for ln in outs[0].splitlines() if ln.startswith("RESULT ")][-1][len("RESULT "):])

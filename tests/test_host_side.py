@@ -10,6 +10,8 @@ import sys
 
 import numpy as np
 import pytest
+
+from conftest import free_port  # noqa: E402
 import torch
 
 import dftk_jl_amd as dftk
@@ -296,7 +298,7 @@ def test_kpoint_sharding_gloo_world2(tmp_path):
     """N > 1 path on CPU: 2 ranks over gloo (k-point split, weights, reductions, Fermi level)."""
     script = tmp_path / "worker.py"
     script.write_text(GLOO_WORKER)
-    port = str(29500 + os.getpid() % 2000)
+    port = free_port()
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", PORT=port, REPO=ROOT, MASTER_ADDR="127.0.0.1")
@@ -895,7 +897,7 @@ def test_host_staged_communicator_callbacks_gloo_world2(tmp_path):
     sharded block reduces and transposes through when the process group is not nccl) with 2 ranks on the CPU."""
     script = tmp_path / "pw_worker.py"
     script.write_text(PW_GLOO_WORKER)
-    port = str(27500 + os.getpid() % 2000)
+    port = free_port()
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", PORT=port, REPO=ROOT, MASTER_ADDR="127.0.0.1")

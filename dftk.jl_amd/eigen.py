@@ -234,13 +234,21 @@ def interpolate_kpoint(data_in: torch.Tensor, kpoint_in, kpoint_out) -> torch.Te
 
 def _chain_width(basis) -> int:
     """How many k-points start from random orbitals when no guess is given; k-point ik > width interpolates the solution
-    of k-point ik - width (the reference: width 1, diag.jl:39-42; here the number of concurrent lanes, or -- when the k loop
-    is one batched library call -- half of the local k-points, at least 16)."""
+    of an already solved k-point (the reference: the previous one, diag.jl:39-42; here the k-point of the same lane, or -- when
+    the k loop is one batched library call -- the nearest k-point of a small first wave, see diagonalize_all_kblocks)."""
     if getattr(basis, "kbatch", False) and basis.n_lanes == 1:
         # at most two waves, at least 16 k-points wide: a wave costs (iterations of its slowest k-point) x (one lock-step
         # round), and a round is latency, not throughput, up to dozens of k-points -- Al 72 k-points, first SCF step:
         # 57 / 46 / 42 / 39 / 45 ms at widths 8 / 16 / 24 / 36 / 72 (more random starts cost iterations, fewer waves save rounds)
-        default = max(16, -(-len(basis.kpoints) // 2))
+        n_k = len(basis.kpoints)
+        if os.environ.get("DFTK_MI_KBATCH_WAVES", "two") == "equal":
+            default = max(16, -(-n_k // 2))
+        else:
+            # two waves (a few k-points spread over the mesh from random orbitals, then all the others from their nearest
+            # solved neighbour) pay from a few dozen k-points on: Al 72 k-points, first step 39 ms (two equal waves of 36) ->
+            # 25-27 ms at 1 ... 6 first-wave k-points (4.0-4.8 instead of 7.3 LOBPCG iterations per k-point); 8 / 12 k-points
+            # (Si, graphene) are faster as ONE wave of random starts (277 vs 258-288, 75 vs 68-70 SCF it/s)
+            default = n_k if n_k <= 24 else max(4, n_k // 16)
         return max(1, int(os.environ.get("DFTK_MI_KBATCH_CHAIN", str(default))))
     return basis.n_lanes
 
@@ -253,7 +261,18 @@ def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None
     local k-points run concurrently on the basis' stream lanes, so "previous" means the previous k-point of the same
     lane (identical to the reference for ``n_lanes = 1``); the first k-point of every lane starts from random
     orbitals."""
+    # k-points that start from random orbitals when no guess is given (the others interpolate): the first W of the k loop, or --
+    # batched small blocks, two waves -- W k-points SPREAD over the list, so that every other k-point has a solved neighbour
     guesses = []
+    basis_ = ham[0].basis if ham else None
+    W_ = _chain_width(basis_) if ham else 1
+    two_waves = (bool(ham) and eigensolver is lobpcg_hyper and getattr(basis_, "kbatch", False) and basis_.n_lanes == 1
+                 and os.environ.get("DFTK_MI_KBATCH_WAVES", "two") != "equal")
+    if two_waves and len(ham) > W_:
+        first_set = sorted({int(i * len(ham) / W_) for i in range(W_)})
+    else:
+        first_set = list(range(min(W_, len(ham))))
+    in_first = set(first_set)
     for ik, Hk in enumerate(ham):                 # start vectors first, in k order: one deterministic RNG stream
         kpt, basis = Hk.kpoint, Hk.basis
         if kpt.n_G < nev_per_kpoint:
@@ -268,7 +287,7 @@ def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None
             elif g.shape[0] < nev_per_kpoint:
                 extra = random_orbitals(basis, kpt, nev_per_kpoint - g.shape[0], generator)
                 g = torch.cat([g, extra * np.sqrt(2 * kpt.n_G)], dim=0)
-        elif interpolate_kpoints and ik >= _chain_width(basis) and basis.comm_pw.size == 1:
+        elif interpolate_kpoints and ik not in in_first and basis.comm_pw.size == 1:
             g = None                                   # filled in by the lane from its previous k-point
         else:
             g = random_orbitals(basis, kpt, nev_per_kpoint, generator)
@@ -284,11 +303,27 @@ def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None
         # k-point ik - W like the lanes of the non-batched path (W = _chain_width), i.e. waves of W k-points.
         W = _chain_width(basis0)
         results = [None] * len(ham)
-        for w0 in range(0, len(ham), W if any(g is None for g in guesses) else len(ham)):
-            wave = list(range(w0, min(len(ham), w0 + (W if any(g is None for g in guesses) else len(ham)))))
+        # waves: [0, W) from random orbitals, then ALL the others at once, each from the interpolated solution of the NEAREST
+        # k-point of the first wave (DFTK_MI_KBATCH_WAVES=equal: waves of W, k-point ik from k-point ik - W, as before round 6)
+        no_guess = any(g is None for g in guesses)
+        equal_waves = os.environ.get("DFTK_MI_KBATCH_WAVES", "two") == "equal"
+        if not no_guess:
+            waves = [list(range(len(ham)))]
+        elif equal_waves:
+            waves = [list(range(w0, min(len(ham), w0 + W))) for w0 in range(0, len(ham), W)]
+        else:
+            waves = [first_set] + ([[ik for ik in range(len(ham)) if ik not in in_first]] if len(ham) > len(first_set) else [])
+        first = np.array([np.asarray(ham[i].kpoint.coordinate, dtype=float) for i in first_set])
+        for wave in waves:
             for ik in wave:
                 if guesses[ik] is None:
-                    guesses[ik] = interpolate_kpoint(results[ik - W].X, ham[ik - W].kpoint, ham[ik].kpoint)
+                    if equal_waves:
+                        src = ik - W
+                    else:      # nearest solved k-point (fractional coordinates, periodic images)
+                        d = first - np.asarray(ham[ik].kpoint.coordinate, dtype=float)[None, :]
+                        d -= np.round(d)
+                        src = first_set[int(np.argmin((d * d).sum(axis=1)))]
+                    guesses[ik] = interpolate_kpoint(results[src].X, ham[src].kpoint, ham[ik].kpoint)
             multi = [ik for ik in wave if not getattr(ham[ik].kpoint, "gamma_real", False)]
             if len(multi) > 1:
                 out = lobpcg_hyper_multi([ham[ik] for ik in multi], [guesses[ik] for ik in multi], maxiter=maxiter,

@@ -90,6 +90,8 @@ def parse():
                     help="Gamma-only modes: iterate general complex orbitals exactly as the reference does, instead of the "
                          "real-symmetric ones (psi(-G) = conj psi(G)) the library uses at k = 0 by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-random-start-leg", action="store_true",
+                    help="skip the leg that repeats the timed SCF without the two-level start (random_start_value)")
     ap.add_argument("--no-complex-leg", action="store_true",
                     help="skip the second timed SCF with general complex orbitals (config.complex_iteration)")
     ap.add_argument("--cpu-step-budget", type=float, default=100.0,
@@ -467,14 +469,14 @@ def device_late_step(dftk, basis, info, tol, diagtol):
 
 
 # ------------------------------------------------------------------------------------------ the timed SCF
-def run_scf(dftk, lib, basis, args, barrier, world, dist, torch):
+def run_scf(dftk, lib, basis, args, barrier, world, dist, torch, coarse_start=True):
     """--warmup steps on a throw-away stepper, then ONE whole self_consistent_field capped at --steps, HIP-event
     family timings switched on for the timed part.  Returns the numbers of the JSON line."""
     from dftk_jl_amd._lib import check
     if args.prof_all:
         check(lib.dftk_mi_prof_enable(basis.handle, 1))
     if args.warmup > 0:
-        warm = dftk.ScfStepper(basis, tol=args.tol)
+        warm = dftk.ScfStepper(basis, tol=args.tol, coarse_start=coarse_start)
         for _ in range(args.warmup):
             if warm.step()["converged"]:
                 break
@@ -491,8 +493,9 @@ def run_scf(dftk, lib, basis, args, barrier, world, dist, torch):
     # self_consistent_field would (the only difference: the last timed step also mixes, ~4 ms inside the timed region)
     ptol = min(PARITY_SCF_TOL, args.tol)
     stepper = dftk.ScfStepper(basis, tol=args.tol, is_converged=lambda info_: info_["history_drho"][-1] < ptol,
-                              phase_timers=(args.mode != "kpoints"))
+                              phase_timers=(args.mode != "kpoints"), coarse_start=coarse_start)
     info = None
+    nmv_coarse = 0
     for _ in range(max(args.steps, 1)):
         ts = time.time()
         info = stepper.step()
@@ -500,6 +503,7 @@ def run_scf(dftk, lib, basis, args, barrier, world, dist, torch):
         iters.append(float(np.mean(info["diagonalization"]["n_iter"])))
         diagtols.append(info["diagtol"])
         nmv_steps.append(int(info["n_matvec_step"]))
+        nmv_coarse += int(info.get("n_matvec_coarse", 0))
         for k_, v_ in info["timers"].items():
             host_timers[k_] = host_timers.get(k_, 0.0) + v_
         if os.environ.get("DFTK_MI_BENCH_STEP_TIMERS"):      # where a slow step spent its time (stderr, rank 0)
@@ -531,7 +535,7 @@ def run_scf(dftk, lib, basis, args, barrier, world, dist, torch):
     except Exception:
         shapes = []
     return dict(zgemm_shapes=shapes, info=info, elapsed=elapsed, iters=iters, diagtols=diagtols, step_s=step_s, nmv_steps=nmv_steps,
-                host_timers=host_timers, fam=fam, stepper=stepper,
+                host_timers=host_timers, fam=fam, stepper=stepper, n_matvec_coarse=nmv_coarse,
                 library_launches=counts1[0] - counts0[0], library_host_syncs=counts1[1] - counts0[1])
 
 
@@ -1082,13 +1086,37 @@ def main():
         out["config"].update(step_roofline(fam, elapsed, steps_run, run["step_s"], run["iters"]))
         out["config"]["roofline_frac_zgemm"] = round(roof["frac"], 4) if roof.get("bound") == "mfma" else None
         out["config"]["heev_ms_per_step"] = round(fam[7][0] / steps_run, 2)
+    # ---- the same iteration WITHOUT the two-level start (random orbitals in the first diagonalisation, as the reference and as
+    # rounds 1-5 of this repo): same basis, same run, same box
+    if (world == 1 and args.mode == "gamma" and not args.no_random_start_leg and getattr(basis, "coarse", None) is not None):
+        rrun = run_scf(dftk, lib, basis, args, barrier, world, dist, torch, coarse_start=False)
+        ri = rrun["info"]
+        rrun.pop("stepper", None)
+        if rank == 0:
+            out["random_start_value"] = round(ri["n_iter"] / rrun["elapsed"], 4)
+            out["random_start_unit"] = "SCF iterations/s"
+            out["config"]["random_start_value"] = out["random_start_value"]
+            out["config"]["random_start"] = {
+                "what": "the same self_consistent_field with the first diagonalisation started from random orbitals (the "
+                        "reference's start; rounds 1-5 of this repo) instead of the two-level start",
+                "value": ri["n_iter"] / rrun["elapsed"], "steps": int(ri["n_iter"]), "converged": bool(ri["converged"]),
+                "scf_wall_s": round(rrun["elapsed"], 3), "E_total": ri["energies"].total,
+                "lobpcg_iters_per_step": rrun["iters"], "step_wall_s": [round(s_, 3) for s_ in rrun["step_s"]],
+                "n_matvec": int(ri["n_matvec"])}
+            out["config"]["first_step_start"] = (
+                "two-level: LOBPCG from random orbitals on the companion basis at Ecut / 4 (its H psi applies: "
+                f"{run['n_matvec_coarse']}, counted in the timed region but not in n_matvec), zero-padded eigenvectors as start "
+                "vectors; the companion basis is built with the basis (config.setup_s)")
+        del rrun, ri
+        torch.cuda.empty_cache()
     # ---- the reference's own iteration (general complex orbitals) on the same cell, same run, same box
     if (world == 1 and args.mode == "gamma" and not args.no_gamma_real and not args.no_complex_leg
             and bool(getattr(basis.kpoints[0], "gamma_real", False))):
-        cbasis = dftk.PlaneWaveBasis(model, ecut, dftk.MonkhorstPack((1, 1, 1)), device=device, gamma_real=False)
+        cbasis = dftk.PlaneWaveBasis(model, ecut, dftk.MonkhorstPack((1, 1, 1)), device=device, gamma_real=False,
+                                     coarse_start=False)       # the reference's algorithm in full: random start orbitals
         run.pop("stepper", None)                     # (the real leg's orbitals and LOBPCG workspace are not needed any more)
         torch.cuda.empty_cache()
-        crun = run_scf(dftk, lib, cbasis, args, barrier, world, dist, torch)
+        crun = run_scf(dftk, lib, cbasis, args, barrier, world, dist, torch, coarse_start=False)
         ci = crun["info"]
         if parity is not None:
             cpar = continue_to_parity(crun["stepper"])
@@ -1118,7 +1146,10 @@ def main():
         # `value` is the real-symmetric Gamma iteration, an extension the reference does not have
         out["complex_iteration_value"] = round(ci["n_iter"] / crun["elapsed"], 4)
         out["complex_iteration_unit"] = "SCF iterations/s"
-        out["value_algorithm"] = "real-symmetric Gamma orbitals (extension); complex_iteration_value = the reference's iteration"
+        out["value_algorithm"] = ("real-symmetric Gamma orbitals" + (" + two-level start of the first diagonalisation" if
+                                  getattr(basis, "coarse", None) is not None else "") + " (extensions); random_start_value = "
+                                  "the same from random orbitals; complex_iteration_value = the reference's iteration "
+                                  "(general complex orbitals, random start)")
         out["config"]["complex_iteration_frac"] = round(croof["frac"], 4)
         out["config"]["complex_iteration_steps"] = int(ci["n_iter"])
         del crun, ci, cbasis

@@ -146,6 +146,9 @@ class Kpoint:
             pass
 
 
+COARSE_ECUT_RATIO = 0.25      # companion basis of the two-level start: Ecut / 4 = half the sphere radius, 1 / 8 of the plane waves
+
+
 class PlaneWaveBasis:
     """``PlaneWaveBasis(model; Ecut, kgrid, fft_size, architecture=GPU, comm_kpts)``.
 
@@ -158,7 +161,8 @@ class PlaneWaveBasis:
 
     def __init__(self, model: Model, Ecut: float, kgrid=None, fft_size=None, device="cuda",
                  comm_kpts: KptComm | None = None, build_terms=True, comm_pw: KptComm | None = None,
-                 use_symmetries_for_kpoint_reduction=True, n_lanes: int | None = None, gamma_real: bool | None = None):
+                 use_symmetries_for_kpoint_reduction=True, n_lanes: int | None = None, gamma_real: bool | None = None,
+                 coarse_start: bool | None = None):
         from . import symmetry as _sym
         # gamma_real: None = automatic at k = 0 (env DFTK_MI_GAMMA_REAL=0 switches it off), True = required, False = off
         if gamma_real is None and os.environ.get("DFTK_MI_GAMMA_REAL", "1") == "0":
@@ -282,6 +286,20 @@ class PlaneWaveBasis:
         if build_terms:
             from .terms import instantiate_terms
             self.terms = instantiate_terms(self)
+        # Two-level start of the FIRST diagonalisation (an extension; DFTK_MI_COARSE_START=0 or coarse_start=False switch it
+        # off): a companion basis at Ecut / 4 (half the cube) on which the first Hamiltonian is solved from random orbitals,
+        # its eigenvectors zero-padded into this basis as start vectors (eigen.py: diagonalize_all_kblocks).  For the large
+        # k-blocks only -- the 1000-electron cell: 15-16 LOBPCG iterations from random orbitals (1.2 s, 27 % of a 20-step
+        # SCF) become 12 coarse ones (0.25 s) + 3 fine ones (0.35 s); small k-blocks are latency-bound and batch instead.
+        self.coarse = None
+        if coarse_start is None:
+            coarse_start = (os.environ.get("DFTK_MI_COARSE_START", "1") != "0" and build_terms and self.handle is not None
+                            and not self.kbatch and self.comm_pw.size == 1 and min(self.fft_size) >= 96
+                            and model.n_spin_components == 1)
+        if coarse_start:
+            self.coarse = PlaneWaveBasis(model, self.Ecut * COARSE_ECUT_RATIO, ExplicitKpoints([list(k) for k in kc], list(kw)),
+                                         device=self.device, build_terms=True, n_lanes=self.n_lanes,
+                                         gamma_real=self.gamma_real, coarse_start=False)
 
     # ---- grids ---------------------------------------------------------------------------
     def G_vectors_cube(self):

@@ -232,6 +232,59 @@ def interpolate_kpoint(data_in: torch.Tensor, kpoint_in, kpoint_out) -> torch.Te
     return out
 
 
+def lowpass_to_coarse(basis, coarse, f: torch.Tensor) -> torch.Tensor:
+    """A real cube of ``basis`` on the (smaller) cube of ``coarse`` by Fourier truncation: the coefficients of the plane waves
+    the coarse cube represents (|g_i| < n_i / 2; the unpaired Nyquist planes are dropped) through the library's cube FFTs."""
+    fG = basis.fft(f)
+    nx, ny, nz = basis.fft_size
+    cx, cy, cz = coarse.fft_size
+    dev = f.device
+
+    def axis(nc, nf):
+        g = torch.arange(nc, device=dev)
+        g = torch.where(g < (nc + 1) // 2, g, g - nc)               # frequency of coarse index
+        keep = (2 * g.abs() < nc) if nc % 2 == 0 else torch.ones_like(g, dtype=torch.bool)
+        return g % nf, keep
+    ix, kx = axis(cx, nx)
+    iy, ky = axis(cy, ny)
+    iz, kz = axis(cz, nz)
+    out = fG[iz[:, None, None], iy[None, :, None], ix[None, None, :]]
+    out = out * (kz[:, None, None] & ky[None, :, None] & kx[None, None, :])
+    return coarse.irfft(out.contiguous())
+
+
+def zero_pad_to_fine(X_coarse: torch.Tensor, kpt_c, kpt_f, basis_f) -> torch.Tensor:
+    """Coefficients on the coarse sphere -> the fine sphere of the same k-point (zero elsewhere), matched by integer G."""
+    nx, ny, nz = basis_f.fft_size
+    inv = getattr(kpt_f, "_inv_mapping", None)
+    if inv is None:
+        inv = torch.full((nx * ny * nz,), -1, dtype=torch.int32, device=X_coarse.device)
+        inv[kpt_f.mapping_device] = torch.arange(kpt_f.n_G, dtype=torch.int32, device=X_coarse.device)
+        kpt_f._inv_mapping = inv
+    G = kpt_c.G_vectors
+    lin = (G[:, 0] % nx) + nx * ((G[:, 1] % ny) + ny * (G[:, 2] % nz))
+    pos = inv[lin].to(torch.int64)
+    if bool((pos < 0).any()):
+        raise RuntimeError("two-level start: the coarse sphere is not contained in the fine one")
+    out = torch.zeros((X_coarse.shape[0], kpt_f.n_G), dtype=X_coarse.dtype, device=X_coarse.device)
+    out[:, pos] = X_coarse
+    return out
+
+
+def _coarse_start_vectors(eigensolver, Hk, ik, nev, prec_type, tol, miniter, maxiter, n_conv_check, generator, seed):
+    """Start vectors of the two-level start for one k-point: LOBPCG from random orbitals on the companion basis (the SAME
+    potential, Fourier-truncated), zero-padded into the fine sphere.  Returns (X, n_matvec on the coarse basis)."""
+    basis = Hk.basis
+    coarse = basis.coarse
+    kc = coarse.kpoints[ik]
+    Vc = lowpass_to_coarse(basis, coarse, Hk.potential)
+    Hc = DftHamiltonianBlock(coarse, kc, Vc)
+    g = random_orbitals(coarse, kc, nev, generator)
+    rc = eigensolver(Hc, g, prec=prec_type(Hc) if prec_type is not None else None, tol=tol, miniter=miniter, maxiter=maxiter,
+                     n_conv_check=n_conv_check, seed=seed + ik)
+    return zero_pad_to_fine(rc.X, kc, Hk.kpoint, basis), int(rc.n_matvec)
+
+
 def _chain_width(basis) -> int:
     """How many k-points start from random orbitals when no guess is given; k-point ik > width interpolates the solution
     of an already solved k-point (the reference: the previous one, diag.jl:39-42; here the k-point of the same lane, or -- when
@@ -255,12 +308,14 @@ def _chain_width(basis) -> int:
 
 def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None, prec_type=PreconditionerTPA,
                             tol: float = 1e-6, miniter: int = 1, maxiter: int = 100, n_conv_check=None,
-                            generator: torch.Generator | None = None, seed: int = 0, interpolate_kpoints: bool = True):
+                            generator: torch.Generator | None = None, seed: int = 0, interpolate_kpoints: bool = True,
+                            coarse_start: bool = True):
     """diag.jl:9-65.  ``interpolate_kpoints`` (default true as the reference): without a guess, a k-point starts
     from the interpolated solution of the PREVIOUS k-point (:39-42).  The reference's k loop is sequential; here the
     local k-points run concurrently on the basis' stream lanes, so "previous" means the previous k-point of the same
     lane (identical to the reference for ``n_lanes = 1``); the first k-point of every lane starts from random
-    orbitals."""
+    orbitals.  ``coarse_start`` (an extension, used when the basis carries a companion basis ``basis.coarse``): a k-point without
+    a guess is first solved on the companion basis at Ecut / 4 from random orbitals, the result zero-padded into its sphere."""
     # k-points that start from random orbitals when no guess is given (the others interpolate): the first W of the k loop, or --
     # batched small blocks, two waves -- W k-points SPREAD over the list, so that every other k-point has a solved neighbour
     guesses = []
@@ -273,6 +328,7 @@ def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None
     else:
         first_set = list(range(min(W_, len(ham))))
     in_first = set(first_set)
+    n_matvec_coarse = 0
     for ik, Hk in enumerate(ham):                 # start vectors first, in k order: one deterministic RNG stream
         kpt, basis = Hk.kpoint, Hk.basis
         if kpt.n_G < nev_per_kpoint:
@@ -289,6 +345,12 @@ def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None
                 g = torch.cat([g, extra * np.sqrt(2 * kpt.n_G)], dim=0)
         elif interpolate_kpoints and ik not in in_first and basis.comm_pw.size == 1:
             g = None                                   # filled in by the lane from its previous k-point
+        elif (coarse_start and getattr(basis, "coarse", None) is not None and eigensolver is lobpcg_hyper and basis.comm_pw.size == 1
+              and kpt.spin == 1 and getattr(Hk, "potential", None) is not None and kpt.n_G >= 8 * nev_per_kpoint):
+            # two-level start: solve on the companion basis first (counted in n_matvec_coarse, inside the caller's timing)
+            g, nmv_c = _coarse_start_vectors(eigensolver, Hk, ik, nev_per_kpoint, prec_type, tol, miniter, maxiter,
+                                             n_conv_check, generator, seed)
+            n_matvec_coarse += nmv_c
         else:
             g = random_orbitals(basis, kpt, nev_per_kpoint, generator)
         guesses.append(g)
@@ -340,7 +402,8 @@ def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None
         return dict(λ=[r.λ for r in results], X=[r.X for r in results],
                     residual_norms=[r.residual_norms for r in results], n_iter=[r.n_iter for r in results],
                     converged=all(r.converged for r in results), n_matvec=sum(r.n_matvec for r in results),
-                    real_symmetric=[bool(getattr(r, "real_symmetric", False)) for r in results])
+                    real_symmetric=[bool(getattr(r, "real_symmetric", False)) for r in results],
+                    n_matvec_coarse=n_matvec_coarse)
 
     done = {}
 
@@ -357,4 +420,5 @@ def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None
     return dict(λ=[r.λ for r in results], X=[r.X for r in results],
                 residual_norms=[r.residual_norms for r in results], n_iter=[r.n_iter for r in results],
                 converged=all(r.converged for r in results), n_matvec=sum(r.n_matvec for r in results),
-                real_symmetric=[bool(getattr(r, "real_symmetric", False)) for r in results])
+                real_symmetric=[bool(getattr(r, "real_symmetric", False)) for r in results],
+                n_matvec_coarse=n_matvec_coarse)

@@ -180,7 +180,7 @@ class FixedBands:
 
 
 def next_density(ham, nbandsalg, eigensolver=lobpcg_hyper, psi=None, eigenvalues=None, occupation=None,
-                 tol=1e-6, generator=None, seed=0, timers=None, extra_weights=None):
+                 tol=1e-6, generator=None, seed=0, timers=None, extra_weights=None, coarse_start=True):
     """self_consistent_field.jl:80-129.  ``extra_weights(basis, eigenvalues, eF, psi) -> (weights, threshold) | None``: a second
     set of band weights accumulated in the density pass (``rho_extra`` of the result; the stepper passes the LDOS weights of
     its mixing)."""
@@ -191,7 +191,7 @@ def next_density(ham, nbandsalg, eigensolver=lobpcg_hyper, psi=None, eigenvalues
     n_comp = int(basis.comm_kpts.max_scalar(n_comp))                       # mpi_max(n_bands_compute)
     t0 = time.time()
     eig = diagonalize_all_kblocks(eigensolver, ham, n_comp, psiguess=psi, n_conv_check=n_conv, tol=tol,
-                                  miniter=1, generator=generator, seed=seed)
+                                  miniter=1, generator=generator, seed=seed, coarse_start=coarse_start)
     t1 = time.time()
     occ, eF = compute_occupation(basis, eig["λ"], tol_n_elec=nbandsalg.occupation_threshold)
     # extra_weights (optional callback of the mixing: LdosMixing's local density of states): accumulated in the same pass
@@ -209,7 +209,8 @@ def next_density(ham, nbandsalg, eigensolver=lobpcg_hyper, psi=None, eigenvalues
         timers["occupation+density"] = timers.get("occupation+density", 0.0) + time.time() - t1
     n_matvec = int(basis.comm_kpts.sum_scalar(eig["n_matvec"]))    # (not over comm_pw: those ranks share the blocks)
     return dict(psi=eig["X"], eigenvalues=eig["λ"], occupation=occ, eF=eF, rho=rho, diagonalization=eig,
-                n_bands_converge=n_conv, n_matvec=n_matvec, rho_extra=rho_extra)
+                n_bands_converge=n_conv, n_matvec=n_matvec, rho_extra=rho_extra,
+                n_matvec_coarse=int(eig.get("n_matvec_coarse", 0)))
 
 
 # ---------------------------------------------------------------------------------- Anderson
@@ -389,9 +390,11 @@ class ScfStepper:
 
     def __init__(self, basis, rho=None, psi=None, tol=1e-6, damping=0.8, nbandsalg=None, is_converged=None,
                  eigensolver=lobpcg_hyper, anderson_m=10, seed=0, determine_tol=determine_diagtol, mixing=None,
-                 phase_timers=None):
+                 phase_timers=None, coarse_start=True):
         basis._require_gpu()
         self.basis = basis
+        # two-level start of the first diagonalisation when the basis carries a companion basis (basis.py; an extension)
+        self.coarse_start = bool(coarse_start)
         self.phase_timers = (os.environ.get("DFTK_MI_PHASE_TIMERS") is not None) if phase_timers is None else bool(phase_timers)
         # mixing = LdosMixing() as the reference (self_consistent_field.jl:177): simple mixing at T = 0
         self.mixing = mixing if mixing is not None else LdosMixing()
@@ -442,7 +445,8 @@ class ScfStepper:
         diagtol = self.determine_tol(info["n_iter"], info["history_drho"])
         nxt = next_density(ham, self.nbandsalg, self.eigensolver, psi=info["psi"], eigenvalues=info["eigenvalues"],
                            occupation=info["occupation"], tol=diagtol, generator=self.gen, seed=self.seed,
-                           timers=timers, extra_weights=getattr(self.mixing, "extra_density_weights", None))
+                           timers=timers, extra_weights=getattr(self.mixing, "extra_density_weights", None),
+                           coarse_start=self.coarse_start)
         t = time.time()
         # int V_in rho_out (Ritz-value form of the nonlocal energy) and ||rho_out - rho_in||^2 in one library call / one fetch
         ritz_pot = self._ritz_potential(ham) if self.ritz_energies else None
@@ -518,13 +522,13 @@ class ScfStepper:
 
 def self_consistent_field(basis, rho=None, psi=None, tol=1e-6, maxiter=100, damping=0.8, nbandsalg=None,
                           is_converged=None, callback=None, eigensolver=lobpcg_hyper, anderson_m=10, seed=0,
-                          determine_tol=determine_diagtol, mixing=None):
+                          determine_tol=determine_diagtol, mixing=None, coarse_start=True):
     """``self_consistent_field(basis; rho, psi, tol, maxiter, damping, nbandsalg, is_converged, callback,
     eigensolver)`` (self_consistent_field.jl:164-289)."""
     t0 = time.time()
     stepper = ScfStepper(basis, rho=rho, psi=psi, tol=tol, damping=damping, nbandsalg=nbandsalg,
                          is_converged=is_converged, eigensolver=eigensolver, anderson_m=anderson_m, seed=seed,
-                         determine_tol=determine_tol, mixing=mixing)
+                         determine_tol=determine_tol, mixing=mixing, coarse_start=coarse_start)
     for _ in range(maxiter):
         info = stepper.step()
         if callback is not None:

@@ -16,7 +16,7 @@ python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee -a $O/r0
 ./tools/bin/abi_c_check 1 2>&1 | tail -3 | tee -a $O/r06_pytest_gpu.log
 if [ "${SKIP_PMC:-0}" != "1" ]; then
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --no-complex-leg --no-parity --no-amdahl-probe --prof-all"
+ARGS="--no-cpu-baseline --no-complex-leg --no-random-start-leg --no-parity --no-amdahl-probe --prof-all"
 export DFTK_MI_HEEV_PARTIAL=0
 export PMC_NOTE="; Rayleigh-Ritz by the full Jacobi in these passes (DFTK_MI_HEEV_PARTIAL=0) so that all k_zgemm dispatches are booked zgemm calls; read back from the rocpd database (tools/rocpd_export_csv.py)"
 rm -rf /tmp/pf /tmp/pw
@@ -43,7 +43,7 @@ for f in ("r06_bench_cfg5_driver_args", "r06_bench_cfg5"):
 PY
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt
-timeout -s KILL 420 rocprofv3 --kernel-trace -d /tmp/kt -o p -- python $R/bench.py --no-cpu-baseline --no-complex-leg --no-parity --no-amdahl-probe > /tmp/bench_kt.json 2>/tmp/bench_kt.err
+timeout -s KILL 420 rocprofv3 --kernel-trace -d /tmp/kt -o p -- python $R/bench.py --no-cpu-baseline --no-complex-leg --no-random-start-leg --no-parity --no-amdahl-probe > /tmp/bench_kt.json 2>/tmp/bench_kt.err
 DB=$(ls /tmp/kt/*results.db | head -1)
 python $R/tools/rocpd_stats.py $DB 44 > $O/r06_kernel_trace_cfg5.txt
 tail -1 /tmp/bench_kt.json >> $O/r06_kernel_trace_cfg5.txt

@@ -294,12 +294,12 @@ class PlaneWaveBasis:
         self.coarse = None
         if coarse_start is None:
             coarse_start = (os.environ.get("DFTK_MI_COARSE_START", "1") != "0" and build_terms and self.handle is not None
-                            and not self.kbatch and self.comm_pw.size == 1 and min(self.fft_size) >= 96
-                            and model.n_spin_components == 1)
+                            and not self.kbatch and min(self.fft_size) >= 96 and model.n_spin_components == 1)
         if coarse_start:
             self.coarse = PlaneWaveBasis(model, self.Ecut * COARSE_ECUT_RATIO, ExplicitKpoints([list(k) for k in kc], list(kw)),
                                          device=self.device, build_terms=True, n_lanes=self.n_lanes,
-                                         gamma_real=self.gamma_real, coarse_start=False)
+                                         gamma_real=self.gamma_real, coarse_start=False,
+                                         comm_pw=self.comm_pw if self.comm_pw.size > 1 else None)
 
     # ---- grids ---------------------------------------------------------------------------
     def G_vectors_cube(self):

@@ -266,6 +266,19 @@ def zero_pad_to_fine(X_coarse: torch.Tensor, kpt_c, kpt_f, basis_f) -> torch.Ten
     pos = inv[lin].to(torch.int64)
     if bool((pos < 0).any()):
         raise RuntimeError("two-level start: the coarse sphere is not contained in the fine one")
+    pw = basis_f.comm_pw
+    if pw.size > 1:
+        # plane-wave sharded block: every rank needs the coarse rows that land in ITS slab of the fine sphere -- the slabs of
+        # the (8x smaller) coarse block are summed into the whole block on every rank (one all-reduce per SCF), then cut
+        full = torch.zeros((X_coarse.shape[0], kpt_c.n_G), dtype=X_coarse.dtype, device=X_coarse.device)
+        full[:, kpt_c.row0:kpt_c.row1] = X_coarse
+        basis_f.pre_call()
+        pw.sum_(torch.view_as_real(full).reshape(-1), basis_f.stream_ptr)
+        basis_f.post_call()
+        mine = (pos >= kpt_f.row0) & (pos < kpt_f.row1)
+        out = torch.zeros((X_coarse.shape[0], kpt_f.n_loc), dtype=X_coarse.dtype, device=X_coarse.device)
+        out[:, pos[mine] - kpt_f.row0] = full[:, mine]
+        return out
     out = torch.zeros((X_coarse.shape[0], kpt_f.n_G), dtype=X_coarse.dtype, device=X_coarse.device)
     out[:, pos] = X_coarse
     return out
@@ -345,7 +358,7 @@ def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None
                 g = torch.cat([g, extra * np.sqrt(2 * kpt.n_G)], dim=0)
         elif interpolate_kpoints and ik not in in_first and basis.comm_pw.size == 1:
             g = None                                   # filled in by the lane from its previous k-point
-        elif (coarse_start and getattr(basis, "coarse", None) is not None and eigensolver is lobpcg_hyper and basis.comm_pw.size == 1
+        elif (coarse_start and getattr(basis, "coarse", None) is not None and eigensolver is lobpcg_hyper
               and kpt.spin == 1 and getattr(Hk, "potential", None) is not None and kpt.n_G >= 8 * nev_per_kpoint):
             # two-level start: solve on the companion basis first (counted in n_matvec_coarse, inside the caller's timing)
             g, nmv_c = _coarse_start_vectors(eigensolver, Hk, ik, nev_per_kpoint, prec_type, tol, miniter, maxiter,

@@ -78,3 +78,64 @@ def test_two_level_start_needs_fewer_fine_iterations_and_converges_to_the_same_s
     assert res["two-level"][1] > 0 and res["random"][1] == 0 and res["no companion"][1] == 0
     assert res["two-level"][0] < 0.6 * res["random"][0], res            # fine LOBPCG iterations of the first step
     assert abs(res["two-level"][2] - res["random"][2]) < 1e-8 and abs(res["no companion"][2] - res["random"][2]) < 1e-8
+
+
+TWO_RANK_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, os.environ["REPO"])
+import numpy as np, torch, torch.distributed as dist
+import dftk_jl_amd as dftk
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["PORT"],
+                        rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+comm = dftk.KptComm.from_torch()
+lat, atoms, pos = dftk.silicon_cell((2, 2, 2))
+model = dftk.model_DFT(lat, atoms, pos, functionals=("lda_x", "lda_c_pw"))
+basis = dftk.PlaneWaveBasis(model, 16, dftk.MonkhorstPack((1, 1, 1)), device="cuda:0", comm_pw=comm, coarse_start=True)
+assert basis.coarse is not None and basis.coarse.comm_pw.size == 2
+st = dftk.ScfStepper(basis, tol=1e-9, seed=5)
+first = st.step()
+it1 = float(np.mean(first["diagonalization"]["n_iter"]))
+nc = int(first.get("n_matvec_coarse", 0))
+info = first
+for _ in range(60):
+    if info["converged"]:
+        break
+    info = st.step()
+fin = st.finalize()
+if comm.rank == 0:
+    print("RESULT " + json.dumps({"E": fin["energies"].total, "converged": bool(info["converged"]), "it1": it1, "nc": nc}))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_two_level_start_of_a_plane_wave_sharded_block_two_ranks_one_gpu(tmp_path):
+    """The companion basis of a plane-wave sharded basis is sharded the same way; the zero-padding sums the slabs of the coarse
+    block over the ranks and cuts this rank's slab of the fine sphere.  Two ranks on one GPU (host-staged communicator): the
+    first step takes the coarse path with as few fine iterations as the one-rank run, the converged energy is the one-rank one."""
+    import json
+    import os
+    import sys
+    from conftest import free_port
+    from test_gpu_multirank import _spawn, ROOT
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    script = tmp_path / "two_level_worker.py"
+    script.write_text(TWO_RANK_WORKER)
+    base = dict(os.environ, WORLD_SIZE="2", PORT=free_port(), REPO=ROOT, MASTER_ADDR="127.0.0.1")
+    outs = _spawn([([sys.executable, str(script)], dict(base, RANK=str(r))) for r in range(2)], timeout=900.0)
+    got = json.loads([ln for ln in outs[0].splitlines() if ln.startswith("RESULT ")][-1][len("RESULT "):])
+    assert got["converged"] and got["nc"] > 0
+    lat, atoms, pos = dftk.silicon_cell((2, 2, 2))
+    model = dftk.model_DFT(lat, atoms, pos, functionals=("lda_x", "lda_c_pw"))
+    basis = dftk.PlaneWaveBasis(model, 16, dftk.MonkhorstPack((1, 1, 1)), coarse_start=True)
+    st = dftk.ScfStepper(basis, tol=1e-9, seed=5)
+    first = st.step()
+    it1 = float(np.mean(first["diagonalization"]["n_iter"]))
+    info = first
+    for _ in range(60):
+        if info["converged"]:
+            break
+        info = st.step()
+    assert info["converged"]
+    assert got["it1"] <= it1 + 2, (got["it1"], it1)
+    assert abs(got["E"] - st.finalize()["energies"].total) < 1e-8 * 16

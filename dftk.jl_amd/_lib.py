@@ -137,6 +137,8 @@ _SIGNATURES = {
                                    C.c_double, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int),
                                    C.POINTER(C.c_int)]),
     "dftk_mi_launch_count": (C.c_int, [C.POINTER(_i64), C.POINTER(_i64)]),
+    "dftk_mi_kblock_reuse_AX": (C.c_int, [C.c_void_p, C.c_int]),
+    "dftk_mi_ax_reuse_count": (C.c_int, [C.POINTER(_i64)]),
     "dftk_mi_step_sums": (C.c_int, [C.c_void_p, _i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dftk_mi_fermi_bisection": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double,
                                           C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double)]),

@@ -507,6 +507,8 @@ extern "C" int dftk_mi_kblock_destroy(dftk_mi_kblock* kb) {
     hipSetDevice(kb->device);
     hipDeviceSynchronize();   // the basis may already be gone: never dereference it here
     release_Vs(kb);
+    if (kb->d_Vs_ax) hipFree(kb->d_Vs_ax);
+    if (kb->d_dVs) hipFree(kb->d_dVs);
     void* ptrs[] = {kb->d_cpos, kb->d_cx, kb->d_line_start, kb->d_line_ypos, kb->d_line_yval, kb->d_zls,
                     kb->d_zpos, kb->d_zval, kb->d_kin, kb->d_D, kb->lob_buf};
     for (void* p : ptrs)
@@ -1340,6 +1342,12 @@ extern "C" int dftk_mi_fermi_bisection(int n_k, const int* n_bands, const double
             hi = mid;
     }
     *eF_out = 0.5 * (lo + hi);
+    return 0;
+}
+
+extern "C" int dftk_mi_kblock_reuse_AX(dftk_mi_kblock* kb, int on) {
+    if (!kb) return DFTK_MI_EINVAL;
+    kb->ax_reuse_next = on != 0 && kb->ax_keep != nullptr;
     return 0;
 }
 

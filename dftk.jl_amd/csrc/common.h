@@ -199,6 +199,13 @@ struct dftk_mi_kblock {
     // LOBPCG workspace (owned, grown on demand)
     cd* lob_buf; size_t lob_bytes;
     cd* last_AX;
+    // A X of the last dftk_mi_lobpcg exit in the driver's own format (general driver; points into lob_buf), its shape, and the
+    // padded potential that was bound then: the next call may start from A_new X = A_old X + (V_new - V_old) X instead of a
+    // full H X (dftk_mi_kblock_reuse_AX: kinetic and nonlocal parts do not change between SCF steps)
+    cd* ax_keep; int ax_M; int64_t ax_rows; int64_t ax_ld;
+    double* d_Vs_ax;              // [nz*ny*nxp] snapshot of d_Vs at that exit (owned)
+    double* d_dVs;                // [nz*ny*nxp] scratch: V_new - V_old (owned)
+    bool ax_reuse_next;           // the caller's one-shot promise: X0 of the next call IS the X returned by the last one
     // plane-wave (row-slab) sharding of this block over a communicator (dftk_mi_kblock_set_shard): orbital blocks
     // handed to apply_H / lobpcg / density_accumulate and the projector matrix are the rows
     // [sh_rows[rank], sh_rows[rank + 1]) of the sphere; the sphere tables / potential above stay complete
@@ -272,6 +279,8 @@ int ew_tpa(dftk_mi_basis* b, int64_t n, int m, const cd* src, int64_t lds, cd* d
            const double* mean_kin_d, double* norms_d, double default_shift = 1.0);
 int ew_scale_cols(dftk_mi_basis* b, int64_t n, int m, cd* X, int64_t ldx, const double* s_d, bool invert);
 int ew_copy(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, cd* Y, int64_t ldy);
+int ew_add(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, cd* Y, int64_t ldy);          // Y += X
+int ew_sub_real(dftk_mi_basis* b, int64_t n, const double* a, const double* c, double* out);            // out = a - c
 int ew_fill_zero(dftk_mi_basis* b, cd* X, size_t count);
 int ew_sub_identity_shifted(dftk_mi_basis* b, int rows, int cols, cd* C, int64_t ldc, int row0);
 int ew_gather_cols(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, const int* perm_d,

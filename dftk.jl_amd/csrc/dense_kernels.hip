@@ -1933,6 +1933,37 @@ int ew_copy(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, cd* Y,
     HIPCHK(hipGetLastError());
     return 0;
 }
+__global__ __launch_bounds__(256) void k_add_cols(int64_t n, int m, const cd* __restrict__ X, int64_t ldx, cd* __restrict__ Y,
+                                                  int64_t ldy) {
+    const int c = blockIdx.y;
+    const cd* x = X + (int64_t)c * ldx;
+    cd* y = Y + (int64_t)c * ldy;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const cd a = x[i];
+        cd v = y[i];
+        v.x += a.x;
+        v.y += a.y;
+        y[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_sub_real(int64_t n, const double* __restrict__ a, const double* __restrict__ c,
+                                                  double* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = a[i] - c[i];
+}
+int ew_add(dftk_mi_basis* b, int64_t n, int m, const cd* X, int64_t ldx, cd* Y, int64_t ldy) {
+    if (m <= 0 || n <= 0) return 0;
+    ProfScope prof_scope(b, PROF_EW, n >= 4096 ? 48.0 * (double)n * m : 0.0);
+    hipLaunchKernelGGL(k_add_cols, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048), m), dim3(256), 0, b->stream, n, m, X, ldx,
+                       Y, ldy);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int ew_sub_real(dftk_mi_basis* b, int64_t n, const double* a, const double* c, double* out) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_sub_real, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, b->stream, n, a, c, out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 int ew_fill_zero(dftk_mi_basis* b, cd* X, size_t count) {
     if (batching()) {
         BOp o;

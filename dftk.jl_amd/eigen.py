@@ -93,7 +93,7 @@ class EigResult:
 
 
 def lobpcg_hyper(A: DftHamiltonianBlock, X0: torch.Tensor, maxiter: int = 100, prec=None, tol: float | None = None,
-                 n_conv_check: int | None = None, miniter: int = 1, seed: int = 0) -> EigResult:
+                 n_conv_check: int | None = None, miniter: int = 1, seed: int = 0, reuse_AX: bool = False) -> EigResult:
     """``lobpcg_hyper(A, X0; prec, tol, maxiter, miniter, n_conv_check)``.  X0: (M, n_G) complex128
     CUDA tensor (rows = bands); it is not modified."""
     basis = A.basis
@@ -110,6 +110,9 @@ def lobpcg_hyper(A: DftHamiltonianBlock, X0: torch.Tensor, maxiter: int = 100, p
     res = np.zeros(M)
     n_iter, conv, nmv = C.c_int(), C.c_int(), C.c_int64()
     basis.pre_call()
+    # reuse_AX: X0 IS the block the last call on this k-point returned (the orbitals of the previous SCF step): the library
+    # then starts from A_new X = A_old X inv(R) + (V_new - V_old) X instead of a full H X (dftk_mi_kblock_reuse_AX)
+    _lib.check(basis.lib.dftk_mi_kblock_reuse_AX(A.kpoint.handle, 1 if reuse_AX else 0))
     _lib.check(basis.lib.dftk_mi_lobpcg(A.kpoint.handle, M, X.data_ptr(), X.stride(0), float(tol), int(miniter),
                                         int(maxiter), int(n_conv_check or 0), 1 if prec is not None else 0,
                                         int(seed) & (2 ** 64 - 1), lam.ctypes.data, res.ctypes.data,
@@ -426,8 +429,14 @@ def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None
         if g is None:
             prev = ik - Hk.basis.n_lanes           # previous k-point of this lane (already solved: lanes run in order)
             g = interpolate_kpoint(done[prev].X, ham[prev].kpoint, Hk.kpoint)
+        kw = {}
+        if eigensolver is lobpcg_hyper and os.environ.get("DFTK_MI_AX_REUSE", "1") != "0":
+            # the guess is the very block this k-point's last solve returned (an SCF step hands the orbitals back)
+            kw["reuse_AX"] = psiguess is not None and g is psiguess[ik] and g is getattr(Hk.kpoint, "_last_X", None)
         done[ik] = eigensolver(Hk, g, prec=prec, tol=tol, miniter=miniter, maxiter=maxiter,
-                               n_conv_check=n_conv_check, seed=seed + ik)
+                               n_conv_check=n_conv_check, seed=seed + ik, **kw)
+        if eigensolver is lobpcg_hyper:
+            Hk.kpoint._last_X = done[ik].X
         return done[ik]
     results = ham[0].basis.run_on_lanes(solve, ham) if ham else []
     return dict(λ=[r.λ for r in results], X=[r.X for r in results],

@@ -276,6 +276,17 @@ int dftk_mi_lobpcg_small_stats(int64_t* calls, int64_t* restarts);
 int dftk_mi_ortho_small(dftk_mi_basis* basis, int64_t n, int m, dftk_mi_cplx* X_d, int64_t ldx, int ny, const dftk_mi_cplx* Y_d,
                         int64_t ldy, const double* norms_d, double tol, double* res4_h);
 int dftk_mi_lobpcg_history(dftk_mi_kblock* kb, int* M, int* n_iter, double* hist_h, size_t cap, int* n_svd);
+/* One-shot promise for the NEXT dftk_mi_lobpcg call on this block: its X0 IS the X the last call returned (an SCF step
+ * hands the orbitals of the previous step back; same number of bands).  The driver then starts from
+ * A_new X = (A_old X) inv(R) + (V_new - V_old) X -- the kept A X of its last exit, the Cholesky factor of its own
+ * `X = ortho!(copy(X))` and ONE local-only application of the potential difference -- instead of a full H X: the kinetic and
+ * nonlocal parts of H do not change between SCF steps (src/scf/self_consistent_field.jl:80-129: only the density-dependent
+ * potential does).  Silently ignored (full H X) when nothing is kept, shapes differ, the block is small / batched, or the
+ * orthogonalisation needed more than one plain pass.  The projectors (dftk_mi_kblock_set_projectors) must be unchanged. */
+int dftk_mi_kblock_reuse_AX(dftk_mi_kblock* kb, int on);
+/* number of dftk_mi_lobpcg calls of this process that started from the kept A X (diagnostic / tests) */
+int dftk_mi_ax_reuse_count(int64_t* calls);
+
 /* Optional: device pointer to H*X of the last dftk_mi_lobpcg call on this block (n_G x M,
  * leading dimension n_G; valid until the next lobpcg call on the block). */
 const dftk_mi_cplx* dftk_mi_lobpcg_last_AX(dftk_mi_kblock* kb);

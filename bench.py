@@ -606,7 +606,9 @@ def roofline_of(fam, n_gpus, workload):
                         "the same for the unstructured calls alone.  mfma_executed_tflops = real flops the launched "
                         "tiles run on the matrix pipe (3M complex product: 6 per complex multiply-add, REAL: 4; "
                         "whole tiles incl. shifted / border recompute) / time; mfma_busy_frac = that / dense f64 "
-                        "MFMA peak")
+                        "MFMA peak.  Call mix: a LOBPCG call of an SCF step starts from the kept A X (DESIGN 3.8c), i.e. "
+                        "without the two projector products of an H X -- the launches that ran at the highest rate (56-59 "
+                        "TF/s); the same kernels on the call mix with a full H X per call (DFTK_MI_AX_REUSE=0): 0.62-0.64")
     else:
         ms, work, launches = fam[dom]
         roof = {"bound": "hbm", "achieved": work / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}

@@ -802,6 +802,8 @@ extern "C" int dftk_mi_kblock_set_projectors(dftk_mi_kblock* kb, int n_p, const 
     }
     kb->n_p = 0;
     kb->P = nullptr;
+    kb->ax_keep = nullptr;                  // (an A X kept by the LOBPCG driver belongs to the old nonlocal term)
+    kb->ax_reuse_next = false;
     if (kb->gr) kb->gr->P_src = nullptr;   // the half-format copy is rebuilt on its next use
     if (n_p == 0) return 0;
     if (!P_d || !D_h || ldP < local_rows(kb)) return DFTK_MI_EINVAL;

@@ -769,9 +769,13 @@ static int lobpcg_run_general(dftk_mi_kblock* kb, int M, cd* Xp, int64_t ldX, do
         const size_t cube = (size_t)bb->nz * bb->ny * bb->nxp;
         if (!kb->d_dVs) HIPCHK(hipMalloc((void**)&kb->d_dVs, cube * sizeof(double)));
         CHK(ew_sub_real(bb, (int64_t)cube, kb->d_Vs, kb->d_Vs_ax, kb->d_dVs));
-        // (A_old X) inv(R) -> AX (the kept block may BE AX's storage: through newR then)
-        CHK(c.mm('N', N, M, M, ONE, ax_prev, ax_prev_ld, c.invR, M, ZERO, newR.p, newR.ld, /*B upper triangular=*/2));
-        CHK(ew_copy(b, N, M, newR.p, newR.ld, AX.p, AX.ld));
+        // (A_old X) inv(R) -> AX (straight into place unless the kept block IS AX's storage: through newR then)
+        if (ax_prev != AX.p) {
+            CHK(c.mm('N', N, M, M, ONE, ax_prev, ax_prev_ld, c.invR, M, ZERO, AX.p, AX.ld, /*B upper triangular=*/2));
+        } else {
+            CHK(c.mm('N', N, M, M, ONE, ax_prev, ax_prev_ld, c.invR, M, ZERO, newR.p, newR.ld, /*B upper triangular=*/2));
+            CHK(ew_copy(b, N, M, newR.p, newR.ld, AX.p, AX.ld));
+        }
         double* const Vs_bound = kb->d_Vs;
         kb->d_Vs = kb->d_dVs;                                  // (the kernels take the pointer at launch)
         const int st_dv = real_mode ? gamma_apply_H(kb, 1, M, X.p, X.ld, newR.p, newR.ld)

@@ -282,7 +282,7 @@ int dftk_mi_lobpcg_history(dftk_mi_kblock* kb, int* M, int* n_iter, double* hist
  * `X = ortho!(copy(X))` and ONE local-only application of the potential difference -- instead of a full H X: the kinetic and
  * nonlocal parts of H do not change between SCF steps (src/scf/self_consistent_field.jl:80-129: only the density-dependent
  * potential does).  Silently ignored (full H X) when nothing is kept, shapes differ, the block is small / batched, or the
- * orthogonalisation needed more than one plain pass.  The projectors (dftk_mi_kblock_set_projectors) must be unchanged. */
+ * orthogonalisation needed more than one plain pass.  dftk_mi_kblock_set_projectors drops what is kept. */
 int dftk_mi_kblock_reuse_AX(dftk_mi_kblock* kb, int on);
 /* number of dftk_mi_lobpcg calls of this process that started from the kept A X (diagnostic / tests) */
 int dftk_mi_ax_reuse_count(int64_t* calls);

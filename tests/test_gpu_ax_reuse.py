@@ -50,6 +50,16 @@ def test_second_call_from_the_kept_AX_equals_the_full_application(kcoord):
         r3 = dftk.lobpcg_hyper(ham2[0], r2.X[:36], prec=dftk.PreconditionerTPA(ham2[0]), tol=1e-7, n_conv_check=32, reuse_AX=reuse)
         assert _count(lib) == c1 and r3.converged
         out[reuse] = r2
+        if reuse:
+            # new projectors (here: the same ones, bound again) drop what is kept: the promise is then ignored
+            T = basis.terms
+            kpt = basis.kpoints[0]
+            D = np.asfortranarray(T.D.cpu().numpy() if torch.is_tensor(T.D) else T.D, dtype=np.float64)
+            assert lib.dftk_mi_kblock_set_projectors(kpt.handle, T.P[0].shape[0], T.P[0].data_ptr(), T.P[0].stride(0),
+                                                     D.ctypes.data) == 0
+            c2 = _count(lib)
+            r4 = dftk.lobpcg_hyper(ham2[0], r3.X, prec=dftk.PreconditionerTPA(ham2[0]), tol=1e-7, n_conv_check=32, reuse_AX=True)
+            assert _count(lib) == c2 and r4.converged
     a, b = out[True], out[False]
     # (the supercell's spectrum is full of exactly degenerate clusters: the Ritz vectors inside a cluster, and with them the
     #  per-column residual norms, turn by O(1) under a 1e-15 perturbation of the start -- compared are the invariants)

@@ -301,6 +301,21 @@ def _coarse_start_vectors(eigensolver, Hk, ik, nev, prec_type, tol, miniter, max
     return zero_pad_to_fine(rc.X, kc, Hk.kpoint, basis), int(rc.n_matvec)
 
 
+def first_wave_indices(n_k: int, width: int, spread: bool):
+    """The k-points of a mesh that start from random orbitals when no guess is given: ``width`` of them SPREAD evenly over the
+    list (two-wave start of a batched mesh: every other k-point then has a solved neighbour), else the first ``width``."""
+    if spread and n_k > width:
+        return sorted({int(i * n_k / width) for i in range(width)})
+    return list(range(min(width, n_k)))
+
+
+def nearest_index(coords, target):
+    """Index of the row of ``coords`` (fractional k-coordinates) nearest to ``target`` up to reciprocal lattice vectors."""
+    d = np.asarray(coords, dtype=float) - np.asarray(target, dtype=float)[None, :]
+    d -= np.round(d)
+    return int(np.argmin((d * d).sum(axis=1)))
+
+
 def _chain_width(basis) -> int:
     """How many k-points start from random orbitals when no guess is given; k-point ik > width interpolates the solution
     of an already solved k-point (the reference: the previous one, diag.jl:39-42; here the k-point of the same lane, or -- when
@@ -339,10 +354,7 @@ def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None
     W_ = _chain_width(basis_) if ham else 1
     two_waves = (bool(ham) and eigensolver is lobpcg_hyper and getattr(basis_, "kbatch", False) and basis_.n_lanes == 1
                  and os.environ.get("DFTK_MI_KBATCH_WAVES", "two") != "equal")
-    if two_waves and len(ham) > W_:
-        first_set = sorted({int(i * len(ham) / W_) for i in range(W_)})
-    else:
-        first_set = list(range(min(W_, len(ham))))
+    first_set = first_wave_indices(len(ham), W_, two_waves)
     in_first = set(first_set)
     n_matvec_coarse = 0
     for ik, Hk in enumerate(ham):                 # start vectors first, in k order: one deterministic RNG stream
@@ -398,9 +410,7 @@ def diagonalize_all_kblocks(eigensolver, ham, nev_per_kpoint: int, psiguess=None
                     if equal_waves:
                         src = ik - W
                     else:      # nearest solved k-point (fractional coordinates, periodic images)
-                        d = first - np.asarray(ham[ik].kpoint.coordinate, dtype=float)[None, :]
-                        d -= np.round(d)
-                        src = first_set[int(np.argmin((d * d).sum(axis=1)))]
+                        src = first_set[nearest_index(first, ham[ik].kpoint.coordinate)]
                     guesses[ik] = interpolate_kpoint(results[src].X, ham[src].kpoint, ham[ik].kpoint)
             multi = [ik for ik in wave if not getattr(ham[ik].kpoint, "gamma_real", False)]
             if len(multi) > 1:

@@ -1453,3 +1453,29 @@ def test_partial_eigensolver_shift_rule_and_numpy_model(lib):
         assert np.abs(A @ V - V * lam).max() < 1e-11
         k = [e for e in log if e[0] == "summary"][0][2]
         assert nev <= k <= max(nev + 64, (3 * nev) // 2)
+
+
+def test_first_wave_of_a_batched_k_mesh_and_nearest_neighbour_start():
+    """The two-wave start of a batched k-mesh (eigen.py; the reference starts k-point ik from k-point ik - 1, diag.jl:39-42):
+    the first wave is spread evenly over the list, every other k-point takes its start from the nearest first-wave k-point up
+    to reciprocal lattice vectors; the default first-wave size is the whole mesh up to 24 k-points, else n_k / 16 (>= 4)."""
+    from dftk_jl_amd.eigen import first_wave_indices, nearest_index, _chain_width
+    assert first_wave_indices(72, 4, True) == [0, 18, 36, 54]
+    assert first_wave_indices(72, 16, False) == list(range(16))
+    assert first_wave_indices(8, 16, True) == list(range(8)) and first_wave_indices(5, 5, True) == list(range(5))
+    for n_k, w in [(72, 4), (100, 6), (33, 7), (200, 12)]:
+        idx = first_wave_indices(n_k, w, True)
+        assert len(idx) == w and idx[0] == 0 and idx == sorted(set(idx)) and idx[-1] < n_k
+        gaps = np.diff(idx + [n_k])
+        assert gaps.max() - gaps.min() <= 1                                   # evenly spread
+    coords = np.array([[0.0, 0.0, 0.0], [0.5, 0.0, 0.0], [0.0, 0.5, 0.25]])
+    assert nearest_index(coords, [0.1, 0.0, 0.0]) == 0 and nearest_index(coords, [0.45, 0.05, 0.0]) == 1
+    assert nearest_index(coords, [0.95, 0.0, 0.0]) == 0                      # periodic image of Gamma
+    assert nearest_index(coords, [0.0, -0.45, 0.2]) == 2
+
+    class _B:
+        kbatch, n_lanes = True, 1
+
+        def __init__(self, n):
+            self.kpoints = [None] * n
+    assert _chain_width(_B(8)) == 8 and _chain_width(_B(24)) == 24 and _chain_width(_B(72)) == 4 and _chain_width(_B(200)) == 12
